@@ -1,0 +1,124 @@
+/*
+ * elpasso.h — C-ABI of the MI355X-native (HIP, gfx950) hot path under the PS-signature / EL PASSO protocol layer.
+ *
+ * The reference (Zhiyi-Zhang/PS-Signature-and-EL-PASSO) has no FFI boundary: src/ps-*.cc call herumi/mcl's C++ API
+ * directly.  This header is the boundary a maintainer would bind instead of mcl for the batched path;
+ * each entry point cites the reference code it replaces.  Plain C types only; the caller owns every buffer; no
+ * exceptions cross the ABI (int status, per-item results in uint8_t flag arrays).  One elp_ctx per host thread.
+ *
+ * Encodings ("std" = canonical integers, little-endian; F = 32 bytes for BN254, 48 for BLS12-381):
+ *   Fr        : 32 bytes                                      (mcl Fr::serialize)
+ *   G1 affine : x[F] | y[F]              all-zero = infinity  (uncompressed; mcl wire form is x with a parity flag)
+ *   G2 affine : x.a[F] | x.b[F] | y.a[F] | y.b[F]
+ *   G1 wire   : F bytes, G2 wire: 2F bytes                    (mcl G1/G2::serialize, src/ps-encoding.cc:167,199)
+ *   GT        : 12 x F bytes, tower order c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (each a | b)
+ * All buffers must be 4-byte aligned.
+ */
+#ifndef ELPASSO_H_
+#define ELPASSO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct elp_ctx elp_ctx;
+
+enum { ELP_CURVE_BN254 = 0, ELP_CURVE_BLS12_381 = 1 };
+enum {
+  ELP_OK = 0,
+  ELP_ERR_ARG = -1,      /* bad argument */
+  ELP_ERR_HIP = -2,      /* HIP runtime error (see elp_last_error) */
+  ELP_ERR_STATE = -3,    /* required key material not set */
+  ELP_ERR_NODEVICE = -4, /* no usable GPU: there is NO CPU fallback */
+  ELP_ERR_POINT = -5     /* a key/base point is not on the curve */
+};
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+/* replaces mcl::bls12::initPairing() (test/ps-tests.cc:142): selects the curve and the GPU. */
+int elp_init(int curve, int device, elp_ctx** out);
+void elp_destroy(elp_ctx* ctx);
+const char* elp_last_error(const elp_ctx* ctx);
+int elp_field_bytes(int curve);               /* F */
+const char* elp_version(void);
+
+/* ---- key material (builds fixed-base window tables and the Miller-loop lines of gg in HBM) ------------------ */
+/* PSPubKey{g, gg, XX, Yi[A], YYi[A]} (src/ps-encoding.h:111-140) as affine std points. window_bits 0 = default (8). */
+int elp_set_pubkey(elp_ctx* ctx, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
+                   const uint8_t* YYi, int window_bits);
+/* RP parameters of el_passo_verify_id (src/ps-verifier.h:45-49): service name (hashAndMapToG1 is evaluated on the GPU),
+ * ElGamal authority_pk, g, h (G1 affine std; NULL when id-retrieval is not used). */
+int elp_set_rp(elp_ctx* ctx, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk,
+               const uint8_t* g, const uint8_t* h);
+/* PSSigner's secret X = g^x (src/ps-signer.h:94), G1 affine std. */
+int elp_set_signer_secret(elp_ctx* ctx, const uint8_t* X);
+
+/* ---- batched primitives over host buffers (n independent items) ---------------------------------------------- */
+/* G1/G2::deserialize (point decompression; src/ps-encoding.cc:192,224): wire -> affine std; ok[i] = 0 if invalid */
+int elp_g1_decompress(elp_ctx* ctx, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok);
+int elp_g2_decompress(elp_ctx* ctx, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok);
+/* G1::mul / G2::mul, variable base (e.g. src/ps-verifier.cc:73,92; src/ps-requester.cc:109,144-146) */
+int elp_g1_mul(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
+int elp_g2_mul(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
+/* G1::add / G2::add (src/ps-verifier.cc:28,81) */
+int elp_g1_add(elp_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+int elp_g2_add(elp_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+/* sum_t scalars[i][t] * base[base_ids[t]] over the key's fixed bases (loops of G?::mul + G?::add over pk.Yi / YYi / g /
+ * gg / XX, src/ps-verifier.cc:76-88,220-227; src/ps-signer.cc:88-94,121-128).
+ * G1 base ids: 0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_elgamal, A+3 = authority_pk, A+4 = h, A+5 = X.
+ * G2 base ids: 0 = gg, 1 = XX, 2+i = YY_i. */
+int elp_g1_msm_fixed(elp_ctx* ctx, size_t n, int nterms, const int32_t* base_ids, const uint8_t* scalars, uint8_t* out);
+int elp_g2_msm_fixed(elp_ctx* ctx, size_t n, int nterms, const int32_t* base_ids, const uint8_t* scalars, uint8_t* out);
+/* hashAndMapToG1 (src/ps-verifier.cc:94; BN254: mcl's Shallue-van de Woestijne map). msgs concatenated, offsets[n+1]. */
+int elp_hash_to_g1(elp_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, uint8_t* out);
+/* pairing(GT&, G1, G2) (src/ps-verifier.cc:32-33) */
+int elp_pairing(elp_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt);
+/* prod_{j<npairs} e(P[i][j], Q[i][j]) == 1, one final exponentiation per item (npairs = 1..4) */
+int elp_pairing_check(elp_ctx* ctx, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok);
+
+/* ---- fused protocol batches ------------------------------------------------------------------------------------ */
+/* Record sizes in bytes. H = popcount(hidden_mask) */
+size_t elp_verify_id_record_size(int curve, int nattr, int nhidden, int with_retrieval);
+size_t elp_ps_verify_record_size(int curve, int nattr);
+size_t elp_provide_id_record_size(int curve, int nattr, int nhidden);
+
+/* PSVerifier::el_passo_verify_id / _without_id_retrieval (src/ps-verifier.cc:37-138,140-212).
+ * record i: sig1 | sig2 | phi | [E1 | E2] | k | c | rs[H+2 or H+1] | m[A-H]   (G1,G1,G1,[G1,G1],G2,Fr,...)
+ *   hidden_mask bit j set <=> proof.attributes[j] == "" ; m = Fr::setHashOf(attribute) of the revealed ones, in order.
+ * associated data: ad_off == NULL -> the same ad[0..ad_len) for every item, else item i uses ad[ad_off[i]..ad_off[i+1]).
+ * flags[i] = 1 iff the reference would return true; *accepted = number of ones. */
+int elp_verify_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval,
+                        const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted);
+/* PSVerifier::verify (src/ps-verifier.cc:13-35). record i: sig1 | sig2 | m[nattr] */
+int elp_ps_verify_batch(elp_ctx* ctx, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted);
+/* PSSigner::el_passo_provide_id (src/ps-signer.cc:63-146). record i: A | c | rs[H+1] | m[A-H] | u  (u = the nonce that
+ * sign_commitment draws with setByCSPRNG, src/ps-signer.cc:135-136, injected for reproducibility).
+ * sigs[i] = sig1 | sig2 (zeros when rejected). */
+int elp_provide_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, const uint8_t* ad,
+                         const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
+
+/* Same fused batches over DEVICE buffers, asynchronous on `stream` (hipStream_t; NULL = default stream).  Nothing is
+ * copied or synchronised; *d_accepted (uint64 in device memory) is atomically incremented. */
+int elp_verify_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
+                            int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
+                            void* d_accepted);
+int elp_ps_verify_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, int nattr, void* d_flags,
+                            void* d_accepted);
+int elp_provide_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
+                             const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags,
+                             void* d_accepted);
+
+/* ---- measurement helpers ---------------------------------------------------------------------------------------- */
+/* Times `reps` launches of the verify_id kernel with HIP events on `stream`; returns the average ms per launch. */
+int elp_time_verify_id_dev(elp_ctx* ctx, void* stream, int reps, size_t n, const void* d_records, uint64_t hidden_mask,
+                           int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
+                           void* d_accepted, float* avg_ms);
+/* Base-field multiplication micro-benchmark: every lane runs `iters` dependent Montgomery products; returns ms. */
+int elp_bench_fp_mul(elp_ctx* ctx, size_t lanes, int iters, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELPASSO_H_ */

@@ -1,0 +1,36 @@
+// Common macros for the host/device arithmetic headers of the EL PASSO HIP path.
+//
+// The headers under csrc/elp/ are written once and compiled twice:
+//   * by hipcc for gfx950 (the product: kernels in ../kernels.hip behind the C-ABI of include/elpasso.h)
+//   * by g++ for the host, ONLY by tests/host_twin (unit-testing the same formulas in a container
+//     that has no GPU).  The host build is test infrastructure and is never linked into the product.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ELP_HD __host__ __device__
+#else
+#define ELP_HD
+#endif
+
+#define ELP_INL ELP_HD inline __attribute__((always_inline))
+
+// "Heavy" routines are real (non-inlined) functions on the device: a pairing inlined into one kernel would be
+// several MB of straight-line code; a call hierarchy (fp_mul <- fp2_mul <- fp6_mul <- fp12_mul ...) keeps the
+// hot loop inside the instruction cache.  On the host the attribute does not matter.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ELP_HEAVY ELP_HD __attribute__((noinline))
+#define ELP_UNROLL _Pragma("unroll")
+#define ELP_NOUNROLL _Pragma("nounroll")
+#else
+#define ELP_HEAVY ELP_HD inline
+#define ELP_UNROLL
+#define ELP_NOUNROLL
+#endif
+
+namespace elp {
+typedef uint32_t u32;
+typedef uint64_t u64;
+}  // namespace elp

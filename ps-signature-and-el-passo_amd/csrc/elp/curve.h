@@ -1,0 +1,317 @@
+// G1 = E(Fp): y^2 = x^3 + b and G2 = E'(Fp2): y^2 = x^3 + b' (sextic twist), Jacobian coordinates.
+// Replaces mcl G1/G2 ::add/::sub/::mul (call sites: src/ps-verifier.cc:21-29,72-108,220-227,
+// src/ps-signer.cc:35-52,83-94,121-143, src/ps-requester.cc:38-66,109-110,144-146,165-261).
+#pragma once
+#include "tower.h"
+
+namespace elp {
+
+// ---- field-operation adaptors so that the group law is written once for Fp and Fp2
+template <class C>
+struct F1 {
+  typedef Fp<C> T;
+  typedef C Curve;
+  ELP_INL static T mul(const T& a, const T& b) { return fp_mul<C>(a, b); }
+  ELP_INL static T sqr(const T& a) { return fp_sqr<C>(a); }
+  ELP_INL static T add(const T& a, const T& b) { return fp_add(a, b); }
+  ELP_INL static T sub(const T& a, const T& b) { return fp_sub(a, b); }
+  ELP_INL static T dbl(const T& a) { return fp_dbl(a); }
+  ELP_INL static T neg(const T& a) { return fp_neg(a); }
+  ELP_INL static bool is_zero(const T& a) { return fp_is_zero(a); }
+  ELP_INL static bool eq(const T& a, const T& b) { return fp_eq(a, b); }
+  ELP_INL static T zero() { return fp_zero<C>(); }
+  ELP_INL static T one() { return fp_one<C>(); }
+  ELP_INL static T inv(const T& a) { return fp_inv<C>(a); }
+  ELP_INL static T select(bool c, const T& a, const T& b) { return fp_select(c, a, b); }
+  ELP_INL static T curve_b() {
+    T b;
+    ELP_LOAD_FP(b, C::curve_b(i_));
+    return b;
+  }
+};
+template <class C>
+struct F2 {
+  typedef Fp2<C> T;
+  typedef C Curve;
+  ELP_INL static T mul(const T& a, const T& b) { return fp2_mulv<C>(a, b); }
+  ELP_INL static T sqr(const T& a) { return fp2_sqrv<C>(a); }
+  ELP_INL static T add(const T& a, const T& b) { return fp2_add(a, b); }
+  ELP_INL static T sub(const T& a, const T& b) { return fp2_sub(a, b); }
+  ELP_INL static T dbl(const T& a) { return fp2_dbl(a); }
+  ELP_INL static T neg(const T& a) { return fp2_neg(a); }
+  ELP_INL static bool is_zero(const T& a) { return fp2_is_zero(a); }
+  ELP_INL static bool eq(const T& a, const T& b) { return fp2_eq(a, b); }
+  ELP_INL static T zero() { return fp2_zero<C>(); }
+  ELP_INL static T one() { return fp2_one<C>(); }
+  ELP_INL static T inv(const T& a) {
+    T r;
+    fp2_inv<C>(r, a);
+    return r;
+  }
+  ELP_INL static T select(bool c, const T& a, const T& b) { return fp2_select(c, a, b); }
+  ELP_INL static T curve_b() {
+    T b;
+    ELP_LOAD_FP(b.c0, C::twist_b(0, i_));
+    ELP_LOAD_FP(b.c1, C::twist_b(1, i_));
+    return b;
+  }
+};
+
+template <class F>
+struct Aff {  // affine point; (0,0) encodes the point at infinity (never on the curve since b != 0)
+  typename F::T x, y;
+};
+template <class F>
+struct Jac {  // Jacobian: (X/Z^2, Y/Z^3); Z == 0 encodes infinity
+  typename F::T X, Y, Z;
+};
+
+template <class F>
+ELP_INL bool aff_is_inf(const Aff<F>& p) {
+  return F::is_zero(p.x) && F::is_zero(p.y);
+}
+template <class F>
+ELP_INL void aff_set_inf(Aff<F>& p) {
+  p.x = F::zero();
+  p.y = F::zero();
+}
+template <class F>
+ELP_INL bool jac_is_inf(const Jac<F>& p) {
+  return F::is_zero(p.Z);
+}
+template <class F>
+ELP_INL void jac_set_inf(Jac<F>& p) {
+  p.X = F::one();
+  p.Y = F::one();
+  p.Z = F::zero();
+}
+template <class F>
+ELP_INL void jac_from_aff(Jac<F>& r, const Aff<F>& p) {
+  if (aff_is_inf(p)) {
+    jac_set_inf(r);
+  } else {
+    r.X = p.x;
+    r.Y = p.y;
+    r.Z = F::one();
+  }
+}
+template <class F>
+ELP_INL void jac_neg(Jac<F>& r, const Jac<F>& p) {
+  r.X = p.X;
+  r.Y = F::neg(p.Y);
+  r.Z = p.Z;
+}
+template <class F>
+ELP_INL void aff_neg(Aff<F>& r, const Aff<F>& p) {
+  r.x = p.x;
+  r.y = F::neg(p.y);
+}
+template <class F>
+ELP_HEAVY bool aff_on_curve(const Aff<F>& p) {
+  if (aff_is_inf(p)) return true;
+  typename F::T l = F::sqr(p.y);
+  typename F::T r = F::add(F::mul(F::sqr(p.x), p.x), F::curve_b());
+  return F::eq(l, r);
+}
+
+// dbl-2009-l (a = 0): 2M + 5S
+template <class F>
+ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+  typedef typename F::T T;
+  T A = F::sqr(p.X);
+  T B = F::sqr(p.Y);
+  T Cc = F::sqr(B);
+  T D = F::sub(F::sub(F::sqr(F::add(p.X, B)), A), Cc);
+  D = F::dbl(D);
+  T E = F::add(F::dbl(A), A);
+  T Fq = F::sqr(E);
+  T Z3 = F::dbl(F::mul(p.Y, p.Z));
+  T X3 = F::sub(Fq, F::dbl(D));
+  T C8 = F::dbl(F::dbl(F::dbl(Cc)));
+  r.Y = F::sub(F::mul(E, F::sub(D, X3)), C8);
+  r.X = X3;
+  r.Z = Z3;  // Y == 0 never happens on prime-order curves; Z == 0 stays 0
+}
+
+// madd-2007-bl: Jacobian + affine, 7M + 4S, with the exceptional cases handled
+template <class F>
+ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
+  typedef typename F::T T;
+  if (aff_is_inf(q)) {
+    r = p;
+    return;
+  }
+  if (jac_is_inf(p)) {
+    r.X = q.x;
+    r.Y = q.y;
+    r.Z = F::one();
+    return;
+  }
+  T Z1Z1 = F::sqr(p.Z);
+  T U2 = F::mul(q.x, Z1Z1);
+  T S2 = F::mul(F::mul(q.y, p.Z), Z1Z1);
+  T H = F::sub(U2, p.X);
+  T rr = F::sub(S2, p.Y);
+  if (F::is_zero(H)) {
+    if (F::is_zero(rr)) {
+      jac_dbl<F>(r, p);
+    } else {
+      jac_set_inf(r);
+    }
+    return;
+  }
+  rr = F::dbl(rr);
+  T HH = F::sqr(H);
+  T I = F::dbl(F::dbl(HH));
+  T J = F::mul(H, I);
+  T V = F::mul(p.X, I);
+  T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));
+  T Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::dbl(F::mul(p.Y, J)));
+  T Z3 = F::sub(F::sub(F::sqr(F::add(p.Z, H)), Z1Z1), HH);
+  r.X = X3;
+  r.Y = Y3;
+  r.Z = Z3;
+}
+
+// add-2007-bl: Jacobian + Jacobian, 11M + 5S
+template <class F>
+ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+  typedef typename F::T T;
+  if (jac_is_inf(q)) {
+    r = p;
+    return;
+  }
+  if (jac_is_inf(p)) {
+    r = q;
+    return;
+  }
+  T Z1Z1 = F::sqr(p.Z);
+  T Z2Z2 = F::sqr(q.Z);
+  T U1 = F::mul(p.X, Z2Z2);
+  T U2 = F::mul(q.X, Z1Z1);
+  T S1 = F::mul(F::mul(p.Y, q.Z), Z2Z2);
+  T S2 = F::mul(F::mul(q.Y, p.Z), Z1Z1);
+  T H = F::sub(U2, U1);
+  T rr = F::sub(S2, S1);
+  if (F::is_zero(H)) {
+    if (F::is_zero(rr)) {
+      jac_dbl<F>(r, p);
+    } else {
+      jac_set_inf(r);
+    }
+    return;
+  }
+  rr = F::dbl(rr);
+  T I = F::sqr(F::dbl(H));
+  T J = F::mul(H, I);
+  T V = F::mul(U1, I);
+  T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));
+  T Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::dbl(F::mul(S1, J)));
+  T Z3 = F::mul(F::sub(F::sub(F::sqr(F::add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+  r.X = X3;
+  r.Y = Y3;
+  r.Z = Z3;
+}
+
+// Jacobian -> affine given zinv = 1/Z (or anything when Z == 0)
+template <class F>
+ELP_INL void jac_to_aff_with_zinv(Aff<F>& r, const Jac<F>& p, const typename F::T& zinv) {
+  if (jac_is_inf(p)) {
+    aff_set_inf(r);
+    return;
+  }
+  typename F::T zi2 = F::sqr(zinv);
+  r.x = F::mul(p.X, zi2);
+  r.y = F::mul(F::mul(p.Y, zi2), zinv);
+}
+template <class F>
+ELP_HEAVY void jac_to_aff(Aff<F>& r, const Jac<F>& p) {
+  if (jac_is_inf(p)) {
+    aff_set_inf(r);
+    return;
+  }
+  jac_to_aff_with_zinv<F>(r, p, F::inv(p.Z));
+}
+
+// ---- scalars: 256-bit little-endian limbs (values < r; any 256-bit value is handled correctly)
+struct Scalar {
+  u32 v[8];
+};
+ELP_INL int scalar_window(const Scalar& k, int bit, int w) {  // bits [bit, bit+w)
+  int limb = bit >> 5, sh = bit & 31;
+  u64 t = k.v[limb];
+  if (limb + 1 < 8) t |= (u64)k.v[limb + 1] << 32;
+  return (int)((t >> sh) & ((1u << w) - 1));
+}
+ELP_INL bool scalar_is_zero(const Scalar& k) {
+  u32 t = 0;
+  for (int i = 0; i < 8; i++) t |= k.v[i];
+  return t == 0;
+}
+
+// Variable-base scalar multiplication: fixed 4-bit windows, uniform control flow across lanes
+// (64 x (4 dbl + 1 table add)); the per-lane table lives in private memory.
+template <class F>
+ELP_HEAVY void jac_mul_var(Jac<F>& r, const Aff<F>& p, const Scalar& k) {
+  Jac<F> tbl[16];
+  jac_set_inf(tbl[0]);
+  jac_from_aff(tbl[1], p);
+  ELP_NOUNROLL
+  for (int i = 2; i < 16; i++) {
+    if (i & 1)
+      jac_madd<F>(tbl[i], tbl[i - 1], p);
+    else
+      jac_dbl<F>(tbl[i], tbl[i >> 1]);
+  }
+  Jac<F> acc;
+  jac_set_inf(acc);
+  ELP_NOUNROLL
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) {
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+    }
+    int d = scalar_window(k, 4 * w, 4);
+    jac_add<F>(acc, acc, tbl[d]);
+  }
+  r = acc;
+}
+
+// Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,
+// j = 0 .. ceil(256/W)-1.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
+template <class F>
+ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scalar& k) {
+  const int nwin = (256 + W - 1) / W;
+  const int per = (1 << W) - 1;
+  ELP_NOUNROLL
+  for (int j = 0; j < nwin; j++) {
+    int bit = j * W;
+    int w = (bit + W <= 256) ? W : 256 - bit;
+    int d = scalar_window(k, bit, w);
+    if (d != 0) {
+      Aff<F> e = table[(size_t)j * per + (d - 1)];
+      jac_madd<F>(acc, acc, e);
+    }
+  }
+}
+
+// psi-twisted Frobenius on G2 (affine): pi(x, y) = (conj(x) g2, conj(y) g3)  [D-type] (inverse coefficients for M-type)
+template <class C>
+ELP_HEAVY void g2_frob(Aff<F2<C>>& r, const Aff<F2<C>>& q, int n) {
+  Fp2<C> x = (n & 1) ? fp2_conj(q.x) : q.x;
+  Fp2<C> y = (n & 1) ? fp2_conj(q.y) : q.y;
+  if (C::TWIST_D) {
+    fp2_mul<C>(r.x, x, fp2_frob_coeff<C>(n, 2));
+    fp2_mul<C>(r.y, y, fp2_frob_coeff<C>(n, 3));
+  } else {
+    Fp2<C> g;
+    fp2_inv<C>(g, fp2_frob_coeff<C>(n, 2));
+    fp2_mul<C>(r.x, x, g);
+    fp2_inv<C>(g, fp2_frob_coeff<C>(n, 3));
+    fp2_mul<C>(r.y, y, g);
+  }
+}
+
+}  // namespace elp

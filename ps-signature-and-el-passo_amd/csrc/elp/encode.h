@@ -1,0 +1,184 @@
+// mcl-compatible encodings and hashes (conventions pinned by tests/golden/bn254_*.json):
+//   Fr/Fp : FBYTES little-endian;  G1: x LE, top bit of last byte = y odd, all-zero = infinity;
+//   G2: x.a LE || x.b LE, top bit of last byte = y.a odd;  serializeToHexStr = lowercase hex of those bytes;
+//   Fr::setHashOf(m) = LE(SHA-256(m)) masked to bitlen(r) bits, top bit cleared if still >= r.
+// Replaces G1/G2::serialize/deserialize/serializeToHexStr, Fr::setHashOf, hashAndMapToG1
+// (src/ps-verifier.cc:25,94,112-122,224; src/ps-encoding.cc:167,192,199,224,231,256).
+#pragma once
+#include "curve.h"
+#include "sha256.h"
+
+namespace elp {
+
+// ---- Fr helpers (plain integers mod r, 8 limbs, no Montgomery form: only add/sub/compare are needed on device)
+template <class C>
+ELP_INL bool scalar_geq_r(const Scalar& a) {
+  u64 br = 0;
+  for (int i = 0; i < 8; i++) {
+    u64 t = (u64)a.v[i] - C::rmod(i) - br;
+    br = (t >> 32) & 1;
+  }
+  return br == 0;
+}
+template <class C>
+ELP_INL Scalar scalar_sub_mod_r(const Scalar& a, const Scalar& b) {  // a, b < r
+  Scalar r;
+  u64 br = 0;
+  for (int i = 0; i < 8; i++) {
+    u64 t = (u64)a.v[i] - b.v[i] - br;
+    r.v[i] = (u32)t;
+    br = (t >> 32) & 1;
+  }
+  if (br) {
+    u64 c = 0;
+    for (int i = 0; i < 8; i++) {
+      u64 t = (u64)r.v[i] + C::rmod(i) + c;
+      r.v[i] = (u32)t;
+      c = t >> 32;
+    }
+  }
+  return r;
+}
+ELP_INL bool scalar_eq(const Scalar& a, const Scalar& b) {
+  u32 t = 0;
+  for (int i = 0; i < 8; i++) t |= a.v[i] ^ b.v[i];
+  return t == 0;
+}
+ELP_INL Scalar scalar_load_le(const uint8_t* b) {
+  Scalar r;
+  for (int i = 0; i < 8; i++)
+    r.v[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
+  return r;
+}
+// mask a 32-byte digest (LE integer) the way mcl's setHashOf/setArrayMask does for a modulus of `bits` bits
+template <class C>
+ELP_INL Scalar scalar_from_digest(const uint8_t d[32]) {
+  Scalar s = scalar_load_le(d);
+  const int bits = C::RBITS;
+  if (bits < 256) s.v[7] &= (u32)((1ull << (bits - 224)) - 1);
+  if (scalar_geq_r<C>(s)) s.v[7] &= (u32)((1ull << (bits - 1 - 224)) - 1);
+  return s;
+}
+
+// ---- point serialisation (inputs affine, Montgomery form)
+template <class C>
+ELP_HEAVY void g1_serialize(uint8_t* out, const Aff<F1<C>>& p) {
+  if (aff_is_inf(p)) {
+    for (int i = 0; i < C::FBYTES; i++) out[i] = 0;
+    return;
+  }
+  Fp<C> x = fp_to_std<C>(p.x), y = fp_to_std<C>(p.y);
+  fp_store_le<C>(out, x);
+  if (y.v[0] & 1) out[C::FBYTES - 1] |= 0x80;
+}
+template <class C>
+ELP_HEAVY void g2_serialize(uint8_t* out, const Aff<F2<C>>& p) {
+  if (aff_is_inf(p)) {
+    for (int i = 0; i < 2 * C::FBYTES; i++) out[i] = 0;
+    return;
+  }
+  Fp<C> xa = fp_to_std<C>(p.x.c0), xb = fp_to_std<C>(p.x.c1), ya = fp_to_std<C>(p.y.c0);
+  fp_store_le<C>(out, xa);
+  fp_store_le<C>(out + C::FBYTES, xb);
+  if (ya.v[0] & 1) out[2 * C::FBYTES - 1] |= 0x80;
+}
+// Decompression; returns false for x >= p or x not on the curve.  (mcl ignores such failures at
+// src/ps-encoding.cc:192,224; we surface them and let the caller reject the item.)
+template <class C>
+ELP_HEAVY bool g1_deserialize(Aff<F1<C>>& p, const uint8_t* in) {
+  uint8_t tmp[C::FBYTES];
+  u32 any = 0;
+  for (int i = 0; i < C::FBYTES; i++) {
+    tmp[i] = in[i];
+    any |= in[i];
+  }
+  if (!any) {
+    aff_set_inf(p);
+    return true;
+  }
+  bool odd = (tmp[C::FBYTES - 1] & 0x80) != 0;
+  tmp[C::FBYTES - 1] &= 0x7f;
+  Fp<C> xs = fp_load_le<C>(tmp);
+  if (!fp_std_in_range<C>(xs)) return false;
+  Fp<C> x = fp_from_std<C>(xs);
+  Fp<C> b;
+  ELP_LOAD_FP(b, C::curve_b(i_));
+  Fp<C> rhs = fp_add(fp_mul<C>(fp_sqr<C>(x), x), b);
+  Fp<C> y;
+  if (!fp_sqrt<C>(y, rhs)) return false;
+  Fp<C> ys = fp_to_std<C>(y);
+  if (((ys.v[0] & 1) != 0) != odd) y = fp_neg(y);
+  p.x = x;
+  p.y = y;
+  return true;
+}
+template <class C>
+ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in) {
+  uint8_t tmp[2 * C::FBYTES];
+  u32 any = 0;
+  for (int i = 0; i < 2 * C::FBYTES; i++) {
+    tmp[i] = in[i];
+    any |= in[i];
+  }
+  if (!any) {
+    aff_set_inf(p);
+    return true;
+  }
+  bool odd = (tmp[2 * C::FBYTES - 1] & 0x80) != 0;
+  tmp[2 * C::FBYTES - 1] &= 0x7f;
+  Fp<C> xa = fp_load_le<C>(tmp), xb = fp_load_le<C>(tmp + C::FBYTES);
+  if (!fp_std_in_range<C>(xa) || !fp_std_in_range<C>(xb)) return false;
+  Fp2<C> x;
+  x.c0 = fp_from_std<C>(xa);
+  x.c1 = fp_from_std<C>(xb);
+  Fp2<C> rhs = fp2_add(fp2_mulv<C>(fp2_sqrv<C>(x), x), F2<C>::curve_b());
+  Fp2<C> y;
+  if (!fp2_sqrt<C>(y, rhs)) return false;
+  Fp<C> ya = fp_to_std<C>(y.c0);
+  if (((ya.v[0] & 1) != 0) != odd) y = fp2_neg(y);
+  p.x = x;
+  p.y = y;
+  return true;
+}
+
+// ---- Fp::setHashOf + BN Shallue-van de Woestijne map (mcl hashAndMapToG1 on BN curves)
+template <class C>
+ELP_HEAVY void map_to_g1_svdw(Aff<F1<C>>& out, const Fp<C>& t) {  // t != 0, Montgomery form
+  Fp<C> c1, c2, b, one = fp_one<C>();
+  ELP_LOAD_FP(c1, C::svdw_c1(i_));
+  ELP_LOAD_FP(c2, C::svdw_c2(i_));
+  ELP_LOAD_FP(b, C::curve_b(i_));
+  bool neg = fp_legendre<C>(t) < 0;
+  Fp<C> w = fp_add(fp_add(fp_sqr<C>(t), b), one);
+  w = fp_mul<C>(fp_mul<C>(c1, t), fp_inv<C>(w));
+  Fp<C> x, y;
+  for (int i = 0; i < 3; i++) {
+    if (i == 0)
+      x = fp_sub(c2, fp_mul<C>(t, w));
+    else if (i == 1)
+      x = fp_sub(fp_neg(x), one);
+    else
+      x = fp_add(one, fp_inv<C>(fp_sqr<C>(w)));
+    Fp<C> rhs = fp_add(fp_mul<C>(fp_sqr<C>(x), x), b);
+    if (fp_sqrt<C>(y, rhs)) break;
+  }
+  if (neg) y = fp_neg(y);
+  out.x = x;
+  out.y = y;
+}
+template <class C>
+ELP_HEAVY void hash_and_map_to_g1(Aff<F1<C>>& out, const uint8_t* msg, size_t len) {
+  Sha256 s;
+  sha256_init(s);
+  sha256_update(s, msg, len);
+  uint8_t d[32];
+  sha256_final(s, d);
+  // Fp::setHashOf: mask to bitlen(p) bits, clear one more bit if still >= p
+  Fp<C> t = fp_load_le<C>(d);   // BN254: FBYTES == 32
+  const int bits = C::PBITS;
+  if (bits < 32 * C::N) t.v[C::N - 1] &= (u32)((1ull << (bits - 32 * (C::N - 1))) - 1);
+  if (!fp_std_in_range<C>(t)) t.v[C::N - 1] &= (u32)((1ull << (bits - 1 - 32 * (C::N - 1))) - 1);
+  map_to_g1_svdw<C>(out, fp_from_std<C>(t));
+}
+
+}  // namespace elp

@@ -1,0 +1,281 @@
+// Optimal ate multi-pairing: shared-squaring Miller loop over several (P, Q) pairs + one final exponentiation.
+// Replaces mcl pairing()/GT== (src/ps-verifier.cc:31-34,134-137,208-211; src/ps-requester.cc:133-136):
+// the reference computes e(sig1,K) == e(sig2,gg) with two full pairings; GT never leaves the library, so the
+// product form  e(sig1,K) * e(-sig2,gg) == 1  with one final exponentiation is observationally identical.
+#pragma once
+#include "curve.h"
+
+namespace elp {
+
+template <class C>
+struct G2Proj {  // homogeneous projective point on the twist (x = X/Z, y = Y/Z)
+  Fp2<C> X, Y, Z;
+};
+template <class C>
+struct LineCoef {  // un-evaluated line: (a * y_P, b * x_P, c)
+  Fp2<C> a, b, c;
+};
+
+template <class C>
+ELP_INL Fp2<C> fp2_twist_3b() {
+  Fp2<C> b;
+  ELP_LOAD_FP(b.c0, C::twist_3b(0, i_));
+  ELP_LOAD_FP(b.c1, C::twist_3b(1, i_));
+  return b;
+}
+
+// Tangent line at T and T <- 2T.   line = 2YZ * y_P  -  3X^2 * x_P  +  (Y^2 - 3b'Z^2)
+template <class C>
+ELP_HEAVY void ml_dbl_step(G2Proj<C>& T, LineCoef<C>& l) {
+  Fp<C> inv2;
+  ELP_LOAD_FP(inv2, C::inv2(i_));
+  Fp2<C> A, B, Cz, E, Fq, G, H, J, t;
+  fp2_mul<C>(A, T.X, T.Y);
+  A = fp2_mul_fp(A, inv2);
+  fp2_sqr<C>(B, T.Y);
+  fp2_sqr<C>(Cz, T.Z);
+  fp2_mul<C>(E, Cz, fp2_twist_3b<C>());
+  Fq = fp2_add(fp2_dbl(E), E);
+  G = fp2_mul_fp(fp2_add(B, Fq), inv2);
+  fp2_sqr<C>(H, fp2_add(T.Y, T.Z));
+  H = fp2_sub(H, fp2_add(B, Cz));
+  fp2_sqr<C>(J, T.X);
+  l.a = H;
+  l.b = fp2_neg(fp2_add(fp2_dbl(J), J));
+  l.c = fp2_sub(B, E);
+  fp2_mul<C>(T.X, A, fp2_sub(B, Fq));
+  fp2_sqr<C>(t, G);
+  Fp2<C> E2;
+  fp2_sqr<C>(E2, E);
+  T.Y = fp2_sub(t, fp2_add(fp2_dbl(E2), E2));
+  fp2_mul<C>(T.Z, B, H);
+}
+
+// Chord through T and Q (affine) and T <- T + Q.   line = mu * y_P - theta * x_P + (theta x_Q - mu y_Q)
+template <class C>
+ELP_HEAVY void ml_add_step(G2Proj<C>& T, LineCoef<C>& l, const Fp2<C>& xq, const Fp2<C>& yq) {
+  Fp2<C> theta, mu, t, Cc, D, E, Fq, G, H;
+  fp2_mul<C>(t, yq, T.Z);
+  theta = fp2_sub(T.Y, t);
+  fp2_mul<C>(t, xq, T.Z);
+  mu = fp2_sub(T.X, t);
+  l.a = mu;
+  l.b = fp2_neg(theta);
+  fp2_mul<C>(t, theta, xq);
+  fp2_mul<C>(Cc, mu, yq);
+  l.c = fp2_sub(t, Cc);
+  fp2_sqr<C>(Cc, theta);
+  fp2_sqr<C>(D, mu);
+  fp2_mul<C>(E, mu, D);
+  fp2_mul<C>(Fq, T.Z, Cc);
+  fp2_mul<C>(G, T.X, D);
+  H = fp2_sub(fp2_add(E, Fq), fp2_dbl(G));
+  fp2_mul<C>(T.X, mu, H);
+  fp2_mul<C>(t, theta, fp2_sub(G, H));
+  fp2_mul<C>(Cc, E, T.Y);
+  T.Y = fp2_sub(t, Cc);
+  fp2_mul<C>(T.Z, T.Z, E);
+}
+
+template <class C>
+ELP_HEAVY void ml_apply_line(Fp12<C>& f, const LineCoef<C>& l, const Fp<C>& xp, const Fp<C>& yp) {
+  Fp2<C> a = fp2_mul_fp(l.a, yp);
+  Fp2<C> b = fp2_mul_fp(l.b, xp);
+  if (C::TWIST_D)
+    fp12_mul_by_line<C>(f, a, b, l.c);
+  else
+    fp12_mul_by_line<C>(f, l.c, b, a);
+}
+
+// number of line coefficients produced for one fixed G2 argument
+template <class C>
+ELP_HD constexpr int ml_num_lines() {
+  int n = 0;
+  for (int i = 0; i < C::ATE_LEN; i++) n += 1 + (C::ate_naf(i) != 0 ? 1 : 0);
+  return n + (C::IS_BN ? 2 : 0);
+}
+
+// Walk the Miller loop for a fixed Q and record every line (used once per public key for gg).
+template <class C>
+ELP_HEAVY void ml_precompute(LineCoef<C>* out, const Aff<F2<C>>& q) {
+  G2Proj<C> T;
+  T.X = q.x;
+  T.Y = q.y;
+  T.Z = fp2_one<C>();
+  Fp2<C> nqy = fp2_neg(q.y);
+  int n = 0;
+  ELP_NOUNROLL
+  for (int i = 0; i < C::ATE_LEN; i++) {
+    ml_dbl_step<C>(T, out[n++]);
+    int d = C::ate_naf(i);
+    if (d != 0) ml_add_step<C>(T, out[n++], q.x, d > 0 ? q.y : nqy);
+  }
+  if (C::IS_BN) {
+    if (C::Z_NEG) T.Y = fp2_neg(T.Y);
+    Aff<F2<C>> q1, q2;
+    g2_frob<C>(q1, q, 1);
+    g2_frob<C>(q2, q, 2);
+    ml_add_step<C>(T, out[n++], q1.x, q1.y);
+    ml_add_step<C>(T, out[n++], q2.x, fp2_neg(q2.y));
+  }
+}
+
+// f = prod_i f_{s,Q_i}(P_i) over NV pairs with run-time Q and NF pairs whose lines were precomputed.
+// Pairs with P or Q at infinity contribute 1 (e(O, Q) = e(P, O) = 1).
+template <class C, int NV, int NF>
+ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* qv, const Aff<F1<C>>* pf,
+                           const LineCoef<C>* const* lines) {
+  G2Proj<C> T[NV > 0 ? NV : 1];
+  Fp2<C> nqy[NV > 0 ? NV : 1];
+  bool live_v[NV > 0 ? NV : 1];
+  bool live_f[NF > 0 ? NF : 1];
+  for (int k = 0; k < NV; k++) {
+    live_v[k] = !(aff_is_inf(pv[k]) || aff_is_inf(qv[k]));
+    T[k].X = qv[k].x;
+    T[k].Y = qv[k].y;
+    T[k].Z = fp2_one<C>();
+    nqy[k] = fp2_neg(qv[k].y);
+  }
+  for (int k = 0; k < NF; k++) live_f[k] = !aff_is_inf(pf[k]);
+  fp12_set_one(f);
+  LineCoef<C> l;
+  int n = 0;
+  ELP_NOUNROLL
+  for (int i = 0; i < C::ATE_LEN; i++) {
+    if (i != 0) fp12_sqr<C>(f, f);
+    for (int k = 0; k < NV; k++)
+      if (live_v[k]) {
+        ml_dbl_step<C>(T[k], l);
+        ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+      }
+    for (int k = 0; k < NF; k++)
+      if (live_f[k]) ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+    n++;
+    int d = C::ate_naf(i);
+    if (d != 0) {
+      for (int k = 0; k < NV; k++)
+        if (live_v[k]) {
+          ml_add_step<C>(T[k], l, qv[k].x, d > 0 ? qv[k].y : nqy[k]);
+          ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+        }
+      for (int k = 0; k < NF; k++)
+        if (live_f[k]) ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+      n++;
+    }
+  }
+  if (C::Z_NEG) fp12_conj(f, f);
+  if (C::IS_BN) {
+    for (int k = 0; k < NV; k++)
+      if (live_v[k]) {
+        if (C::Z_NEG) T[k].Y = fp2_neg(T[k].Y);
+        Aff<F2<C>> q1, q2;
+        g2_frob<C>(q1, qv[k], 1);
+        g2_frob<C>(q2, qv[k], 2);
+        ml_add_step<C>(T[k], l, q1.x, q1.y);
+        ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+        ml_add_step<C>(T[k], l, q2.x, fp2_neg(q2.y));
+        ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+      }
+    for (int k = 0; k < NF; k++)
+      if (live_f[k]) {
+        ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+        ml_apply_line<C>(f, lines[k][n + 1], pf[k].x, pf[k].y);
+      }
+  }
+}
+
+// a^|z| for a in the cyclotomic subgroup
+template <class C>
+ELP_HEAVY void fp12_exp_absz(Fp12<C>& r, const Fp12<C>& a) {
+  Fp12<C> acc = a;
+  int top = 63;
+  while (!((C::ZABS >> top) & 1)) top--;
+  ELP_NOUNROLL
+  for (int i = top - 1; i >= 0; i--) {
+    fp12_cyc_sqr<C>(acc, acc);
+    if ((C::ZABS >> i) & 1) fp12_mul<C>(acc, acc, a);
+  }
+  r = acc;
+}
+// a^z (signed z) in the cyclotomic subgroup, where inversion is conjugation
+template <class C>
+ELP_INL void fp12_exp_z(Fp12<C>& r, const Fp12<C>& a) {
+  fp12_exp_absz<C>(r, a);
+  if (C::Z_NEG) fp12_conj(r, r);
+}
+
+// f^((p^12 - 1)/r): easy part (p^6 - 1)(p^2 + 1), then the hard part (p^4 - p^2 + 1)/r.
+template <class C>
+ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in) {
+  Fp12<C> f, t0, t1;
+  fp12_inv<C>(t0, f_in);
+  fp12_conj(t1, f_in);
+  fp12_mul<C>(f, t1, t0);      // f^(p^6 - 1)
+  fp12_frob<C>(t0, f, 2);
+  fp12_mul<C>(f, t0, f);       // ^(p^2 + 1)
+  if (C::IS_BN) {
+    // Devegili-Scott-Dahab: (p^4-p^2+1)/r = p^3 + (6z^2+1) p^2 + (-36z^3-18z^2-12z+1) p + (-36z^3-30z^2-18z-2)
+    // evaluated with the vectorial addition chain  y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36.
+    Fp12<C> fz, fz2, fz3, y0, y1, y2, y3, y4, y5, y6, T0, T1, t;
+    fp12_exp_z<C>(fz, f);
+    fp12_exp_z<C>(fz2, fz);
+    fp12_exp_z<C>(fz3, fz2);
+    fp12_frob<C>(y0, f, 1);
+    fp12_frob<C>(t, f, 2);
+    fp12_mul<C>(y0, y0, t);
+    fp12_frob<C>(t, f, 3);
+    fp12_mul<C>(y0, y0, t);                 // f^p f^p2 f^p3
+    fp12_conj(y1, f);                       // f^-1
+    fp12_frob<C>(y2, fz2, 2);               // (f^z2)^p2
+    fp12_frob<C>(y3, fz, 1);
+    fp12_conj(y3, y3);                      // ((f^z)^p)^-1
+    fp12_frob<C>(t, fz2, 1);
+    fp12_mul<C>(y4, fz, t);
+    fp12_conj(y4, y4);                      // (f^z (f^z2)^p)^-1
+    fp12_conj(y5, fz2);                     // (f^z2)^-1
+    fp12_frob<C>(t, fz3, 1);
+    fp12_mul<C>(y6, fz3, t);
+    fp12_conj(y6, y6);                      // (f^z3 (f^z3)^p)^-1
+    fp12_cyc_sqr<C>(T0, y6);
+    fp12_mul<C>(T0, T0, y4);
+    fp12_mul<C>(T0, T0, y5);
+    fp12_mul<C>(T1, y3, y5);
+    fp12_mul<C>(T1, T1, T0);
+    fp12_mul<C>(T0, T0, y2);
+    fp12_cyc_sqr<C>(T1, T1);
+    fp12_mul<C>(T1, T1, T0);
+    fp12_cyc_sqr<C>(T1, T1);
+    fp12_mul<C>(T0, T1, y1);
+    fp12_mul<C>(T1, T1, y0);
+    fp12_cyc_sqr<C>(T0, T0);
+    fp12_mul<C>(r, T0, T1);
+  } else {
+    // BLS12: (p^4-p^2+1)/r = ((z-1)^2 (z+p)(z^2+p^2-1))/3 + 1 ; we compute the cube-free multiple
+    // 3*(hard part) = (z-1)^2 (z+p)(z^2+p^2-1) + 3  (gcd(3, r) = 1, so ==1 tests and GT equality are preserved).
+    Fp12<C> a, b, c, t;
+    // a = f^((z-1)^2)
+    fp12_exp_z<C>(t, f);
+    fp12_conj(b, f);
+    fp12_mul<C>(a, t, b);                   // f^(z-1)
+    fp12_exp_z<C>(t, a);
+    fp12_conj(b, a);
+    fp12_mul<C>(a, t, b);                   // f^((z-1)^2)
+    // b = a^(z+p)
+    fp12_exp_z<C>(t, a);
+    fp12_frob<C>(b, a, 1);
+    fp12_mul<C>(b, b, t);
+    // c = b^(z^2 + p^2 - 1)
+    fp12_exp_z<C>(t, b);
+    fp12_exp_z<C>(t, t);
+    fp12_frob<C>(c, b, 2);
+    fp12_mul<C>(c, c, t);
+    fp12_conj(t, b);
+    fp12_mul<C>(c, c, t);
+    // * f^3
+    fp12_cyc_sqr<C>(t, f);
+    fp12_mul<C>(t, t, f);
+    fp12_mul<C>(r, c, t);
+  }
+}
+
+}  // namespace elp

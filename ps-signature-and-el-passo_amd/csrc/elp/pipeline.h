@@ -1,0 +1,448 @@
+// Per-item bodies of the batched hot path.  Each function processes ONE independent item (credential / proof);
+// ../kernels.hip wraps them in __global__ kernels (one item per lane), tests/host_twin wraps them in host loops.
+//
+// Reference call stacks restated here (optimised structure: fixed-base tables, one shared final exponentiation):
+//   verify_id_item        <- PSVerifier::el_passo_verify_id                       src/ps-verifier.cc:37-138
+//   verify_id_item(noretr)<- PSVerifier::el_passo_verify_id_without_id_retrieval  src/ps-verifier.cc:140-212
+//   ps_verify_item        <- PSVerifier::verify / PSRequester::verify             src/ps-verifier.cc:13-35
+//   provide_id_item       <- PSSigner::el_passo_provide_id                        src/ps-signer.cc:63-146
+#pragma once
+#include "encode.h"
+#include "pairing.h"
+
+namespace elp {
+
+// Wire-independent record formats (all integers little-endian, "std" = canonical non-Montgomery):
+//   G1 affine : x[F] y[F]            (all-zero = infinity)          F = C::FBYTES
+//   G2 affine : x.a[F] x.b[F] y.a[F] y.b[F]
+//   Fr        : 32 bytes
+template <class C>
+struct Sizes {
+  static constexpr int F = C::FBYTES;
+  static constexpr int G1 = 2 * F;
+  static constexpr int G2 = 4 * F;
+  static constexpr int FR = 32;
+  static constexpr int GT = 12 * F;
+};
+
+// Device-resident key context (built once per public key by elp_set_pubkey / elp_set_rp).
+template <class C>
+struct KeyCtx {
+  int A;                          // attributes in the key
+  int W;                          // fixed-base window width
+  int nwin, per;                  // windows per scalar, entries per window
+  const Aff<F1<C>>* t1;           // G1 tables: base b at t1 + b * nwin * per
+  const Aff<F2<C>>* t2;           // G2 tables
+  const Aff<F1<C>>* b1;           // G1 bases (affine):  0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X (signer secret)
+  const Aff<F2<C>>* b2;           // G2 bases (affine):  0 = gg, 1 = XX, 2+i = YY_i
+  const LineCoef<C>* gg_lines;    // precomputed Miller lines of gg
+};
+enum { G1_BASE_G = 0, G1_BASE_Y0 = 1 };
+enum { G2_BASE_GG = 0, G2_BASE_XX = 1, G2_BASE_YY0 = 2 };
+template <class C>
+ELP_INL int g1_base_hs(const KeyCtx<C>& k) { return k.A + 1; }
+template <class C>
+ELP_INL int g1_base_geg(const KeyCtx<C>& k) { return k.A + 2; }
+template <class C>
+ELP_INL int g1_base_apk(const KeyCtx<C>& k) { return k.A + 3; }
+template <class C>
+ELP_INL int g1_base_h(const KeyCtx<C>& k) { return k.A + 4; }
+template <class C>
+ELP_INL int g1_base_skx(const KeyCtx<C>& k) { return k.A + 5; }
+template <class C>
+ELP_INL int g1_num_bases(int A) { return A + 6; }
+template <class C>
+ELP_INL int g2_num_bases(int A) { return A + 2; }
+
+// ---- word-wise loads/stores of std-form values (buffers are 4-byte aligned)
+template <class C>
+ELP_INL Fp<C> fp_load_w(const u32* w) {
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::N; i++) r.v[i] = w[i];
+  return r;
+}
+template <class C>
+ELP_INL void fp_store_w(u32* w, const Fp<C>& a) {
+  ELP_UNROLL
+  for (int i = 0; i < C::N; i++) w[i] = a.v[i];
+}
+ELP_INL Scalar scalar_load_w(const u32* w) {
+  Scalar s;
+  for (int i = 0; i < 8; i++) s.v[i] = w[i];
+  return s;
+}
+// returns false if a coordinate is >= p or the point is not on the curve
+template <class C>
+ELP_HEAVY bool g1_load(Aff<F1<C>>& p, const u32* w) {
+  Fp<C> x = fp_load_w<C>(w), y = fp_load_w<C>(w + C::N);
+  if (fp_is_zero(x) && fp_is_zero(y)) {
+    aff_set_inf(p);
+    return true;
+  }
+  if (!fp_std_in_range<C>(x) || !fp_std_in_range<C>(y)) return false;
+  p.x = fp_from_std<C>(x);
+  p.y = fp_from_std<C>(y);
+  return aff_on_curve<F1<C>>(p);
+}
+template <class C>
+ELP_HEAVY bool g2_load(Aff<F2<C>>& p, const u32* w) {
+  Fp<C> a = fp_load_w<C>(w), b = fp_load_w<C>(w + C::N), c = fp_load_w<C>(w + 2 * C::N), d = fp_load_w<C>(w + 3 * C::N);
+  if (fp_is_zero(a) && fp_is_zero(b) && fp_is_zero(c) && fp_is_zero(d)) {
+    aff_set_inf(p);
+    return true;
+  }
+  if (!fp_std_in_range<C>(a) || !fp_std_in_range<C>(b) || !fp_std_in_range<C>(c) || !fp_std_in_range<C>(d)) return false;
+  p.x.c0 = fp_from_std<C>(a);
+  p.x.c1 = fp_from_std<C>(b);
+  p.y.c0 = fp_from_std<C>(c);
+  p.y.c1 = fp_from_std<C>(d);
+  return aff_on_curve<F2<C>>(p);
+}
+template <class C>
+ELP_HEAVY void g1_store(u32* w, const Aff<F1<C>>& p) {
+  if (aff_is_inf(p)) {
+    for (int i = 0; i < 2 * C::N; i++) w[i] = 0;
+    return;
+  }
+  fp_store_w<C>(w, fp_to_std<C>(p.x));
+  fp_store_w<C>(w + C::N, fp_to_std<C>(p.y));
+}
+template <class C>
+ELP_HEAVY void g2_store(u32* w, const Aff<F2<C>>& p) {
+  if (aff_is_inf(p)) {
+    for (int i = 0; i < 4 * C::N; i++) w[i] = 0;
+    return;
+  }
+  fp_store_w<C>(w, fp_to_std<C>(p.x.c0));
+  fp_store_w<C>(w + C::N, fp_to_std<C>(p.x.c1));
+  fp_store_w<C>(w + 2 * C::N, fp_to_std<C>(p.y.c0));
+  fp_store_w<C>(w + 3 * C::N, fp_to_std<C>(p.y.c1));
+}
+template <class C>
+ELP_HEAVY void gt_store(u32* w, const Fp12<C>& f) {  // order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (each a, b)
+  const Fp2<C>* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  for (int i = 0; i < 6; i++) {
+    fp_store_w<C>(w + (2 * i) * C::N, fp_to_std<C>(e[i]->c0));
+    fp_store_w<C>(w + (2 * i + 1) * C::N, fp_to_std<C>(e[i]->c1));
+  }
+}
+
+// ---- fixed-base accumulation against the key tables
+template <class C>
+ELP_INL void acc_fixed_g1(Jac<F1<C>>& acc, const KeyCtx<C>& k, int base, const Scalar& s) {
+  jac_acc_fixed<F1<C>>(acc, k.t1 + (size_t)base * k.nwin * k.per, k.W, s);
+}
+template <class C>
+ELP_INL void acc_fixed_g2(Jac<F2<C>>& acc, const KeyCtx<C>& k, int base, const Scalar& s) {
+  jac_acc_fixed<F2<C>>(acc, k.t2 + (size_t)base * k.nwin * k.per, k.W, s);
+}
+
+// 1/Z for several Jacobian Z's with ONE base-field inversion (Montgomery's trick); Z == 0 entries are skipped.
+template <class C, int N1, int N2>
+ELP_HEAVY void batch_zinv(Fp<C>* zi1, const Fp<C>* z1, Fp2<C>* zi2, const Fp2<C>* z2) {
+  constexpr int NT = N1 + N2;
+  Fp<C> v[NT], pre[NT];
+  for (int i = 0; i < N1; i++) v[i] = fp_is_zero(z1[i]) ? fp_one<C>() : z1[i];
+  for (int i = 0; i < N2; i++) {
+    Fp<C> n = fp_add(fp_sqr<C>(z2[i].c0), fp_sqr<C>(z2[i].c1));   // norm
+    v[N1 + i] = fp_is_zero(n) ? fp_one<C>() : n;
+  }
+  Fp<C> acc = fp_one<C>();
+  for (int i = 0; i < NT; i++) {
+    pre[i] = acc;
+    acc = fp_mul<C>(acc, v[i]);
+  }
+  Fp<C> inv = fp_inv<C>(acc);
+  for (int i = NT - 1; i >= 0; i--) {
+    Fp<C> vi = fp_mul<C>(inv, pre[i]);
+    inv = fp_mul<C>(inv, v[i]);
+    if (i < N1) {
+      zi1[i] = vi;
+    } else {
+      const Fp2<C>& z = z2[i - N1];
+      zi2[i - N1].c0 = fp_mul<C>(z.c0, vi);
+      zi2[i - N1].c1 = fp_neg(fp_mul<C>(z.c1, vi));
+    }
+  }
+}
+
+// Fiat-Shamir challenge: Fr::setHashOf( SHA256( hex(part_0) || ... || ad ) )  (SHA-256 applied twice)
+struct Transcript {
+  Sha256 s;
+};
+ELP_INL void transcript_init(Transcript& t) { sha256_init(t.s); }
+template <class C>
+ELP_INL void transcript_g1(Transcript& t, const Aff<F1<C>>& p) {
+  uint8_t b[C::FBYTES];
+  g1_serialize<C>(b, p);
+  sha256_update_hex(t.s, b, C::FBYTES);
+}
+template <class C>
+ELP_INL void transcript_g2(Transcript& t, const Aff<F2<C>>& p) {
+  uint8_t b[2 * C::FBYTES];
+  g2_serialize<C>(b, p);
+  sha256_update_hex(t.s, b, 2 * C::FBYTES);
+}
+template <class C>
+ELP_INL Scalar transcript_challenge(Transcript& t, const uint8_t* ad, size_t ad_len) {
+  sha256_update(t.s, ad, ad_len);
+  uint8_t d[32];
+  sha256_final(t.s, d);
+  Sha256 s2;
+  sha256_init(s2);
+  sha256_update(s2, d, 32);
+  sha256_final(s2, d);
+  return scalar_from_digest<C>(d);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// EL PASSO VerifyID.  Record (words): sig1 | sig2 | phi | [E1 | E2] | k | c | rs[H+1 or H+2] | m[A-H]
+//   hidden_mask bit i set <=> attribute i is hidden (proof.attributes[i] == "");  m = Fr::setHashOf(attribute)
+//   for the revealed attributes in attribute order.
+template <class C>
+ELP_HD constexpr int verify_id_record_words(int A, int H, bool retr) {
+  return ((retr ? 5 : 3) * 2 * C::N) + 4 * C::N + 8 * (1 + H + (retr ? 2 : 1) + (A - H));
+}
+
+template <class C>
+ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad,
+                              size_t ad_len) {
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  const int A = key.A;
+  int H = 0;
+  for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+  const int nrs = H + (retr ? 2 : 1);
+  Aff<G1F> sig1, sig2, phi, E1, E2;
+  Aff<G2F> kk;
+  bool ok = true;
+  const u32* p = rec;
+  ok &= g1_load<C>(sig1, p); p += 2 * C::N;
+  ok &= g1_load<C>(sig2, p); p += 2 * C::N;
+  ok &= g1_load<C>(phi, p);  p += 2 * C::N;
+  if (retr) {
+    ok &= g1_load<C>(E1, p); p += 2 * C::N;
+    ok &= g1_load<C>(E2, p); p += 2 * C::N;
+  }
+  ok &= g2_load<C>(kk, p); p += 4 * C::N;
+  if (!ok) return false;
+  const Scalar c = scalar_load_w(p); p += 8;
+  const u32* rs = p; p += 8 * nrs;
+  const u32* ms = p;
+
+  // V_k = k^c * prod_{hidden} YY_j^{r_j} * gg^{r_t} * XX^{1-c}          (src/ps-verifier.cc:72-88)
+  // K   = k * prod_{revealed} YY_i^{m_i}                                 (src/ps-verifier.cc:214-229)
+  Jac<G2F> Vk, K;
+  jac_mul_var<G2F>(Vk, kk, c);
+  jac_from_aff(K, kk);
+  {
+    int jh = 0, jr = 0;
+    for (int i = 0; i < A; i++) {
+      if ((hidden_mask >> i) & 1) {
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, scalar_load_w(rs + 8 * jh));
+        jh++;
+      } else {
+        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(ms + 8 * jr));
+        jr++;
+      }
+    }
+  }
+  const Scalar r_t = scalar_load_w(rs + 8 * (retr ? nrs - 2 : nrs - 1));
+  acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
+  Scalar one;
+  for (int i = 0; i < 8; i++) one.v[i] = 0;
+  one.v[0] = 1;
+  Scalar cred = c;  // 1 - c mod r (c >= r cannot match the recomputed challenge; reduce defensively)
+  if (scalar_geq_r<C>(cred)) {
+    Scalar rr;
+    for (int i = 0; i < 8; i++) rr.v[i] = C::rmod(i);
+    cred = scalar_sub_mod_r<C>(cred, rr);
+  }
+  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, scalar_sub_mod_r<C>(one, cred));
+
+  // V_phi = phi^c * H1(service)^{r_0}                                     (src/ps-verifier.cc:91-96)
+  Jac<G1F> Vphi, VE1, VE2;
+  jac_mul_var<G1F>(Vphi, phi, c);
+  acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), scalar_load_w(rs));
+  if (retr) {
+    const Scalar r_e = scalar_load_w(rs + 8 * (nrs - 1));
+    // V_E1 = E1^c * g^{r_eps} ; V_E2 = E2^c * y^{r_eps} * h^{r_1}         (src/ps-verifier.cc:99-108)
+    jac_mul_var<G1F>(VE1, E1, c);
+    acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
+    jac_mul_var<G1F>(VE2, E2, c);
+    acc_fixed_g1<C>(VE2, key, g1_base_apk(key), r_e);
+    acc_fixed_g1<C>(VE2, key, g1_base_h(key), scalar_load_w(rs + 8));
+  }
+
+  // canonical affine forms with one shared inversion
+  Fp<C> z1[3], zi1[3];
+  Fp2<C> z2[2], zi2[2];
+  z1[0] = Vphi.Z;
+  z1[1] = retr ? VE1.Z : fp_one<C>();
+  z1[2] = retr ? VE2.Z : fp_one<C>();
+  z2[0] = Vk.Z;
+  z2[1] = K.Z;
+  batch_zinv<C, 3, 2>(zi1, z1, zi2, z2);
+  Aff<G2F> aVk, aK;
+  Aff<G1F> aVphi, aVE1, aVE2;
+  jac_to_aff_with_zinv<G2F>(aVk, Vk, zi2[0]);
+  jac_to_aff_with_zinv<G2F>(aK, K, zi2[1]);
+  jac_to_aff_with_zinv<G1F>(aVphi, Vphi, zi1[0]);
+
+  // c' = Hr(SHA256(hex k | hex phi | [hex E1 | hex E2] | hex V_k | hex V_phi | [hex V_E1 | hex V_E2] | ad))
+  Transcript t;
+  transcript_init(t);
+  transcript_g2<C>(t, kk);
+  transcript_g1<C>(t, phi);
+  if (retr) {
+    transcript_g1<C>(t, E1);
+    transcript_g1<C>(t, E2);
+  }
+  transcript_g2<C>(t, aVk);
+  transcript_g1<C>(t, aVphi);
+  if (retr) {
+    jac_to_aff_with_zinv<G1F>(aVE1, VE1, zi1[1]);
+    jac_to_aff_with_zinv<G1F>(aVE2, VE2, zi1[2]);
+    transcript_g1<C>(t, aVE1);
+    transcript_g1<C>(t, aVE2);
+  }
+  const Scalar c2 = transcript_challenge<C>(t, ad, ad_len);
+  if (!scalar_eq(c2, c)) return false;
+
+  // e(sig1, K) == e(sig2, gg)  <=>  e(sig1, K) * e(-sig2, gg) == 1       (src/ps-verifier.cc:133-137)
+  Aff<G1F> nsig2;
+  aff_neg(nsig2, sig2);
+  if (aff_is_inf(sig2)) aff_set_inf(nsig2);
+  Fp12<C> f, g;
+  const LineCoef<C>* lines[1] = {key.gg_lines};
+  miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
+  final_exp<C>(g, f);
+  return fp12_is_one(g);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Plain PS verification.  Record: sig1 | sig2 | m[A]   (src/ps-verifier.cc:13-35)
+template <class C>
+ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  Aff<G1F> sig1, sig2;
+  if (!g1_load<C>(sig1, rec)) return false;
+  if (!g1_load<C>(sig2, rec + 2 * C::N)) return false;
+  if (aff_is_inf(sig1)) return false;                       // src/ps-verifier.cc:16-18
+  const u32* ms = rec + 4 * C::N;
+  Jac<G2F> K;
+  jac_from_aff(K, key.b2[G2_BASE_XX]);
+  for (int i = 0; i < nattr; i++) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(ms + 8 * i));
+  Aff<G2F> aK;
+  jac_to_aff<G2F>(aK, K);
+  Aff<G1F> nsig2;
+  aff_neg(nsig2, sig2);
+  if (aff_is_inf(sig2)) aff_set_inf(nsig2);
+  Fp12<C> f, g;
+  const LineCoef<C>* lines[1] = {key.gg_lines};
+  miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
+  final_exp<C>(g, f);
+  return fp12_is_one(g);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// EL PASSO ProvideID (IdP issuance).  Record: A | c | rs[H+1] | m[A-H] | u      Output: sig1 | sig2
+//   (src/ps-signer.cc:63-146; the CSPRNG nonce u of sign_commitment is an input so results are reproducible)
+template <class C>
+ELP_HD constexpr int provide_id_record_words(int A, int H) {
+  return 2 * C::N + 8 * (1 + (H + 1) + (A - H) + 1);
+}
+template <class C>
+ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, const uint8_t* ad, size_t ad_len,
+                               u32* out) {
+  typedef F1<C> G1F;
+  const int A = key.A;
+  int H = 0;
+  for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+  Aff<G1F> Ac;
+  for (int i = 0; i < 4 * C::N; i++) out[i] = 0;
+  if (!g1_load<C>(Ac, rec)) return false;
+  const u32* p = rec + 2 * C::N;
+  const Scalar c = scalar_load_w(p); p += 8;
+  const u32* rs = p; p += 8 * (H + 1);
+  const u32* ms = p; p += 8 * (A - H);
+  const Scalar u = scalar_load_w(p);
+  // V = A^c * g^{r_0} * prod_{hidden} Y_i^{r_j}                           (src/ps-signer.cc:82-94)
+  Jac<G1F> V, Ap;
+  jac_mul_var<G1F>(V, Ac, c);
+  acc_fixed_g1<C>(V, key, G1_BASE_G, scalar_load_w(rs));
+  jac_from_aff(Ap, Ac);
+  {
+    int jh = 1, jr = 0;
+    for (int i = 0; i < A; i++) {
+      if ((hidden_mask >> i) & 1) {
+        acc_fixed_g1<C>(V, key, G1_BASE_Y0 + i, scalar_load_w(rs + 8 * jh));
+        jh++;
+      } else {
+        // A' = A * prod_{revealed} Y_i^{m_i}; skipped entirely when the key has one attribute (src/ps-signer.cc:115-117)
+        if (A != 1) acc_fixed_g1<C>(Ap, key, G1_BASE_Y0 + i, scalar_load_w(ms + 8 * jr));
+        jr++;
+      }
+    }
+  }
+  Aff<G1F> aV;
+  jac_to_aff<G1F>(aV, V);
+  Transcript t;
+  transcript_init(t);
+  transcript_g1<C>(t, Ac);
+  transcript_g1<C>(t, aV);
+  const Scalar c2 = transcript_challenge<C>(t, ad, ad_len);
+  if (!scalar_eq(c2, c)) return false;
+  // sigma = (g^u, (X * A')^u)                                             (src/ps-signer.cc:132-146)
+  Jac<G1F> s1, s2;
+  jac_set_inf(s1);
+  acc_fixed_g1<C>(s1, key, G1_BASE_G, u);
+  jac_madd<G1F>(Ap, Ap, key.b1[g1_base_skx(key)]);
+  Aff<G1F> aAp;
+  jac_to_aff<G1F>(aAp, Ap);
+  jac_mul_var<G1F>(s2, aAp, u);
+  Fp<C> z[2], zi[2];
+  z[0] = s1.Z;
+  z[1] = s2.Z;
+  batch_zinv<C, 2, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
+  Aff<G1F> a1, a2;
+  jac_to_aff_with_zinv<G1F>(a1, s1, zi[0]);
+  jac_to_aff_with_zinv<G1F>(a2, s2, zi[1]);
+  g1_store<C>(out, a1);
+  g1_store<C>(out + 2 * C::N, a2);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Setup helpers
+
+// entry (j, d) of the fixed-base table of `base`:  d * 2^(W j) * base, d = 1..2^W-1; one call fills entries
+// [d0, d0+cnt) of window j.  bj = 2^(W j) * base (affine).
+template <class F>
+ELP_HEAVY void table_fill_chunk(Aff<F>* win, const Aff<F>& bj, int d0, int cnt) {
+  Scalar s;
+  for (int i = 0; i < 8; i++) s.v[i] = 0;
+  s.v[0] = (u32)d0;
+  Jac<F> acc;
+  jac_mul_var<F>(acc, bj, s);
+  for (int d = d0; d < d0 + cnt; d++) {
+    Aff<F> e;
+    jac_to_aff<F>(e, acc);
+    win[d - 1] = e;
+    jac_madd<F>(acc, acc, bj);
+  }
+}
+// bj[j] = 2^(W j) * base for all windows (sequential doublings, one lane per base)
+template <class F>
+ELP_HEAVY void table_window_bases(Aff<F>* bj, const Aff<F>& base, int W, int nwin) {
+  Jac<F> acc;
+  jac_from_aff(acc, base);
+  for (int j = 0; j < nwin; j++) {
+    jac_to_aff<F>(bj[j], acc);
+    for (int t = 0; t < W; t++) jac_dbl<F>(acc, acc);
+  }
+}
+
+}  // namespace elp

@@ -1,0 +1,441 @@
+// Extension tower Fp2 = Fp[i]/(i^2+1), Fp6 = Fp2[v]/(v^3 - xi), Fp12 = Fp6[w]/(w^2 - v), xi = 1 + i.
+// Replaces mcl::Fp2T / Fp6T / Fp12T (third-parties/mcl) as used under pairing() at src/ps-verifier.cc:31-34,134-137.
+#pragma once
+#include "fp.h"
+
+namespace elp {
+
+// ------------------------------------------------------------------ Fp2
+template <class C>
+struct Fp2 {
+  Fp<C> c0, c1;
+};
+
+template <class C>
+ELP_INL Fp2<C> fp2_zero() {
+  Fp2<C> r;
+  r.c0 = fp_zero<C>();
+  r.c1 = fp_zero<C>();
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_one() {
+  Fp2<C> r;
+  r.c0 = fp_one<C>();
+  r.c1 = fp_zero<C>();
+  return r;
+}
+template <class C>
+ELP_INL bool fp2_is_zero(const Fp2<C>& a) {
+  return fp_is_zero(a.c0) && fp_is_zero(a.c1);
+}
+template <class C>
+ELP_INL bool fp2_eq(const Fp2<C>& a, const Fp2<C>& b) {
+  return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1);
+}
+template <class C>
+ELP_INL Fp2<C> fp2_add(const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  r.c0 = fp_add(a.c0, b.c0);
+  r.c1 = fp_add(a.c1, b.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_sub(const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  r.c0 = fp_sub(a.c0, b.c0);
+  r.c1 = fp_sub(a.c1, b.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_neg(const Fp2<C>& a) {
+  Fp2<C> r;
+  r.c0 = fp_neg(a.c0);
+  r.c1 = fp_neg(a.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_dbl(const Fp2<C>& a) {
+  Fp2<C> r;
+  r.c0 = fp_dbl(a.c0);
+  r.c1 = fp_dbl(a.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_conj(const Fp2<C>& a) {
+  Fp2<C> r;
+  r.c0 = a.c0;
+  r.c1 = fp_neg(a.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_select(bool c, const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  r.c0 = fp_select(c, a.c0, b.c0);
+  r.c1 = fp_select(c, a.c1, b.c1);
+  return r;
+}
+// (a0 + a1 i)(1 + i) = (a0 - a1) + (a0 + a1) i
+template <class C>
+ELP_INL Fp2<C> fp2_mul_xi(const Fp2<C>& a) {
+  Fp2<C> r;
+  r.c0 = fp_sub(a.c0, a.c1);
+  r.c1 = fp_add(a.c0, a.c1);
+  return r;
+}
+template <class C>
+ELP_HEAVY void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // Karatsuba, 3 Fp mul
+  Fp<C> t0 = fp_mul<C>(a.c0, b.c0);
+  Fp<C> t1 = fp_mul<C>(a.c1, b.c1);
+  Fp<C> s = fp_mul<C>(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+  r.c0 = fp_sub(t0, t1);
+  r.c1 = fp_sub(fp_sub(s, t0), t1);
+}
+template <class C>
+ELP_HEAVY void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul
+  Fp<C> t = fp_mul<C>(a.c0, a.c1);
+  Fp<C> u = fp_mul<C>(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1));
+  r.c0 = u;
+  r.c1 = fp_dbl(t);
+}
+template <class C>
+ELP_INL Fp2<C> fp2_mulv(const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  fp2_mul<C>(r, a, b);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_sqrv(const Fp2<C>& a) {
+  Fp2<C> r;
+  fp2_sqr<C>(r, a);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_mul_fp(const Fp2<C>& a, const Fp<C>& s) {
+  Fp2<C> r;
+  r.c0 = fp_mul<C>(a.c0, s);
+  r.c1 = fp_mul<C>(a.c1, s);
+  return r;
+}
+template <class C>
+ELP_HEAVY void fp2_inv(Fp2<C>& r, const Fp2<C>& a) {
+  Fp<C> n = fp_add(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1));
+  Fp<C> ni = fp_inv<C>(n);
+  r.c0 = fp_mul<C>(a.c0, ni);
+  r.c1 = fp_neg(fp_mul<C>(a.c1, ni));
+}
+// Square root in Fp2 for p = 3 (mod 4) ("complex method").  Returns false when a is not a square.
+template <class C>
+ELP_HEAVY bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a) {
+  if (fp_is_zero(a.c1)) {
+    Fp<C> s;
+    if (fp_sqrt<C>(s, a.c0)) {
+      r.c0 = s;
+      r.c1 = fp_zero<C>();
+      return true;
+    }
+    bool ok = fp_sqrt<C>(s, fp_neg(a.c0));
+    r.c0 = fp_zero<C>();
+    r.c1 = s;
+    return ok;
+  }
+  Fp<C> n;
+  if (!fp_sqrt<C>(n, fp_add(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1)))) return false;
+  Fp<C> inv2;
+  ELP_LOAD_FP(inv2, C::inv2(i_));
+  Fp<C> t = fp_mul<C>(fp_add(a.c0, n), inv2);
+  Fp<C> x;
+  if (!fp_sqrt<C>(x, t)) {
+    t = fp_mul<C>(fp_sub(a.c0, n), inv2);
+    if (!fp_sqrt<C>(x, t)) return false;
+  }
+  Fp<C> y = fp_mul<C>(a.c1, fp_inv<C>(fp_dbl(x)));
+  r.c0 = x;
+  r.c1 = y;
+  return true;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_frob_coeff(int n, int k) {  // gamma_{n,k} = xi^(k (p^n - 1)/6), k = 1..5
+  Fp2<C> g;
+  if (n == 1) {
+    ELP_LOAD_FP(g.c0, C::frob1(k, 0, i_));
+    ELP_LOAD_FP(g.c1, C::frob1(k, 1, i_));
+  } else if (n == 2) {
+    ELP_LOAD_FP(g.c0, C::frob2(k, 0, i_));
+    ELP_LOAD_FP(g.c1, C::frob2(k, 1, i_));
+  } else {
+    ELP_LOAD_FP(g.c0, C::frob3(k, 0, i_));
+    ELP_LOAD_FP(g.c1, C::frob3(k, 1, i_));
+  }
+  return g;
+}
+
+// ------------------------------------------------------------------ Fp6
+template <class C>
+struct Fp6 {
+  Fp2<C> c0, c1, c2;
+};
+template <class C>
+ELP_INL void fp6_add(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
+  r.c0 = fp2_add(a.c0, b.c0);
+  r.c1 = fp2_add(a.c1, b.c1);
+  r.c2 = fp2_add(a.c2, b.c2);
+}
+template <class C>
+ELP_INL void fp6_sub(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
+  r.c0 = fp2_sub(a.c0, b.c0);
+  r.c1 = fp2_sub(a.c1, b.c1);
+  r.c2 = fp2_sub(a.c2, b.c2);
+}
+template <class C>
+ELP_INL void fp6_neg(Fp6<C>& r, const Fp6<C>& a) {
+  r.c0 = fp2_neg(a.c0);
+  r.c1 = fp2_neg(a.c1);
+  r.c2 = fp2_neg(a.c2);
+}
+template <class C>
+ELP_INL void fp6_mul_by_v(Fp6<C>& r, const Fp6<C>& a) {  // (c0,c1,c2) v = (xi c2, c0, c1)
+  Fp2<C> t = fp2_mul_xi(a.c2);
+  r.c2 = a.c1;
+  r.c1 = a.c0;
+  r.c0 = t;
+}
+template <class C>
+ELP_HEAVY void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karatsuba, 6 Fp2 mul
+  Fp2<C> t0, t1, t2, s;
+  fp2_mul<C>(t0, a.c0, b.c0);
+  fp2_mul<C>(t1, a.c1, b.c1);
+  fp2_mul<C>(t2, a.c2, b.c2);
+  Fp2<C> r0, r1, r2;
+  fp2_mul<C>(s, fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2));
+  r0 = fp2_add(t0, fp2_mul_xi(fp2_sub(fp2_sub(s, t1), t2)));
+  fp2_mul<C>(s, fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1));
+  r1 = fp2_add(fp2_sub(fp2_sub(s, t0), t1), fp2_mul_xi(t2));
+  fp2_mul<C>(s, fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2));
+  r2 = fp2_add(fp2_sub(fp2_sub(s, t0), t2), t1);
+  r.c0 = r0;
+  r.c1 = r1;
+  r.c2 = r2;
+}
+template <class C>
+ELP_HEAVY void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {  // CH-SQR2: 2 mul + 3 sqr in Fp2
+  Fp2<C> s0, s1, s2, s3, s4;
+  fp2_sqr<C>(s0, a.c0);
+  fp2_mul<C>(s1, a.c0, a.c1);
+  s1 = fp2_dbl(s1);
+  fp2_sqr<C>(s2, fp2_add(fp2_sub(a.c0, a.c1), a.c2));
+  fp2_mul<C>(s3, a.c1, a.c2);
+  s3 = fp2_dbl(s3);
+  fp2_sqr<C>(s4, a.c2);
+  r.c0 = fp2_add(s0, fp2_mul_xi(s3));
+  r.c1 = fp2_add(s1, fp2_mul_xi(s4));
+  r.c2 = fp2_sub(fp2_add(fp2_add(s1, s2), s3), fp2_add(s0, s4));
+}
+// a * (b0 + b1 v)
+template <class C>
+ELP_HEAVY void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {  // 5 Fp2 mul
+  Fp2<C> t0, t1, s, r0, r1, r2;
+  fp2_mul<C>(t0, a.c0, b0);
+  fp2_mul<C>(t1, a.c1, b1);
+  fp2_mul<C>(s, fp2_add(a.c1, a.c2), b1);  // a1 b1 + a2 b1
+  r0 = fp2_add(t0, fp2_mul_xi(fp2_sub(s, t1)));
+  fp2_mul<C>(s, fp2_add(a.c0, a.c1), fp2_add(b0, b1));
+  r1 = fp2_sub(fp2_sub(s, t0), t1);
+  fp2_mul<C>(s, a.c2, b0);
+  r2 = fp2_add(s, t1);
+  r.c0 = r0;
+  r.c1 = r1;
+  r.c2 = r2;
+}
+template <class C>
+ELP_HEAVY void fp6_mul_by_fp2(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b) {  // 3 Fp2 mul
+  fp2_mul<C>(r.c0, a.c0, b);
+  fp2_mul<C>(r.c1, a.c1, b);
+  fp2_mul<C>(r.c2, a.c2, b);
+}
+template <class C>
+ELP_HEAVY void fp6_inv(Fp6<C>& r, const Fp6<C>& x) {
+  Fp2<C> A, B, Cc, t, F;
+  fp2_sqr<C>(A, x.c0);
+  fp2_mul<C>(t, x.c1, x.c2);
+  A = fp2_sub(A, fp2_mul_xi(t));
+  fp2_sqr<C>(B, x.c2);
+  B = fp2_mul_xi(B);
+  fp2_mul<C>(t, x.c0, x.c1);
+  B = fp2_sub(B, t);
+  fp2_sqr<C>(Cc, x.c1);
+  fp2_mul<C>(t, x.c0, x.c2);
+  Cc = fp2_sub(Cc, t);
+  Fp2<C> u, v;
+  fp2_mul<C>(u, x.c2, B);
+  fp2_mul<C>(v, x.c1, Cc);
+  fp2_mul<C>(F, x.c0, A);
+  F = fp2_add(F, fp2_mul_xi(fp2_add(u, v)));
+  Fp2<C> Fi;
+  fp2_inv<C>(Fi, F);
+  fp2_mul<C>(r.c0, A, Fi);
+  fp2_mul<C>(r.c1, B, Fi);
+  fp2_mul<C>(r.c2, Cc, Fi);
+}
+
+// ------------------------------------------------------------------ Fp12
+template <class C>
+struct Fp12 {
+  Fp6<C> c0, c1;
+};
+template <class C>
+ELP_INL void fp12_set_one(Fp12<C>& r) {
+  r.c0.c0 = fp2_one<C>();
+  r.c0.c1 = fp2_zero<C>();
+  r.c0.c2 = fp2_zero<C>();
+  r.c1.c0 = fp2_zero<C>();
+  r.c1.c1 = fp2_zero<C>();
+  r.c1.c2 = fp2_zero<C>();
+}
+template <class C>
+ELP_INL bool fp12_is_one(const Fp12<C>& a) {
+  return fp2_eq(a.c0.c0, fp2_one<C>()) && fp2_is_zero(a.c0.c1) && fp2_is_zero(a.c0.c2) && fp2_is_zero(a.c1.c0) &&
+         fp2_is_zero(a.c1.c1) && fp2_is_zero(a.c1.c2);
+}
+template <class C>
+ELP_INL bool fp12_eq(const Fp12<C>& a, const Fp12<C>& b) {
+  return fp2_eq(a.c0.c0, b.c0.c0) && fp2_eq(a.c0.c1, b.c0.c1) && fp2_eq(a.c0.c2, b.c0.c2) && fp2_eq(a.c1.c0, b.c1.c0) &&
+         fp2_eq(a.c1.c1, b.c1.c1) && fp2_eq(a.c1.c2, b.c1.c2);
+}
+template <class C>
+ELP_HEAVY void fp12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {  // 3 Fp6 mul
+  Fp6<C> t0, t1, s, u;
+  fp6_mul<C>(t0, a.c0, b.c0);
+  fp6_mul<C>(t1, a.c1, b.c1);
+  fp6_add(s, a.c0, a.c1);
+  fp6_add(u, b.c0, b.c1);
+  fp6_mul<C>(s, s, u);
+  fp6_sub(s, s, t0);
+  fp6_sub(r.c1, s, t1);
+  fp6_mul_by_v(t1, t1);
+  fp6_add(r.c0, t0, t1);
+}
+template <class C>
+ELP_HEAVY void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {  // complex squaring, 2 Fp6 mul
+  Fp6<C> t, s, u;
+  fp6_mul<C>(t, a.c0, a.c1);           // a0 a1
+  fp6_add(s, a.c0, a.c1);               // a0 + a1
+  fp6_mul_by_v(u, a.c1);
+  fp6_add(u, u, a.c0);                  // a0 + v a1
+  fp6_mul<C>(s, s, u);                  // (a0+a1)(a0+v a1) = a0^2 + v a1^2 + (1+v) a0 a1
+  fp6_sub(s, s, t);
+  fp6_mul_by_v(u, t);
+  fp6_sub(r.c0, s, u);
+  fp6_add(r.c1, t, t);
+}
+template <class C>
+ELP_INL void fp12_conj(Fp12<C>& r, const Fp12<C>& a) {  // a^(p^6)
+  r.c0 = a.c0;
+  fp6_neg(r.c1, a.c1);
+}
+template <class C>
+ELP_HEAVY void fp12_inv(Fp12<C>& r, const Fp12<C>& a) {
+  Fp6<C> t0, t1;
+  fp6_sqr<C>(t0, a.c0);
+  fp6_sqr<C>(t1, a.c1);
+  fp6_mul_by_v(t1, t1);
+  fp6_sub(t0, t0, t1);
+  fp6_inv<C>(t1, t0);
+  fp6_mul<C>(r.c0, a.c0, t1);
+  fp6_mul<C>(t0, a.c1, t1);
+  fp6_neg(r.c1, t0);
+}
+// a^(p^n), n = 1, 2, 3.  Coefficient of v^i w^j (= w^(2i+j)) is conjugated n times and scaled by gamma_{n,2i+j}.
+template <class C>
+ELP_HEAVY void fp12_frob(Fp12<C>& r, const Fp12<C>& a, int n) {
+  const bool cj = (n & 1) != 0;
+  Fp2<C> t;
+  t = a.c0.c0;
+  r.c0.c0 = cj ? fp2_conj(t) : t;
+  t = a.c1.c0;
+  fp2_mul<C>(r.c1.c0, cj ? fp2_conj(t) : t, fp2_frob_coeff<C>(n, 1));
+  t = a.c0.c1;
+  fp2_mul<C>(r.c0.c1, cj ? fp2_conj(t) : t, fp2_frob_coeff<C>(n, 2));
+  t = a.c1.c1;
+  fp2_mul<C>(r.c1.c1, cj ? fp2_conj(t) : t, fp2_frob_coeff<C>(n, 3));
+  t = a.c0.c2;
+  fp2_mul<C>(r.c0.c2, cj ? fp2_conj(t) : t, fp2_frob_coeff<C>(n, 4));
+  t = a.c1.c2;
+  fp2_mul<C>(r.c1.c2, cj ? fp2_conj(t) : t, fp2_frob_coeff<C>(n, 5));
+}
+
+// Sparse product used by the Miller loop.
+//  D-type twist: line = a + b w + c w^3   -> c0 = (a,0,0), c1 = (b,c,0)      ("034")
+//  M-type twist: line = a + b w^2 + c w^3 -> c0 = (a,b,0), c1 = (0,c,0)      ("014")
+template <class C>
+ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c) {
+  if (C::TWIST_D) {
+    Fp6<C> t0, t1, t2, s;
+    fp6_mul_by_fp2<C>(t0, f.c0, a);          // f0 * a
+    fp6_mul_by_01<C>(t1, f.c1, b, c);        // f1 * (b + c v)
+    fp6_add(s, f.c0, f.c1);
+    fp6_mul_by_01<C>(t2, s, fp2_add(a, b), c);  // (f0+f1)(a + b + c v)
+    fp6_sub(t2, t2, t0);
+    fp6_sub(f.c1, t2, t1);
+    fp6_mul_by_v(t1, t1);
+    fp6_add(f.c0, t0, t1);
+  } else {
+    Fp6<C> t0, t1, t2, s;
+    fp6_mul_by_01<C>(t0, f.c0, a, b);        // f0 * (a + b v)
+    // f1 * (c v): (x0,x1,x2) * c v = (xi x2 c, x0 c, x1 c)
+    fp6_mul_by_fp2<C>(t1, f.c1, c);
+    fp6_mul_by_v(t1, t1);
+    fp6_add(s, f.c0, f.c1);
+    fp6_mul_by_01<C>(t2, s, a, fp2_add(b, c));  // (f0+f1)(a + (b+c) v)
+    fp6_sub(t2, t2, t0);
+    fp6_sub(f.c1, t2, t1);
+    fp6_mul_by_v(t1, t1);
+    fp6_add(f.c0, t0, t1);
+  }
+}
+
+// Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final exponentiation).
+template <class C>
+ELP_HEAVY void fp12_cyc_sqr(Fp12<C>& r, const Fp12<C>& a) {
+  // view Fp12 as three Fp4 = Fp2[s]/(s^2 - xi):  (g0 + g1 s) with pairs (c0.c0,c1.c1), (c1.c0,c0.c2), (c0.c1,c1.c2)
+  const Fp2<C>&z0 = a.c0.c0, &z4 = a.c0.c1, &z3 = a.c0.c2, &z2 = a.c1.c0, &z1 = a.c1.c1, &z5 = a.c1.c2;
+  Fp2<C> t0, t1, t2, t3, t4, t5, tmp;
+  // (z0 + z1 s)^2 = (z0^2 + xi z1^2) + 2 z0 z1 s
+  fp2_sqr<C>(t0, z0);
+  fp2_sqr<C>(t1, z1);
+  fp2_sqr<C>(tmp, fp2_add(z0, z1));
+  t5 = fp2_sub(fp2_sub(tmp, t0), t1);          // 2 z0 z1
+  t0 = fp2_add(t0, fp2_mul_xi(t1));            // z0^2 + xi z1^2
+  Fp2<C> A0 = t0, A1 = t5;
+  fp2_sqr<C>(t0, z2);
+  fp2_sqr<C>(t1, z3);
+  fp2_sqr<C>(tmp, fp2_add(z2, z3));
+  t5 = fp2_sub(fp2_sub(tmp, t0), t1);
+  t0 = fp2_add(t0, fp2_mul_xi(t1));
+  Fp2<C> B0 = t0, B1 = t5;
+  fp2_sqr<C>(t0, z4);
+  fp2_sqr<C>(t1, z5);
+  fp2_sqr<C>(tmp, fp2_add(z4, z5));
+  t5 = fp2_sub(fp2_sub(tmp, t0), t1);
+  t0 = fp2_add(t0, fp2_mul_xi(t1));
+  Fp2<C> C0 = t0, C1 = t5;
+  // z0' = 3 A0 - 2 z0 ; z1' = 3 A1 + 2 z1
+  Fp2<C> n0 = fp2_add(fp2_dbl(fp2_sub(A0, z0)), A0);
+  Fp2<C> n1 = fp2_add(fp2_dbl(fp2_add(A1, z1)), A1);
+  // z2' = 3 xi C1 + 2 z2 ; z3' = 3 C0 - 2 z3
+  Fp2<C> xc1 = fp2_mul_xi(C1);
+  Fp2<C> n2 = fp2_add(fp2_dbl(fp2_add(xc1, z2)), xc1);
+  Fp2<C> n3 = fp2_add(fp2_dbl(fp2_sub(C0, z3)), C0);
+  // z4' = 3 B0 - 2 z4 ; z5' = 3 B1 + 2 z5
+  Fp2<C> n4 = fp2_add(fp2_dbl(fp2_sub(B0, z4)), B0);
+  Fp2<C> n5 = fp2_add(fp2_dbl(fp2_add(B1, z5)), B1);
+  (void)t2; (void)t3; (void)t4;
+  r.c0.c0 = n0;
+  r.c0.c1 = n4;
+  r.c0.c2 = n3;
+  r.c1.c0 = n2;
+  r.c1.c1 = n1;
+  r.c1.c2 = n5;
+}
+
+}  // namespace elp

@@ -1,0 +1,858 @@
+// HIP kernels (gfx950 / MI355X) and the C-ABI of include/elpasso.h.
+// One independent item (credential / proof / point) per lane; all arithmetic lives in elp/*.h.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/elpasso.h"
+#include "elp/params_bn254.h"
+#include "elp/pipeline.h"
+
+using namespace elp;
+
+// ------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------
+#define ELP_BLOCK 64
+
+__device__ __forceinline__ void count_accept(bool ok, unsigned long long* counter) {
+  unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b != 0 && counter) atomicAdd(counter, (unsigned long long)__popcll(b));
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_verify_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+                                                         const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
+                                                         unsigned long long* accepted, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = verify_id_item<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al);
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_ps_verify(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* flags,
+                                                         unsigned long long* accepted, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    ok = ps_verify_item<C>(key, recs + i * (size_t)rec_words, nattr);
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_provide_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
+                                                          const u32* ad_off, u32 ad_len, u32* sigs, uint8_t* flags,
+                                                          unsigned long long* accepted, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = provide_id_item<C>(key, recs + i * (size_t)rec_words, mask, a, al, sigs + i * (size_t)(4 * C::N));
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
+template <class C, int G>  // G = 1: G1, 2: G2
+__global__ void __launch_bounds__(ELP_BLOCK) k_decompress(const uint8_t* wire, u32* out, uint8_t* okf, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (G == 1) {
+    Aff<F1<C>> p;
+    bool ok = g1_deserialize<C>(p, wire + i * C::FBYTES);
+    if (!ok) aff_set_inf(p);
+    g1_store<C>(out + i * 2 * C::N, p);
+    okf[i] = ok;
+  } else {
+    Aff<F2<C>> p;
+    bool ok = g2_deserialize<C>(p, wire + i * 2 * C::FBYTES);
+    if (!ok) aff_set_inf(p);
+    g2_store<C>(out + i * 4 * C::N, p);
+    okf[i] = ok;
+  }
+}
+
+template <class C, int G>
+__global__ void __launch_bounds__(ELP_BLOCK) k_mul(const u32* pts, const u32* ks, u32* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (G == 1) {
+    Aff<F1<C>> p, r;
+    Jac<F1<C>> j;
+    if (!g1_load<C>(p, pts + i * 2 * C::N)) aff_set_inf(p);
+    jac_mul_var<F1<C>>(j, p, scalar_load_w(ks + i * 8));
+    jac_to_aff<F1<C>>(r, j);
+    g1_store<C>(out + i * 2 * C::N, r);
+  } else {
+    Aff<F2<C>> p, r;
+    Jac<F2<C>> j;
+    if (!g2_load<C>(p, pts + i * 4 * C::N)) aff_set_inf(p);
+    jac_mul_var<F2<C>>(j, p, scalar_load_w(ks + i * 8));
+    jac_to_aff<F2<C>>(r, j);
+    g2_store<C>(out + i * 4 * C::N, r);
+  }
+}
+
+template <class C, int G>
+__global__ void __launch_bounds__(ELP_BLOCK) k_add(const u32* a, const u32* b, u32* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (G == 1) {
+    Aff<F1<C>> p, q, r;
+    Jac<F1<C>> j;
+    if (!g1_load<C>(p, a + i * 2 * C::N)) aff_set_inf(p);
+    if (!g1_load<C>(q, b + i * 2 * C::N)) aff_set_inf(q);
+    jac_from_aff(j, p);
+    jac_madd<F1<C>>(j, j, q);
+    jac_to_aff<F1<C>>(r, j);
+    g1_store<C>(out + i * 2 * C::N, r);
+  } else {
+    Aff<F2<C>> p, q, r;
+    Jac<F2<C>> j;
+    if (!g2_load<C>(p, a + i * 4 * C::N)) aff_set_inf(p);
+    if (!g2_load<C>(q, b + i * 4 * C::N)) aff_set_inf(q);
+    jac_from_aff(j, p);
+    jac_madd<F2<C>>(j, j, q);
+    jac_to_aff<F2<C>>(r, j);
+    g2_store<C>(out + i * 4 * C::N, r);
+  }
+}
+
+template <class C, int G>
+__global__ void __launch_bounds__(ELP_BLOCK) k_msm_fixed(KeyCtx<C> key, int nterms, const int* base_ids, const u32* ks, u32* out,
+                                                         size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (G == 1) {
+    Jac<F1<C>> acc;
+    jac_set_inf(acc);
+    for (int t = 0; t < nterms; t++) acc_fixed_g1<C>(acc, key, base_ids[t], scalar_load_w(ks + (i * nterms + t) * 8));
+    Aff<F1<C>> r;
+    jac_to_aff<F1<C>>(r, acc);
+    g1_store<C>(out + i * 2 * C::N, r);
+  } else {
+    Jac<F2<C>> acc;
+    jac_set_inf(acc);
+    for (int t = 0; t < nterms; t++) acc_fixed_g2<C>(acc, key, base_ids[t], scalar_load_w(ks + (i * nterms + t) * 8));
+    Aff<F2<C>> r;
+    jac_to_aff<F2<C>>(r, acc);
+    g2_store<C>(out + i * 4 * C::N, r);
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_hash_to_g1(const uint8_t* msgs, const u32* off, u32* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p;
+  hash_and_map_to_g1<C>(p, msgs + off[i], off[i + 1] - off[i]);
+  g1_store<C>(out + i * 2 * C::N, p);
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_pairing(const u32* g1, const u32* g2, u32* gt, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p;
+  Aff<F2<C>> q;
+  if (!g1_load<C>(p, g1 + i * 2 * C::N)) aff_set_inf(p);
+  if (!g2_load<C>(q, g2 + i * 4 * C::N)) aff_set_inf(q);
+  Fp12<C> f, g;
+  miller_loop<C, 1, 0>(f, &p, &q, (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0);
+  final_exp<C>(g, f);
+  gt_store<C>(gt + i * 12 * C::N, g);
+}
+
+template <class C, int NP>
+__global__ void __launch_bounds__(ELP_BLOCK) k_pairing_check(const u32* g1, const u32* g2, uint8_t* okf, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F1<C>> p[NP];
+  Aff<F2<C>> q[NP];
+  bool ok = true;
+  for (int j = 0; j < NP; j++) {
+    ok &= g1_load<C>(p[j], g1 + (i * NP + j) * 2 * C::N);
+    ok &= g2_load<C>(q[j], g2 + (i * NP + j) * 4 * C::N);
+  }
+  if (ok) {
+    Fp12<C> f, g;
+    miller_loop<C, NP, 0>(f, p, q, (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0);
+    final_exp<C>(g, f);
+    ok = fp12_is_one(g);
+  }
+  okf[i] = ok;
+}
+
+// ---- setup kernels
+template <class F>
+__global__ void __launch_bounds__(ELP_BLOCK) k_window_bases(const Aff<F>* bases, int nb, int W, int nwin, Aff<F>* bj) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  if (aff_is_inf(bases[b])) {
+    for (int j = 0; j < nwin; j++) aff_set_inf(bj[(size_t)b * nwin + j]);
+    return;
+  }
+  table_window_bases<F>(bj + (size_t)b * nwin, bases[b], W, nwin);
+}
+template <class F>
+__global__ void __launch_bounds__(ELP_BLOCK) k_table_fill(Aff<F>* tbl, const Aff<F>* bj, int nb, int nwin, int per, int chunk) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int nchunk = (per + chunk - 1) / chunk;
+  size_t total = (size_t)nb * nwin * nchunk;
+  if (t >= total) return;
+  int c = (int)(t % nchunk);
+  size_t bw = t / nchunk;  // b * nwin + j
+  Aff<F>* win = tbl + bw * per;
+  int d0 = 1 + c * chunk;
+  int cnt = (d0 + chunk - 1 <= per) ? chunk : per - d0 + 1;
+  Aff<F> base = bj[bw];
+  if (aff_is_inf(base)) {
+    for (int d = d0; d < d0 + cnt; d++) aff_set_inf(win[d - 1]);
+    return;
+  }
+  table_fill_chunk<F>(win, base, d0, cnt);
+}
+template <class C>
+__global__ void k_lines(const Aff<F2<C>>* gg, LineCoef<C>* out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ml_precompute<C>(out, gg[0]);
+}
+template <class C>
+__global__ void k_load_bases(const u32* g1w, int n1, const u32* g2w, int n2, Aff<F1<C>>* b1, Aff<F2<C>>* b2, int* bad) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n1) {
+    if (!g1_load<C>(b1[t], g1w + (size_t)t * 2 * C::N)) {
+      aff_set_inf(b1[t]);
+      atomicAdd(bad, 1);
+    }
+  } else if (t < n1 + n2) {
+    int u = t - n1;
+    if (!g2_load<C>(b2[u], g2w + (size_t)u * 4 * C::N)) {
+      aff_set_inf(b2[u]);
+      atomicAdd(bad, 1);
+    }
+  }
+}
+template <class C>
+__global__ void k_bench_fp_mul(u32* out, int iters, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp<C> a, b;
+  for (int k = 0; k < C::N; k++) {
+    a.v[k] = C::one(k) ^ (u32)(i * 2654435761u + k);
+    b.v[k] = C::r2(k) + (u32)i;
+  }
+  a.v[C::N - 1] &= 0x0fffffffu;
+  b.v[C::N - 1] &= 0x0fffffffu;
+  for (int it = 0; it < iters; it++) {
+    a = fp_mul<C>(a, b);
+    b = fp_mul<C>(b, a);
+  }
+  u32 acc = 0;
+  for (int k = 0; k < C::N; k++) acc ^= a.v[k] ^ b.v[k];
+  out[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ------------------------------------------------------------------------------------------------------------
+struct elp_ctx {
+  int curve;
+  int device;
+  hipStream_t stream;
+  std::string err;
+  // key state (device memory)
+  int A = 0, W = 0, nwin = 0, per = 0;
+  void* b1 = nullptr;   // Aff<F1>[A+6]
+  void* b2 = nullptr;   // Aff<F2>[A+2]
+  void* t1 = nullptr;
+  void* t2 = nullptr;
+  void* lines = nullptr;
+  std::vector<uint8_t> h_b1;  // host mirror of the G1 base words (std form) so set_rp / set_signer_secret can rebuild
+  bool have_pk = false;
+};
+
+#define HIPCHK(ctx, expr)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+      return ELP_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + ELP_BLOCK - 1) / ELP_BLOCK); }
+
+template <class C>
+static KeyCtx<C> make_key(const elp_ctx* c) {
+  KeyCtx<C> k;
+  k.A = c->A;
+  k.W = c->W;
+  k.nwin = c->nwin;
+  k.per = c->per;
+  k.t1 = (const Aff<F1<C>>*)c->t1;
+  k.t2 = (const Aff<F2<C>>*)c->t2;
+  k.b1 = (const Aff<F1<C>>*)c->b1;
+  k.b2 = (const Aff<F2<C>>*)c->b2;
+  k.gg_lines = (const LineCoef<C>*)c->lines;
+  return k;
+}
+
+// RAII device buffer for the host-buffer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+};
+
+// (definitions below get C linkage from their declarations in include/elpasso.h)
+
+const char* elp_version(void) { return "elpasso-hip 0.1 (gfx950)"; }
+
+int elp_field_bytes(int curve) { return curve == ELP_CURVE_BN254 ? 32 : curve == ELP_CURVE_BLS12_381 ? 48 : 0; }
+
+int elp_init(int curve, int device, elp_ctx** out) {
+  if (!out) return ELP_ERR_ARG;
+  *out = nullptr;
+  if (curve != ELP_CURVE_BN254) return ELP_ERR_ARG;  // BLS12-381 instantiation: see DESIGN.md (next)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELP_ERR_NODEVICE;
+  if (device < 0 || device >= ndev) return ELP_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return ELP_ERR_NODEVICE;
+  elp_ctx* c = new elp_ctx();
+  c->curve = curve;
+  c->device = device;
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    return ELP_ERR_HIP;
+  }
+  *out = c;
+  return ELP_OK;
+}
+
+static void free_key(elp_ctx* c) {
+  void** ps[] = {&c->b1, &c->b2, &c->t1, &c->t2, &c->lines};
+  for (void** p : ps) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  c->have_pk = false;
+}
+
+void elp_destroy(elp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_key(c);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* elp_last_error(const elp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// (re)build every device-side key structure from host copies of the base points
+template <class C>
+static int rebuild_key(elp_ctx* c, const uint8_t* g2_bases_std) {
+  const int A = c->A, n1 = A + 6, n2 = A + 2;
+  const bool g2_changed = g2_bases_std != nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf w1, w2, bad;
+  HIPCHK(c, w1.alloc((size_t)n1 * Sizes<C>::G1));
+  HIPCHK(c, bad.alloc(4));
+  HIPCHK(c, hipMemsetAsync(bad.p, 0, 4, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w1.p, c->h_b1.data(), (size_t)n1 * Sizes<C>::G1, hipMemcpyHostToDevice, c->stream));
+  if (!c->b1) HIPCHK(c, hipMalloc(&c->b1, sizeof(Aff<F1<C>>) * n1));
+  if (g2_changed) {
+    HIPCHK(c, w2.alloc((size_t)n2 * Sizes<C>::G2));
+    HIPCHK(c, hipMemcpyAsync(w2.p, g2_bases_std, (size_t)n2 * Sizes<C>::G2, hipMemcpyHostToDevice, c->stream));
+    if (!c->b2) HIPCHK(c, hipMalloc(&c->b2, sizeof(Aff<F2<C>>) * n2));
+  }
+  hipLaunchKernelGGL((k_load_bases<C>), dim3(grid_for(n1 + n2)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)w1.p, n1,
+                     (const u32*)w2.p, g2_changed ? n2 : 0, (Aff<F1<C>>*)c->b1, (Aff<F2<C>>*)c->b2, (int*)bad.p);
+  int hbad = 0;
+  HIPCHK(c, hipMemcpyAsync(&hbad, bad.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (hbad) {
+    c->err = "a key point is not a valid curve point";
+    return ELP_ERR_POINT;
+  }
+  const int nwin = c->nwin, per = c->per, W = c->W;
+  const int chunk = per < 32 ? per : 32;
+  const int nchunk = (per + chunk - 1) / chunk;
+  {
+    DevBuf bj;
+    HIPCHK(c, bj.alloc(sizeof(Aff<F1<C>>) * (size_t)n1 * nwin));
+    if (!c->t1) HIPCHK(c, hipMalloc(&c->t1, sizeof(Aff<F1<C>>) * (size_t)n1 * nwin * per));
+    hipLaunchKernelGGL((k_window_bases<F1<C>>), dim3(grid_for(n1)), dim3(ELP_BLOCK), 0, c->stream, (const Aff<F1<C>>*)c->b1, n1, W,
+                       nwin, (Aff<F1<C>>*)bj.p);
+    hipLaunchKernelGGL((k_table_fill<F1<C>>), dim3(grid_for((size_t)n1 * nwin * nchunk)), dim3(ELP_BLOCK), 0, c->stream,
+                       (Aff<F1<C>>*)c->t1, (const Aff<F1<C>>*)bj.p, n1, nwin, per, chunk);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (g2_changed) {
+    DevBuf bj;
+    HIPCHK(c, bj.alloc(sizeof(Aff<F2<C>>) * (size_t)n2 * nwin));
+    if (!c->t2) HIPCHK(c, hipMalloc(&c->t2, sizeof(Aff<F2<C>>) * (size_t)n2 * nwin * per));
+    if (!c->lines) HIPCHK(c, hipMalloc(&c->lines, sizeof(LineCoef<C>) * ml_num_lines<C>()));
+    hipLaunchKernelGGL((k_window_bases<F2<C>>), dim3(grid_for(n2)), dim3(ELP_BLOCK), 0, c->stream, (const Aff<F2<C>>*)c->b2, n2, W,
+                       nwin, (Aff<F2<C>>*)bj.p);
+    hipLaunchKernelGGL((k_table_fill<F2<C>>), dim3(grid_for((size_t)n2 * nwin * nchunk)), dim3(ELP_BLOCK), 0, c->stream,
+                       (Aff<F2<C>>*)c->t2, (const Aff<F2<C>>*)bj.p, n2, nwin, per, chunk);
+    hipLaunchKernelGGL((k_lines<C>), dim3(1), dim3(64), 0, c->stream, (const Aff<F2<C>>*)c->b2, (LineCoef<C>*)c->lines);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+
+int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
+                   const uint8_t* YYi, int window_bits) {
+  typedef BN254 C;
+  if (!c || nattr < 1 || nattr > 62 || !g || !gg || !XX || !Yi || !YYi) return ELP_ERR_ARG;
+  if (window_bits == 0) window_bits = 8;
+  if (window_bits < 2 || window_bits > 16) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  free_key(c);
+  c->A = nattr;
+  c->W = window_bits;
+  c->nwin = (256 + window_bits - 1) / window_bits;
+  c->per = (1 << window_bits) - 1;
+  const size_t G1 = Sizes<C>::G1, G2 = Sizes<C>::G2;
+  c->h_b1.assign((size_t)(nattr + 6) * G1, 0);
+  memcpy(c->h_b1.data(), g, G1);
+  memcpy(c->h_b1.data() + G1, Yi, (size_t)nattr * G1);
+  std::vector<uint8_t> h2((size_t)(nattr + 2) * G2);
+  memcpy(h2.data(), gg, G2);
+  memcpy(h2.data() + G2, XX, G2);
+  memcpy(h2.data() + 2 * G2, YYi, (size_t)nattr * G2);
+  int rc = rebuild_key<C>(c, h2.data());
+  if (rc != ELP_OK) {
+    free_key(c);
+    return rc;
+  }
+  c->have_pk = true;
+  return ELP_OK;
+}
+
+int elp_set_rp(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
+               const uint8_t* h) {
+  typedef BN254 C;
+  if (!c) return ELP_ERR_ARG;
+  if (!c->have_pk) {
+    c->err = "elp_set_pubkey must be called first";
+    return ELP_ERR_STATE;
+  }
+  const size_t G1 = Sizes<C>::G1;
+  const int A = c->A;
+  uint8_t hs[Sizes<C>::G1];
+  memset(hs, 0, sizeof hs);
+  if (service_name) {
+    uint32_t off[2] = {0, (uint32_t)service_len};
+    int rc = elp_hash_to_g1(c, 1, service_name, off, hs);
+    if (rc != ELP_OK) return rc;
+  }
+  memcpy(c->h_b1.data() + (size_t)(A + 1) * G1, hs, G1);
+  const uint8_t* src[3] = {g, authority_pk, h};
+  for (int i = 0; i < 3; i++) {
+    if (src[i])
+      memcpy(c->h_b1.data() + (size_t)(A + 2 + i) * G1, src[i], G1);
+    else
+      memset(c->h_b1.data() + (size_t)(A + 2 + i) * G1, 0, G1);
+  }
+  return rebuild_key<C>(c, nullptr);
+}
+
+int elp_set_signer_secret(elp_ctx* c, const uint8_t* X) {
+  typedef BN254 C;
+  if (!c || !X) return ELP_ERR_ARG;
+  if (!c->have_pk) {
+    c->err = "elp_set_pubkey must be called first";
+    return ELP_ERR_STATE;
+  }
+  memcpy(c->h_b1.data() + (size_t)(c->A + 5) * Sizes<C>::G1, X, Sizes<C>::G1);
+  return rebuild_key<C>(c, nullptr);
+}
+
+// ---- generic "copy in, launch, copy out" helper for the host-buffer primitives
+struct IoSpec {
+  const void* src;
+  size_t bytes;
+};
+#define MAX_IO 4
+template <class Launch>
+static int run_host(elp_ctx* c, const IoSpec* ins, int nin, void* const* outs, const size_t* out_bytes, int nout, Launch launch) {
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf din[MAX_IO], dout[MAX_IO];
+  void* pin[MAX_IO] = {0};
+  void* pout[MAX_IO] = {0};
+  for (int i = 0; i < nin; i++) {
+    if (!ins[i].src) continue;
+    HIPCHK(c, din[i].alloc(ins[i].bytes));
+    HIPCHK(c, hipMemcpyAsync(din[i].p, ins[i].src, ins[i].bytes, hipMemcpyHostToDevice, c->stream));
+    pin[i] = din[i].p;
+  }
+  for (int i = 0; i < nout; i++) {
+    HIPCHK(c, dout[i].alloc(out_bytes[i]));
+    HIPCHK(c, hipMemsetAsync(dout[i].p, 0, out_bytes[i], c->stream));
+    pout[i] = dout[i].p;
+  }
+  launch(pin, pout);
+  HIPCHK(c, hipGetLastError());
+  for (int i = 0; i < nout; i++)
+    if (outs[i]) HIPCHK(c, hipMemcpyAsync(outs[i], dout[i].p, out_bytes[i], hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ELP_OK;
+}
+
+template <int G>
+static int decompress_impl(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+  typedef BN254 C;
+  if (!c || (n && (!wire || !out || !ok))) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  IoSpec ins[1] = {{wire, n * (size_t)(G * C::FBYTES)}};
+  void* outs[2] = {out, ok};
+  size_t ob[2] = {n * (size_t)(G == 1 ? Sizes<C>::G1 : Sizes<C>::G2), n};
+  return run_host(c, ins, 1, outs, ob, 2, [&](void** pi, void** po) {
+    hipLaunchKernelGGL((k_decompress<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const uint8_t*)pi[0], (u32*)po[0],
+                       (uint8_t*)po[1], n);
+  });
+}
+int elp_g1_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+  return decompress_impl<1>(c, n, wire, out, ok);
+}
+int elp_g2_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+  return decompress_impl<2>(c, n, wire, out, ok);
+}
+
+template <int G>
+static int mul_impl(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
+  typedef BN254 C;
+  if (!c || (n && (!pts || !ks || !out))) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
+  IoSpec ins[2] = {{pts, n * P}, {ks, n * 32}};
+  void* outs[1] = {out};
+  size_t ob[1] = {n * P};
+  return run_host(c, ins, 2, outs, ob, 1, [&](void** pi, void** po) {
+    hipLaunchKernelGGL((k_mul<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)pi[0], (const u32*)pi[1],
+                       (u32*)po[0], n);
+  });
+}
+int elp_g1_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<1>(c, n, p, k, o); }
+int elp_g2_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<2>(c, n, p, k, o); }
+
+template <int G>
+static int add_impl(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  typedef BN254 C;
+  if (!c || (n && (!a || !b || !out))) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
+  IoSpec ins[2] = {{a, n * P}, {b, n * P}};
+  void* outs[1] = {out};
+  size_t ob[1] = {n * P};
+  return run_host(c, ins, 2, outs, ob, 1, [&](void** pi, void** po) {
+    hipLaunchKernelGGL((k_add<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)pi[0], (const u32*)pi[1],
+                       (u32*)po[0], n);
+  });
+}
+int elp_g1_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<1>(c, n, a, b, o); }
+int elp_g2_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<2>(c, n, a, b, o); }
+
+template <int G>
+static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
+  typedef BN254 C;
+  if (!c || nterms < 1 || (n && (!ids || !ks || !out))) return ELP_ERR_ARG;
+  if (!c->have_pk) {
+    c->err = "elp_set_pubkey must be called first";
+    return ELP_ERR_STATE;
+  }
+  const int nb = G == 1 ? c->A + 6 : c->A + 2;
+  for (int t = 0; t < nterms; t++)
+    if (ids[t] < 0 || ids[t] >= nb) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
+  IoSpec ins[2] = {{ids, (size_t)nterms * 4}, {ks, n * (size_t)nterms * 32}};
+  void* outs[1] = {out};
+  size_t ob[1] = {n * P};
+  KeyCtx<C> key = make_key<C>(c);
+  return run_host(c, ins, 2, outs, ob, 1, [&](void** pi, void** po) {
+    hipLaunchKernelGGL((k_msm_fixed<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, key, nterms, (const int*)pi[0],
+                       (const u32*)pi[1], (u32*)po[0], n);
+  });
+}
+int elp_g1_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
+  return msm_fixed_impl<1>(c, n, nt, ids, ks, o);
+}
+int elp_g2_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
+  return msm_fixed_impl<2>(c, n, nt, ids, ks, o);
+}
+
+int elp_hash_to_g1(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
+  typedef BN254 C;
+  if (!c || (n && (!off || !out))) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  uint8_t dummy[4] = {0};
+  IoSpec ins[2] = {{off[n] ? msgs : dummy, off[n] ? (size_t)off[n] : 4}, {off, (n + 1) * 4}};
+  void* outs[1] = {out};
+  size_t ob[1] = {n * Sizes<C>::G1};
+  return run_host(c, ins, 2, outs, ob, 1, [&](void** pi, void** po) {
+    hipLaunchKernelGGL((k_hash_to_g1<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const uint8_t*)pi[0], (const u32*)pi[1],
+                       (u32*)po[0], n);
+  });
+}
+
+int elp_pairing(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+  typedef BN254 C;
+  if (!c || (n && (!g1 || !g2 || !gt))) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  IoSpec ins[2] = {{g1, n * Sizes<C>::G1}, {g2, n * Sizes<C>::G2}};
+  void* outs[1] = {gt};
+  size_t ob[1] = {n * Sizes<C>::GT};
+  return run_host(c, ins, 2, outs, ob, 1, [&](void** pi, void** po) {
+    hipLaunchKernelGGL((k_pairing<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)pi[0], (const u32*)pi[1],
+                       (u32*)po[0], n);
+  });
+}
+
+int elp_pairing_check(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
+  typedef BN254 C;
+  if (!c || npairs < 1 || npairs > 4 || (n && (!g1 || !g2 || !ok))) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  IoSpec ins[2] = {{g1, n * npairs * Sizes<C>::G1}, {g2, n * npairs * Sizes<C>::G2}};
+  void* outs[1] = {ok};
+  size_t ob[1] = {n};
+  return run_host(c, ins, 2, outs, ob, 1, [&](void** pi, void** po) {
+    const u32* a = (const u32*)pi[0];
+    const u32* b = (const u32*)pi[1];
+    uint8_t* o = (uint8_t*)po[0];
+    switch (npairs) {
+      case 1: hipLaunchKernelGGL((k_pairing_check<C, 1>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, a, b, o, n); break;
+      case 2: hipLaunchKernelGGL((k_pairing_check<C, 2>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, a, b, o, n); break;
+      case 3: hipLaunchKernelGGL((k_pairing_check<C, 3>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, a, b, o, n); break;
+      default: hipLaunchKernelGGL((k_pairing_check<C, 4>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, a, b, o, n); break;
+    }
+  });
+}
+
+// ---- fused batches
+static int popcount_mask(uint64_t m, int A) {
+  int h = 0;
+  for (int i = 0; i < A; i++) h += (int)((m >> i) & 1);
+  return h;
+}
+size_t elp_verify_id_record_size(int curve, int A, int H, int retr) {
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)verify_id_record_words<BN254>(A, H, retr != 0);
+}
+size_t elp_ps_verify_record_size(int curve, int A) {
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)(4 * BN254::N + 8 * A);
+}
+size_t elp_provide_id_record_size(int curve, int A, int H) {
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)provide_id_record_words<BN254>(A, H);
+}
+
+static int check_fused(elp_ctx* c, uint64_t mask) {
+  if (!c) return ELP_ERR_ARG;
+  if (!c->have_pk) {
+    c->err = "elp_set_pubkey must be called first";
+    return ELP_ERR_STATE;
+  }
+  if (c->A < 64 && (mask >> c->A) != 0) return ELP_ERR_ARG;
+  return ELP_OK;
+}
+
+int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+                            const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  typedef BN254 C;
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (n == 0) return ELP_OK;
+  const int H = popcount_mask(mask, c->A);
+  if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
+  const int words = verify_id_record_words<C>(c->A, H, retr != 0);
+  hipLaunchKernelGGL((k_verify_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+                     (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
+                     (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+int elp_ps_verify_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
+  typedef BN254 C;
+  int rc = check_fused(c, 0);
+  if (rc) return rc;
+  if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  hipLaunchKernelGGL((k_ps_verify<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+                     (const u32*)d_records, 4 * C::N + 8 * nattr, nattr, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+                             const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
+  typedef BN254 C;
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (n == 0) return ELP_OK;
+  const int H = popcount_mask(mask, c->A);
+  const int words = provide_id_record_words<C>(c->A, H);
+  hipLaunchKernelGGL((k_provide_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+                     (const u32*)d_records, words, (u64)mask, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (u32*)d_sigs,
+                     (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+
+// host-buffer wrappers: stage inputs, call the _dev entry point on the context stream, copy results back
+static int stage_ad(elp_ctx* c, size_t n, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, DevBuf& dad, DevBuf& doff,
+                    const void** p_ad, const void** p_off) {
+  size_t total = ad_off ? ad_off[n] : ad_len;
+  HIPCHK(c, dad.alloc(total));
+  if (total) HIPCHK(c, hipMemcpyAsync(dad.p, ad, total, hipMemcpyHostToDevice, c->stream));
+  *p_ad = dad.p;
+  *p_off = nullptr;
+  if (ad_off) {
+    HIPCHK(c, doff.alloc((n + 1) * 4));
+    HIPCHK(c, hipMemcpyAsync(doff.p, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    *p_off = doff.p;
+  }
+  return ELP_OK;
+}
+
+int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
+                        const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
+  DevBuf drec, dad, doff, dfl, dcnt;
+  const void *pad, *poff;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_verify_id_batch_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_ps_verify_batch(elp_ctx* c, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted) {
+  int rc = check_fused(c, 0);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_ps_verify_record_size(c->curve, nattr);
+  DevBuf drec, dfl, dcnt;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = elp_ps_verify_batch_dev(c, c->stream, n, drec.p, nattr, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
+                         size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
+  typedef BN254 C;
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags || !sigs || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_provide_id_record_size(c->curve, c->A, popcount_mask(mask, c->A));
+  DevBuf drec, dad, doff, dfl, dcnt, dsig;
+  const void *pad, *poff;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, dsig.alloc(n * 2 * Sizes<C>::G1));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_provide_id_batch_dev(c, c->stream, n, drec.p, mask, pad, poff, ad_len, dsig.p, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sigs, dsig.p, n * 2 * Sizes<C>::G1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const void* d_records, uint64_t mask, int retr,
+                           const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted, float* avg_ms) {
+  if (!c || reps < 1 || !avg_ms) return ELP_ERR_ARG;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, (hipStream_t)stream));
+  for (int r = 0; r < reps; r++) {
+    int rc = elp_verify_id_batch_dev(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipEventRecord(e1, (hipStream_t)stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / reps;
+  return ELP_OK;
+}
+
+int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
+  typedef BN254 C;
+  if (!c || !ms || lanes == 0) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf out;
+  HIPCHK(c, out.alloc(lanes * 4));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_bench_fp_mul<C>), dim3(grid_for(lanes)), dim3(ELP_BLOCK), 0, c->stream, (u32*)out.p, 1, lanes);  // warm-up
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  hipLaunchKernelGGL((k_bench_fp_mul<C>), dim3(grid_for(lanes)), dim3(ELP_BLOCK), 0, c->stream, (u32*)out.p, iters, lanes);
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  HIPCHK(c, hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ELP_OK;
+}
+

@@ -1,0 +1,249 @@
+"""ctypes binding of include/elpasso.h (the HIP hot path).  There is NO CPU fallback: if the shared library is
+missing, or no GPU is present, every entry point raises."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libelpasso_hip.so")
+
+CURVE_BN254 = 0
+CURVE_BLS12_381 = 1
+
+_c = ctypes
+_u8p = _c.c_void_p
+_SIGS = {
+    "elp_init": (_c.c_int, [_c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "elp_destroy": (None, [_c.c_void_p]),
+    "elp_last_error": (_c.c_char_p, [_c.c_void_p]),
+    "elp_field_bytes": (_c.c_int, [_c.c_int]),
+    "elp_version": (_c.c_char_p, []),
+    "elp_set_pubkey": (_c.c_int, [_c.c_void_p, _c.c_int, _u8p, _u8p, _u8p, _u8p, _u8p, _c.c_int]),
+    "elp_set_rp": (_c.c_int, [_c.c_void_p, _u8p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_set_signer_secret": (_c.c_int, [_c.c_void_p, _u8p]),
+    "elp_g1_decompress": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g2_decompress": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g1_mul": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g2_mul": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g1_add": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g2_add": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g1_msm_fixed": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
+    "elp_g2_msm_fixed": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
+    "elp_hash_to_g1": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_pairing": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_pairing_check": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
+    "elp_verify_id_record_size": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "elp_ps_verify_record_size": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "elp_provide_id_record_size": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    "elp_verify_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _c.c_int, _u8p, _u8p, _c.c_size_t, _u8p,
+                                       _c.POINTER(_c.c_uint64)]),
+    "elp_ps_verify_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_int, _u8p, _c.POINTER(_c.c_uint64)]),
+    "elp_provide_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _u8p, _u8p, _c.c_size_t, _u8p, _u8p,
+                                        _c.POINTER(_c.c_uint64)]),
+    "elp_verify_id_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p,
+                                           _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
+    "elp_ps_verify_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "elp_provide_id_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_void_p,
+                                            _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "elp_time_verify_id_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int,
+                                          _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
+                                          _c.POINTER(_c.c_float)]),
+    "elp_bench_fp_mul": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.POINTER(_c.c_float)]),
+}
+EXPORTED_SYMBOLS = sorted(_SIGS)
+
+_lib = None
+
+
+class ElpassoError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libelpasso_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ElpassoError("HIP library %s is missing: run `python -m __graft_entry__` / build.py first; "
+                               "there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _buf(x):
+    """bytes / bytearray / numpy array -> (keepalive, void*)"""
+    if x is None:
+        return None, None
+    if isinstance(x, np.ndarray):
+        a = np.ascontiguousarray(x)
+        return a, a.ctypes.data
+    a = np.frombuffer(bytes(x), dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+class Context:
+    """One elp_ctx (one GPU, one stream)."""
+
+    def __init__(self, curve=CURVE_BN254, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.elp_init(curve, device, ctypes.byref(h))
+        if rc != 0:
+            raise ElpassoError("elp_init failed (%d)%s" % (rc, ": no GPU, and there is no CPU fallback" if rc == -4 else ""))
+        self.h = h
+        self.curve = curve
+        self.F = self.lib.elp_field_bytes(curve)
+        self.G1, self.G2, self.GT = 2 * self.F, 4 * self.F, 12 * self.F
+        self.A = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.elp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ElpassoError("elpasso error %d: %s" % (rc, self.lib.elp_last_error(self.h).decode()))
+
+    # ---- setup
+    def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
+        A = len(Yi) // self.G1
+        assert len(YYi) == A * self.G2
+        ka = [_buf(x) for x in (g, gg, XX, Yi, YYi)]
+        self._chk(self.lib.elp_set_pubkey(self.h, A, ka[0][1], ka[1][1], ka[2][1], ka[3][1], ka[4][1], window_bits))
+        self.A = A
+
+    def set_rp(self, service_name, authority_pk=None, g=None, h=None):
+        sn = bytes(service_name) if service_name is not None else None
+        ka = [_buf(x) for x in (sn, authority_pk, g, h)]
+        self._chk(self.lib.elp_set_rp(self.h, ka[0][1], len(sn) if sn is not None else 0, ka[1][1], ka[2][1], ka[3][1]))
+
+    def set_signer_secret(self, X):
+        k = _buf(X)
+        self._chk(self.lib.elp_set_signer_secret(self.h, k[1]))
+
+    # ---- primitives (bytes in, bytes out)
+    def _dec(self, fn, n, wire, osz):
+        out = np.zeros(n * osz, dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        k = _buf(wire)
+        self._chk(fn(self.h, n, k[1], out.ctypes.data, ok.ctypes.data))
+        return out.tobytes(), ok
+
+    def g1_decompress(self, wire):
+        return self._dec(self.lib.elp_g1_decompress, len(wire) // self.F, wire, self.G1)
+
+    def g2_decompress(self, wire):
+        return self._dec(self.lib.elp_g2_decompress, len(wire) // (2 * self.F), wire, self.G2)
+
+    def _bin(self, fn, n, a, b, osz):
+        out = np.zeros(n * osz, dtype=np.uint8)
+        ka, kb = _buf(a), _buf(b)
+        self._chk(fn(self.h, n, ka[1], kb[1], out.ctypes.data))
+        return out.tobytes()
+
+    def g1_mul(self, pts, ks):
+        return self._bin(self.lib.elp_g1_mul, len(pts) // self.G1, pts, ks, self.G1)
+
+    def g2_mul(self, pts, ks):
+        return self._bin(self.lib.elp_g2_mul, len(pts) // self.G2, pts, ks, self.G2)
+
+    def g1_add(self, a, b):
+        return self._bin(self.lib.elp_g1_add, len(a) // self.G1, a, b, self.G1)
+
+    def g2_add(self, a, b):
+        return self._bin(self.lib.elp_g2_add, len(a) // self.G2, a, b, self.G2)
+
+    def _msm(self, fn, base_ids, scalars, osz):
+        ids = np.asarray(base_ids, dtype=np.int32)
+        nt = len(ids)
+        n = len(scalars) // (32 * nt)
+        out = np.zeros(n * osz, dtype=np.uint8)
+        ks = _buf(scalars)
+        self._chk(fn(self.h, n, nt, ids.ctypes.data, ks[1], out.ctypes.data))
+        return out.tobytes()
+
+    def g1_msm_fixed(self, base_ids, scalars):
+        return self._msm(self.lib.elp_g1_msm_fixed, base_ids, scalars, self.G1)
+
+    def g2_msm_fixed(self, base_ids, scalars):
+        return self._msm(self.lib.elp_g2_msm_fixed, base_ids, scalars, self.G2)
+
+    def hash_to_g1(self, msgs):
+        off = np.zeros(len(msgs) + 1, dtype=np.uint32)
+        for i, m in enumerate(msgs):
+            off[i + 1] = off[i] + len(m)
+        data = _buf(b"".join(bytes(m) for m in msgs) or b"\0")
+        out = np.zeros(len(msgs) * self.G1, dtype=np.uint8)
+        self._chk(self.lib.elp_hash_to_g1(self.h, len(msgs), data[1], off.ctypes.data, out.ctypes.data))
+        return out.tobytes()
+
+    def pairing(self, g1, g2):
+        return self._bin(self.lib.elp_pairing, len(g1) // self.G1, g1, g2, self.GT)
+
+    def pairing_check(self, npairs, g1, g2):
+        n = len(g1) // (self.G1 * npairs)
+        ok = np.zeros(n, dtype=np.uint8)
+        ka, kb = _buf(g1), _buf(g2)
+        self._chk(self.lib.elp_pairing_check(self.h, n, npairs, ka[1], kb[1], ok.ctypes.data))
+        return ok
+
+    # ---- fused batches over host buffers
+    @staticmethod
+    def _ad(ad):
+        """ad: bytes (shared) or list of bytes (per item) -> (data, offsets or None, ad_len)."""
+        if isinstance(ad, (bytes, bytearray)):
+            return bytes(ad), None, len(ad)
+        off = np.zeros(len(ad) + 1, dtype=np.uint32)
+        for i, a in enumerate(ad):
+            off[i + 1] = off[i] + len(a)
+        return b"".join(bytes(a) for a in ad), off, 0
+
+    def verify_id_batch(self, records, hidden_mask, with_retrieval, ad):
+        H = bin(hidden_mask).count("1")
+        rsz = self.lib.elp_verify_id_record_size(self.curve, self.A, H, int(with_retrieval))
+        n = len(records) // rsz
+        assert n * rsz == len(records), "record size mismatch"
+        data, off, adl = self._ad(ad)
+        flags = np.zeros(n, dtype=np.uint8)
+        cnt = ctypes.c_uint64(0)
+        kr, kd = _buf(records), _buf(data or b"\0")
+        self._chk(self.lib.elp_verify_id_batch(self.h, n, kr[1], hidden_mask, int(with_retrieval), kd[1],
+                                               off.ctypes.data if off is not None else None, adl, flags.ctypes.data,
+                                               ctypes.byref(cnt)))
+        return flags, cnt.value
+
+    def ps_verify_batch(self, records, nattr):
+        rsz = self.lib.elp_ps_verify_record_size(self.curve, nattr)
+        n = len(records) // rsz
+        flags = np.zeros(n, dtype=np.uint8)
+        cnt = ctypes.c_uint64(0)
+        kr = _buf(records)
+        self._chk(self.lib.elp_ps_verify_batch(self.h, n, kr[1], nattr, flags.ctypes.data, ctypes.byref(cnt)))
+        return flags, cnt.value
+
+    def provide_id_batch(self, records, hidden_mask, ad):
+        H = bin(hidden_mask).count("1")
+        rsz = self.lib.elp_provide_id_record_size(self.curve, self.A, H)
+        n = len(records) // rsz
+        assert n * rsz == len(records), "record size mismatch"
+        data, off, adl = self._ad(ad)
+        flags = np.zeros(n, dtype=np.uint8)
+        sigs = np.zeros(n * 2 * self.G1, dtype=np.uint8)
+        cnt = ctypes.c_uint64(0)
+        kr, kd = _buf(records), _buf(data or b"\0")
+        self._chk(self.lib.elp_provide_id_batch(self.h, n, kr[1], hidden_mask, kd[1], off.ctypes.data if off is not None else None,
+                                                adl, sigs.ctypes.data, flags.ctypes.data, ctypes.byref(cnt)))
+        return sigs.tobytes(), flags, cnt.value

@@ -1,0 +1,117 @@
+"""Shared test helpers: byte packing of records for the C-ABI / host twin from oracle-model objects."""
+import base64
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle.pymodel import BN254, Codec, Mcl, Protocol, scalar_stream  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def fb(x, n=32):
+    return int(x).to_bytes(n, "little")
+
+
+def ib(b):
+    return int.from_bytes(b, "little")
+
+
+def g1b(P, n=32):
+    return bytes(2 * n) if P is None else fb(P[0], n) + fb(P[1], n)
+
+
+def g2b(P, n=32):
+    return bytes(4 * n) if P is None else fb(P[0][0], n) + fb(P[0][1], n) + fb(P[1][0], n) + fb(P[1][1], n)
+
+
+def g1u(b, n=32):
+    x, y = ib(b[:n]), ib(b[n:2 * n])
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def g2u(b, n=32):
+    v = [ib(b[n * i:n * i + n]) for i in range(4)]
+    return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+
+
+def hidden_mask(attributes):
+    """bit i set <=> attributes[i] is hidden (empty placeholder)."""
+    m = 0
+    for i, a in enumerate(attributes):
+        if len(a) == 0:
+            m |= 1 << i
+    return m
+
+
+def pack_verify_id(m, pr):
+    """sig1 | sig2 | phi | [E1 | E2] | k | c | rs | m_revealed   (csrc/elp/pipeline.h verify_id_item)."""
+    out = g1b(pr.sig1) + g1b(pr.sig2) + g1b(pr.phi)
+    if pr.has_E:
+        out += g1b(pr.E1) + g1b(pr.E2)
+    out += g2b(pr.k) + fb(pr.c)
+    for r in pr.rs:
+        out += fb(r)
+    for a in pr.attributes:
+        if len(a):
+            out += fb(m.fr_hash(bytes(a)))
+    return out
+
+
+def pack_ps_verify(m, cred, all_attributes):
+    out = g1b(cred.sig1) + g1b(cred.sig2)
+    for a in all_attributes:
+        out += fb(m.fr_hash(a.encode() if isinstance(a, str) else bytes(a)))
+    return out
+
+
+def pack_provide_id(m, rq, u):
+    out = g1b(rq.A) + fb(rq.c)
+    for r in rq.rs:
+        out += fb(r)
+    for a in rq.attributes:
+        if len(a):
+            out += fb(m.fr_hash(bytes(a)))
+    return out + fb(u)
+
+
+def g1_bases(m, pk, svc=None, g_eg=None, apk=None, h=None, skX=None):
+    """0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X."""
+    hs = m.hash_to_g1(svc) if svc is not None else None
+    pts = [pk.g] + list(pk.Yi) + [hs, g_eg, apk, h, skX]
+    return b"".join(g1b(P) for P in pts)
+
+
+def g2_bases(m, pk):
+    return b"".join(g2b(P) for P in [pk.gg, pk.XX] + list(pk.YYi))
+
+
+_twin = None
+
+
+def twin():
+    """Host (g++) build of the device headers — test-only library, built on demand."""
+    global _twin
+    if _twin is None:
+        so = os.path.join(ROOT, "tests", "host_twin", "libtwin.so")
+        src = os.path.join(ROOT, "tests", "host_twin", "twin.cpp")
+        inc = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc")
+        newest = max(os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(inc) for f in fs if f.endswith(".h"))
+        newest = max(newest, os.path.getmtime(src))
+        if not os.path.exists(so) or os.path.getmtime(so) < newest:
+            import subprocess
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", so, src])
+        _twin = ctypes.CDLL(so)
+        for n in ("twin_bn254_ctx_new",):
+            getattr(_twin, n).restype = ctypes.c_void_p
+    return _twin

@@ -1,0 +1,281 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the C-ABI (ctypes) and is compared
+bit-for-bit with the oracle (oracle/pymodel.py, pinned to the reference's wasm by tests/golden/*) or with the golden
+verdicts themselves."""
+import base64
+import random
+
+import numpy as np
+import pytest
+
+from elp_testlib import (BN254, Codec, Mcl, Protocol, fb, g1_bases, g1b, g1u, g2_bases, g2b, g2u, hidden_mask, load_golden,
+                         pack_provide_id, pack_ps_verify, pack_verify_id, scalar_stream)
+
+pytestmark = pytest.mark.gpu
+
+M = Mcl(BN254)
+CD = Codec(M)
+PR = Protocol(M)
+G = M.G
+
+
+def _set_key(ctx, pk, svc=None, g_eg=None, apk=None, h=None, skX=None, W=8):
+    ctx.set_pubkey(g1b(pk.g), g2b(pk.gg), g2b(pk.XX), b"".join(g1b(P) for P in pk.Yi), b"".join(g2b(P) for P in pk.YYi), W)
+    if svc is not None:
+        ctx.set_rp(svc.encode() if isinstance(svc, str) else svc, g1b(apk) if apk else None, g1b(g_eg) if g_eg else None,
+                   g1b(h) if h else None)
+    if skX is not None:
+        ctx.set_signer_secret(g1b(skX))
+
+
+def _pk0():
+    d = load_golden("bn254_oracle_flows.json")
+    return CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
+
+
+def test_hash_to_g1(gpu_ctx):
+    msgs = [b"abc", b"ghi", b"jkl", b"service", b"", b"a" * 100] + [bytes([i]) * (i + 1) for i in range(20)]
+    out = gpu_ctx.hash_to_g1(msgs)
+    for i, m in enumerate(msgs):
+        if M.fp_hash(m) == 0:
+            continue
+        assert g1u(out[64 * i:64 * i + 64]) == M.hash_to_g1(m), m
+
+
+def test_g1_g2_mul_add(gpu_ctx):
+    rnd = random.Random(7)
+    pk = _pk0()
+    g, gg = pk.g, pk.gg
+    ks = [0, 1, 2, 3, 15, 16, 17, M.r - 1, M.r, M.r + 5, 2**256 - 1] + [rnd.randrange(M.r) for _ in range(21)]
+    pts = g1b(g) * len(ks)
+    out = gpu_ctx.g1_mul(pts, b"".join(fb(k) for k in ks))
+    for i, k in enumerate(ks):
+        assert g1u(out[64 * i:64 * i + 64]) == G.g1_mul(g, k % M.r), k
+    ks2 = ks[:14]
+    out = gpu_ctx.g2_mul(g2b(gg) * len(ks2), b"".join(fb(k) for k in ks2))
+    for i, k in enumerate(ks2):
+        assert g2u(out[128 * i:128 * i + 128]) == G.g2_mul(gg, k % M.r), k
+    # additions incl. the exceptional cases P+P, P+(-P), P+O, O+P
+    P, Q = G.g1_mul(g, 5), G.g1_mul(g, 11)
+    cases = [(P, Q), (P, P), (P, G.g1_neg(P)), (P, None), (None, Q), (None, None)]
+    out = gpu_ctx.g1_add(b"".join(g1b(a) for a, _ in cases), b"".join(g1b(b) for _, b in cases))
+    for i, (a, b) in enumerate(cases):
+        assert g1u(out[64 * i:64 * i + 64]) == G.g1_add(a, b)
+    P2, Q2 = G.g2_mul(gg, 5), G.g2_mul(gg, 11)
+    cases = [(P2, Q2), (P2, P2), (P2, G.g2_neg(P2)), (P2, None), (None, Q2)]
+    out = gpu_ctx.g2_add(b"".join(g2b(a) for a, _ in cases), b"".join(g2b(b) for _, b in cases))
+    for i, (a, b) in enumerate(cases):
+        assert g2u(out[128 * i:128 * i + 128]) == G.g2_add(a, b)
+
+
+def test_decompress(gpu_ctx):
+    pk = _pk0()
+    pts1 = [pk.g, G.g1_neg(pk.g), None] + list(pk.Yi)
+    out, ok = gpu_ctx.g1_decompress(b"".join(M.g1_ser(P) for P in pts1))
+    assert ok.all()
+    for i, P in enumerate(pts1):
+        assert g1u(out[64 * i:64 * i + 64]) == P
+    pts2 = [pk.gg, pk.XX, G.g2_neg(pk.XX), None] + list(pk.YYi)
+    out, ok = gpu_ctx.g2_decompress(b"".join(M.g2_ser(P) for P in pts2))
+    assert ok.all()
+    for i, P in enumerate(pts2):
+        assert g2u(out[128 * i:128 * i + 128]) == P
+    # invalid encodings: x with no square root on the curve, x >= p
+    bad = []
+    x = 1
+    while M.F.sqrt((x**3 + 2) % M.p) is not None:
+        x += 1
+    bad.append(fb(x))
+    bad.append(fb(M.p + 1))
+    out, ok = gpu_ctx.g1_decompress(b"".join(bad))
+    assert not ok.any()
+
+
+def test_pairing_matches_oracle(gpu_ctx):
+    pk = _pk0()
+    P = [G.g1_mul(pk.g, 12345), G.g1_mul(pk.g, 777)]
+    Q = [G.g2_mul(pk.gg, 6789), pk.XX]
+    out = gpu_ctx.pairing(b"".join(g1b(x) for x in P), b"".join(g2b(x) for x in Q))
+    order = [0, 2, 4, 1, 3, 5]   # tower order c0.c0,c0.c1,c0.c2,c1.c0,c1.c1,c1.c2 = w^0,w^2,w^4,w^1,w^3,w^5
+    for i in range(2):
+        e = G.pairing(P[i], Q[i])
+        want = b"".join(fb(e[k][0]) + fb(e[k][1]) for k in order)
+        assert out[384 * i:384 * i + 384] == want
+
+
+def test_pairing_check_bilinear(gpu_ctx):
+    pk = _pk0()
+    g, gg = pk.g, pk.gg
+    a, b = 1234567, 7654321
+    # e(aP, bQ) e(-abP, Q) == 1 ; e(aP,bQ) e(P,Q) != 1 ; infinity handling
+    items = [
+        ([G.g1_mul(g, a), G.g1_neg(G.g1_mul(g, a * b))], [G.g2_mul(gg, b), gg], 1),
+        ([G.g1_mul(g, a), g], [G.g2_mul(gg, b), gg], 0),
+        ([None, None], [gg, gg], 1),
+        ([g, None], [gg, gg], 0),
+    ]
+    ok = gpu_ctx.pairing_check(2, b"".join(g1b(p) for it in items for p in it[0]), b"".join(g2b(q) for it in items for q in it[1]))
+    assert list(ok) == [it[2] for it in items]
+
+
+def test_msm_fixed(gpu_ctx):
+    pk = _pk0()
+    _set_key(gpu_ctx, pk, svc="svc")
+    A = len(pk.Yi)
+    rnd = random.Random(3)
+    n = 5
+    ids1 = [0] + [1 + i for i in range(A)] + [A + 1]
+    sc = [[rnd.randrange(M.r) for _ in ids1] for _ in range(n)]
+    sc[0][0] = 0
+    sc[1] = [0] * len(ids1)
+    out = gpu_ctx.g1_msm_fixed(ids1, b"".join(fb(s) for row in sc for s in row))
+    bases1 = [pk.g] + list(pk.Yi) + [M.hash_to_g1("svc")]
+    for i in range(n):
+        want = None
+        for bse, s in zip(bases1, sc[i]):
+            want = G.g1_add(want, G.g1_mul(bse, s))
+        assert g1u(out[64 * i:64 * i + 64]) == want
+    ids2 = [0, 1] + [2 + i for i in range(A)]
+    sc = [[rnd.randrange(M.r) for _ in ids2] for _ in range(3)]
+    out = gpu_ctx.g2_msm_fixed(ids2, b"".join(fb(s) for row in sc for s in row))
+    bases2 = [pk.gg, pk.XX] + list(pk.YYi)
+    for i in range(3):
+        want = None
+        for bse, s in zip(bases2, sc[i]):
+            want = G.g2_add(want, G.g2_mul(bse, s))
+        assert g2u(out[128 * i:128 * i + 128]) == want
+
+
+@pytest.mark.parametrize("W", [8, 5])
+def test_verify_id_golden_no_retrieval(gpu_ctx, W):
+    """Every verdict the reference's wasm gave (tests/golden/bn254_oracle_flows.json) must be reproduced."""
+    d = load_golden("bn254_oracle_flows.json")
+    total = 0
+    for s in d["scenarios"]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        # group cases by (service, mask) so each group is one batch call
+        groups = {}
+        for p in s["proofs"]:
+            for c in p["cases"]:
+                P = CD.proof_decode(base64.b64decode(c["proof"]))
+                groups.setdefault((c["svc"], hidden_mask(P.attributes)), []).append((pack_verify_id(M, P), c["ad"].encode(), c["expect"], c["label"]))
+        _set_key(gpu_ctx, pk, W=W)
+        for (svc, mask), items in groups.items():
+            gpu_ctx.set_rp(svc.encode())
+            flags, cnt = gpu_ctx.verify_id_batch(b"".join(i[0] for i in items), mask, False, [i[1] for i in items])
+            for f, it in zip(flags, items):
+                assert bool(f) == it[2], (s["name"], svc, it[3])
+            assert cnt == sum(1 for it in items if it[2])
+            total += len(items)
+        if W != 8 and s["A"] >= 8:
+            break
+    assert total > 100
+
+
+def test_verify_id_golden_with_retrieval(gpu_ctx):
+    w = load_golden("bn254_oracle_with_retrieval.json")
+    for r in w["runs"]:
+        pk = CD.pk_decode(base64.b64decode(r["pk"]))
+        g, apk, h = M.hash_to_g1(r["g_seed"]), M.hash_to_g1(r["authority_pk_seed"]), M.hash_to_g1(r["h_seed"])
+        P = CD.proof_decode(base64.b64decode(r["proof"]))
+        assert P.has_E
+        _set_key(gpu_ctx, pk, svc=r["svc"], g_eg=g, apk=apk, h=h)
+        rec = pack_verify_id(M, P)
+        # original + tampered variants; expected verdicts from the oracle model (pinned to the same fixtures)
+        import copy
+        variants = [(P, r["ad"])]
+        for fld in ("E1", "E2", "phi", "sig1"):
+            Q = copy.copy(P)
+            setattr(Q, fld, G.g1_add(getattr(P, fld), pk.g))
+            variants.append((Q, r["ad"]))
+        Q = copy.copy(P)
+        Q.rs = list(P.rs)
+        Q.rs[-1] = (Q.rs[-1] + 1) % M.r
+        variants.append((Q, r["ad"]))
+        variants.append((P, r["ad"] + "x"))
+        recs = b"".join(pack_verify_id(M, v) for v, _ in variants)
+        flags, cnt = gpu_ctx.verify_id_batch(recs, hidden_mask(P.attributes), True, [a.encode() for _, a in variants])
+        want = [PR.verify_id(pk, v, a, r["svc"], apk, g, h) for v, a in variants]
+        assert want[0] is True and not any(want[1:])
+        assert [bool(f) for f in flags] == want
+        assert len(rec) == len(recs) // len(variants)
+
+
+def test_ps_verify_golden(gpu_ctx):
+    d = load_golden("bn254_oracle_flows.json")
+    for s in d["scenarios"][:3]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        _set_key(gpu_ctx, pk)
+        ub = CD.cred_decode(base64.b64decode(s["requests"][0]["unblinded"]))
+        blinded = CD.cred_decode(base64.b64decode(s["requests"][0]["credential"]))
+        vals = s["attr_values"]
+        from oracle.pymodel import Credential
+        items = [
+            (ub, vals, True),
+            (blinded, vals, False),                                     # still blinded: must fail
+            (ub, vals[:-1] + [vals[-1] + "x"], False),
+            (Credential(None, ub.sig2), vals, False),                    # sig1 == 0 rejected (src/ps-verifier.cc:16)
+            (PR.randomize(ub, 123456789), vals, True),
+        ]
+        flags, cnt = gpu_ctx.ps_verify_batch(b"".join(pack_ps_verify(M, c, a) for c, a, _ in items), s["A"])
+        assert [bool(f) for f in flags] == [e for _, _, e in items], s["name"]
+        assert cnt == 2
+
+
+def test_provide_id_bit_exact(gpu_ctx):
+    """IdP issuance with injected nonce: signatures must equal the oracle's byte for byte; NIZK verdicts for the golden
+    requests must equal the reference's."""
+    seed = 20211
+    A, H = 4, 2
+    g, gg = M.hash_to_g1("abc"), _pk0().gg
+    x = scalar_stream(seed, 0, M.r)
+    ys = [scalar_stream(seed, 1 + i, M.r) for i in range(A)]
+    pk, skX = PR.key_gen(g, gg, x, ys)
+    _set_key(gpu_ctx, pk, skX=skX)
+    recs, want, ads = [], [], []
+    for n in range(6):
+        attrs = [(("a%d-%d" % (i, n)).encode(), i < H) for i in range(A)]
+        rnd = [scalar_stream(seed, 100 + 10 * n + j, M.r) for j in range(2 + H)]
+        ad = b"ad%d" % n
+        rq, t1 = PR.request_id(pk, attrs, ad, rnd)
+        if n == 4:
+            rq.c ^= 1
+        if n == 5:
+            ad = b"other"
+        u = scalar_stream(seed, 1000 + n, M.r)
+        recs.append(pack_provide_id(M, rq, u))
+        ads.append(ad)
+        want.append(PR.provide_id(pk, skX, rq, ad, u))
+    sigs, flags, cnt = gpu_ctx.provide_id_batch(b"".join(recs), (1 << H) - 1, ads)
+    for i, w in enumerate(want):
+        assert bool(flags[i]) == (w is not None)
+        got = sigs[128 * i:128 * i + 128]
+        assert got == (g1b(w.sig1) + g1b(w.sig2) if w is not None else bytes(128))
+    assert cnt == 4
+    # golden requests (reference-generated): accept / reject verdicts
+    d = load_golden("bn254_oracle_flows.json")
+    for s in d["scenarios"][:2] + d["scenarios"][-1:]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        _set_key(gpu_ctx, pk, skX=pk.g)     # any point: only the verdict is compared here
+        items = []
+        for rq in s["requests"]:
+            q = CD.req_decode(base64.b64decode(rq["request"]))
+            qf = CD.req_decode(base64.b64decode(rq["request_flip_c"]))
+            items += [(q, s["ad"], rq["accept"]), (q, s["ad"] + "x", rq["wrong_ad_accept"]), (qf, s["ad"], rq["flip_c_accept"])]
+        mask = hidden_mask(items[0][0].attributes)
+        sigs, flags, cnt = gpu_ctx.provide_id_batch(b"".join(pack_provide_id(M, q, 5) for q, _, _ in items), mask,
+                                                    [a.encode() for _, a, _ in items])
+        assert [bool(f) for f in flags] == [e for _, _, e in items], s["name"]
+
+
+def test_empty_and_ragged_batches(gpu_ctx):
+    pk = _pk0()
+    _set_key(gpu_ctx, pk, svc="svc")
+    flags, cnt = gpu_ctx.verify_id_batch(b"", 0b011, False, b"x")
+    assert len(flags) == 0 and cnt == 0
+    assert gpu_ctx.g1_mul(b"", b"") == b""
+    # 65 items = one full wave + 1 lane (ragged tail), all-garbage records must be rejected, never crash
+    rsz = gpu_ctx.lib.elp_verify_id_record_size(0, 3, 2, 0)
+    rnd = np.random.RandomState(1)
+    recs = rnd.randint(0, 256, size=65 * rsz, dtype=np.uint8).tobytes()
+    flags, cnt = gpu_ctx.verify_id_batch(recs, 0b011, False, b"ad")
+    assert cnt == 0 and not flags.any()

@@ -1,0 +1,159 @@
+"""CPU-side checks of the device formulas: the arithmetic headers under csrc/elp/ are compiled for the host (g++) into a
+TEST-ONLY library and compared with the oracle.  This is how the HIP code is debugged in a container with no GPU; the
+product never loads this library."""
+import base64
+import ctypes
+import random
+
+import pytest
+
+from elp_testlib import (BN254, Codec, Mcl, Protocol, fb, g1_bases, g1b, g1u, g2_bases, g2b, g2u, hidden_mask, ib, load_golden,
+                         pack_provide_id, pack_ps_verify, pack_verify_id, scalar_stream, twin)
+
+M = Mcl(BN254)
+CD = Codec(M)
+PR = Protocol(M)
+G = M.G
+W_TEST = 4   # small windows keep the host-side table build fast
+
+
+@pytest.fixture(scope="module")
+def L():
+    return twin()
+
+
+def _ctx(L, pk, W=W_TEST, **kw):
+    h = L.twin_bn254_ctx_new(len(pk.Yi), W, g1_bases(M, pk, **kw), g2_bases(M, pk))
+    assert h
+    return ctypes.c_void_p(h)
+
+
+def test_fp_arith(L):
+    rnd = random.Random(1)
+    p = M.p
+    o = ctypes.create_string_buffer(32)
+    cases = [(rnd.randrange(p), rnd.randrange(p)) for _ in range(300)] + [(p - 1, p - 1), (0, 5), (1, 1), (p - 1, 1), (0, 0)]
+    for a, b in cases:
+        L.twin_bn254_fp_mul(fb(a), fb(b), o)
+        assert ib(o.raw) == a * b % p
+    for a, _ in cases[:50]:
+        L.twin_bn254_fp_inv(fb(a), o)
+        assert ib(o.raw) == pow(a, -1, p)
+        ok = L.twin_bn254_fp_sqrt(fb(a * a % p), o)
+        assert ok and ib(o.raw) in (a, p - a)
+    o2 = ctypes.create_string_buffer(64)
+    F = M.F
+    for _ in range(20):
+        x = (rnd.randrange(p), rnd.randrange(p))
+        sq = F.f2_sqr(x)
+        assert L.twin_bn254_fp2_sqrt(fb(sq[0]) + fb(sq[1]), o2)
+        r = (ib(o2.raw[:32]), ib(o2.raw[32:]))
+        assert F.f2_sqr(r) == sq
+
+
+def test_hash_to_g1_all_branches(L):
+    o = ctypes.create_string_buffer(64)
+    seen = set()
+    for s in ["abc", "ghi", "jkl", "service", "svc"] + [chr(97 + i) for i in range(26)]:
+        L.twin_bn254_hash_to_g1(s.encode(), len(s), o)
+        assert g1u(o.raw) == M.hash_to_g1(s), s
+        seen.add(M._last_branch)
+    assert len(seen) == 6
+
+
+def test_group_ops(L):
+    rnd = random.Random(2)
+    d = load_golden("bn254_oracle_flows.json")
+    pk = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
+    g, gg = pk.g, pk.gg
+    o, o2 = ctypes.create_string_buffer(64), ctypes.create_string_buffer(128)
+    for k in [0, 1, 2, 3, 15, 16, 17, M.r - 1, M.r, rnd.randrange(M.r), rnd.randrange(2**256)]:
+        assert L.twin_bn254_g1_mul(g1b(g), fb(k), o)
+        assert g1u(o.raw) == G.g1_mul(g, k)
+    for k in [0, 1, 2, 5, M.r - 1, rnd.randrange(M.r)]:
+        assert L.twin_bn254_g2_mul(g2b(gg), fb(k), o2)
+        assert g2u(o2.raw) == G.g2_mul(gg, k)
+    P = G.g1_mul(g, 5)
+    for a, b in [(P, g), (P, P), (P, G.g1_neg(P)), (P, None), (None, g), (None, None)]:
+        assert L.twin_bn254_g1_add(g1b(a), g1b(b), o)
+        assert g1u(o.raw) == G.g1_add(a, b)
+    assert not L.twin_bn254_g1_mul(fb(1) + fb(1), fb(1), o)      # (1,1) is not on the curve
+    assert L.twin_bn254_g1_decompress(M.g1_ser(G.g1_neg(g)), o) and g1u(o.raw) == G.g1_neg(g)
+    for Q in (pk.XX, G.g2_neg(pk.XX), pk.YYi[0]):
+        assert L.twin_bn254_g2_decompress(M.g2_ser(Q), o2) and g2u(o2.raw) == Q
+
+
+def test_pairing_value_and_cyclotomic(L):
+    d = load_golden("bn254_oracle_flows.json")
+    pk = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
+    P, Q = G.g1_mul(pk.g, 12345), G.g2_mul(pk.gg, 6789)
+    og = ctypes.create_string_buffer(384)
+    e = G.pairing(P, Q)
+    want = b"".join(fb(e[k][0]) + fb(e[k][1]) for k in [0, 2, 4, 1, 3, 5])
+    assert L.twin_bn254_pairing(g1b(P), g2b(Q), og, 0) == 1 and og.raw == want
+    assert L.twin_bn254_pairing(g1b(P), g2b(Q), og, 2) == 1           # Granger-Scott squaring == generic squaring
+    assert L.twin_bn254_pairing_fixedq(g1b(P), g2b(Q), og) == 1 and og.raw == want
+
+
+def test_verify_id_golden(L):
+    d = load_golden("bn254_oracle_flows.json")
+    n = 0
+    for s in d["scenarios"]:
+        if s["A"] > 8:
+            continue
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        ctxs = {}
+        for p in s["proofs"][:2]:
+            for c in p["cases"]:
+                if c["svc"] not in ctxs:
+                    ctxs[c["svc"]] = _ctx(L, pk, svc=c["svc"])
+                P = CD.proof_decode(base64.b64decode(c["proof"]))
+                ad = c["ad"].encode()
+                got = L.twin_bn254_verify_id(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
+                assert bool(got) == c["expect"], (s["name"], c["label"])
+                n += 1
+    assert n > 80
+
+
+def test_verify_id_with_retrieval_golden(L):
+    w = load_golden("bn254_oracle_with_retrieval.json")
+    for r in w["runs"]:
+        pk = CD.pk_decode(base64.b64decode(r["pk"]))
+        g, apk, h = M.hash_to_g1(r["g_seed"]), M.hash_to_g1(r["authority_pk_seed"]), M.hash_to_g1(r["h_seed"])
+        P = CD.proof_decode(base64.b64decode(r["proof"]))
+        ctx = _ctx(L, pk, svc=r["svc"], g_eg=g, apk=apk, h=h)
+        rec = pack_verify_id(M, P)
+        for ad, exp in ((b"hello", 1), (b"hellO", 0)):
+            assert L.twin_bn254_verify_id(ctx, rec, ctypes.c_uint64(hidden_mask(P.attributes)), 1, ad, len(ad)) == exp
+
+
+def test_ps_verify_and_provide_id(L):
+    seed = 20211
+    A, H = 4, 2
+    d = load_golden("bn254_oracle_flows.json")
+    gg = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"])).gg
+    g = M.hash_to_g1("abc")
+    x = scalar_stream(seed, 0, M.r)
+    ys = [scalar_stream(seed, 1 + i, M.r) for i in range(A)]
+    pk, skX = PR.key_gen(g, gg, x, ys)
+    ctx = _ctx(L, pk, skX=skX)
+    out = ctypes.create_string_buffer(128)
+    for n in range(3):
+        attrs = [(("a%d-%d" % (i, n)).encode(), i < H) for i in range(A)]
+        rnd = [scalar_stream(seed, 100 + 10 * n + j, M.r) for j in range(2 + H)]
+        ad = b"ad%d" % n
+        rq, t1 = PR.request_id(pk, attrs, ad, rnd)
+        if n == 2:
+            rq.c ^= 1
+        u = scalar_stream(seed, 1000 + n, M.r)
+        want = PR.provide_id(pk, skX, rq, ad, u)
+        got = L.twin_bn254_provide_id(ctx, pack_provide_id(M, rq, u), ctypes.c_uint64((1 << H) - 1), ad, len(ad), out)
+        assert bool(got) == (want is not None)
+        if want is not None:
+            assert out.raw == g1b(want.sig1) + g1b(want.sig2)
+            ub = PR.unblind(want, t1)
+            vals = [a for a, _ in attrs]
+            assert L.twin_bn254_ps_verify(ctx, pack_ps_verify(M, ub, vals), A) == 1
+            assert L.twin_bn254_ps_verify(ctx, pack_ps_verify(M, want, vals), A) == 0     # still blinded
+        else:
+            assert out.raw == bytes(128)
