@@ -1,0 +1,1061 @@
+/*
+ * elp_oracle.c -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; it is never on the
+ * product path (the product is the HIP library behind include/elpasso.h and has no CPU fallback).
+ *
+ * What is restated, in the reference's own structure (one independent scalar multiplication per term, two full
+ * pairings compared in GT, no fixed-base tables, no batching):
+ *   el_passo_verify_id                       /root/reference/src/ps-verifier.cc:37-138
+ *   el_passo_verify_id_without_id_retrieval  /root/reference/src/ps-verifier.cc:140-212
+ *   prepare_hybrid_verification              /root/reference/src/ps-verifier.cc:214-229
+ *   PSVerifier::verify                       /root/reference/src/ps-verifier.cc:13-35
+ *   el_passo_provide_id / nizk_verify / sign_hybrid / sign_commitment   /root/reference/src/ps-signer.cc:63-146
+ * The arithmetic underneath lives in herumi/mcl (third-parties/mcl, an un-vendored submodule whose sources and pinned
+ * commit are absent from /root/reference; approx. v1.2x).  Its published algorithms are restated here for the curve
+ * the reference actually runs on (mcl's default BN254: p = 36z^4+36z^3+24z^2+6z+1, z = -(2^62+2^55+1), y^2 = x^3+2,
+ * Fp2 = Fp[i]/(i^2+1), xi = 1+i, D-type twist): Montgomery Fp, Fp2/Fp6/Fp12 tower, Jacobian G1/G2 with width-5 NAF
+ * scalar multiplication, optimal ate Miller loop, final exponentiation, little-endian serialisation with y-parity
+ * flag, Fr::setHashOf masking, Shallue-van de Woestijne hashAndMapToG1, SHA-256.
+ *
+ * Pinning: tests/test_oracle_golden.py checks this library against every golden vector captured from the reference's
+ * own prebuilt wasm (tests/golden/bn254_*.json) and against the independent big-int model oracle/pymodel.py.
+ *
+ * Representation: 4 x 64-bit limbs, unsigned __int128 products (deliberately different from the HIP path's 8 x 32-bit
+ * limbs; the Miller loop uses Jacobian line formulas, the HIP path homogeneous ones).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------------------ Fp */
+typedef struct { u64 v[4]; } fp;
+
+static const u64 P[4] = {0xa700000000000013ull, 0x6121000000000013ull, 0xba344d8000000008ull, 0x2523648240000001ull};
+static const u64 RORD[4] = {0xa10000000000000dull, 0xff9f800000000010ull, 0xba344d8000000007ull, 0x2523648240000001ull};
+static const u64 ZABS = 0x4080000000000001ull; /* |z|, z < 0 */
+static u64 PINV;                                /* -p^-1 mod 2^64 */
+static fp FP_ONE, FP_R2, FP_ZERO;
+static int g_init = 0;
+
+static int geq_p(const u64* a) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > P[i]) return 1;
+    if (a[i] < P[i]) return 0;
+  }
+  return 1;
+}
+static void sub_p(u64* a) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 t = (u128)a[i] - P[i] - br;
+    a[i] = (u64)t;
+    br = (t >> 64) & 1;
+  }
+}
+static void fp_add(fp* r, const fp* a, const fp* b) {
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a->v[i] + b->v[i];
+    r->v[i] = (u64)c;
+    c >>= 64;
+  }
+  if (geq_p(r->v)) sub_p(r->v);
+}
+static void fp_sub(fp* r, const fp* a, const fp* b) {
+  u128 br = 0;
+  u64 t[4];
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a->v[i] - b->v[i] - br;
+    t[i] = (u64)d;
+    br = (d >> 64) & 1;
+  }
+  if (br) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)t[i] + P[i];
+      t[i] = (u64)c;
+      c >>= 64;
+    }
+  }
+  memcpy(r->v, t, 32);
+}
+static int fp_is_zero(const fp* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
+static int fp_eq(const fp* a, const fp* b) { return memcmp(a->v, b->v, 32) == 0; }
+static void fp_neg(fp* r, const fp* a) {
+  if (fp_is_zero(a)) { *r = *a; return; }
+  fp_sub(r, &FP_ZERO, a);
+}
+static void fp_dbl(fp* r, const fp* a) { fp_add(r, a, a); }
+/* Montgomery multiplication, operand scanning (separate product and reduction passes) */
+static void fp_mul(fp* r, const fp* a, const fp* b) {
+  u64 t[9] = {0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a->v[j] * b->v[i] + t[i + j];
+      t[i + j] = (u64)c;
+      c >>= 64;
+    }
+    t[i + 4] = (u64)c;
+  }
+  for (int i = 0; i < 4; i++) {
+    u64 m = t[i] * PINV;
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)m * P[j] + t[i + j];
+      t[i + j] = (u64)c;
+      c >>= 64;
+    }
+    for (int k = i + 4; c && k < 9; k++) {
+      c += t[k];
+      t[k] = (u64)c;
+      c >>= 64;
+    }
+  }
+  u64 o[4] = {t[4], t[5], t[6], t[7]};
+  if (t[8] || geq_p(o)) sub_p(o);
+  memcpy(r->v, o, 32);
+}
+static void fp_sqr(fp* r, const fp* a) { fp_mul(r, a, a); }
+static void fp_pow(fp* r, const fp* a, const u64* e, int nl) {
+  fp acc = FP_ONE, base = *a;
+  for (int i = nl * 64 - 1; i >= 0; i--) {
+    fp_sqr(&acc, &acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) fp_mul(&acc, &acc, &base);
+  }
+  *r = acc;
+}
+static void sub_small(u64* o, const u64* a, u64 k) { /* o = a - k */
+  u128 br = k;
+  for (int i = 0; i < 4; i++) {
+    u128 t = (u128)a[i] - br;
+    o[i] = (u64)t;
+    br = (t >> 64) & 1;
+  }
+}
+static void shr(u64* a, int s) {
+  for (int i = 0; i < 4; i++) a[i] = (a[i] >> s) | (i < 3 ? a[i + 1] << (64 - s) : 0);
+}
+static void fp_inv(fp* r, const fp* a) { /* a^(p-2) */
+  u64 e[4];
+  sub_small(e, P, 2);
+  fp_pow(r, a, e, 4);
+}
+static int fp_sqrt(fp* r, const fp* a) { /* p = 3 mod 4: a^((p+1)/4) */
+  u64 e[4];
+  u128 c = 1;
+  for (int i = 0; i < 4; i++) {
+    c += P[i];
+    e[i] = (u64)c;
+    c >>= 64;
+  }
+  shr(e, 2);
+  fp t, s;
+  fp_pow(&t, a, e, 4);
+  fp_sqr(&s, &t);
+  int ok = fp_eq(&s, a);   /* r may alias a */
+  *r = t;
+  return ok;
+}
+static int fp_legendre(const fp* a) {
+  if (fp_is_zero(a)) return 0;
+  u64 e[4];
+  sub_small(e, P, 1);
+  shr(e, 1);
+  fp t;
+  fp_pow(&t, a, e, 4);
+  return fp_eq(&t, &FP_ONE) ? 1 : -1;
+}
+static void fp_from_u64(fp* r, u64 x) {
+  fp t = {{x, 0, 0, 0}};
+  fp_mul(r, &t, &FP_R2);
+}
+static void fp_from_le(fp* r, const uint8_t* b) { /* canonical LE bytes -> Montgomery (no range check) */
+  fp t;
+  memcpy(t.v, b, 32);
+  fp_mul(r, &t, &FP_R2);
+}
+static void fp_to_le(uint8_t* b, const fp* a) {
+  fp one = {{1, 0, 0, 0}}, t;
+  fp_mul(&t, a, &one);
+  memcpy(b, t.v, 32);
+}
+static int le_lt_p(const uint8_t* b) {
+  u64 t[4];
+  memcpy(t, b, 32);
+  return !geq_p(t);
+}
+
+/* ------------------------------------------------------------------------------------------------ Fp2 */
+typedef struct { fp a, b; } fp2;
+static fp2 F2_ZERO, F2_ONE;
+static void fp2_add(fp2* r, const fp2* x, const fp2* y) { fp_add(&r->a, &x->a, &y->a); fp_add(&r->b, &x->b, &y->b); }
+static void fp2_sub(fp2* r, const fp2* x, const fp2* y) { fp_sub(&r->a, &x->a, &y->a); fp_sub(&r->b, &x->b, &y->b); }
+static void fp2_neg(fp2* r, const fp2* x) { fp_neg(&r->a, &x->a); fp_neg(&r->b, &x->b); }
+static void fp2_dbl(fp2* r, const fp2* x) { fp2_add(r, x, x); }
+static void fp2_conj(fp2* r, const fp2* x) { r->a = x->a; fp_neg(&r->b, &x->b); }
+static int fp2_is_zero(const fp2* x) { return fp_is_zero(&x->a) && fp_is_zero(&x->b); }
+static int fp2_eq(const fp2* x, const fp2* y) { return fp_eq(&x->a, &y->a) && fp_eq(&x->b, &y->b); }
+static void fp2_mul(fp2* r, const fp2* x, const fp2* y) {
+  fp t0, t1, s0, s1, u;
+  fp_mul(&t0, &x->a, &y->a);
+  fp_mul(&t1, &x->b, &y->b);
+  fp_add(&s0, &x->a, &x->b);
+  fp_add(&s1, &y->a, &y->b);
+  fp_mul(&u, &s0, &s1);
+  fp_sub(&r->a, &t0, &t1);
+  fp_sub(&u, &u, &t0);
+  fp_sub(&r->b, &u, &t1);
+}
+static void fp2_sqr(fp2* r, const fp2* x) {
+  fp s, d, m;
+  fp_add(&s, &x->a, &x->b);
+  fp_sub(&d, &x->a, &x->b);
+  fp_mul(&m, &x->a, &x->b);
+  fp_mul(&r->a, &s, &d);
+  fp_dbl(&r->b, &m);
+}
+static void fp2_mul_fp(fp2* r, const fp2* x, const fp* s) { fp_mul(&r->a, &x->a, s); fp_mul(&r->b, &x->b, s); }
+static void fp2_mul_xi(fp2* r, const fp2* x) { /* (a+bi)(1+i) */
+  fp t;
+  fp_sub(&t, &x->a, &x->b);
+  fp_add(&r->b, &x->a, &x->b);
+  r->a = t;
+}
+static void fp2_inv(fp2* r, const fp2* x) {
+  fp n, t;
+  fp_sqr(&n, &x->a);
+  fp_sqr(&t, &x->b);
+  fp_add(&n, &n, &t);
+  fp_inv(&n, &n);
+  fp_mul(&r->a, &x->a, &n);
+  fp_mul(&t, &x->b, &n);
+  fp_neg(&r->b, &t);
+}
+static void fp2_pow(fp2* r, const fp2* x, const u64* e, int nl) {
+  fp2 acc = F2_ONE, base = *x;
+  for (int i = nl * 64 - 1; i >= 0; i--) {
+    fp2_sqr(&acc, &acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) fp2_mul(&acc, &acc, &base);
+  }
+  *r = acc;
+}
+static int fp2_sqrt(fp2* r, const fp2* x) {
+  if (fp_is_zero(&x->b)) {
+    fp s;
+    if (fp_sqrt(&s, &x->a)) { r->a = s; r->b = FP_ZERO; return 1; }
+    fp na;
+    fp_neg(&na, &x->a);
+    if (!fp_sqrt(&s, &na)) return 0;
+    r->a = FP_ZERO;
+    r->b = s;
+    return 1;
+  }
+  fp n, t, u, half, two;
+  fp_sqr(&n, &x->a);
+  fp_sqr(&t, &x->b);
+  fp_add(&n, &n, &t);
+  if (!fp_sqrt(&n, &n)) return 0;
+  fp_from_u64(&two, 2);
+  fp_inv(&half, &two);
+  fp_add(&t, &x->a, &n);
+  fp_mul(&t, &t, &half);
+  if (!fp_sqrt(&u, &t)) {
+    fp_sub(&t, &x->a, &n);
+    fp_mul(&t, &t, &half);
+    if (!fp_sqrt(&u, &t)) return 0;
+  }
+  fp d;
+  fp_dbl(&d, &u);
+  fp_inv(&d, &d);
+  r->a = u;
+  fp_mul(&r->b, &x->b, &d);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ Fp6, Fp12 */
+typedef struct { fp2 c0, c1, c2; } fp6;      /* Fp2[v]/(v^3 - xi) */
+typedef struct { fp6 c0, c1; } fp12;         /* Fp6[w]/(w^2 - v)  */
+static fp2 FROB[4][6];                        /* FROB[n][k] = xi^(k (p^n - 1)/6), n = 1..3 */
+static fp2 TWIST_B;                           /* b/xi */
+
+static void fp6_add(fp6* r, const fp6* x, const fp6* y) { fp2_add(&r->c0, &x->c0, &y->c0); fp2_add(&r->c1, &x->c1, &y->c1); fp2_add(&r->c2, &x->c2, &y->c2); }
+static void fp6_sub(fp6* r, const fp6* x, const fp6* y) { fp2_sub(&r->c0, &x->c0, &y->c0); fp2_sub(&r->c1, &x->c1, &y->c1); fp2_sub(&r->c2, &x->c2, &y->c2); }
+static void fp6_neg(fp6* r, const fp6* x) { fp2_neg(&r->c0, &x->c0); fp2_neg(&r->c1, &x->c1); fp2_neg(&r->c2, &x->c2); }
+static void fp6_mul_v(fp6* r, const fp6* x) {
+  fp2 t;
+  fp2_mul_xi(&t, &x->c2);
+  r->c2 = x->c1;
+  r->c1 = x->c0;
+  r->c0 = t;
+}
+static void fp6_mul(fp6* r, const fp6* x, const fp6* y) { /* schoolbook with Karatsuba cross terms */
+  fp2 t0, t1, t2, a, b, s, r0, r1, r2;
+  fp2_mul(&t0, &x->c0, &y->c0);
+  fp2_mul(&t1, &x->c1, &y->c1);
+  fp2_mul(&t2, &x->c2, &y->c2);
+  fp2_add(&a, &x->c1, &x->c2); fp2_add(&b, &y->c1, &y->c2); fp2_mul(&s, &a, &b);
+  fp2_sub(&s, &s, &t1); fp2_sub(&s, &s, &t2); fp2_mul_xi(&s, &s); fp2_add(&r0, &s, &t0);
+  fp2_add(&a, &x->c0, &x->c1); fp2_add(&b, &y->c0, &y->c1); fp2_mul(&s, &a, &b);
+  fp2_sub(&s, &s, &t0); fp2_sub(&s, &s, &t1); fp2_mul_xi(&a, &t2); fp2_add(&r1, &s, &a);
+  fp2_add(&a, &x->c0, &x->c2); fp2_add(&b, &y->c0, &y->c2); fp2_mul(&s, &a, &b);
+  fp2_sub(&s, &s, &t0); fp2_sub(&s, &s, &t2); fp2_add(&r2, &s, &t1);
+  r->c0 = r0; r->c1 = r1; r->c2 = r2;
+}
+static void fp6_sqr(fp6* r, const fp6* x) { fp6_mul(r, x, x); }
+static void fp6_mul_fp2(fp6* r, const fp6* x, const fp2* s) { fp2_mul(&r->c0, &x->c0, s); fp2_mul(&r->c1, &x->c1, s); fp2_mul(&r->c2, &x->c2, s); }
+static void fp6_inv(fp6* r, const fp6* x) {
+  fp2 A, B, C, t, F;
+  fp2_sqr(&A, &x->c0); fp2_mul(&t, &x->c1, &x->c2); fp2_mul_xi(&t, &t); fp2_sub(&A, &A, &t);
+  fp2_sqr(&B, &x->c2); fp2_mul_xi(&B, &B); fp2_mul(&t, &x->c0, &x->c1); fp2_sub(&B, &B, &t);
+  fp2_sqr(&C, &x->c1); fp2_mul(&t, &x->c0, &x->c2); fp2_sub(&C, &C, &t);
+  fp2 u, v;
+  fp2_mul(&u, &x->c2, &B); fp2_mul(&v, &x->c1, &C); fp2_add(&u, &u, &v); fp2_mul_xi(&u, &u);
+  fp2_mul(&F, &x->c0, &A); fp2_add(&F, &F, &u);
+  fp2_inv(&F, &F);
+  fp2_mul(&r->c0, &A, &F); fp2_mul(&r->c1, &B, &F); fp2_mul(&r->c2, &C, &F);
+}
+static void fp12_one(fp12* r) { memset(r, 0, sizeof *r); r->c0.c0 = F2_ONE; }
+static int fp12_eq(const fp12* x, const fp12* y) {
+  return fp2_eq(&x->c0.c0, &y->c0.c0) && fp2_eq(&x->c0.c1, &y->c0.c1) && fp2_eq(&x->c0.c2, &y->c0.c2) &&
+         fp2_eq(&x->c1.c0, &y->c1.c0) && fp2_eq(&x->c1.c1, &y->c1.c1) && fp2_eq(&x->c1.c2, &y->c1.c2);
+}
+static void fp12_mul(fp12* r, const fp12* x, const fp12* y) {
+  fp6 t0, t1, a, b, s;
+  fp6_mul(&t0, &x->c0, &y->c0);
+  fp6_mul(&t1, &x->c1, &y->c1);
+  fp6_add(&a, &x->c0, &x->c1);
+  fp6_add(&b, &y->c0, &y->c1);
+  fp6_mul(&s, &a, &b);
+  fp6_sub(&s, &s, &t0);
+  fp6_sub(&r->c1, &s, &t1);
+  fp6_mul_v(&t1, &t1);
+  fp6_add(&r->c0, &t0, &t1);
+}
+static void fp12_sqr(fp12* r, const fp12* x) {
+  fp6 t, a, b, s;
+  fp6_mul(&t, &x->c0, &x->c1);
+  fp6_add(&a, &x->c0, &x->c1);
+  fp6_mul_v(&b, &x->c1);
+  fp6_add(&b, &b, &x->c0);
+  fp6_mul(&s, &a, &b);
+  fp6_sub(&s, &s, &t);
+  fp6_mul_v(&a, &t);
+  fp6_sub(&r->c0, &s, &a);
+  fp6_add(&r->c1, &t, &t);
+}
+static void fp12_conj(fp12* r, const fp12* x) { r->c0 = x->c0; fp6_neg(&r->c1, &x->c1); }
+static void fp12_inv(fp12* r, const fp12* x) {
+  fp6 t0, t1;
+  fp6_sqr(&t0, &x->c0);
+  fp6_sqr(&t1, &x->c1);
+  fp6_mul_v(&t1, &t1);
+  fp6_sub(&t0, &t0, &t1);
+  fp6_inv(&t1, &t0);
+  fp6_mul(&r->c0, &x->c0, &t1);
+  fp6_mul(&t0, &x->c1, &t1);
+  fp6_neg(&r->c1, &t0);
+}
+static void fp12_frob(fp12* r, const fp12* x, int n) { /* coefficient of w^k, k = 2i + j for v^i w^j */
+  fp2* o[6] = {&r->c0.c0, &r->c1.c0, &r->c0.c1, &r->c1.c1, &r->c0.c2, &r->c1.c2};
+  const fp2* in[6] = {&x->c0.c0, &x->c1.c0, &x->c0.c1, &x->c1.c1, &x->c0.c2, &x->c1.c2};
+  for (int k = 0; k < 6; k++) {
+    fp2 t = *in[k];
+    if (n & 1) fp2_conj(&t, &t);
+    if (k) fp2_mul(&t, &t, &FROB[n][k]);
+    *o[k] = t;
+  }
+}
+/* f * (a + b w + c w^3): the D-twist line shape */
+static void fp12_mul_line(fp12* f, const fp2* a, const fp2* b, const fp2* c) {
+  fp12 l;
+  memset(&l, 0, sizeof l);
+  l.c0.c0 = *a;
+  l.c1.c0 = *b;
+  l.c1.c1 = *c;
+  fp12_mul(f, f, &l);
+}
+static void fp12_pow_u64(fp12* r, const fp12* x, u64 e) {
+  fp12 acc = *x;
+  int top = 63;
+  while (!((e >> top) & 1)) top--;
+  for (int i = top - 1; i >= 0; i--) {
+    fp12_sqr(&acc, &acc);
+    if ((e >> i) & 1) fp12_mul(&acc, &acc, x);
+  }
+  *r = acc;
+}
+
+/* ------------------------------------------------------------------------------------------------ groups */
+typedef struct { fp x, y; int inf; } g1a;
+typedef struct { fp X, Y, Z; } g1j;        /* Z = 0: infinity */
+typedef struct { fp2 x, y; int inf; } g2a;
+typedef struct { fp2 X, Y, Z; } g2j;
+static fp CURVE_B;
+
+/* The group law is written once with macros over the field type */
+#define DEFINE_GROUP(G, F, FZERO, FONE)                                                                         \
+  static int G##_is_inf(const G##j* p) { return F##_is_zero(&p->Z); }                                           \
+  static void G##_set_inf(G##j* p) { p->X = FONE; p->Y = FONE; p->Z = FZERO; }                                  \
+  static void G##_from_aff(G##j* r, const G##a* p) {                                                            \
+    if (p->inf) { G##_set_inf(r); return; }                                                                     \
+    r->X = p->x; r->Y = p->y; r->Z = FONE;                                                                      \
+  }                                                                                                             \
+  static void G##_dbl(G##j* r, const G##j* p) { /* dbl-2009-l */                                                \
+    if (G##_is_inf(p)) { *r = *p; return; }                                                                     \
+    F A, B, C, D, E, Fq, t, X3, Y3, Z3;                                                                         \
+    F##_sqr(&A, &p->X); F##_sqr(&B, &p->Y); F##_sqr(&C, &B);                                                    \
+    F##_add(&t, &p->X, &B); F##_sqr(&t, &t); F##_sub(&t, &t, &A); F##_sub(&t, &t, &C); F##_dbl(&D, &t);         \
+    F##_dbl(&E, &A); F##_add(&E, &E, &A); F##_sqr(&Fq, &E);                                                     \
+    F##_dbl(&t, &D); F##_sub(&X3, &Fq, &t);                                                                     \
+    F##_sub(&t, &D, &X3); F##_mul(&Y3, &E, &t); F##_dbl(&C, &C); F##_dbl(&C, &C); F##_dbl(&C, &C);              \
+    F##_sub(&Y3, &Y3, &C);                                                                                      \
+    F##_mul(&Z3, &p->Y, &p->Z); F##_dbl(&Z3, &Z3);                                                              \
+    r->X = X3; r->Y = Y3; r->Z = Z3;                                                                            \
+  }                                                                                                             \
+  static void G##_add(G##j* r, const G##j* p, const G##j* q) { /* add-2007-bl */                                \
+    if (G##_is_inf(p)) { *r = *q; return; }                                                                     \
+    if (G##_is_inf(q)) { *r = *p; return; }                                                                     \
+    F Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, rr, V, t, X3, Y3, Z3;                                                \
+    F##_sqr(&Z1Z1, &p->Z); F##_sqr(&Z2Z2, &q->Z);                                                               \
+    F##_mul(&U1, &p->X, &Z2Z2); F##_mul(&U2, &q->X, &Z1Z1);                                                     \
+    F##_mul(&S1, &p->Y, &q->Z); F##_mul(&S1, &S1, &Z2Z2);                                                       \
+    F##_mul(&S2, &q->Y, &p->Z); F##_mul(&S2, &S2, &Z1Z1);                                                       \
+    F##_sub(&H, &U2, &U1); F##_sub(&rr, &S2, &S1);                                                              \
+    if (F##_is_zero(&H)) {                                                                                      \
+      if (F##_is_zero(&rr)) { G##_dbl(r, p); } else { G##_set_inf(r); }                                         \
+      return;                                                                                                   \
+    }                                                                                                           \
+    F##_dbl(&rr, &rr);                                                                                          \
+    F##_dbl(&I, &H); F##_sqr(&I, &I); F##_mul(&J, &H, &I); F##_mul(&V, &U1, &I);                                \
+    F##_sqr(&X3, &rr); F##_sub(&X3, &X3, &J); F##_dbl(&t, &V); F##_sub(&X3, &X3, &t);                           \
+    F##_sub(&t, &V, &X3); F##_mul(&Y3, &rr, &t); F##_mul(&t, &S1, &J); F##_dbl(&t, &t); F##_sub(&Y3, &Y3, &t);  \
+    F##_add(&Z3, &p->Z, &q->Z); F##_sqr(&Z3, &Z3); F##_sub(&Z3, &Z3, &Z1Z1); F##_sub(&Z3, &Z3, &Z2Z2);          \
+    F##_mul(&Z3, &Z3, &H);                                                                                      \
+    r->X = X3; r->Y = Y3; r->Z = Z3;                                                                            \
+  }                                                                                                             \
+  static void G##_neg(G##j* r, const G##j* p) { r->X = p->X; r->Z = p->Z; F##_neg(&r->Y, &p->Y); }              \
+  static void G##_to_aff(G##a* r, const G##j* p) {                                                              \
+    if (G##_is_inf(p)) { memset(r, 0, sizeof *r); r->inf = 1; return; }                                         \
+    F zi, zi2;                                                                                                  \
+    F##_inv(&zi, &p->Z); F##_sqr(&zi2, &zi);                                                                    \
+    F##_mul(&r->x, &p->X, &zi2); F##_mul(&zi2, &zi2, &zi); F##_mul(&r->y, &p->Y, &zi2);                         \
+    r->inf = 0;                                                                                                 \
+  }                                                                                                             \
+  /* G::mul: width-5 NAF, the shape of mcl's generic window method (no GLV/GLS) */                              \
+  static void G##_mul(G##j* r, const G##a* p, const u64* k) {                                                   \
+    signed char naf[260];                                                                                       \
+    u64 e[5] = {k[0], k[1], k[2], k[3], 0};                                                                     \
+    int n = 0;                                                                                                  \
+    while (e[0] | e[1] | e[2] | e[3] | e[4]) {                                                                  \
+      int d = 0;                                                                                                \
+      if (e[0] & 1) {                                                                                           \
+        d = (int)(e[0] & 31);                                                                                   \
+        if (d >= 16) d -= 32;                                                                                   \
+        if (d > 0) { u128 br = (u64)d; for (int i = 0; i < 5; i++) { u128 t = (u128)e[i] - br; e[i] = (u64)t; br = (t >> 64) & 1; } } \
+        else { u128 c = (u64)(-d); for (int i = 0; i < 5; i++) { c += e[i]; e[i] = (u64)c; c >>= 64; } }        \
+      }                                                                                                         \
+      naf[n++] = (signed char)d;                                                                                \
+      for (int i = 0; i < 5; i++) e[i] = (e[i] >> 1) | (i < 4 ? e[i + 1] << 63 : 0);                            \
+    }                                                                                                           \
+    G##j tbl[8], p2, acc, t;                                                                                    \
+    G##_from_aff(&tbl[0], p);                                                                                   \
+    G##_dbl(&p2, &tbl[0]);                                                                                      \
+    for (int i = 1; i < 8; i++) G##_add(&tbl[i], &tbl[i - 1], &p2);                                             \
+    G##_set_inf(&acc);                                                                                          \
+    for (int i = n - 1; i >= 0; i--) {                                                                          \
+      G##_dbl(&acc, &acc);                                                                                      \
+      if (naf[i] > 0) G##_add(&acc, &acc, &tbl[naf[i] >> 1]);                                                   \
+      else if (naf[i] < 0) { G##_neg(&t, &tbl[(-naf[i]) >> 1]); G##_add(&acc, &acc, &t); }                      \
+    }                                                                                                           \
+    *r = acc;                                                                                                   \
+  }
+
+DEFINE_GROUP(g1, fp, FP_ZERO, FP_ONE)
+DEFINE_GROUP(g2, fp2, F2_ZERO, F2_ONE)
+
+static int g1_on_curve(const g1a* p) {
+  if (p->inf) return 1;
+  fp l, r;
+  fp_sqr(&l, &p->y);
+  fp_sqr(&r, &p->x); fp_mul(&r, &r, &p->x); fp_add(&r, &r, &CURVE_B);
+  return fp_eq(&l, &r);
+}
+static int g2_on_curve(const g2a* p) {
+  if (p->inf) return 1;
+  fp2 l, r;
+  fp2_sqr(&l, &p->y);
+  fp2_sqr(&r, &p->x); fp2_mul(&r, &r, &p->x); fp2_add(&r, &r, &TWIST_B);
+  return fp2_eq(&l, &r);
+}
+
+/* ------------------------------------------------------------------------------------------------ pairing */
+/* pi_p on the twist: (conj(x) gamma_{1,2}, conj(y) gamma_{1,3}); pi_p^2: (x gamma_{2,2}, y gamma_{2,3}) */
+static void g2_frob(g2a* r, const g2a* q, int n) {
+  fp2 x = q->x, y = q->y;
+  if (n & 1) { fp2_conj(&x, &x); fp2_conj(&y, &y); }
+  fp2_mul(&r->x, &x, &FROB[n][2]);
+  fp2_mul(&r->y, &y, &FROB[n][3]);
+  r->inf = q->inf;
+}
+/* Jacobian tangent:  l = Z3 Z^2 y_P - 3 X^2 Z^2 x_P w + (3 X^3 - 2 Y^2) w^3 ;  T <- 2T */
+static void ml_dbl(fp12* f, g2j* T, const g1a* p) {
+  fp2 X2, Y2, Z2, t, a, b, c, X3c;
+  fp2_sqr(&X2, &T->X); fp2_sqr(&Y2, &T->Y); fp2_sqr(&Z2, &T->Z);
+  fp2_mul(&X3c, &X2, &T->X);
+  fp2_dbl(&c, &X3c); fp2_add(&c, &c, &X3c);          /* 3 X^3 */
+  fp2_dbl(&t, &Y2); fp2_sub(&c, &c, &t);             /* - 2 Y^2 */
+  fp2_dbl(&b, &X2); fp2_add(&b, &b, &X2); fp2_mul(&b, &b, &Z2); fp2_neg(&b, &b);   /* -3 X^2 Z^2 */
+  g2j T2;
+  g2_dbl(&T2, T);
+  fp2_mul(&a, &T2.Z, &Z2);                            /* Z3 Z^2 */
+  fp2_mul_fp(&a, &a, &p->y);
+  fp2_mul_fp(&b, &b, &p->x);
+  fp12_mul_line(f, &a, &b, &c);
+  *T = T2;
+}
+/* chord through T and affine Q:  l = Z3 y_P - r x_P w + (r x_Q - Z3 y_Q) w^3,  r = y_Q Z^3 - Y, Z3 = Z (x_Q Z^2 - X) */
+static void ml_add(fp12* f, g2j* T, const g2a* q, const g1a* p) {
+  fp2 Z2, Z3, H, rr, Z3n, a, b, c, t;
+  fp2_sqr(&Z2, &T->Z);
+  fp2_mul(&Z3, &Z2, &T->Z);
+  fp2_mul(&H, &q->x, &Z2); fp2_sub(&H, &H, &T->X);
+  fp2_mul(&rr, &q->y, &Z3); fp2_sub(&rr, &rr, &T->Y);
+  fp2_mul(&Z3n, &T->Z, &H);
+  fp2_mul(&c, &rr, &q->x); fp2_mul(&t, &Z3n, &q->y); fp2_sub(&c, &c, &t);
+  fp2_mul_fp(&a, &Z3n, &p->y);
+  fp2_neg(&b, &rr); fp2_mul_fp(&b, &b, &p->x);
+  fp12_mul_line(f, &a, &b, &c);
+  g2j Q;
+  g2_from_aff(&Q, q);
+  g2_add(T, T, &Q);
+}
+static void miller_loop(fp12* f, const g1a* p, const g2a* q) {
+  fp12_one(f);
+  if (p->inf || q->inf) return;
+  /* s = |6z + 2| = 6|z| - 2, plain binary expansion */
+  u128 s = (u128)6 * ZABS - 2;
+  int top = 127;
+  while (!((s >> top) & 1)) top--;
+  g2j T;
+  g2_from_aff(&T, q);
+  for (int i = top - 1; i >= 0; i--) {
+    fp12_sqr(f, f);
+    ml_dbl(f, &T, p);
+    if ((s >> i) & 1) ml_add(f, &T, q, p);
+  }
+  /* z < 0: f <- conj(f), T <- -T ; then the two Frobenius line steps of the BN optimal ate pairing */
+  fp12_conj(f, f);
+  g2_neg(&T, &T);
+  g2a q1, q2;
+  g2_frob(&q1, q, 1);
+  g2_frob(&q2, q, 2);
+  fp2_neg(&q2.y, &q2.y);
+  ml_add(f, &T, &q1, p);
+  ml_add(f, &T, &q2, p);
+}
+static void fp12_pow_z(fp12* r, const fp12* x) { /* x^z, z = -|z|, x unitary after the easy part */
+  fp12_pow_u64(r, x, ZABS);
+  fp12_conj(r, r);
+}
+static void final_exp(fp12* r, const fp12* fin) {
+  fp12 f, t0, t1;
+  fp12_inv(&t0, fin);
+  fp12_conj(&t1, fin);
+  fp12_mul(&f, &t1, &t0);
+  fp12_frob(&t0, &f, 2);
+  fp12_mul(&f, &t0, &f);
+  /* hard part (p^4-p^2+1)/r = p^3 + (6z^2+1) p^2 + (-36z^3-18z^2-12z+1) p + (-36z^3-30z^2-18z-2)  [Devegili et al.] */
+  fp12 fz, fz2, fz3, y0, y1, y2, y3, y4, y5, y6, T0, T1, t;
+  fp12_pow_z(&fz, &f); fp12_pow_z(&fz2, &fz); fp12_pow_z(&fz3, &fz2);
+  fp12_frob(&y0, &f, 1); fp12_frob(&t, &f, 2); fp12_mul(&y0, &y0, &t); fp12_frob(&t, &f, 3); fp12_mul(&y0, &y0, &t);
+  fp12_conj(&y1, &f);
+  fp12_frob(&y2, &fz2, 2);
+  fp12_frob(&y3, &fz, 1); fp12_conj(&y3, &y3);
+  fp12_frob(&t, &fz2, 1); fp12_mul(&y4, &fz, &t); fp12_conj(&y4, &y4);
+  fp12_conj(&y5, &fz2);
+  fp12_frob(&t, &fz3, 1); fp12_mul(&y6, &fz3, &t); fp12_conj(&y6, &y6);
+  fp12_sqr(&T0, &y6); fp12_mul(&T0, &T0, &y4); fp12_mul(&T0, &T0, &y5);
+  fp12_mul(&T1, &y3, &y5); fp12_mul(&T1, &T1, &T0);
+  fp12_mul(&T0, &T0, &y2);
+  fp12_sqr(&T1, &T1); fp12_mul(&T1, &T1, &T0); fp12_sqr(&T1, &T1);
+  fp12_mul(&T0, &T1, &y1); fp12_mul(&T1, &T1, &y0);
+  fp12_sqr(&T0, &T0); fp12_mul(r, &T0, &T1);
+}
+static void pairing(fp12* r, const g1a* p, const g2a* q) {
+  fp12 f;
+  miller_loop(&f, p, q);
+  final_exp(r, &f);
+}
+
+/* ------------------------------------------------------------------------------------------------ SHA-256 */
+typedef struct { uint32_t h[8]; uint8_t buf[64]; u64 len; } sha256_t;
+static const uint32_t SK[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha_block(sha256_t* s, const uint8_t* b) {
+  uint32_t w[64], a, bb, c, d, e, f, g, h;
+  for (int i = 0; i < 16; i++) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+  for (int i = 16; i < 64; i++) {
+    uint32_t s0 = ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  a = s->h[0]; bb = s->h[1]; c = s->h[2]; d = s->h[3]; e = s->h[4]; f = s->h[5]; g = s->h[6]; h = s->h[7];
+  for (int i = 0; i < 64; i++) {
+    uint32_t t1 = h + (ROR(e, 6) ^ ROR(e, 11) ^ ROR(e, 25)) + ((e & f) ^ (~e & g)) + SK[i] + w[i];
+    uint32_t t2 = (ROR(a, 2) ^ ROR(a, 13) ^ ROR(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+  }
+  s->h[0] += a; s->h[1] += bb; s->h[2] += c; s->h[3] += d; s->h[4] += e; s->h[5] += f; s->h[6] += g; s->h[7] += h;
+}
+static void sha_init(sha256_t* s) {
+  static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  memcpy(s->h, iv, 32);
+  s->len = 0;
+}
+static void sha_update(sha256_t* s, const uint8_t* p, size_t n) {
+  while (n--) {
+    s->buf[s->len++ & 63] = *p++;
+    if ((s->len & 63) == 0) sha_block(s, s->buf);
+  }
+}
+static void sha_final(sha256_t* s, uint8_t out[32]) {
+  u64 bits = s->len * 8;
+  uint8_t pad = 0x80, z = 0, lb[8];
+  sha_update(s, &pad, 1);
+  while ((s->len & 63) != 56) sha_update(s, &z, 1);
+  for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+  sha_update(s, lb, 8);
+  for (int i = 0; i < 8; i++) { out[4 * i] = s->h[i] >> 24; out[4 * i + 1] = s->h[i] >> 16; out[4 * i + 2] = s->h[i] >> 8; out[4 * i + 3] = s->h[i]; }
+}
+static void sha_update_hex(sha256_t* s, const uint8_t* p, size_t n) { /* serializeToHexStr: lowercase hex */
+  static const char hx[] = "0123456789abcdef";
+  for (size_t i = 0; i < n; i++) {
+    uint8_t c[2] = {(uint8_t)hx[p[i] >> 4], (uint8_t)hx[p[i] & 15]};
+    sha_update(s, c, 2);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ mcl conventions */
+static int u256_geq(const u64* a, const u64* m) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > m[i]) return 1;
+    if (a[i] < m[i]) return 0;
+  }
+  return 1;
+}
+/* Fr::setHashOf / Fp::setHashOf: LE(SHA-256(m)) masked to 254 bits; if still >= modulus, to 253 bits */
+static void set_hash_of(u64 out[4], const uint8_t* msg, size_t len, const u64* mod) {
+  sha256_t s;
+  uint8_t d[32];
+  sha_init(&s); sha_update(&s, msg, len); sha_final(&s, d);
+  memcpy(out, d, 32);
+  out[3] &= (1ull << 62) - 1;
+  if (u256_geq(out, mod)) out[3] &= (1ull << 61) - 1;
+}
+static void g1_ser(uint8_t out[32], const g1a* p) {
+  if (p->inf) { memset(out, 0, 32); return; }
+  uint8_t y[32];
+  fp_to_le(out, &p->x); fp_to_le(y, &p->y);
+  if (y[0] & 1) out[31] |= 0x80;
+}
+static void g2_ser(uint8_t out[64], const g2a* p) {
+  if (p->inf) { memset(out, 0, 64); return; }
+  uint8_t y[32];
+  fp_to_le(out, &p->x.a); fp_to_le(out + 32, &p->x.b); fp_to_le(y, &p->y.a);
+  if (y[0] & 1) out[63] |= 0x80;
+}
+static int g1_de(g1a* p, const uint8_t in[32]) {
+  uint8_t t[32];
+  memcpy(t, in, 32);
+  int any = 0;
+  for (int i = 0; i < 32; i++) any |= t[i];
+  memset(p, 0, sizeof *p);
+  if (!any) { p->inf = 1; return 1; }
+  int odd = t[31] >> 7;
+  t[31] &= 0x7f;
+  if (!le_lt_p(t)) return 0;
+  fp_from_le(&p->x, t);
+  fp rhs;
+  fp_sqr(&rhs, &p->x); fp_mul(&rhs, &rhs, &p->x); fp_add(&rhs, &rhs, &CURVE_B);
+  if (!fp_sqrt(&p->y, &rhs)) return 0;
+  uint8_t y[32];
+  fp_to_le(y, &p->y);
+  if ((y[0] & 1) != odd) fp_neg(&p->y, &p->y);
+  return 1;
+}
+static int g2_de(g2a* p, const uint8_t in[64]) {
+  uint8_t t[64];
+  memcpy(t, in, 64);
+  int any = 0;
+  for (int i = 0; i < 64; i++) any |= t[i];
+  memset(p, 0, sizeof *p);
+  if (!any) { p->inf = 1; return 1; }
+  int odd = t[63] >> 7;
+  t[63] &= 0x7f;
+  if (!le_lt_p(t) || !le_lt_p(t + 32)) return 0;
+  fp_from_le(&p->x.a, t); fp_from_le(&p->x.b, t + 32);
+  fp2 rhs;
+  fp2_sqr(&rhs, &p->x); fp2_mul(&rhs, &rhs, &p->x); fp2_add(&rhs, &rhs, &TWIST_B);
+  if (!fp2_sqrt(&p->y, &rhs)) return 0;
+  uint8_t y[32];
+  fp_to_le(y, &p->y.a);
+  if ((y[0] & 1) != odd) fp2_neg(&p->y, &p->y);
+  return 1;
+}
+/* hashAndMapToG1 on BN curves: t = Fp::setHashOf(msg), then the Shallue-van de Woestijne map */
+static fp SVDW_C1, SVDW_C2;
+static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
+  u64 tv[4];
+  set_hash_of(tv, msg, len, P);
+  fp t, w, x, y, one = FP_ONE, tmp;
+  fp_from_le(&t, (const uint8_t*)tv);
+  int neg = fp_legendre(&t) < 0;
+  fp_sqr(&w, &t); fp_add(&w, &w, &CURVE_B); fp_add(&w, &w, &one);
+  fp_inv(&w, &w); fp_mul(&w, &w, &t); fp_mul(&w, &w, &SVDW_C1);
+  for (int i = 0; i < 3; i++) {
+    if (i == 0) { fp_mul(&tmp, &t, &w); fp_sub(&x, &SVDW_C2, &tmp); }
+    else if (i == 1) { fp_neg(&x, &x); fp_sub(&x, &x, &one); }
+    else { fp_sqr(&tmp, &w); fp_inv(&tmp, &tmp); fp_add(&x, &tmp, &one); }
+    fp_sqr(&tmp, &x); fp_mul(&tmp, &tmp, &x); fp_add(&tmp, &tmp, &CURVE_B);
+    if (fp_sqrt(&y, &tmp)) break;
+  }
+  if (neg) fp_neg(&y, &y);
+  out->x = x; out->y = y; out->inf = 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ init */
+void elpo_init(void) {
+  if (g_init) return;
+  /* -p^-1 mod 2^64 by Newton iteration */
+  u64 inv = 1;
+  for (int i = 0; i < 6; i++) inv *= 2 - P[0] * inv;
+  PINV = (u64)0 - inv;
+  memset(&FP_ZERO, 0, sizeof FP_ZERO);
+  /* R mod p and R^2 mod p by repeated doubling of 1 */
+  fp t = {{1, 0, 0, 0}};
+  for (int i = 0; i < 256; i++) fp_add(&t, &t, &t);
+  FP_ONE = t;
+  for (int i = 0; i < 256; i++) fp_add(&t, &t, &t);
+  FP_R2 = t;
+  F2_ZERO.a = FP_ZERO; F2_ZERO.b = FP_ZERO;
+  F2_ONE.a = FP_ONE; F2_ONE.b = FP_ZERO;
+  fp_from_u64(&CURVE_B, 2);
+  fp2 xi = {FP_ONE, FP_ONE}, xinv, b2 = {CURVE_B, FP_ZERO};
+  fp2_inv(&xinv, &xi);
+  fp2_mul(&TWIST_B, &b2, &xinv);
+  /* gamma_{1,k} = xi^(k (p-1)/6); gamma_{2,k} = gamma_{1,k} conj(gamma_{1,k}); gamma_{3,k} = gamma_{1,k} * gamma_{2,k}^p...
+     computed directly: gamma_{n,k} = gamma_{1,k}^(1 + p + ... + p^(n-1)), with x^p = conj(x) in Fp2 */
+  u64 e[4];
+  sub_small(e, P, 1);
+  { /* e = (p-1)/6 */
+    u128 rem = 0;
+    for (int i = 3; i >= 0; i--) {
+      u128 cur = (rem << 64) | e[i];
+      e[i] = (u64)(cur / 6);
+      rem = cur % 6;
+    }
+  }
+  fp2 g1;
+  fp2_pow(&g1, &xi, e, 4);
+  for (int k = 0; k < 6; k++) {
+    fp2 a = F2_ONE;
+    for (int j = 0; j < k; j++) fp2_mul(&a, &a, &g1);
+    fp2 ac, a2, a3;
+    fp2_conj(&ac, &a);
+    fp2_mul(&a2, &a, &ac);        /* a^(1+p) */
+    fp2_conj(&a3, &a2);           /* a^(p+p^2) */
+    fp2_mul(&a3, &a3, &a);        /* a^(1+p+p^2) */
+    FROB[1][k] = a; FROB[2][k] = a2; FROB[3][k] = a3;
+  }
+  /* SvdW constants: c1 = sqrt(-3) (the root mcl uses has even canonical value ...04), c2 = (c1 - 1)/2 */
+  fp m3, two, half;
+  fp_from_u64(&m3, 3); fp_neg(&m3, &m3);
+  fp_sqrt(&SVDW_C1, &m3);
+  uint8_t c1b[32];
+  fp_to_le(c1b, &SVDW_C1);
+  if (c1b[0] != 0x04) fp_neg(&SVDW_C1, &SVDW_C1);
+  fp_from_u64(&two, 2); fp_inv(&half, &two);
+  fp_sub(&SVDW_C2, &SVDW_C1, &FP_ONE); fp_mul(&SVDW_C2, &SVDW_C2, &half);
+  g_init = 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ byte-level API */
+/* Formats are those of include/elpasso.h: G1 = x|y (32+32 LE, zeros = infinity), G2 = x.a|x.b|y.a|y.b, Fr = 32 LE. */
+static int g1_load(g1a* p, const uint8_t* b) {
+  int any = 0;
+  for (int i = 0; i < 64; i++) any |= b[i];
+  memset(p, 0, sizeof *p);
+  if (!any) { p->inf = 1; return 1; }
+  if (!le_lt_p(b) || !le_lt_p(b + 32)) return 0;
+  fp_from_le(&p->x, b); fp_from_le(&p->y, b + 32);
+  return g1_on_curve(p);
+}
+static int g2_load(g2a* p, const uint8_t* b) {
+  int any = 0;
+  for (int i = 0; i < 128; i++) any |= b[i];
+  memset(p, 0, sizeof *p);
+  if (!any) { p->inf = 1; return 1; }
+  for (int i = 0; i < 4; i++) if (!le_lt_p(b + 32 * i)) return 0;
+  fp_from_le(&p->x.a, b); fp_from_le(&p->x.b, b + 32); fp_from_le(&p->y.a, b + 64); fp_from_le(&p->y.b, b + 96);
+  return g2_on_curve(p);
+}
+static void g1_store(uint8_t* b, const g1a* p) {
+  if (p->inf) { memset(b, 0, 64); return; }
+  fp_to_le(b, &p->x); fp_to_le(b + 32, &p->y);
+}
+static void g2_store(uint8_t* b, const g2a* p) {
+  if (p->inf) { memset(b, 0, 128); return; }
+  fp_to_le(b, &p->x.a); fp_to_le(b + 32, &p->x.b); fp_to_le(b + 64, &p->y.a); fp_to_le(b + 96, &p->y.b);
+}
+static void k_load(u64 k[4], const uint8_t* b) { memcpy(k, b, 32); }
+
+int elpo_g1_mul(const uint8_t* P_, const uint8_t* k_, uint8_t* out) {
+  g1a p, r; g1j j; u64 k[4];
+  if (!g1_load(&p, P_)) return 0;
+  k_load(k, k_); g1_mul(&j, &p, k); g1_to_aff(&r, &j); g1_store(out, &r);
+  return 1;
+}
+int elpo_g2_mul(const uint8_t* P_, const uint8_t* k_, uint8_t* out) {
+  g2a p, r; g2j j; u64 k[4];
+  if (!g2_load(&p, P_)) return 0;
+  k_load(k, k_); g2_mul(&j, &p, k); g2_to_aff(&r, &j); g2_store(out, &r);
+  return 1;
+}
+int elpo_g1_add(const uint8_t* a_, const uint8_t* b_, uint8_t* out) {
+  g1a a, b, r; g1j ja, jb;
+  if (!g1_load(&a, a_) || !g1_load(&b, b_)) return 0;
+  g1_from_aff(&ja, &a); g1_from_aff(&jb, &b); g1_add(&ja, &ja, &jb); g1_to_aff(&r, &ja); g1_store(out, &r);
+  return 1;
+}
+int elpo_g2_add(const uint8_t* a_, const uint8_t* b_, uint8_t* out) {
+  g2a a, b, r; g2j ja, jb;
+  if (!g2_load(&a, a_) || !g2_load(&b, b_)) return 0;
+  g2_from_aff(&ja, &a); g2_from_aff(&jb, &b); g2_add(&ja, &ja, &jb); g2_to_aff(&r, &ja); g2_store(out, &r);
+  return 1;
+}
+int elpo_g1_decompress(const uint8_t* w, uint8_t* out) { g1a p; if (!g1_de(&p, w)) return 0; g1_store(out, &p); return 1; }
+int elpo_g2_decompress(const uint8_t* w, uint8_t* out) { g2a p; if (!g2_de(&p, w)) return 0; g2_store(out, &p); return 1; }
+int elpo_g1_compress(const uint8_t* a_, uint8_t* w) { g1a p; if (!g1_load(&p, a_)) return 0; g1_ser(w, &p); return 1; }
+int elpo_g2_compress(const uint8_t* a_, uint8_t* w) { g2a p; if (!g2_load(&p, a_)) return 0; g2_ser(w, &p); return 1; }
+void elpo_hash_to_g1(const uint8_t* msg, size_t len, uint8_t* out) { g1a p; hash_and_map_g1(&p, msg, len); g1_store(out, &p); }
+void elpo_fr_set_hash_of(const uint8_t* msg, size_t len, uint8_t* out) { u64 k[4]; set_hash_of(k, msg, len, RORD); memcpy(out, k, 32); }
+static void gt_store(uint8_t* out, const fp12* f) {
+  const fp2* e[6] = {&f->c0.c0, &f->c0.c1, &f->c0.c2, &f->c1.c0, &f->c1.c1, &f->c1.c2};
+  for (int i = 0; i < 6; i++) { fp_to_le(out + 64 * i, &e[i]->a); fp_to_le(out + 64 * i + 32, &e[i]->b); }
+}
+int elpo_pairing(const uint8_t* P_, const uint8_t* Q_, uint8_t* gt) {
+  g1a p; g2a q; fp12 e;
+  if (!g1_load(&p, P_) || !g2_load(&q, Q_)) return 0;
+  pairing(&e, &p, &q); gt_store(gt, &e);
+  return 1;
+}
+
+/* ---- key container: plain copies of the points, no precomputation (reference structure) */
+typedef struct {
+  int A;
+  g1a g, *Yi, hs, g_eg, apk, h, skX;
+  g2a gg, XX, *YYi;
+} elpo_key;
+
+/* g1_bases: (A+6) points in the order of include/elpasso.h (g, Y_i, H1(svc), g_eg, authority_pk, h, X);
+   g2_bases: (A+2) points (gg, XX, YY_i). */
+elpo_key* elpo_key_new(int A, const uint8_t* g1_bases, const uint8_t* g2_bases) {
+  elpo_init();
+  elpo_key* k = (elpo_key*)calloc(1, sizeof *k);
+  k->A = A;
+  k->Yi = (g1a*)calloc(A, sizeof(g1a));
+  k->YYi = (g2a*)calloc(A, sizeof(g2a));
+  int ok = g1_load(&k->g, g1_bases);
+  for (int i = 0; i < A; i++) ok &= g1_load(&k->Yi[i], g1_bases + 64 * (1 + i));
+  ok &= g1_load(&k->hs, g1_bases + 64 * (A + 1));
+  ok &= g1_load(&k->g_eg, g1_bases + 64 * (A + 2));
+  ok &= g1_load(&k->apk, g1_bases + 64 * (A + 3));
+  ok &= g1_load(&k->h, g1_bases + 64 * (A + 4));
+  ok &= g1_load(&k->skX, g1_bases + 64 * (A + 5));
+  ok &= g2_load(&k->gg, g2_bases);
+  ok &= g2_load(&k->XX, g2_bases + 128);
+  for (int i = 0; i < A; i++) ok &= g2_load(&k->YYi[i], g2_bases + 128 * (2 + i));
+  if (!ok) { free(k->Yi); free(k->YYi); free(k); return 0; }
+  return k;
+}
+void elpo_key_free(elpo_key* k) { if (k) { free(k->Yi); free(k->YYi); free(k); } }
+
+static void g1_mul_add(g1j* acc, const g1a* base, const u64* k) { g1j t; g1_mul(&t, base, k); g1_add(acc, acc, &t); }
+static void g2_mul_add(g2j* acc, const g2a* base, const u64* k) { g2j t; g2_mul(&t, base, k); g2_add(acc, acc, &t); }
+static void fr_one_minus(u64 out[4], const u64 c[4]) { /* (1 - c) mod r, c < r */
+  u64 one[4] = {1, 0, 0, 0};
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 t = (u128)one[i] - c[i] - br; out[i] = (u64)t; br = (t >> 64) & 1; }
+  if (br) { u128 cy = 0; for (int i = 0; i < 4; i++) { cy += (u128)out[i] + RORD[i]; out[i] = (u64)cy; cy >>= 64; } }
+}
+static void challenge(u64 out[4], sha256_t* s, const uint8_t* ad, size_t adl) {
+  uint8_t d[32];
+  sha_update(s, ad, adl);
+  sha_final(s, d);                         /* digest_engine.digest(associated_data) */
+  set_hash_of(out, d, 32, RORD);           /* _local_c.setHashOf(_c_str) */
+}
+
+/* record: sig1 | sig2 | phi | [E1 | E2] | k | c | rs[..] | m[..]   (same as elp_verify_id_batch) */
+int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask, int retr, const uint8_t* ad, size_t adl) {
+  const int A = key->A;
+  int H = 0;
+  for (int i = 0; i < A; i++) H += (hidden_mask >> i) & 1;
+  const int nrs = H + (retr ? 2 : 1);
+  g1a sig1, sig2, phi, E1, E2;
+  g2a kk;
+  const uint8_t* p = rec;
+  int ok = g1_load(&sig1, p); p += 64;
+  ok &= g1_load(&sig2, p); p += 64;
+  ok &= g1_load(&phi, p); p += 64;
+  if (retr) { ok &= g1_load(&E1, p); p += 64; ok &= g1_load(&E2, p); p += 64; }
+  ok &= g2_load(&kk, p); p += 128;
+  if (!ok) return 0;
+  u64 c[4], s[4];
+  k_load(c, p); p += 32;
+  const uint8_t* rs = p; p += 32 * nrs;
+  const uint8_t* ms = p;
+  if (u256_geq(c, RORD)) return 0;                             /* a challenge >= r can never equal the recomputed one */
+  /* V_k = k^c * prod YY_j^{r_j} * gg^{r_t} * XX^{1-c}         ps-verifier.cc:72-88 */
+  g2j Vk;
+  g2_mul(&Vk, &kk, c);
+  int j = 0;
+  for (int i = 0; i < A; i++)
+    if ((hidden_mask >> i) & 1) { k_load(s, rs + 32 * j); j++; g2_mul_add(&Vk, &key->YYi[i], s); }
+  k_load(s, rs + 32 * (retr ? nrs - 2 : nrs - 1));
+  g2_mul_add(&Vk, &key->gg, s);
+  fr_one_minus(s, c);
+  g2_mul_add(&Vk, &key->XX, s);
+  /* V_phi = phi^c * H1(svc)^{r_0}                              ps-verifier.cc:91-96 */
+  g1j Vphi, VE1, VE2;
+  g1_mul(&Vphi, &phi, c);
+  k_load(s, rs);
+  g1_mul_add(&Vphi, &key->hs, s);
+  if (retr) {
+    u64 re[4];
+    k_load(re, rs + 32 * (nrs - 1));
+    g1_mul(&VE1, &E1, c); g1_mul_add(&VE1, &key->g_eg, re);                 /* :99-101 */
+    g1_mul(&VE2, &E2, c); g1_mul_add(&VE2, &key->apk, re);                  /* :104-108 */
+    k_load(s, rs + 32); g1_mul_add(&VE2, &key->h, s);
+  }
+  /* c' = Hr(SHA256(hex(k) hex(phi) [hex(E1) hex(E2)] hex(V_k) hex(V_phi) [hex(V_E1) hex(V_E2)] ad))   :111-122 */
+  sha256_t sh;
+  uint8_t b1[32], b2[64];
+  g2a aVk; g1a a1;
+  sha_init(&sh);
+  g2_ser(b2, &kk); sha_update_hex(&sh, b2, 64);
+  g1_ser(b1, &phi); sha_update_hex(&sh, b1, 32);
+  if (retr) { g1_ser(b1, &E1); sha_update_hex(&sh, b1, 32); g1_ser(b1, &E2); sha_update_hex(&sh, b1, 32); }
+  g2_to_aff(&aVk, &Vk); g2_ser(b2, &aVk); sha_update_hex(&sh, b2, 64);
+  g1_to_aff(&a1, &Vphi); g1_ser(b1, &a1); sha_update_hex(&sh, b1, 32);
+  if (retr) {
+    g1_to_aff(&a1, &VE1); g1_ser(b1, &a1); sha_update_hex(&sh, b1, 32);
+    g1_to_aff(&a1, &VE2); g1_ser(b1, &a1); sha_update_hex(&sh, b1, 32);
+  }
+  u64 c2[4];
+  challenge(c2, &sh, ad, adl);
+  if (memcmp(c2, c, 32) != 0) return 0;                                    /* :128-130 */
+  /* K = k * prod_{revealed} YY_i^{m_i} ; e(sig1, K) == e(sig2, gg)         :133-137, :214-229 */
+  g2j K;
+  g2_from_aff(&K, &kk);
+  j = 0;
+  for (int i = 0; i < A; i++)
+    if (!((hidden_mask >> i) & 1)) { k_load(s, ms + 32 * j); j++; g2_mul_add(&K, &key->YYi[i], s); }
+  g2a aK;
+  g2_to_aff(&aK, &K);
+  fp12 lhs, rhs;
+  pairing(&lhs, &sig1, &aK);
+  pairing(&rhs, &sig2, &key->gg);
+  return fp12_eq(&lhs, &rhs);
+}
+
+/* record: sig1 | sig2 | m[nattr]        ps-verifier.cc:13-35 */
+int elpo_ps_verify(const elpo_key* key, const uint8_t* rec, int nattr) {
+  g1a sig1, sig2;
+  if (!g1_load(&sig1, rec) || !g1_load(&sig2, rec + 64)) return 0;
+  if (sig1.inf) return 0;
+  g2j K;
+  g2_from_aff(&K, &key->XX);
+  u64 s[4];
+  for (int i = 0; i < nattr; i++) { k_load(s, rec + 128 + 32 * i); g2_mul_add(&K, &key->YYi[i], s); }
+  g2a aK;
+  g2_to_aff(&aK, &K);
+  fp12 lhs, rhs;
+  pairing(&lhs, &sig1, &aK);
+  pairing(&rhs, &sig2, &key->gg);
+  return fp12_eq(&lhs, &rhs);
+}
+
+/* record: A | c | rs[H+1] | m[A-H] | u ; out: sig1 | sig2        ps-signer.cc:63-146 */
+int elpo_provide_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask, const uint8_t* ad, size_t adl, uint8_t* out) {
+  const int A = key->A;
+  int H = 0;
+  for (int i = 0; i < A; i++) H += (hidden_mask >> i) & 1;
+  memset(out, 0, 128);
+  g1a Ac;
+  if (!g1_load(&Ac, rec)) return 0;
+  const uint8_t* p = rec + 64;
+  u64 c[4], s[4], u[4];
+  k_load(c, p); p += 32;
+  const uint8_t* rs = p; p += 32 * (H + 1);
+  const uint8_t* ms = p; p += 32 * (A - H);
+  k_load(u, p);
+  g1j V;
+  g1_mul(&V, &Ac, c);                                                     /* :83 */
+  k_load(s, rs); g1_mul_add(&V, &key->g, s);                              /* :85-86 */
+  int j = 1;
+  for (int i = 0; i < A; i++)
+    if ((hidden_mask >> i) & 1) { k_load(s, rs + 32 * j); j++; g1_mul_add(&V, &key->Yi[i], s); }   /* :88-94 */
+  sha256_t sh;
+  uint8_t b1[32];
+  g1a aV;
+  sha_init(&sh);
+  g1_ser(b1, &Ac); sha_update_hex(&sh, b1, 32);
+  g1_to_aff(&aV, &V); g1_ser(b1, &aV); sha_update_hex(&sh, b1, 32);
+  u64 c2[4];
+  challenge(c2, &sh, ad, adl);
+  if (memcmp(c2, c, 32) != 0) return 0;                                   /* :106-108 */
+  g1j Ap;
+  g1_from_aff(&Ap, &Ac);
+  if (A != 1) {                                                           /* quirk :115-117 */
+    j = 0;
+    for (int i = 0; i < A; i++)
+      if (!((hidden_mask >> i) & 1)) { k_load(s, ms + 32 * j); j++; g1_mul_add(&Ap, &key->Yi[i], s); }
+  }
+  g1j s1, s2, X;
+  g1_mul(&s1, &key->g, u);                                                /* :138 */
+  g1_from_aff(&X, &key->skX);
+  g1_add(&Ap, &Ap, &X);                                                   /* :140 */
+  g1a aAp, r1, r2;
+  g1_to_aff(&aAp, &Ap);
+  g1_mul(&s2, &aAp, u);                                                   /* :141 */
+  g1_to_aff(&r1, &s1); g1_to_aff(&r2, &s2);
+  g1_store(out, &r1); g1_store(out + 64, &r2);
+  return 1;
+}
+
+/* batch drivers for the CPU baseline (OpenMP over items when available) */
+long elpo_verify_id_batch(const elpo_key* key, long n, const uint8_t* recs, size_t stride, uint64_t mask, int retr,
+                          const uint8_t* ad, size_t adl, uint8_t* flags, int nthreads) {
+  long acc = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : acc)
+#endif
+  for (long i = 0; i < n; i++) {
+    int ok = elpo_verify_id(key, recs + (size_t)i * stride, mask, retr, ad, adl);
+    if (flags) flags[i] = (uint8_t)ok;
+    acc += ok;
+  }
+  (void)nthreads;
+  return acc;
+}

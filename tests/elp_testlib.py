@@ -115,3 +115,39 @@ def twin():
         for n in ("twin_bn254_ctx_new",):
             getattr(_twin, n).restype = ctypes.c_void_p
     return _twin
+
+
+_oracle = None
+
+
+def oracle():
+    """The C oracle (oracle/elp_oracle.c), built on demand with the recipe in oracle/Makefile."""
+    global _oracle
+    if _oracle is None:
+        import subprocess
+        od = os.path.join(ROOT, "oracle")
+        so = os.path.join(od, "libelp_oracle.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(od, "elp_oracle.c")):
+            subprocess.check_call(["make", "-C", od, "-s"])
+        L = ctypes.CDLL(so)
+        L.elpo_key_new.restype = ctypes.c_void_p
+        L.elpo_key_new.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+        L.elpo_key_free.argtypes = [ctypes.c_void_p]
+        L.elpo_verify_id.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        L.elpo_ps_verify.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        L.elpo_provide_id.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.elpo_verify_id_batch.restype = ctypes.c_long
+        L.elpo_verify_id_batch.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64,
+                                           ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        L.elpo_hash_to_g1.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.elpo_fr_set_hash_of.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.elpo_init()
+        _oracle = L
+    return _oracle
+
+
+def oracle_key(m, pk, **kw):
+    L = oracle()
+    h = L.elpo_key_new(len(pk.Yi), g1_bases(m, pk, **kw), g2_bases(m, pk))
+    assert h, "oracle rejected the key"
+    return ctypes.c_void_p(h)
