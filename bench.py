@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- EL PASSO RP verifications/s (el_passo_verify_id, 8 attributes, 4 hidden) on N MI355X.
+
+One "step" = one pass of the hot path (the fused verify_id kernel) over one batch of 65 536 synthetic proofs per GPU,
+records already resident in HBM, followed by the RCCL count all-reduce.  Shards are independent (weak scaling).
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "ps-signature-and-el-passo_amd"
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU per step")
+    ap.add_argument("--attrs", type=int, default=8)
+    ap.add_argument("--hidden", type=int, default=4)
+    ap.add_argument("--window", type=int, default=0, help="fixed-base window bits (0 = library default)")
+    ap.add_argument("--cpu-sample", type=int, default=1536, help="items timed on the CPU oracle (0 disables)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
+    A, H, B = args.attrs, args.hidden, args.batch
+    t_setup = time.time()
+    wl = synth.Workload(ctx, A, seed=20211, window_bits=args.window)
+    recs, mask, expect = wl.verify_id_batch(B, H, first_item=rank * B, with_retrieval=True)
+    t_setup = time.time() - t_setup
+    rsz = len(recs) // B
+    host = np.frombuffer(recs, dtype=np.uint8)
+    d_rec = torch.from_numpy(host.copy()).to(dev)
+    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    d_flags = torch.zeros(B, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        d_cnt.zero_()
+        ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, B, d_rec.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(wl.ad),
+                                                 d_flags.data_ptr(), d_cnt.data_ptr()))
+        if world > 1:
+            dist.all_reduce(d_cnt, op=dist.ReduceOp.SUM)     # the only collective: accepted-count over xGMI
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    total_accepted = int(d_cnt.item())
+    flags = d_flags.cpu().numpy()
+    shard_ok = bool((flags == expect).all())
+    exp_total = torch.tensor([int(expect.sum())], dtype=torch.int64, device=dev)
+    ok_all = torch.tensor([1 if shard_ok else 0], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(exp_total, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    parity_ok = bool(ok_all.item()) and total_accepted == int(exp_total.item())
+
+    # dominant-kernel duration with HIP events on the launch stream (same kernel, same data)
+    ms = ctypes.c_float()
+    ctx._chk(ctx.lib.elp_time_verify_id_dev(ctx.h, stream, max(1, args.steps), B, d_rec.data_ptr(), mask, 1, d_ad.data_ptr(), None,
+                                            len(wl.ad), d_flags.data_ptr(), d_cnt.data_ptr(), ctypes.byref(ms)))
+    kern_ms = float(ms.value)
+    algo_bytes_per_item = rsz + 4                   # affine inputs + 4-byte verdict (804 B at A=8, BN254)
+    achieved = B * algo_bytes_per_item / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # per-launch HBM bytes from the PMC passes, if recorded
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("k_verify_id_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "EL PASSO credential verifications/sec (8 attrs)",
+            "value": value, "unit": "verifications/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "batch of %d EL PASSO RP el_passo_verify_id per GPU, %d attributes with %d hidden, id-retrieval, "
+                                   "curve BN254 (the reference's actual mcl default; golden-vector pinned)" % (B, A, H),
+                       "batch_per_gpu": B, "attrs": A, "hidden": H, "curve": "BN254", "window_bits": wl.ctx.lib and (args.window or 8),
+                       "parallelism": "independent shards x%d + RCCL count all-reduce" % world},
+            "parity_ok": parity_ok, "accepted": total_accepted, "expected_accepted": int(exp_total.item()),
+            "setup_s": t_setup,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_verify_id", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
+                         "note": "integer-VALU bound path: see valu_bound"},
+        }
+        # secondary ceiling: modular multiplications/s of this kernel vs the fp_mul micro-benchmark (same limb code)
+        try:
+            fm = ctypes.c_float()
+            lanes, iters = 256 * 4 * 64 * 8, 1000
+            ctx._chk(ctx.lib.elp_bench_fp_mul(ctx.h, lanes, iters, ctypes.byref(fm)))
+            out["valu_bound"] = {"fp_mul_peak_per_s": lanes * iters * 2 / (fm.value * 1e-3), "unit": "modmul/s",
+                                 "note": "Montgomery products/s of the fp_mul micro-benchmark at 8 waves/SIMD"}
+        except Exception as e:  # pragma: no cover
+            out["valu_bound"] = {"error": str(e)}
+
+    if rank == 0 and world == 1:
+        # PCIe-inclusive rate (host buffers in, flags out) -- reported, never the headline value
+        t1 = time.perf_counter()
+        fl2, cnt2 = ctx.verify_id_batch(recs, mask, True, wl.ad)
+        out["pcie_inclusive_value"] = B / (time.perf_counter() - t1)
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(args.cpu_sample, B))
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit(3)
+
+
+def cpu_baseline(wl, ctx, recs, rsz, mask, gpu_flags, sample):
+    """The C oracle (reference-structure restatement, oracle/elp_oracle.c) timed on the host cores over the first `sample`
+    items of the same workload; its verdicts are also compared with the GPU's."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from elp_testlib import oracle
+    L = oracle()
+    A = wl.A
+    g1 = wl.g + wl.Yi + ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+    g2 = wl.gg + wl.XX + wl.YYi
+    key = ctypes.c_void_p(L.elpo_key_new(A, g1, g2))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    fl = np.zeros(sample, dtype=np.uint8)
+    t0 = time.perf_counter()
+    acc = L.elpo_verify_id_batch(key, sample, recs[:sample * rsz], rsz, mask, 1, wl.ad, len(wl.ad), fl.ctypes.data, cores)
+    dt = time.perf_counter() - t0
+    # single-thread rate on a smaller slice
+    s1 = max(8, sample // (4 * cores))
+    t0 = time.perf_counter()
+    L.elpo_verify_id_batch(key, s1, recs[:s1 * rsz], rsz, mask, 1, wl.ad, len(wl.ad), None, 1)
+    dt1 = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "verifications/s", "cores": cores, "kind": "port",
+            "sample": "first %d items of the same batch, C oracle in reference structure (one scalar-mult per term, two full "
+                      "pairings), OpenMP over items" % sample,
+            "single_thread_value": s1 / dt1, "agrees_with_gpu": bool((fl == gpu_flags[:sample]).all()), "accepted": int(acc)}
+
+
+if __name__ == "__main__":
+    main()

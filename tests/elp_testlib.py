@@ -151,3 +151,87 @@ def oracle_key(m, pk, **kw):
     h = L.elpo_key_new(len(pk.Yi), g1_bases(m, pk, **kw), g2_bases(m, pk))
     assert h, "oracle rejected the key"
     return ctypes.c_void_p(h)
+
+
+class OracleBackedCtx:
+    """Stand-in for elpasso.Context in CPU tests of host-side logic (synthetic generator, host layer): the same method
+    surface, every group operation answered by the C oracle.  Lives in tests/ only."""
+
+    F, G1, G2, GT = 32, 64, 128, 384
+    curve = 0
+
+    def __init__(self):
+        self.L = oracle()
+        self.b1 = {}
+        self.b2 = {}
+        self.A = 0
+
+    def hash_to_g1(self, msgs):
+        out = b""
+        o = ctypes.create_string_buffer(64)
+        for m_ in msgs:
+            self.L.elpo_hash_to_g1(bytes(m_), len(m_), o)
+            out += o.raw
+        return out
+
+    def _mul(self, fn, sz, pts, ks):
+        out = b""
+        o = ctypes.create_string_buffer(sz)
+        for i in range(len(pts) // sz):
+            assert fn(pts[i * sz:(i + 1) * sz], ks[32 * i:32 * i + 32], o)
+            out += o.raw
+        return out
+
+    def g1_mul(self, pts, ks):
+        return self._mul(self.L.elpo_g1_mul, 64, pts, ks)
+
+    def g2_mul(self, pts, ks):
+        return self._mul(self.L.elpo_g2_mul, 128, pts, ks)
+
+    def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
+        A = len(Yi) // 64
+        self.A = A
+        self.b1 = {0: g}
+        for i in range(A):
+            self.b1[1 + i] = Yi[64 * i:64 * i + 64]
+        self.b2 = {0: gg, 1: XX}
+        for i in range(A):
+            self.b2[2 + i] = YYi[128 * i:128 * i + 128]
+
+    def set_rp(self, service, apk=None, g=None, h=None):
+        A = self.A
+        self.b1[A + 1] = self.hash_to_g1([service])
+        self.b1[A + 2], self.b1[A + 3], self.b1[A + 4] = g or bytes(64), apk or bytes(64), h or bytes(64)
+
+    def set_signer_secret(self, X):
+        self.b1[self.A + 5] = X
+
+    def _msm(self, bases, mulfn, addfn, sz, ids, scalars):
+        nt = len(ids)
+        n = len(scalars) // (32 * nt)
+        out = b""
+        o = ctypes.create_string_buffer(sz)
+        for i in range(n):
+            acc = bytes(sz)
+            for t, b in enumerate(ids):
+                k = scalars[32 * (i * nt + t):32 * (i * nt + t) + 32]
+                assert mulfn(bases[b], k, o)
+                term = o.raw
+                assert addfn(acc, term, o)
+                acc = o.raw
+            out += acc
+        return out
+
+    def g1_msm_fixed(self, ids, scalars):
+        return self._msm(self.b1, self.L.elpo_g1_mul, self.L.elpo_g1_add, 64, ids, scalars)
+
+    def g2_msm_fixed(self, ids, scalars):
+        return self._msm(self.b2, self.L.elpo_g2_mul, self.L.elpo_g2_add, 128, ids, scalars)
+
+    def key_handle(self):
+        A = self.A
+        g1 = b"".join(self.b1.get(i, bytes(64)) for i in range(A + 6))
+        g2 = b"".join(self.b2[i] for i in range(A + 2))
+        h = self.L.elpo_key_new(A, g1, g2)
+        assert h
+        return ctypes.c_void_p(h)
