@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--attrs", type=int, default=8)
     ap.add_argument("--hidden", type=int, default=4)
     ap.add_argument("--window", type=int, default=0, help="fixed-base window bits (0 = library default)")
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="items timed on the CPU oracle (0 disables)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(1536, 48 x cores))")
     args = ap.parse_args()
 
     import numpy as np
@@ -143,8 +143,10 @@ def main():
         t1 = time.perf_counter()
         fl2, cnt2 = ctx.verify_id_batch(recs, mask, True, wl.ad)
         out["pcie_inclusive_value"] = B / (time.perf_counter() - t1)
-        if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(args.cpu_sample, B))
+        if args.cpu_sample != 0:
+            ncore = len(os.sched_getaffinity(0))
+            samp = args.cpu_sample if args.cpu_sample > 0 else max(1536, 48 * ncore)
+            out["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(samp, B))
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
@@ -174,7 +176,7 @@ def cpu_baseline(wl, ctx, recs, rsz, mask, gpu_flags, sample):
     acc = L.elpo_verify_id_batch(key, sample, recs[:sample * rsz], rsz, mask, 1, wl.ad, len(wl.ad), fl.ctypes.data, cores)
     dt = time.perf_counter() - t0
     # single-thread rate on a smaller slice
-    s1 = max(8, sample // (4 * cores))
+    s1 = min(sample, 96)
     t0 = time.perf_counter()
     L.elpo_verify_id_batch(key, s1, recs[:s1 * rsz], rsz, mask, 1, wl.ad, len(wl.ad), None, 1)
     dt1 = time.perf_counter() - t0
