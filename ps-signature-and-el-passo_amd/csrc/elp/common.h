@@ -20,6 +20,11 @@
 // "Heavy" routines are real (non-inlined) functions on the device: a pairing inlined into one kernel would be
 // several MB of straight-line code; a call hierarchy (fp_mul <- fp2_mul <- fp6_mul <- fp12_mul ...) keeps the
 // hot loop inside the instruction cache.  On the host the attribute does not matter.
+// ELP_FPMUL: linkage of fp_mul/fp_sqr themselves.  -DELP_FPMUL_INLINE=1 inlines the limb code into the Fp2-level leaf
+// functions (no callee-saved register traffic around every product); 0 keeps them as calls.
+#ifndef ELP_FPMUL_INLINE
+#define ELP_FPMUL_INLINE 1
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ELP_HEAVY ELP_HD __attribute__((noinline))
 #define ELP_UNROLL _Pragma("unroll")
@@ -28,6 +33,12 @@
 #define ELP_HEAVY ELP_HD inline
 #define ELP_UNROLL
 #define ELP_NOUNROLL
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) && !ELP_FPMUL_INLINE
+#define ELP_FPMUL ELP_HEAVY
+#else
+#define ELP_FPMUL ELP_INL
 #endif
 
 namespace elp {

@@ -108,7 +108,7 @@ ELP_INL Fp<C> fp_select(bool c, const Fp<C>& a, const Fp<C>& b) {  // c ? a : b
 // Montgomery product a*b*R^-1 mod p.  CIOS, "no-carry" variant (valid because the top word of p has spare
 // bits: BN254 254/256, BLS12-381 381/384): 2N^2 + N multiply-accumulates, no extra accumulator words.
 template <class C>
-ELP_HEAVY Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
+ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
   constexpr int N = C::N;
   u32 t[N];
   ELP_UNROLL
@@ -139,7 +139,7 @@ ELP_HEAVY Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
 }
 
 template <class C>
-ELP_HEAVY Fp<C> fp_sqr(Fp<C> a) {
+ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
   return fp_mul<C>(a, a);
 }
 

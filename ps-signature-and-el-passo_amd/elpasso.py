@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libelpasso_hip.so")
+LIB_PATH = os.environ.get("ELP_LIB") or os.path.join(HERE, "csrc", "libelpasso_hip.so")   # ELP_LIB: A/B builds of the same HIP library
 
 CURVE_BN254 = 0
 CURVE_BLS12_381 = 1
