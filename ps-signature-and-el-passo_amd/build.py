@@ -37,5 +37,40 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+HOST_SOURCES = ["elp_mcl_compat.cc", "ps-encoding.cc", "elp_key.cc", "ps-signer.cc", "ps-requester.cc", "ps-verifier.cc", "host_capi.cc"]
+
+
+def build_host(force=False, verbose=False):
+    """Host C++ protocol layer (PSSigner / PSRequester / PSVerifier over the C-ABI) -> libelpasso_host.so."""
+    build_hip(force=False, verbose=verbose)
+    hd = os.path.join(CSRC, "host")
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= max(_newest([hd, os.path.join(HERE, "..", "include")]), os.path.getmtime(LIB)):
+        return HOST_LIB
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", hd, "-o", HOST_LIB] + [os.path.join(hd, f) for f in HOST_SOURCES] + \
+          ["-L", CSRC, "-lelpasso_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_cpp_tests(verbose=False):
+    """tests/cpp/ps_tests.cc -> build/ps_tests (asserting counterpart of the reference's test/ps-tests.cc)."""
+    build_host(verbose=verbose)
+    root = os.path.abspath(os.path.join(HERE, ".."))
+    out = os.path.join(root, "build", "ps_tests")
+    src = os.path.join(root, "tests", "cpp", "ps_tests.cc")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(HOST_LIB)):
+        return out
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(CSRC, "host"), "-o", out, src, "-L", CSRC, "-lelpasso_host", "-lelpasso_hip",
+           "-Wl,-rpath," + CSRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

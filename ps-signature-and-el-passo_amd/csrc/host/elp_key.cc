@@ -1,0 +1,64 @@
+#include "elp_key.h"
+
+#include <string.h>
+
+ElpKey::ElpKey(const PSPubKey& pk, int device, int window_bits) {
+  if (pk.Yi.size() != pk.YYi.size() || pk.Yi.empty() || pk.Yi.size() > 62) throw std::runtime_error("ElpKey: bad public key shape");
+  nattr_ = pk.Yi.size();
+  elpCheck(nullptr, elp_init(ELP_CURVE_BN254, device, &ctx_), "elp_init");
+  std::vector<uint8_t> yi(64 * nattr_), yyi(128 * nattr_);
+  for (size_t i = 0; i < nattr_; i++) {
+    memcpy(&yi[64 * i], pk.Yi[i].b, 64);
+    memcpy(&yyi[128 * i], pk.YYi[i].b, 128);
+  }
+  int rc = elp_set_pubkey(ctx_, (int)nattr_, pk.g.b, pk.gg.b, pk.XX.b, yi.data(), yyi.data(), window_bits);
+  if (rc != ELP_OK) {
+    std::string msg = elp_last_error(ctx_);
+    elp_destroy(ctx_);
+    ctx_ = nullptr;
+    throw std::runtime_error("elp_set_pubkey failed: " + msg);
+  }
+}
+ElpKey::~ElpKey() {
+  if (ctx_) elp_destroy(ctx_);
+}
+void ElpKey::useRp(const std::string& service, const G1* apk, const G1* g, const G1* h) {
+  G1 zero;
+  const G1& a = apk ? *apk : zero;
+  const G1& gg = g ? *g : zero;
+  const G1& hh = h ? *h : zero;
+  if (rp_set_ && service == rp_service_ && a == rp_apk_ && gg == rp_g_ && hh == rp_h_) return;
+  elpCheck(ctx_, elp_set_rp(ctx_, (const uint8_t*)service.data(), service.size(), apk ? a.b : nullptr, g ? gg.b : nullptr, h ? hh.b : nullptr),
+           "elp_set_rp");
+  rp_set_ = true;
+  rp_service_ = service;
+  rp_apk_ = a;
+  rp_g_ = gg;
+  rp_h_ = hh;
+}
+void ElpKey::useSignerSecret(const G1& X) {
+  if (sk_set_ && X == sk_X_) return;
+  elpCheck(ctx_, elp_set_signer_secret(ctx_, X.b), "elp_set_signer_secret");
+  sk_set_ = true;
+  sk_X_ = X;
+}
+G1 ElpKey::msmG1(const std::vector<int32_t>& ids, const std::vector<Fr>& scalars) const {
+  std::vector<uint8_t> ks(32 * scalars.size());
+  for (size_t i = 0; i < scalars.size(); i++) memcpy(&ks[32 * i], scalars[i].b, 32);
+  G1 out;
+  elpCheck(ctx_, elp_g1_msm_fixed(ctx_, 1, (int)ids.size(), ids.data(), ks.data(), out.b), "elp_g1_msm_fixed");
+  return out;
+}
+G2 ElpKey::msmG2(const std::vector<int32_t>& ids, const std::vector<Fr>& scalars) const {
+  std::vector<uint8_t> ks(32 * scalars.size());
+  for (size_t i = 0; i < scalars.size(); i++) memcpy(&ks[32 * i], scalars[i].b, 32);
+  G2 out;
+  elpCheck(ctx_, elp_g2_msm_fixed(ctx_, 1, (int)ids.size(), ids.data(), ks.data(), out.b), "elp_g2_msm_fixed");
+  return out;
+}
+uint64_t elpHiddenMask(const std::vector<std::string>& attributes) {
+  uint64_t m = 0;
+  for (size_t i = 0; i < attributes.size() && i < 64; i++)
+    if (attributes[i].empty()) m |= 1ull << i;
+  return m;
+}

@@ -1,0 +1,117 @@
+// RP side.  Reference behaviour: src/ps-verifier.cc:13-35 (verify), :37-138 (el_passo_verify_id),
+// :140-212 (..._without_id_retrieval), :231-235 (get_user_name_from_signon_request).
+// Here each call packs fixed-stride records and runs the fused GPU kernel; proofs are grouped by their hidden-attribute
+// pattern so that one launch covers every proof with the same pattern.
+#include "ps-verifier.h"
+
+#include <string.h>
+
+#include <map>
+
+namespace {
+void put(std::vector<uint8_t>& v, const uint8_t* p, size_t n) { v.insert(v.end(), p, p + n); }
+}  // namespace
+
+PSVerifier::PSVerifier(const PSPubKey& pk) : m_pk(pk), m_key(std::make_shared<ElpKey>(pk)) {}
+
+std::vector<bool> PSVerifier::verify_batch(const std::vector<PSCredential>& sigs,
+                                           const std::vector<std::vector<std::string>>& attrs) const {
+  std::vector<bool> out(sigs.size(), false);
+  // group by attribute count (the record stride depends on it)
+  std::map<size_t, std::vector<size_t>> groups;
+  for (size_t i = 0; i < sigs.size(); i++)
+    if (attrs[i].size() <= m_key->attrs()) groups[attrs[i].size()].push_back(i);
+  for (auto& [na, idx] : groups) {
+    std::vector<uint8_t> recs;
+    for (size_t i : idx) {
+      put(recs, sigs[i].sig1.b, 64);
+      put(recs, sigs[i].sig2.b, 64);
+      for (const std::string& a : attrs[i]) {
+        Fr m;
+        m.setHashOf(a);
+        put(recs, m.b, 32);
+      }
+    }
+    std::vector<uint8_t> flags(idx.size());
+    uint64_t acc = 0;
+    elpCheck(m_key->ctx(), elp_ps_verify_batch(m_key->ctx(), idx.size(), recs.data(), (int)na, flags.data(), &acc), "elp_ps_verify_batch");
+    for (size_t j = 0; j < idx.size(); j++) out[idx[j]] = flags[j] != 0;
+  }
+  return out;
+}
+
+bool PSVerifier::verify(const PSCredential& sig, const std::vector<std::string>& all_attributes) const {
+  return verify_batch({sig}, {all_attributes})[0];
+}
+
+std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retr) const {
+  std::vector<bool> out(proofs.size(), false);
+  const size_t A = m_key->attrs();
+  std::map<uint64_t, std::vector<size_t>> groups;
+  for (size_t i = 0; i < proofs.size(); i++) {
+    const IdProof& p = proofs[i];
+    if (retr && (!p.E1.has_value() || !p.E2.has_value())) continue;      // src/ps-verifier.cc:68-70
+    if (p.attributes.size() != A) continue;                               // the reference indexes YYi[i] unchecked (UB); reject
+    uint64_t mask = elpHiddenMask(p.attributes);
+    size_t H = (size_t)__builtin_popcountll(mask);
+    if (p.rs.size() != H + (retr ? 2 : 1) || H < (retr ? 2u : 1u)) continue;
+    groups[mask].push_back(i);
+  }
+  for (auto& [mask, idx] : groups) {
+    std::vector<uint8_t> recs, adbuf;
+    std::vector<uint32_t> adoff(1, 0);
+    for (size_t i : idx) {
+      const IdProof& p = proofs[i];
+      put(recs, p.sig1.b, 64);
+      put(recs, p.sig2.b, 64);
+      put(recs, p.phi.b, 64);
+      if (retr) {
+        put(recs, p.E1->b, 64);
+        put(recs, p.E2->b, 64);
+      }
+      put(recs, p.k.b, 128);
+      put(recs, p.c.b, 32);
+      for (const Fr& r : p.rs) put(recs, r.b, 32);
+      for (const std::string& a : p.attributes)
+        if (!a.empty()) {
+          Fr m;
+          m.setHashOf(a);                                                 // src/ps-verifier.cc:224
+          put(recs, m.b, 32);
+        }
+      put(adbuf, (const uint8_t*)ads[i].data(), ads[i].size());
+      adoff.push_back((uint32_t)adbuf.size());
+    }
+    if (adbuf.empty()) adbuf.push_back(0);
+    std::vector<uint8_t> flags(idx.size());
+    uint64_t acc = 0;
+    elpCheck(m_key->ctx(),
+             elp_verify_id_batch(m_key->ctx(), idx.size(), recs.data(), mask, retr ? 1 : 0, adbuf.data(), adoff.data(), 0, flags.data(), &acc),
+             "elp_verify_id_batch");
+    for (size_t j = 0; j < idx.size(); j++) out[idx[j]] = flags[j] != 0;
+  }
+  return out;
+}
+
+std::vector<bool> PSVerifier::el_passo_verify_id_batch(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads,
+                                                       const std::string& service_name, const G1& authority_pk, const G1& g,
+                                                       const G1& h) const {
+  if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
+  m_key->useRp(service_name, &authority_pk, &g, &h);
+  return verifyIdImpl(proofs, ads, true);
+}
+std::vector<bool> PSVerifier::el_passo_verify_id_without_id_retrieval_batch(const std::vector<IdProof>& proofs,
+                                                                            const std::vector<std::string>& ads,
+                                                                            const std::string& service_name) const {
+  if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
+  m_key->useRp(service_name, nullptr, nullptr, nullptr);
+  return verifyIdImpl(proofs, ads, false);
+}
+bool PSVerifier::el_passo_verify_id(const IdProof& proof, const std::string& associated_data, const std::string& service_name,
+                                    const G1& authority_pk, const G1& g, const G1& h) const {
+  return el_passo_verify_id_batch({proof}, {associated_data}, service_name, authority_pk, g, h)[0];
+}
+bool PSVerifier::el_passo_verify_id_without_id_retrieval(const IdProof& proof, const std::string& associated_data,
+                                                         const std::string& service_name) const {
+  return el_passo_verify_id_without_id_retrieval_batch({proof}, {associated_data}, service_name)[0];
+}
+std::string PSVerifier::get_user_name_from_signon_request(const IdProof& proof) { return proof.phi.getStr(); }

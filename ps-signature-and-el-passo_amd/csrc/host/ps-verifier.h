@@ -1,0 +1,40 @@
+// PSVerifier: same public interface as the reference's src/ps-verifier.h:11-71, evaluated on the GPU
+// (fused kernels behind elp_verify_id_batch / elp_ps_verify_batch), plus batch entry points.
+#ifndef ELP_HOST_PS_VERIFIER_H_
+#define ELP_HOST_PS_VERIFIER_H_
+
+#include <memory>
+
+#include "elp_key.h"
+#include "ps-encoding.h"
+
+class PSVerifier {
+ public:
+  PSVerifier(const PSPubKey& pk);
+
+  bool verify(const PSCredential& sig, const std::vector<std::string>& all_attributes) const;
+
+  bool el_passo_verify_id(const IdProof& proof, const std::string& associated_data, const std::string& service_name,
+                          const G1& authority_pk, const G1& g, const G1& h) const;
+
+  bool el_passo_verify_id_without_id_retrieval(const IdProof& proof, const std::string& associated_data,
+                                               const std::string& service_name) const;
+
+  static std::string get_user_name_from_signon_request(const IdProof& proof);
+
+  // ---- batch entry points (new): one verdict per proof, each with its own associated data
+  std::vector<bool> el_passo_verify_id_batch(const std::vector<IdProof>& proofs, const std::vector<std::string>& associated_data,
+                                             const std::string& service_name, const G1& authority_pk, const G1& g,
+                                             const G1& h) const;
+  std::vector<bool> el_passo_verify_id_without_id_retrieval_batch(const std::vector<IdProof>& proofs,
+                                                                  const std::vector<std::string>& associated_data,
+                                                                  const std::string& service_name) const;
+  std::vector<bool> verify_batch(const std::vector<PSCredential>& sigs, const std::vector<std::vector<std::string>>& all_attributes) const;
+
+ private:
+  std::vector<bool> verifyIdImpl(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retrieval) const;
+  PSPubKey m_pk;
+  std::shared_ptr<ElpKey> m_key;
+};
+
+#endif  // ELP_HOST_PS_VERIFIER_H_

@@ -1,0 +1,156 @@
+// Asserting counterpart of the reference's flow tests (test/ps-tests.cc:10-137, test/encoding-test.cc:120-270), written
+// against the same public API (PSSigner / PSRequester / PSVerifier, messages through the base64 wire codec).  Unlike the
+// reference's programs it fails loudly and adds negative cases.  Needs a GPU: every group operation goes through the C-ABI.
+#include <ps-requester.h>
+#include <ps-signer.h>
+#include <ps-verifier.h>
+
+#include <chrono>
+#include <iostream>
+
+using namespace mcl::bls12;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      std::cout << "FAIL " << __FILE__ << ":" << __LINE__ << ": " #cond "\n"; \
+      g_fail++;                                                              \
+    }                                                                        \
+  } while (0)
+
+template <class T>
+static T roundTrip(T v) {  // through the wire: toBufferString -> base64 -> fromBufferString
+  return T::fromBufferString(PSBuffer::fromBase64(v.toBufferString().toBase64()));
+}
+
+static void test_ps_sign_verify() {
+  G1 g;
+  G2 gg;
+  hashAndMapToG1(g, "abc");
+  hashAndMapToG2(gg, "edf");
+  PSSigner idp(3, g, gg);
+  PSPubKey pk = idp.key_gen();
+  PSRequester user(roundTrip(pk));
+  std::vector<std::tuple<std::string, bool>> attributes{{"secret1", true}, {"secret2", true}, {"plain1", false}};
+  auto request = user.el_passo_request_id(attributes, "hello");
+  PSCredential sig;
+  CHECK(idp.el_passo_provide_id(roundTrip(request), "hello", sig));
+  PSCredential untouched;
+  CHECK(!idp.el_passo_provide_id(request, "other", untouched));
+  CHECK(untouched.sig1.isZero());                        // sig untouched on failure (src/ps-signer.cc:67-70)
+  auto ub = user.unblind_credential(roundTrip(sig));
+  std::vector<std::string> all{"secret1", "secret2", "plain1"};
+  CHECK(user.verify(ub, all));
+  CHECK(!user.verify(sig, all));                         // still blinded
+  auto rnd = user.randomize_credential(ub);
+  CHECK(user.verify(rnd, all));
+  CHECK(!(rnd.sig1 == ub.sig1));
+  PSVerifier rp(pk);
+  CHECK(rp.verify(rnd, all));
+  CHECK(!rp.verify(rnd, {"secret1", "secret2", "plain2"}));
+  PSCredential zero = rnd;
+  zero.sig1.clear();
+  CHECK(!rp.verify(zero, all));                          // src/ps-verifier.cc:16-18
+}
+
+static void test_el_passo(size_t n) {
+  G1 g;
+  G2 gg;
+  hashAndMapToG1(g, "abc");
+  hashAndMapToG2(gg, "edf");
+  PSSigner idp(n, g, gg);
+  auto t0 = std::chrono::steady_clock::now();
+  auto pk = idp.key_gen();
+  auto t1 = std::chrono::steady_clock::now();
+  std::cout << "IDP-KeyGen over " << n << " attributes (incl. GPU table build): "
+            << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << "[us]\n";
+  PSRequester user(pk);
+  std::vector<std::tuple<std::string, bool>> attributes{{"s", true}, {"gamma", true}, {"tp", false}};
+  for (size_t i = 3; i < n; i++) attributes.emplace_back("extra" + std::to_string(i), i % 2 == 0);
+  auto request = user.el_passo_request_id(attributes, "hello");
+  PSCredential sig;
+  CHECK(idp.el_passo_provide_id(request, "hello", sig));
+  auto ub = user.unblind_credential(sig);
+  G1 authority_pk, h;
+  hashAndMapToG1(authority_pk, "ghi");
+  hashAndMapToG1(h, "jkl");
+  t0 = std::chrono::steady_clock::now();
+  auto prove = user.el_passo_prove_id(ub, attributes, "hello", "service", authority_pk, g, h);
+  t1 = std::chrono::steady_clock::now();
+  std::cout << "User-ProveID: " << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << "[us]\n";
+  auto prove2 = user.el_passo_prove_id_without_id_retrieval(ub, attributes, "hello", "service");
+  PSVerifier rp(roundTrip(pk));
+  t0 = std::chrono::steady_clock::now();
+  bool ok = rp.el_passo_verify_id(roundTrip(prove), "hello", "service", authority_pk, g, h);
+  t1 = std::chrono::steady_clock::now();
+  std::cout << "RP-VerifyID (single item): " << std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() << "[us]\n";
+  CHECK(ok);
+  CHECK(rp.el_passo_verify_id_without_id_retrieval(roundTrip(prove2), "hello", "service"));
+  // negative cases
+  CHECK(!rp.el_passo_verify_id(prove, "hellO", "service", authority_pk, g, h));
+  CHECK(!rp.el_passo_verify_id(prove, "hello", "service2", authority_pk, g, h));
+  CHECK(!rp.el_passo_verify_id(prove, "hello", "service", h, g, h));
+  CHECK(!rp.el_passo_verify_id(prove2, "hello", "service", authority_pk, g, h));      // no E1/E2 -> reject (src/ps-verifier.cc:68-70)
+  IdProof bad = prove;
+  G1::add(bad.sig2, bad.sig2, g);
+  CHECK(!rp.el_passo_verify_id(bad, "hello", "service", authority_pk, g, h));
+  bad = prove;
+  bad.attributes[2] = "tq";
+  CHECK(!rp.el_passo_verify_id(bad, "hello", "service", authority_pk, g, h));
+  CHECK(PSVerifier::get_user_name_from_signon_request(prove) == PSVerifier::get_user_name_from_signon_request(prove2));
+  // batch entry point: mixed verdicts, per-item associated data
+  std::vector<IdProof> batch{prove, bad, prove};
+  auto flags = rp.el_passo_verify_id_batch(batch, {"hello", "hello", "nope"}, "service", authority_pk, g, h);
+  CHECK(flags.size() == 3 && flags[0] && !flags[1] && !flags[2]);
+  // attribute count mismatch throws like the reference (src/ps-requester.cc:31-33)
+  bool threw = false;
+  try {
+    auto shorter = attributes;
+    shorter.pop_back();
+    user.el_passo_request_id(shorter, "hello");
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
+static void test_codec() {
+  G1 g;
+  hashAndMapToG1(g, "abc");
+  PSBuffer b;
+  std::vector<std::string> strs{"", "a", std::string(300, 'x')};
+  b.appendStrList(strs);
+  std::vector<std::string> back;
+  CHECK(b.parseStrList(0, back) == b.size() && back == strs);
+  Fr f;
+  f.setHashOf("x");
+  PSBuffer c;
+  c.appendFrElement(f);
+  c.appendG1Element(g);
+  Fr f2;
+  G1 g2;
+  size_t off = c.parseFrElement(0, f2);
+  CHECK(off == 34 && f2 == f);
+  CHECK(c.parseG1Element(off, g2) == 34 && g2 == g);
+  CHECK(c.parseG1Element(0, g2) == 0);                  // type mismatch -> 0
+  for (size_t n : {0u, 1u, 2u, 3u, 4u, 5u, 100u}) {
+    PSBuffer raw;
+    for (size_t i = 0; i < n; i++) raw.push_back((uint8_t)(i * 37 + 1));
+    PSBuffer rt = PSBuffer::fromBase64(raw.toBase64());
+    CHECK(rt == raw);
+  }
+  CHECK(g.getStr().substr(0, 2) == "1 ");
+  G1 z;
+  CHECK(z.getStr() == "0" && z.isZero());
+}
+
+int main() {
+  initPairing();
+  test_codec();
+  test_ps_sign_verify();
+  test_el_passo(3);
+  test_el_passo(8);
+  std::cout << (g_fail ? "FAILED" : "ALL OK") << std::endl;
+  return g_fail ? 1 : 0;
+}
