@@ -45,11 +45,13 @@ def main():
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
+    shard = importlib.import_module(PKG + ".shard")
     ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
     A, H, B = args.attrs, args.hidden, args.batch
     t_setup = time.time()
     wl = synth.Workload(ctx, A, seed=20211, window_bits=args.window)
-    recs, mask, expect = wl.verify_id_batch(B, H, first_item=rank * B, with_retrieval=True)
+    first, count = shard.shard_range(world * B, rank, world)          # weak scaling: B items per rank
+    recs, mask, expect = wl.verify_id_batch(count, H, first_item=first, with_retrieval=True)
     t_setup = time.time() - t_setup
     rsz = len(recs) // B
     host = np.frombuffer(recs, dtype=np.uint8)
@@ -144,7 +146,7 @@ def main():
         fl2, cnt2 = ctx.verify_id_batch(recs, mask, True, wl.ad)
         out["pcie_inclusive_value"] = B / (time.perf_counter() - t1)
         if args.cpu_sample != 0:
-            ncore = len(os.sched_getaffinity(0))
+            ncore = usable_cores()
             samp = args.cpu_sample if args.cpu_sample > 0 else max(1536, 48 * ncore)
             out["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(samp, B))
     if rank == 0:
@@ -154,6 +156,29 @@ def main():
         dist.destroy_process_group()
     if not parity_ok:
         sys.exit(3)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def cpu_baseline(wl, ctx, recs, rsz, mask, gpu_flags, sample):
@@ -167,10 +192,7 @@ def cpu_baseline(wl, ctx, recs, rsz, mask, gpu_flags, sample):
     g1 = wl.g + wl.Yi + ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
     g2 = wl.gg + wl.XX + wl.YYi
     key = ctypes.c_void_p(L.elpo_key_new(A, g1, g2))
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     fl = np.zeros(sample, dtype=np.uint8)
     t0 = time.perf_counter()
     acc = L.elpo_verify_id_batch(key, sample, recs[:sample * rsz], rsz, mask, 1, wl.ad, len(wl.ad), fl.ctypes.data, cores)

@@ -21,6 +21,12 @@ def host():
     b = importlib.import_module("ps-signature-and-el-passo_amd.build")
     L = ctypes.CDLL(b.build_host())
     L.elph_last_error.restype = ctypes.c_char_p
+    c, cp, sz = ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t
+    L.elph_verify_id_b64.argtypes = [cp, cp, cp, cp, c, cp, cp, cp]
+    L.elph_user_name_b64.argtypes = [cp, cp, sz]
+    L.elph_ps_verify_b64.argtypes = [cp, cp, cp]
+    L.elph_prove_id_b64.argtypes = [cp, cp, cp, cp, cp, c, cp, cp, cp, cp, sz, cp, sz]
+    L.elph_request_id_b64.argtypes = [cp, cp, cp, cp, sz, cp, sz]
     assert L.elph_init(0) == 0, L.elph_last_error()
     return L
 
