@@ -26,7 +26,7 @@
 #define ELP_FPMUL_INLINE 1
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-#define ELP_HEAVY ELP_HD __attribute__((noinline))
+#define ELP_HEAVY static ELP_HD __attribute__((noinline))
 #define ELP_UNROLL _Pragma("unroll")
 #define ELP_NOUNROLL _Pragma("nounroll")
 #else
@@ -39,6 +39,16 @@
 #define ELP_FPMUL ELP_HEAVY
 #else
 #define ELP_FPMUL ELP_INL
+#endif
+// ELP_FP2: linkage of fp2_mul / fp2_sqr.  -DELP_FP2_INLINE=1 inlines them into the Fp6-level and point-formula functions,
+// which then keep their Fp2 temporaries in registers instead of passing them through private memory.
+#ifndef ELP_FP2_INLINE
+#define ELP_FP2_INLINE 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !ELP_FP2_INLINE
+#define ELP_FP2 ELP_HEAVY
+#else
+#define ELP_FP2 ELP_INL
 #endif
 
 namespace elp {

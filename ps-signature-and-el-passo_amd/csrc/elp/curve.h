@@ -17,7 +17,8 @@ struct F1 {
   ELP_INL static T sub(const T& a, const T& b) { return fp_sub(a, b); }
   ELP_INL static T dbl(const T& a) { return fp_dbl(a); }
   ELP_INL static T neg(const T& a) { return fp_neg(a); }
-  ELP_INL static bool is_zero(const T& a) { return fp_is_zero(a); }
+  ELP_INL static bool is_zero(const T& a) { return fp_is_zero<C>(a); }
+  ELP_INL static bool is_zero_exact(const T& a) { return fp_is_zero_exact(a); }
   ELP_INL static bool eq(const T& a, const T& b) { return fp_eq(a, b); }
   ELP_INL static T zero() { return fp_zero<C>(); }
   ELP_INL static T one() { return fp_one<C>(); }
@@ -40,6 +41,7 @@ struct F2 {
   ELP_INL static T dbl(const T& a) { return fp2_dbl(a); }
   ELP_INL static T neg(const T& a) { return fp2_neg(a); }
   ELP_INL static bool is_zero(const T& a) { return fp2_is_zero(a); }
+  ELP_INL static bool is_zero_exact(const T& a) { return fp2_is_zero_exact(a); }
   ELP_INL static bool eq(const T& a, const T& b) { return fp2_eq(a, b); }
   ELP_INL static T zero() { return fp2_zero<C>(); }
   ELP_INL static T one() { return fp2_one<C>(); }
@@ -68,7 +70,7 @@ struct Jac {  // Jacobian: (X/Z^2, Y/Z^3); Z == 0 encodes infinity
 
 template <class F>
 ELP_INL bool aff_is_inf(const Aff<F>& p) {
-  return F::is_zero(p.x) && F::is_zero(p.y);
+  return F::is_zero_exact(p.x) && F::is_zero_exact(p.y);
 }
 template <class F>
 ELP_INL void aff_set_inf(Aff<F>& p) {
@@ -76,8 +78,8 @@ ELP_INL void aff_set_inf(Aff<F>& p) {
   p.y = F::zero();
 }
 template <class F>
-ELP_INL bool jac_is_inf(const Jac<F>& p) {
-  return F::is_zero(p.Z);
+ELP_INL bool jac_is_inf(const Jac<F>& p) {   // infinity is always stored with a literally zero Z
+  return F::is_zero_exact(p.Z);
 }
 template <class F>
 ELP_INL void jac_set_inf(Jac<F>& p) {
@@ -133,7 +135,10 @@ ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
   r.Z = Z3;  // Y == 0 never happens on prime-order curves; Z == 0 stays 0
 }
 
-// madd-2007-bl: Jacobian + affine, 7M + 4S, with the exceptional cases handled
+// madd-2007-bl: Jacobian + affine, 7M + 4S, exceptional cases included.  The test "H == 0 (mod p)" (P == +-Q) is free in
+// this representation: H^2 is needed anyway, and a Montgomery product of two multiples of p is LITERALLY zero
+// ((kp * lp + m p)/R with m = -kl p exactly), while H != 0 (mod p) gives H^2 != 0.  So no modular reduction or
+// comparison is needed on the hot path.
 template <class F>
 ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   typedef typename F::T T;
@@ -152,8 +157,9 @@ ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   T S2 = F::mul(F::mul(q.y, p.Z), Z1Z1);
   T H = F::sub(U2, p.X);
   T rr = F::sub(S2, p.Y);
-  if (F::is_zero(H)) {
-    if (F::is_zero(rr)) {
+  T HH = F::sqr(H);
+  if (F::is_zero_exact(HH)) {            // H == 0 (mod p): same x-coordinate
+    if (F::is_zero_exact(F::sqr(rr))) {  // and same y: doubling
       jac_dbl<F>(r, p);
     } else {
       jac_set_inf(r);
@@ -161,7 +167,6 @@ ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
     return;
   }
   rr = F::dbl(rr);
-  T HH = F::sqr(H);
   T I = F::dbl(F::dbl(HH));
   T J = F::mul(H, I);
   T V = F::mul(p.X, I);
@@ -193,8 +198,9 @@ ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   T S2 = F::mul(F::mul(q.Y, p.Z), Z1Z1);
   T H = F::sub(U2, U1);
   T rr = F::sub(S2, S1);
-  if (F::is_zero(H)) {
-    if (F::is_zero(rr)) {
+  T I = F::sqr(F::dbl(H));
+  if (F::is_zero_exact(I)) {             // H == 0 (mod p), see jac_madd
+    if (F::is_zero_exact(F::sqr(rr))) {
       jac_dbl<F>(r, p);
     } else {
       jac_set_inf(r);
@@ -202,7 +208,6 @@ ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     return;
   }
   rr = F::dbl(rr);
-  T I = F::sqr(F::dbl(H));
   T J = F::mul(H, I);
   T V = F::mul(U1, I);
   T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));

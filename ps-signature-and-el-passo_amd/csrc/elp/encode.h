@@ -67,9 +67,9 @@ ELP_HEAVY void g1_serialize(uint8_t* out, const Aff<F1<C>>& p) {
     for (int i = 0; i < C::FBYTES; i++) out[i] = 0;
     return;
   }
-  Fp<C> x = fp_to_std<C>(p.x), y = fp_to_std<C>(p.y);
-  fp_store_le<C>(out, x);
-  if (y.v[0] & 1) out[C::FBYTES - 1] |= 0x80;
+  StdFp<C> x = fp_to_std<C>(p.x), y = fp_to_std<C>(p.y);
+  std_store_le<C>(out, x);
+  if (y.w[0] & 1) out[C::FBYTES - 1] |= 0x80;
 }
 template <class C>
 ELP_HEAVY void g2_serialize(uint8_t* out, const Aff<F2<C>>& p) {
@@ -77,10 +77,10 @@ ELP_HEAVY void g2_serialize(uint8_t* out, const Aff<F2<C>>& p) {
     for (int i = 0; i < 2 * C::FBYTES; i++) out[i] = 0;
     return;
   }
-  Fp<C> xa = fp_to_std<C>(p.x.c0), xb = fp_to_std<C>(p.x.c1), ya = fp_to_std<C>(p.y.c0);
-  fp_store_le<C>(out, xa);
-  fp_store_le<C>(out + C::FBYTES, xb);
-  if (ya.v[0] & 1) out[2 * C::FBYTES - 1] |= 0x80;
+  StdFp<C> xa = fp_to_std<C>(p.x.c0), xb = fp_to_std<C>(p.x.c1), ya = fp_to_std<C>(p.y.c0);
+  std_store_le<C>(out, xa);
+  std_store_le<C>(out + C::FBYTES, xb);
+  if (ya.w[0] & 1) out[2 * C::FBYTES - 1] |= 0x80;
 }
 // Decompression; returns false for x >= p or x not on the curve.  (mcl ignores such failures at
 // src/ps-encoding.cc:192,224; we surface them and let the caller reject the item.)
@@ -98,16 +98,16 @@ ELP_HEAVY bool g1_deserialize(Aff<F1<C>>& p, const uint8_t* in) {
   }
   bool odd = (tmp[C::FBYTES - 1] & 0x80) != 0;
   tmp[C::FBYTES - 1] &= 0x7f;
-  Fp<C> xs = fp_load_le<C>(tmp);
-  if (!fp_std_in_range<C>(xs)) return false;
+  StdFp<C> xs = std_load_le<C>(tmp);
+  if (!std_in_range<C>(xs)) return false;
   Fp<C> x = fp_from_std<C>(xs);
   Fp<C> b;
   ELP_LOAD_FP(b, C::curve_b(i_));
   Fp<C> rhs = fp_add(fp_mul<C>(fp_sqr<C>(x), x), b);
   Fp<C> y;
   if (!fp_sqrt<C>(y, rhs)) return false;
-  Fp<C> ys = fp_to_std<C>(y);
-  if (((ys.v[0] & 1) != 0) != odd) y = fp_neg(y);
+  StdFp<C> ys = fp_to_std<C>(y);
+  if (((ys.w[0] & 1) != 0) != odd) y = fp_neg(y);
   p.x = x;
   p.y = y;
   return true;
@@ -126,16 +126,16 @@ ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in) {
   }
   bool odd = (tmp[2 * C::FBYTES - 1] & 0x80) != 0;
   tmp[2 * C::FBYTES - 1] &= 0x7f;
-  Fp<C> xa = fp_load_le<C>(tmp), xb = fp_load_le<C>(tmp + C::FBYTES);
-  if (!fp_std_in_range<C>(xa) || !fp_std_in_range<C>(xb)) return false;
+  StdFp<C> xa = std_load_le<C>(tmp), xb = std_load_le<C>(tmp + C::FBYTES);
+  if (!std_in_range<C>(xa) || !std_in_range<C>(xb)) return false;
   Fp2<C> x;
   x.c0 = fp_from_std<C>(xa);
   x.c1 = fp_from_std<C>(xb);
   Fp2<C> rhs = fp2_add(fp2_mulv<C>(fp2_sqrv<C>(x), x), F2<C>::curve_b());
   Fp2<C> y;
   if (!fp2_sqrt<C>(y, rhs)) return false;
-  Fp<C> ya = fp_to_std<C>(y.c0);
-  if (((ya.v[0] & 1) != 0) != odd) y = fp2_neg(y);
+  StdFp<C> ya = fp_to_std<C>(y.c0);
+  if (((ya.w[0] & 1) != 0) != odd) y = fp2_neg(y);
   p.x = x;
   p.y = y;
   return true;
@@ -174,10 +174,10 @@ ELP_HEAVY void hash_and_map_to_g1(Aff<F1<C>>& out, const uint8_t* msg, size_t le
   uint8_t d[32];
   sha256_final(s, d);
   // Fp::setHashOf: mask to bitlen(p) bits, clear one more bit if still >= p
-  Fp<C> t = fp_load_le<C>(d);   // BN254: FBYTES == 32
+  StdFp<C> t = std_load_le<C>(d);   // BN254: FBYTES == 32
   const int bits = C::PBITS;
-  if (bits < 32 * C::N) t.v[C::N - 1] &= (u32)((1ull << (bits - 32 * (C::N - 1))) - 1);
-  if (!fp_std_in_range<C>(t)) t.v[C::N - 1] &= (u32)((1ull << (bits - 1 - 32 * (C::N - 1))) - 1);
+  if (bits < 32 * C::N) t.w[C::N - 1] &= (u32)((1ull << (bits - 32 * (C::N - 1))) - 1);
+  if (!std_in_range<C>(t)) t.w[C::N - 1] &= (u32)((1ull << (bits - 1 - 32 * (C::N - 1))) - 1);
   map_to_g1_svdw<C>(out, fp_from_std<C>(t));
 }
 

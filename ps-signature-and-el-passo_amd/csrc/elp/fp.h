@@ -1,149 +1,231 @@
-// Base-field arithmetic Fp: Montgomery form, saturated 32-bit limbs (N = 8 for BN254, 12 for BLS12-381).
+// Base-field arithmetic Fp for gfx950: Montgomery form over UNSATURATED SIGNED limbs.
 //
-// Replaces mcl::FpT (third-parties/mcl, used through G1/G2/pairing at e.g. src/ps-verifier.cc:73-137).
-// The inner MAC  (hi,lo) = a*b + c + d  is written so that hipcc lowers it to v_mad_u64_u32 on gfx950.
+// Replaces mcl::FpT (third-parties/mcl, reached through G1/G2/pairing at e.g. src/ps-verifier.cc:73-137).
+//
+// Why not 32-bit saturated limbs: gfx950 has v_mad_u64_u32 / v_mad_i64_i32 (64-bit accumulate) but no multiply-add with
+// carry-in, and every carry instruction (v_add_co/v_addc_co, v_lshl_add_u64) issues at the same half rate as the
+// multiply itself (profiles/r01_ubench_valu.log); hipcc's saturated CIOS needs ~640 instructions for 120 MACs.
+// Representation used instead (NL limbs, NL = 9 for BN254, 14 for BLS12-381):
+//     value = sum_i v[i] * 2^(30 i),   v[i] signed 32-bit,   "carried" means |v[i]| <= 2^29 + small for i < NL-1
+//     Montgomery radix R = 2^(30 NL) (>= 16 bits above p).
+//   * a product column  sum_{i+j=k} a_i b_j + m_i p_j  of 2 NL terms of magnitude < 2^58 fits a signed 64-bit accumulator,
+//     so a Montgomery product is 2 NL^2 + NL multiply-accumulates and ~4 cheap instructions per column: no carry chains;
+//   * add / sub / neg are limb-wise (sub needs no "+ k p" correction: limbs are signed) followed by one PARALLEL carry pass;
+//   * values are kept modulo p only loosely: |value| may grow to ~2^8 p between multiplications and a product always
+//     returns |value| < ~1.1 p (R/p = 2^16.8), so no conditional subtractions anywhere on the hot path;
+//   * canonical form (for I/O, hashing, equality) = one Montgomery product by 1 + a sequential carry (fp_to_std).
+// Invariants used by the group law: (1) the point at infinity and literal zeros are stored with all limbs exactly 0
+// (fp_is_zero_exact); (2) the Montgomery product of two multiples of p is literally zero, so "x == 0 (mod p)" can be read
+// off x^2 without any reduction (jac_madd); a general modular zero test (fp_is_zero) costs one product and is kept off the
+// hot loops.
 #pragma once
 #include "common.h"
 
 namespace elp {
 
+typedef int32_t i32;
+typedef int64_t i64;
+
 template <class C>
-struct Fp {
-  u32 v[C::N];
+struct Fp {  // Montgomery form, signed radix-2^30 limbs
+  i32 v[C::NL];
 };
+template <class C>
+struct StdFp {  // canonical integer in [0, p) (or any N-word integer before range checking), little-endian 32-bit words
+  u32 w[C::N];
+};
+
+constexpr i32 ELP_LIMB_BITS = 30;
+constexpr i32 ELP_LIMB_HALF = 1 << 29;
+constexpr u32 ELP_LIMB_MASK = (1u << 30) - 1;
+
+// load a generated constant: ELP_LOAD_FP(x, C::curve_b(i_))
+#define ELP_LOAD_FP(dst, expr_i)                               \
+  do {                                                         \
+    ELP_UNROLL                                                 \
+    for (int i_ = 0; i_ < C::NL; i_++) (dst).v[i_] = (expr_i); \
+  } while (0)
 
 template <class C>
 ELP_INL Fp<C> fp_zero() {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::N; i++) r.v[i] = 0;
+  for (int i = 0; i < C::NL; i++) r.v[i] = 0;
   return r;
 }
 template <class C>
 ELP_INL Fp<C> fp_one() {
   Fp<C> r;
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) r.v[i] = C::one(i);
+  ELP_LOAD_FP(r, C::one(i_));
   return r;
 }
+// all limbs literally zero (see the invariant in the header comment)
 template <class C>
-ELP_INL bool fp_is_zero(const Fp<C>& a) {
-  u32 t = 0;
+ELP_INL bool fp_is_zero_exact(const Fp<C>& a) {
+  i32 t = 0;
   ELP_UNROLL
-  for (int i = 0; i < C::N; i++) t |= a.v[i];
+  for (int i = 0; i < C::NL; i++) t |= a.v[i];
   return t == 0;
-}
-template <class C>
-ELP_INL bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
-  u32 t = 0;
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) t |= a.v[i] ^ b.v[i];
-  return t == 0;
-}
-
-// r = a - p if a >= p else a   (a < 2p)
-template <class C>
-ELP_INL void fp_reduce_once(Fp<C>& a) {
-  u32 d[C::N];
-  u64 br = 0;
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) {
-    u64 t = (u64)a.v[i] - C::mod(i) - br;
-    d[i] = (u32)t;
-    br = (t >> 32) & 1;
-  }
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) a.v[i] = br ? a.v[i] : d[i];
-}
-
-template <class C>
-ELP_INL Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
-  Fp<C> r;
-  u64 c = 0;
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) {
-    u64 t = (u64)a.v[i] + b.v[i] + c;
-    r.v[i] = (u32)t;
-    c = t >> 32;
-  }
-  fp_reduce_once(r);  // p has spare top bits: a + b < 2p < 2^(32N), no carry out
-  return r;
-}
-template <class C>
-ELP_INL Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
-  Fp<C> r;
-  u64 br = 0;
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) {
-    u64 t = (u64)a.v[i] - b.v[i] - br;
-    r.v[i] = (u32)t;
-    br = (t >> 32) & 1;
-  }
-  u32 mask = (u32)0 - (u32)br;
-  u64 c = 0;
-  ELP_UNROLL
-  for (int i = 0; i < C::N; i++) {
-    u64 t = (u64)r.v[i] + (C::mod(i) & mask) + c;
-    r.v[i] = (u32)t;
-    c = t >> 32;
-  }
-  return r;
-}
-template <class C>
-ELP_INL Fp<C> fp_neg(const Fp<C>& a) {
-  return fp_sub(fp_zero<C>(), a);
-}
-template <class C>
-ELP_INL Fp<C> fp_dbl(const Fp<C>& a) {
-  return fp_add(a, a);
 }
 template <class C>
 ELP_INL Fp<C> fp_select(bool c, const Fp<C>& a, const Fp<C>& b) {  // c ? a : b
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::N; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  for (int i = 0; i < C::NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
   return r;
 }
 
-// Montgomery product a*b*R^-1 mod p.  CIOS, "no-carry" variant (valid because the top word of p has spare
-// bits: BN254 254/256, BLS12-381 381/384): 2N^2 + N multiply-accumulates, no extra accumulator words.
+// One parallel carry pass: every limb below the top keeps its balanced low 30 bits and receives the carry of its lower
+// neighbour; no dependency chain.  Any int32 input; for |limb| <= 2^31 - 1 the output is |limb| <= 2^29 + 2.
 template <class C>
-ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
-  constexpr int N = C::N;
-  u32 t[N];
+ELP_INL void fp_carry(Fp<C>& a) {
+  i32 c[C::NL];
   ELP_UNROLL
-  for (int i = 0; i < N; i++) t[i] = 0;
-  ELP_UNROLL
-  for (int i = 0; i < N; i++) {
-    u64 acc = (u64)a.v[0] * b.v[i] + t[0];
-    u32 A = (u32)(acc >> 32);
-    u32 t0 = (u32)acc;
-    u32 m = t0 * C::INV;
-    acc = (u64)m * C::mod(0) + t0;
-    u32 Cc = (u32)(acc >> 32);
-    ELP_UNROLL
-    for (int j = 1; j < N; j++) {
-      acc = (u64)a.v[j] * b.v[i] + t[j] + A;
-      A = (u32)(acc >> 32);
-      acc = (u64)m * C::mod(j) + (u32)acc + Cc;
-      t[j - 1] = (u32)acc;
-      Cc = (u32)(acc >> 32);
-    }
-    t[N - 1] = Cc + A;
+  for (int i = 0; i < C::NL - 1; i++) {
+    c[i] = ((a.v[i] >> (ELP_LIMB_BITS - 1)) + 1) >> 1;          // round(a / 2^30) without overflow for any int32 input
+    a.v[i] -= (i32)((u32)c[i] << ELP_LIMB_BITS);
   }
+  ELP_UNROLL
+  for (int i = 1; i < C::NL; i++) a.v[i] += c[i - 1];
+}
+
+template <class C>
+ELP_INL Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < N; i++) r.v[i] = t[i];
-  fp_reduce_once(r);
+  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] + b.v[i];
+  fp_carry(r);
+  return r;
+}
+template <class C>
+ELP_INL Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] - b.v[i];
+  fp_carry(r);
+  return r;
+}
+template <class C>
+ELP_INL Fp<C> fp_neg(const Fp<C>& a) {
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = -a.v[i];
+  return r;
+}
+template <class C>
+ELP_INL Fp<C> fp_dbl(const Fp<C>& a) {
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] * 2;
+  fp_carry(r);
+  return r;
+}
+// lazy variants: no carry pass (caller guarantees the result feeds at most one side of a product, or carries later)
+template <class C>
+ELP_INL Fp<C> fp_add_lazy(const Fp<C>& a, const Fp<C>& b) {
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+template <class C>
+ELP_INL Fp<C> fp_sub_lazy(const Fp<C>& a, const Fp<C>& b) {
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] - b.v[i];
   return r;
 }
 
-template <class C>
-ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
-  return fp_mul<C>(a, a);
+ELP_INL i32 elp_balanced30(u32 x) {  // low 30 bits of x as a signed value in [-2^29, 2^29)
+  return (i32)(x << 2) >> 2;
 }
 
-// a^e for a public exponent given as N limbs through a constexpr accessor (square-and-multiply, MSB first).
+// Weak modular reduction: subtracts round(value / p) * p, estimated from the top limb (error < 2^-13), leaving
+// |value| <= 0.51 p.  Additions never need it (products bound the magnitude); it exists for the few formulas in which a
+// value is carried forward LINEARLY across many steps without passing through a product (Granger-Scott squaring), where
+// the magnitude would otherwise double per step.  ~6 instructions per limb.
+template <class C>
+ELP_INL void fp_reduce_weak(Fp<C>& a) {
+  constexpr int NL = C::NL;
+  const i32 q = (i32)(((i64)a.v[NL - 1] * C::QK + ((i64)1 << (C::QS - 1))) >> C::QS);
+  i64 t = 0;
+  ELP_UNROLL
+  for (int i = 0; i < NL - 1; i++) {
+    t += (i64)a.v[i] - (i64)q * C::modl(i);
+    i32 lo = elp_balanced30((u32)t);
+    a.v[i] = lo;
+    t = (t - lo) >> ELP_LIMB_BITS;
+  }
+  t += (i64)a.v[NL - 1] - (i64)q * C::modl(NL - 1);
+  a.v[NL - 1] = (i32)t;
+}
+
+// Montgomery product a*b*R^-1 (mod p), column-wise with a single signed 64-bit accumulator.
+// Requirements: |a limb| * |b limb| summed over a column stays below 2^62 (true for carried inputs; one of the two may
+// be a lazy sum of two carried values).  Output is carried and |value| < |a||b|/R + 0.51 p.
+template <class C>
+ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
+  constexpr int NL = C::NL;
+  i32 m[NL];
+  Fp<C> r;
+  i64 acc = 0;
+  ELP_UNROLL
+  for (int k = 0; k < NL; k++) {
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i < k; i++) acc += (i64)m[i] * C::modl(k - i);
+    m[k] = elp_balanced30((u32)acc * C::INV30);
+    acc += (i64)m[k] * C::modl(0);
+    acc >>= ELP_LIMB_BITS;                                      // exact: the low 30 bits are zero now
+  }
+  ELP_UNROLL
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
+    i32 lo = elp_balanced30((u32)acc);
+    r.v[k - NL] = lo;
+    acc = (acc - lo) >> ELP_LIMB_BITS;
+  }
+  r.v[NL - 1] = (i32)acc;
+  return r;
+}
+
+// Montgomery square: the symmetric half of the a*a columns is computed once and doubled.
+template <class C>
+ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
+  constexpr int NL = C::NL;
+  i32 m[NL];
+  Fp<C> r;
+  i64 acc = 0;
+  ELP_UNROLL
+  for (int k = 0; k < 2 * NL - 1; k++) {
+    i64 s = 0;
+    ELP_UNROLL
+    for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) s += (i64)a.v[i] * a.v[k - i];
+    acc += 2 * s;
+    if ((k & 1) == 0) acc += (i64)a.v[k / 2] * a.v[k / 2];
+    if (k < NL) {
+      ELP_UNROLL
+      for (int i = 0; i < k; i++) acc += (i64)m[i] * C::modl(k - i);
+      m[k] = elp_balanced30((u32)acc * C::INV30);
+      acc += (i64)m[k] * C::modl(0);
+      acc >>= ELP_LIMB_BITS;
+    } else {
+      ELP_UNROLL
+      for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
+      i32 lo = elp_balanced30((u32)acc);
+      r.v[k - NL] = lo;
+      acc = (acc - lo) >> ELP_LIMB_BITS;
+    }
+  }
+  r.v[NL - 1] = (i32)acc;
+  return r;
+}
+
+// a^e for a public exponent given as N 32-bit words through a constexpr accessor (square-and-multiply, MSB first).
 template <class C, class E>
 ELP_HEAVY Fp<C> fp_pow_const(const Fp<C>& a, E expo) {
   Fp<C> r = fp_one<C>();
@@ -171,6 +253,71 @@ struct ExpPm1d2 {
   ELP_HD u32 operator()(int i) const { return C::pm1d2(i); }
 };
 
+// ---- canonical form.  fp_to_std: Montgomery product by 1 gives a representative in (-0.6 p, 0.6 p); lift to [0, p) and
+// emit 32-bit words.
+template <class C>
+ELP_HEAVY StdFp<C> fp_to_std(const Fp<C>& a) {
+  constexpr int NL = C::NL;
+  Fp<C> one = fp_zero<C>();
+  one.v[0] = 1;
+  Fp<C> t = fp_mul<C>(a, one);
+  // sequential carry to digits in [0, 2^30); the top limb keeps the sign of the value
+  i32 c = 0;
+  for (int i = 0; i < NL - 1; i++) {
+    i32 x = t.v[i] + c;
+    c = x >> ELP_LIMB_BITS;
+    t.v[i] = x & (i32)ELP_LIMB_MASK;
+  }
+  t.v[NL - 1] += c;
+  if (t.v[NL - 1] < 0) {  // negative representative: add p once
+    c = 0;
+    for (int i = 0; i < NL - 1; i++) {
+      i32 x = t.v[i] + C::modl(i) + c;
+      c = x >> ELP_LIMB_BITS;
+      t.v[i] = x & (i32)ELP_LIMB_MASK;
+    }
+    t.v[NL - 1] += C::modl(NL - 1) + c;
+  }
+  StdFp<C> s;
+  for (int j = 0; j < C::N; j++) {  // pack 30-bit digits into 32-bit words
+    int bit = 32 * j, li = bit / 30, sh = bit % 30;
+    u64 x = (u64)(u32)t.v[li] >> sh;
+    int have = 30 - sh;
+    for (int k = li + 1; have < 32 && k < NL; k++, have += 30) x |= (u64)(u32)t.v[k] << have;
+    s.w[j] = (u32)x;
+  }
+  return s;
+}
+// canonical words (value < 2^(32 N), normally < p) -> Montgomery form
+template <class C>
+ELP_HEAVY Fp<C> fp_from_std(const StdFp<C>& s) {
+  constexpr int NL = C::NL;
+  Fp<C> t;
+  for (int i = 0; i < NL; i++) {  // unpack into unsigned 30-bit digits
+    int bit = 30 * i, wi = bit >> 5, sh = bit & 31;
+    u64 x = 0;
+    if (wi < C::N) x = (u64)s.w[wi] >> sh;
+    if (wi + 1 < C::N && sh > 2) x |= (u64)s.w[wi + 1] << (32 - sh);
+    t.v[i] = (i32)((u32)x & ELP_LIMB_MASK);
+  }
+  fp_carry(t);  // balance the digits
+  Fp<C> r2;
+  ELP_LOAD_FP(r2, C::r2(i_));
+  return fp_mul<C>(t, r2);
+}
+// modular zero / equality tests (one product each; keep out of inner loops)
+template <class C>
+ELP_HEAVY bool fp_is_zero(const Fp<C>& a) {
+  StdFp<C> s = fp_to_std<C>(a);
+  u32 t = 0;
+  for (int i = 0; i < C::N; i++) t |= s.w[i];
+  return t == 0;
+}
+template <class C>
+ELP_INL bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
+  return fp_is_zero<C>(fp_sub_lazy(a, b));
+}
+
 template <class C>
 ELP_HEAVY Fp<C> fp_inv(const Fp<C>& a) {  // a^(p-2); inv(0) = 0
   return fp_pow_const<C>(a, ExpPm2<C>());
@@ -184,58 +331,44 @@ ELP_HEAVY bool fp_sqrt(Fp<C>& r, const Fp<C>& a) {
 // Legendre symbol: +1, 0, -1
 template <class C>
 ELP_HEAVY int fp_legendre(const Fp<C>& a) {
-  if (fp_is_zero(a)) return 0;
+  if (fp_is_zero<C>(a)) return 0;
   Fp<C> t = fp_pow_const<C>(a, ExpPm1d2<C>());
   return fp_eq(t, fp_one<C>()) ? 1 : -1;
 }
 
-// ---- conversions.  "std" = canonical integer in [0,p) as N little-endian 32-bit limbs.
+// ---- std-form helpers (plain integers, not field elements)
 template <class C>
-ELP_INL Fp<C> fp_from_std(const Fp<C>& s) {
-  Fp<C> r2;
+ELP_INL bool std_is_zero(const StdFp<C>& a) {
+  u32 t = 0;
   ELP_UNROLL
-  for (int i = 0; i < C::N; i++) r2.v[i] = C::r2(i);
-  return fp_mul<C>(s, r2);
+  for (int i = 0; i < C::N; i++) t |= a.w[i];
+  return t == 0;
 }
 template <class C>
-ELP_INL Fp<C> fp_to_std(const Fp<C>& m) {
-  Fp<C> one = fp_zero<C>();
-  one.v[0] = 1;
-  return fp_mul<C>(m, one);
-}
-// load a generated constant: ELP_LOAD_FP(x, C::curve_b(i_))
-#define ELP_LOAD_FP(dst, expr_i)                          \
-  do {                                                    \
-    ELP_UNROLL                                            \
-    for (int i_ = 0; i_ < C::N; i_++) (dst).v[i_] = (expr_i); \
-  } while (0)
-// little-endian bytes (FBYTES) -> limbs (no reduction)
-template <class C>
-ELP_INL Fp<C> fp_load_le(const uint8_t* b) {
-  Fp<C> r;
-  for (int i = 0; i < C::N; i++)
-    r.v[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
-  return r;
-}
-template <class C>
-ELP_INL void fp_store_le(uint8_t* b, const Fp<C>& a) {
-  for (int i = 0; i < C::N; i++) {
-    b[4 * i] = (uint8_t)a.v[i];
-    b[4 * i + 1] = (uint8_t)(a.v[i] >> 8);
-    b[4 * i + 2] = (uint8_t)(a.v[i] >> 16);
-    b[4 * i + 3] = (uint8_t)(a.v[i] >> 24);
-  }
-}
-// a < p ?
-template <class C>
-ELP_INL bool fp_std_in_range(const Fp<C>& a) {
+ELP_INL bool std_in_range(const StdFp<C>& a) {  // a < p ?
   u64 br = 0;
   ELP_UNROLL
   for (int i = 0; i < C::N; i++) {
-    u64 t = (u64)a.v[i] - C::mod(i) - br;
+    u64 t = (u64)a.w[i] - C::mod(i) - br;
     br = (t >> 32) & 1;
   }
   return br != 0;
+}
+template <class C>
+ELP_INL StdFp<C> std_load_le(const uint8_t* b) {  // FBYTES little-endian bytes
+  StdFp<C> r;
+  for (int i = 0; i < C::N; i++)
+    r.w[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
+  return r;
+}
+template <class C>
+ELP_INL void std_store_le(uint8_t* b, const StdFp<C>& a) {
+  for (int i = 0; i < C::N; i++) {
+    b[4 * i] = (uint8_t)a.w[i];
+    b[4 * i + 1] = (uint8_t)(a.w[i] >> 8);
+    b[4 * i + 2] = (uint8_t)(a.w[i] >> 16);
+    b[4 * i + 3] = (uint8_t)(a.w[i] >> 24);
+  }
 }
 
 }  // namespace elp

@@ -56,16 +56,16 @@ ELP_INL int g2_num_bases(int A) { return A + 2; }
 
 // ---- word-wise loads/stores of std-form values (buffers are 4-byte aligned)
 template <class C>
-ELP_INL Fp<C> fp_load_w(const u32* w) {
-  Fp<C> r;
+ELP_INL StdFp<C> fp_load_w(const u32* w) {
+  StdFp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::N; i++) r.v[i] = w[i];
+  for (int i = 0; i < C::N; i++) r.w[i] = w[i];
   return r;
 }
 template <class C>
-ELP_INL void fp_store_w(u32* w, const Fp<C>& a) {
+ELP_INL void fp_store_w(u32* w, const StdFp<C>& a) {
   ELP_UNROLL
-  for (int i = 0; i < C::N; i++) w[i] = a.v[i];
+  for (int i = 0; i < C::N; i++) w[i] = a.w[i];
 }
 ELP_INL Scalar scalar_load_w(const u32* w) {
   Scalar s;
@@ -75,24 +75,24 @@ ELP_INL Scalar scalar_load_w(const u32* w) {
 // returns false if a coordinate is >= p or the point is not on the curve
 template <class C>
 ELP_HEAVY bool g1_load(Aff<F1<C>>& p, const u32* w) {
-  Fp<C> x = fp_load_w<C>(w), y = fp_load_w<C>(w + C::N);
-  if (fp_is_zero(x) && fp_is_zero(y)) {
+  StdFp<C> x = fp_load_w<C>(w), y = fp_load_w<C>(w + C::N);
+  if (std_is_zero(x) && std_is_zero(y)) {
     aff_set_inf(p);
     return true;
   }
-  if (!fp_std_in_range<C>(x) || !fp_std_in_range<C>(y)) return false;
+  if (!std_in_range<C>(x) || !std_in_range<C>(y)) return false;
   p.x = fp_from_std<C>(x);
   p.y = fp_from_std<C>(y);
   return aff_on_curve<F1<C>>(p);
 }
 template <class C>
 ELP_HEAVY bool g2_load(Aff<F2<C>>& p, const u32* w) {
-  Fp<C> a = fp_load_w<C>(w), b = fp_load_w<C>(w + C::N), c = fp_load_w<C>(w + 2 * C::N), d = fp_load_w<C>(w + 3 * C::N);
-  if (fp_is_zero(a) && fp_is_zero(b) && fp_is_zero(c) && fp_is_zero(d)) {
+  StdFp<C> a = fp_load_w<C>(w), b = fp_load_w<C>(w + C::N), c = fp_load_w<C>(w + 2 * C::N), d = fp_load_w<C>(w + 3 * C::N);
+  if (std_is_zero(a) && std_is_zero(b) && std_is_zero(c) && std_is_zero(d)) {
     aff_set_inf(p);
     return true;
   }
-  if (!fp_std_in_range<C>(a) || !fp_std_in_range<C>(b) || !fp_std_in_range<C>(c) || !fp_std_in_range<C>(d)) return false;
+  if (!std_in_range<C>(a) || !std_in_range<C>(b) || !std_in_range<C>(c) || !std_in_range<C>(d)) return false;
   p.x.c0 = fp_from_std<C>(a);
   p.x.c1 = fp_from_std<C>(b);
   p.y.c0 = fp_from_std<C>(c);
@@ -143,10 +143,10 @@ template <class C, int N1, int N2>
 ELP_HEAVY void batch_zinv(Fp<C>* zi1, const Fp<C>* z1, Fp2<C>* zi2, const Fp2<C>* z2) {
   constexpr int NT = N1 + N2;
   Fp<C> v[NT], pre[NT];
-  for (int i = 0; i < N1; i++) v[i] = fp_is_zero(z1[i]) ? fp_one<C>() : z1[i];
+  for (int i = 0; i < N1; i++) v[i] = fp_is_zero_exact(z1[i]) ? fp_one<C>() : z1[i];
   for (int i = 0; i < N2; i++) {
-    Fp<C> n = fp_add(fp_sqr<C>(z2[i].c0), fp_sqr<C>(z2[i].c1));   // norm
-    v[N1 + i] = fp_is_zero(n) ? fp_one<C>() : n;
+    Fp<C> n = fp_add(fp_sqr<C>(z2[i].c0), fp_sqr<C>(z2[i].c1));   // norm (exactly 0 for the literal zero of infinity)
+    v[N1 + i] = fp_is_zero_exact(n) ? fp_one<C>() : n;
   }
   Fp<C> acc = fp_one<C>();
   for (int i = 0; i < NT; i++) {
@@ -233,7 +233,21 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
 
   // V_k = k^c * prod_{hidden} YY_j^{r_j} * gg^{r_t} * XX^{1-c}          (src/ps-verifier.cc:72-88)
   // K   = k * prod_{revealed} YY_i^{m_i}                                 (src/ps-verifier.cc:214-229)
+  // V_phi = phi^c * H1(service)^{r_0}                                    (src/ps-verifier.cc:91-96)
+  // V_E1 = E1^c * g^{r_eps} ; V_E2 = E2^c * y^{r_eps} * h^{r_1}          (src/ps-verifier.cc:99-108)
   Jac<G2F> Vk, K;
+  Jac<G1F> Vphi, VE1, VE2;
+  const Scalar r_t = scalar_load_w(rs + 8 * (retr ? nrs - 2 : nrs - 1));
+  Scalar one;
+  for (int i = 0; i < 8; i++) one.v[i] = 0;
+  one.v[0] = 1;
+  Scalar cred = c;  // 1 - c mod r (c >= r cannot match the recomputed challenge; reduce defensively)
+  if (scalar_geq_r<C>(cred)) {
+    Scalar rr;
+    for (int i = 0; i < 8; i++) rr.v[i] = C::rmod(i);
+    cred = scalar_sub_mod_r<C>(cred, rr);
+  }
+  const Scalar one_minus_c = scalar_sub_mod_r<C>(one, cred);
   jac_mul_var<G2F>(Vk, kk, c);
   jac_from_aff(K, kk);
   {
@@ -248,26 +262,12 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
       }
     }
   }
-  const Scalar r_t = scalar_load_w(rs + 8 * (retr ? nrs - 2 : nrs - 1));
   acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
-  Scalar one;
-  for (int i = 0; i < 8; i++) one.v[i] = 0;
-  one.v[0] = 1;
-  Scalar cred = c;  // 1 - c mod r (c >= r cannot match the recomputed challenge; reduce defensively)
-  if (scalar_geq_r<C>(cred)) {
-    Scalar rr;
-    for (int i = 0; i < 8; i++) rr.v[i] = C::rmod(i);
-    cred = scalar_sub_mod_r<C>(cred, rr);
-  }
-  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, scalar_sub_mod_r<C>(one, cred));
-
-  // V_phi = phi^c * H1(service)^{r_0}                                     (src/ps-verifier.cc:91-96)
-  Jac<G1F> Vphi, VE1, VE2;
+  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
   jac_mul_var<G1F>(Vphi, phi, c);
   acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), scalar_load_w(rs));
   if (retr) {
     const Scalar r_e = scalar_load_w(rs + 8 * (nrs - 1));
-    // V_E1 = E1^c * g^{r_eps} ; V_E2 = E2^c * y^{r_eps} * h^{r_1}         (src/ps-verifier.cc:99-108)
     jac_mul_var<G1F>(VE1, E1, c);
     acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
     jac_mul_var<G1F>(VE2, E2, c);

@@ -26,8 +26,12 @@ ELP_INL Fp2<C> fp2_one() {
   return r;
 }
 template <class C>
-ELP_INL bool fp2_is_zero(const Fp2<C>& a) {
-  return fp_is_zero(a.c0) && fp_is_zero(a.c1);
+ELP_INL bool fp2_is_zero(const Fp2<C>& a) {          // modular test (two products)
+  return fp_is_zero<C>(a.c0) && fp_is_zero<C>(a.c1);
+}
+template <class C>
+ELP_INL bool fp2_is_zero_exact(const Fp2<C>& a) {    // literal zero limbs
+  return fp_is_zero_exact(a.c0) && fp_is_zero_exact(a.c1);
 }
 template <class C>
 ELP_INL bool fp2_eq(const Fp2<C>& a, const Fp2<C>& b) {
@@ -84,7 +88,7 @@ ELP_INL Fp2<C> fp2_mul_xi(const Fp2<C>& a) {
   return r;
 }
 template <class C>
-ELP_HEAVY void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // Karatsuba, 3 Fp mul
+ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // Karatsuba, 3 Fp mul
   Fp<C> t0 = fp_mul<C>(a.c0, b.c0);
   Fp<C> t1 = fp_mul<C>(a.c1, b.c1);
   Fp<C> s = fp_mul<C>(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
@@ -92,7 +96,7 @@ ELP_HEAVY void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // Karats
   r.c1 = fp_sub(fp_sub(s, t0), t1);
 }
 template <class C>
-ELP_HEAVY void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul
+ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul
   Fp<C> t = fp_mul<C>(a.c0, a.c1);
   Fp<C> u = fp_mul<C>(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1));
   r.c0 = u;
@@ -127,7 +131,7 @@ ELP_HEAVY void fp2_inv(Fp2<C>& r, const Fp2<C>& a) {
 // Square root in Fp2 for p = 3 (mod 4) ("complex method").  Returns false when a is not a square.
 template <class C>
 ELP_HEAVY bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a) {
-  if (fp_is_zero(a.c1)) {
+  if (fp_is_zero<C>(a.c1)) {
     Fp<C> s;
     if (fp_sqrt<C>(s, a.c0)) {
       r.c0 = s;
@@ -430,6 +434,11 @@ ELP_HEAVY void fp12_cyc_sqr(Fp12<C>& r, const Fp12<C>& a) {
   Fp2<C> n4 = fp2_add(fp2_dbl(fp2_sub(B0, z4)), B0);
   Fp2<C> n5 = fp2_add(fp2_dbl(fp2_add(B1, z5)), B1);
   (void)t2; (void)t3; (void)t4;
+  // every output depends linearly on the matching input coefficient (3 A - 2 z): without a reduction the magnitude
+  // would double per squaring (62 consecutive squarings in fp12_exp_absz)
+  fp_reduce_weak(n0.c0); fp_reduce_weak(n0.c1); fp_reduce_weak(n1.c0); fp_reduce_weak(n1.c1);
+  fp_reduce_weak(n2.c0); fp_reduce_weak(n2.c1); fp_reduce_weak(n3.c0); fp_reduce_weak(n3.c1);
+  fp_reduce_weak(n4.c0); fp_reduce_weak(n4.c1); fp_reduce_weak(n5.c0); fp_reduce_weak(n5.c1);
   r.c0.c0 = n0;
   r.c0.c1 = n4;
   r.c0.c2 = n3;

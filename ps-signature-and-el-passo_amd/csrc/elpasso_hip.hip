@@ -225,11 +225,11 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_table_fill(Aff<F>* tbl, const Aff
   table_fill_chunk<F>(win, base, d0, cnt);
 }
 template <class C>
-__global__ void k_lines(const Aff<F2<C>>* gg, LineCoef<C>* out) {
+__global__ void __launch_bounds__(ELP_BLOCK) k_lines(const Aff<F2<C>>* gg, LineCoef<C>* out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) ml_precompute<C>(out, gg[0]);
 }
 template <class C>
-__global__ void k_load_bases(const u32* g1w, int n1, const u32* g2w, int n2, Aff<F1<C>>* b1, Aff<F2<C>>* b2, int* bad) {
+__global__ void __launch_bounds__(ELP_BLOCK) k_load_bases(const u32* g1w, int n1, const u32* g2w, int n2, Aff<F1<C>>* b1, Aff<F2<C>>* b2, int* bad) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n1) {
     if (!g1_load<C>(b1[t], g1w + (size_t)t * 2 * C::N)) {
@@ -245,22 +245,22 @@ __global__ void k_load_bases(const u32* g1w, int n1, const u32* g2w, int n2, Aff
   }
 }
 template <class C>
-__global__ void k_bench_fp_mul(u32* out, int iters, size_t n) {
+__global__ void __launch_bounds__(ELP_BLOCK) k_bench_fp_mul(u32* out, int iters, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fp<C> a, b;
-  for (int k = 0; k < C::N; k++) {
-    a.v[k] = C::one(k) ^ (u32)(i * 2654435761u + k);
-    b.v[k] = C::r2(k) + (u32)i;
+  for (int k = 0; k < C::NL; k++) {
+    a.v[k] = C::one(k);
+    b.v[k] = C::r2(k);
   }
-  a.v[C::N - 1] &= 0x0fffffffu;
-  b.v[C::N - 1] &= 0x0fffffffu;
+  a.v[0] += (i32)(i & 0xffff);
+  b.v[1] -= (i32)(i >> 16);
   for (int it = 0; it < iters; it++) {
     a = fp_mul<C>(a, b);
     b = fp_mul<C>(b, a);
   }
   u32 acc = 0;
-  for (int k = 0; k < C::N; k++) acc ^= a.v[k] ^ b.v[k];
+  for (int k = 0; k < C::NL; k++) acc ^= (u32)a.v[k] ^ (u32)b.v[k];
   out[i] = acc;
 }
 

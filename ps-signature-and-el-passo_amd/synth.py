@@ -89,8 +89,13 @@ class Workload:
         return [b"a%d-%d" % (i, n) for i in range(self.A)]
 
     # ---------------------------------------------------------------------------------------------------------
-    def verify_id_batch(self, n_items, nhidden, first_item=0, with_retrieval=True, corrupt_every=97, corrupt_at=13):
-        """Returns (records bytes, hidden_mask, expected flags np.uint8[n])."""
+    def verify_id_batch(self, n_items, nhidden, first_item=0, with_retrieval=True, corrupt_every=97, corrupt_at=13,
+                        degenerate_items=(), window_bits=8):
+        """Returns (records bytes, hidden_mask, expected flags np.uint8[n]).
+
+        Items listed in `degenerate_items` are VALID proofs whose blinding t is chosen so that k equals the first table
+        entry added while accumulating K = k * prod YY_i^{m_i} (k == d0 * YY_H with d0 the lowest window digit of m_H):
+        the verifier's group law meets the exceptional case P + P and must still accept."""
         ctx, A, H, r = self.ctx, self.A, nhidden, self.r
         x, ys = self.x, self.ys
         N = n_items
@@ -100,6 +105,10 @@ class Workload:
             m = [fr_set_hash_of(a, r) for a in self.attributes(n)]
             nrnd = 4 + H + 2
             u, t, rr, eps, *rest = self._fresh(nrnd)
+            if n in degenerate_items and H < A:
+                d0 = m[H] & ((1 << window_bits) - 1)
+                if d0:
+                    t = (d0 * ys[H] - x - sum(ys[j] * m[j] for j in range(H))) % r
             rho = rest[:H]
             rho_t, rho_e = rest[H], rest[H + 1]
             full = (x + sum(y * mi for y, mi in zip(ys, m))) % r

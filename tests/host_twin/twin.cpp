@@ -147,6 +147,26 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     gt_store<C>(o, g);                                                                                                 \
     return 1;                                                                                                          \
   }                                                                                                                    \
+  /* Fp12 unary/binary ops on std-form tower elements (debug / unit tests): op 0 mul, 1 sqr, 2 inv, 3 frob(n=arg), 4 cyc_sqr, 5 conj, 6 final_exp */ \
+  void pfx##_fp12_op(int op, int arg, const u32* x, const u32* y, u32* o) {                                            \
+    Fp12<C> a, b, r;                                                                                                   \
+    Fp2<C>* ea[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};                                     \
+    Fp2<C>* eb[6] = {&b.c0.c0, &b.c0.c1, &b.c0.c2, &b.c1.c0, &b.c1.c1, &b.c1.c2};                                     \
+    for (int i = 0; i < 6; i++) {                                                                                      \
+      ea[i]->c0 = fp_from_std<C>(fp_load_w<C>(x + (2 * i) * C::N));                                                    \
+      ea[i]->c1 = fp_from_std<C>(fp_load_w<C>(x + (2 * i + 1) * C::N));                                                \
+      eb[i]->c0 = fp_from_std<C>(fp_load_w<C>(y + (2 * i) * C::N));                                                    \
+      eb[i]->c1 = fp_from_std<C>(fp_load_w<C>(y + (2 * i + 1) * C::N));                                                \
+    }                                                                                                                  \
+    if (op == 0) fp12_mul<C>(r, a, b);                                                                                 \
+    else if (op == 1) fp12_sqr<C>(r, a);                                                                               \
+    else if (op == 2) fp12_inv<C>(r, a);                                                                               \
+    else if (op == 3) fp12_frob<C>(r, a, arg);                                                                         \
+    else if (op == 4) fp12_cyc_sqr<C>(r, a);                                                                           \
+    else if (op == 5) fp12_conj(r, a);                                                                                 \
+    else final_exp<C>(r, a);                                                                                           \
+    gt_store<C>(o, r);                                                                                                 \
+  }                                                                                                                    \
   void* pfx##_ctx_new(int A, int W, const u32* g1b, const u32* g2b) {                                                  \
     TwinCtx<C>* c = new TwinCtx<C>();                                                                                  \
     c->b1.resize(A + 6);                                                                                               \

@@ -157,3 +157,28 @@ def test_ps_verify_and_provide_id(L):
             assert L.twin_bn254_ps_verify(ctx, pack_ps_verify(M, want, vals), A) == 0     # still blinded
         else:
             assert out.raw == bytes(128)
+
+
+def test_exceptional_group_law_cases_take_the_exact_path(L):
+    """A valid proof built so that the K accumulation meets P + P: the optimistic (untested) formulas produce a degenerate
+    accumulator, the lane must redo the section with the exact formulas and ACCEPT, like the oracle."""
+    import importlib
+    from elp_testlib import OracleBackedCtx, oracle
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    O = oracle()
+    octx = OracleBackedCtx()
+    A, H = 4, 2
+    wl = synth.Workload(octx, A)
+    n = 4
+    recs, mask, expect = wl.verify_id_batch(n, H, first_item=0, corrupt_every=0, degenerate_items=(1, 2), window_bits=W_TEST)
+    assert list(expect) == [1] * n
+    g1 = b"".join(octx.b1.get(i, bytes(64)) for i in range(A + 6))
+    g2 = b"".join(octx.b2[i] for i in range(A + 2))
+    h = L.twin_bn254_ctx_new(A, W_TEST, g1, g2)
+    assert h
+    okey = octx.key_handle()
+    rsz = len(recs) // n
+    for i in range(n):
+        rec = recs[i * rsz:(i + 1) * rsz]
+        assert O.elpo_verify_id(okey, rec, mask, 1, b"hello", 5) == 1
+        assert L.twin_bn254_verify_id(ctypes.c_void_p(h), rec, ctypes.c_uint64(mask), 1, b"hello", 5) == 1, i
