@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU per step")
     ap.add_argument("--attrs", type=int, default=8)
     ap.add_argument("--hidden", type=int, default=4)
-    ap.add_argument("--window", type=int, default=0, help="fixed-base window bits (0 = library default)")
+    ap.add_argument("--window", type=int, default=12, help="fixed-base window bits of the key tables (library default 8)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(1536, 48 x cores))")
     args = ap.parse_args()
 
@@ -122,7 +122,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "batch of %d EL PASSO RP el_passo_verify_id per GPU, %d attributes with %d hidden, id-retrieval, "
                                    "curve BN254 (the reference's actual mcl default; golden-vector pinned)" % (B, A, H),
-                       "batch_per_gpu": B, "attrs": A, "hidden": H, "curve": "BN254", "window_bits": wl.ctx.lib and (args.window or 8),
+                       "batch_per_gpu": B, "attrs": A, "hidden": H, "curve": "BN254", "window_bits": args.window or 8,
                        "parallelism": "independent shards x%d + RCCL count all-reduce" % world},
             "parity_ok": parity_ok, "accepted": total_accepted, "expected_accepted": int(exp_total.item()),
             "setup_s": t_setup,

@@ -264,6 +264,59 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_bench_fp_mul(u32* out, int iters,
   out[i] = acc;
 }
 
+// Per-routine micro-benchmark: every lane runs `iters` dependent applications of one device routine on lane-private data.
+// op: 0 fp_mul 1 fp_sqr 2 fp2_mul 3 fp2_sqr 4 fp6_mul 5 fp12_mul 6 fp12_sqr 7 fp12_cyc_sqr 8 mul_by_line
+//     9 jac_dbl<G1> 10 jac_madd<G1> 11 jac_add<G1> 12 jac_dbl<G2> 13 jac_madd<G2> 14 jac_add<G2> 15 ml_dbl_step 16 ml_add_step
+//     17 fp_inv 18 fp_add 19 fp2_add
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_bench_op(int op, u32* out, int iters, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp<C> a = fp_one<C>(), b;
+  ELP_LOAD_FP(b, C::r2(i_));
+  a.v[0] += (i32)(i & 0xffff);
+  b.v[1] -= (i32)(i >> 16);
+  Fp2<C> x, y;
+  x.c0 = a; x.c1 = b; y.c0 = b; y.c1 = fp_add(a, b);
+  Fp12<C> f, g;
+  f.c0.c0 = x; f.c0.c1 = y; f.c0.c2 = x; f.c1.c0 = y; f.c1.c1 = x; f.c1.c2 = y;
+  g = f;
+  Aff<F1<C>> p1; p1.x = a; p1.y = b;
+  Jac<F1<C>> j1; j1.X = b; j1.Y = a; j1.Z = fp_add(a, b);
+  Aff<F2<C>> p2; p2.x = x; p2.y = y;
+  Jac<F2<C>> j2; j2.X = y; j2.Y = x; j2.Z = fp2_add(x, y);
+  G2Proj<C> T; T.X = x; T.Y = y; T.Z = fp2_add(x, y);
+  LineCoef<C> l;
+  for (int it = 0; it < iters; it++) {
+    switch (op) {
+      case 0: a = fp_mul<C>(a, b); break;
+      case 1: a = fp_sqr<C>(a); break;
+      case 2: fp2_mul<C>(x, x, y); break;
+      case 3: fp2_sqr<C>(x, x); break;
+      case 4: fp6_mul<C>(f.c0, f.c0, g.c1); break;
+      case 5: fp12_mul<C>(f, f, g); break;
+      case 6: fp12_sqr<C>(f, f); break;
+      case 7: fp12_cyc_sqr<C>(f, f); break;
+      case 8: fp12_mul_by_line<C>(f, x, y, g.c0.c0); break;
+      case 9: jac_dbl<F1<C>>(j1, j1); break;
+      case 10: jac_madd<F1<C>>(j1, j1, p1); break;
+      case 11: { Jac<F1<C>> t = j1; t.X = b; jac_add<F1<C>>(j1, j1, t); } break;
+      case 12: jac_dbl<F2<C>>(j2, j2); break;
+      case 13: jac_madd<F2<C>>(j2, j2, p2); break;
+      case 14: { Jac<F2<C>> t = j2; t.X = y; jac_add<F2<C>>(j2, j2, t); } break;
+      case 15: ml_dbl_step<C>(T, l); T.Z = fp2_add(T.Z, l.c); break;
+      case 16: ml_add_step<C>(T, l, x, y); T.Z = fp2_add(T.Z, l.c); break;
+      case 17: a = fp_inv<C>(a); break;
+      case 18: a = fp_add(a, b); b = fp_sub(b, a); break;
+      default: x = fp2_add(x, y); y = fp2_sub(y, x); break;
+    }
+  }
+  u32 acc = 0;
+  for (int k = 0; k < C::NL; k++)
+    acc ^= (u32)a.v[k] ^ (u32)x.c0.v[k] ^ (u32)f.c0.c0.c0.v[k] ^ (u32)f.c1.c2.c1.v[k] ^ (u32)j1.X.v[k] ^ (u32)j2.Z.c1.v[k] ^ (u32)T.Z.c0.v[k];
+  out[i] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ------------------------------------------------------------------------------------------------------------
@@ -833,6 +886,26 @@ int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const v
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_ms = ms / reps;
+  return ELP_OK;
+}
+
+int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
+  typedef BN254 C;
+  if (!c || !ms || lanes == 0 || op < 0 || op > 19) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf out;
+  HIPCHK(c, out.alloc(lanes * 4));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_bench_op<C>), dim3(grid_for(lanes)), dim3(ELP_BLOCK), 0, c->stream, op, (u32*)out.p, 1, lanes);  // warm-up
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  hipLaunchKernelGGL((k_bench_op<C>), dim3(grid_for(lanes)), dim3(ELP_BLOCK), 0, c->stream, op, (u32*)out.p, iters, lanes);
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  HIPCHK(c, hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return ELP_OK;
 }
 

@@ -50,6 +50,7 @@ _SIGS = {
                                           _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p,
                                           _c.POINTER(_c.c_float)]),
     "elp_bench_fp_mul": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.POINTER(_c.c_float)]),
+    "elp_bench_op": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_int, _c.POINTER(_c.c_float)]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
 

@@ -34,7 +34,7 @@ def main():
     pk, skX = PR.key_gen(g, gg, x, ys)
     apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
     t0 = time.time()
-    ctx.set_pubkey(g1b(pk.g), g2b(pk.gg), g2b(pk.XX), b"".join(g1b(P) for P in pk.Yi), b"".join(g2b(P) for P in pk.YYi), 8)
+    ctx.set_pubkey(g1b(pk.g), g2b(pk.gg), g2b(pk.XX), b"".join(g1b(P) for P in pk.Yi), b"".join(g2b(P) for P in pk.YYi), int(os.environ.get("ELP_W", "8")))
     ctx.set_rp(b"service", g1b(apk), g1b(g), g1b(h))
     print("key setup %.2fs" % (time.time() - t0))
     recs = []

@@ -1,0 +1,52 @@
+"""Scratch GPU probe: per-phase timing of the primitives that make up one verification (host-buffer entry points, so each
+figure includes PCIe copies of the operands; compute dominates at these sizes)."""
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+elp = importlib.import_module("ps-signature-and-el-passo_amd")
+synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    ctx = elp.Context()
+    A = 8
+    wl = synth.Workload(ctx, A, window_bits=int(os.environ.get("ELP_W", "8")))
+    rnd = np.random.RandomState(1)
+    ks = rnd.randint(0, 256, size=N * 32, dtype=np.uint8)
+    ks[31::32] &= 0x1f
+    ks = ks.tobytes()
+
+    def t(name, fn, reps=2):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        dt = (time.perf_counter() - t0) / reps
+        print("%-34s %8.2f ms  (%.0f items/s)" % (name, dt * 1e3, N / dt))
+        return dt
+
+    g1pts = ctx.g1_mul(wl.g * 64, ks[:64 * 32]) * (N // 64)
+    g2pts = ctx.g2_mul(wl.gg * 64, ks[:64 * 32]) * (N // 64)
+    t("g1_mul (variable base)", lambda: ctx.g1_mul(g1pts, ks))
+    t("g2_mul (variable base)", lambda: ctx.g2_mul(g2pts, ks))
+    ks4 = (ks * 4)
+    ks10 = (ks * 10)
+    t("g1_msm_fixed 4 terms", lambda: ctx.g1_msm_fixed([0, 1, 2, 3], ks4))
+    t("g2_msm_fixed 10 terms", lambda: ctx.g2_msm_fixed(list(range(10)), ks10))
+    t("g2_msm_fixed 1 term", lambda: ctx.g2_msm_fixed([0], ks))
+    t("pairing (miller + final exp)", lambda: ctx.pairing(g1pts, g2pts))
+    t("pairing_check 2 pairs", lambda: ctx.pairing_check(2, g1pts * 2, g2pts * 2))
+    t("g1_add", lambda: ctx.g1_add(g1pts, g1pts))
+    t("g2_decompress", lambda: ctx.g2_decompress(synth.g2_wire(g2pts).tobytes()))
+    t("hash_to_g1 (8-byte msgs)", lambda: ctx.hash_to_g1([b"m%07d" % i for i in range(N)]), reps=1)
+
+
+if __name__ == "__main__":
+    main()
