@@ -532,11 +532,37 @@ class Mcl:
 
     # ---- hash to G1 (BN: Shallue-van de Woestijne as in mcl MapTo::calcBN)
     def hash_to_g1(self, msg):
-        assert self.cv.is_bn, "only the BN map is pinned by golden vectors"
-        p, b = self.p, self.cv.b
-        F = self.F
+        if isinstance(msg, str):
+            msg = msg.encode()
+        if not self.cv.is_bn:
+            return self.hash_to_g1_tai(msg)      # BLS12-381: project-defined map (mcl's is unpinned), see csrc/elp/encode.h
         t = self.fp_hash(msg)
         return self.map_to_g1(t)
+
+    def hash_to_g1_tai(self, msg: bytes):
+        """Try-and-increment + cofactor clearing (mirrors hash_and_map_to_g1 for non-BN curves in csrc/elp/encode.h)."""
+        p, b, n = self.p, self.cv.b, self.fb
+        h1 = (self.cv.z - 1) ** 2 // 3
+        ctr = 0
+        while True:
+            d = hashlib.sha256(msg + bytes([ctr & 0xFF, 0])).digest() + hashlib.sha256(msg + bytes([ctr & 0xFF, 1])).digest()
+            ctr += 1
+            x = int.from_bytes(d[:n], "little") & ((1 << p.bit_length()) - 1)
+            if x >= p:
+                x &= (1 << (p.bit_length() - 1)) - 1
+            y = self.F.sqrt((x * x * x + b) % p)
+            if y is None:
+                continue
+            if y & 1:
+                y = p - y
+            R = None
+            for bit in bin(h1)[2:]:
+                R = self.G.g1_add(R, R)
+                if bit == "1":
+                    R = self.G.g1_add(R, (x, y))
+            if R is None:
+                continue
+            return R
 
     def map_to_g1(self, t):
         p, b = self.p, self.cv.b

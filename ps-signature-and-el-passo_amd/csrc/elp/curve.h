@@ -302,21 +302,24 @@ ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scal
   }
 }
 
-// psi-twisted Frobenius on G2 (affine): pi(x, y) = (conj(x) g2, conj(y) g3)  [D-type] (inverse coefficients for M-type)
+// psi^n = twist o Frobenius^n o untwist on G2 (affine): (x, y) -> (conj^n(x) g_x, conj^n(y) g_y), constants per twist type
 template <class C>
 ELP_HEAVY void g2_frob(Aff<F2<C>>& r, const Aff<F2<C>>& q, int n) {
   Fp2<C> x = (n & 1) ? fp2_conj(q.x) : q.x;
   Fp2<C> y = (n & 1) ? fp2_conj(q.y) : q.y;
-  if (C::TWIST_D) {
-    fp2_mul<C>(r.x, x, fp2_frob_coeff<C>(n, 2));
-    fp2_mul<C>(r.y, y, fp2_frob_coeff<C>(n, 3));
+  Fp2<C> gx, gy;
+  if (n == 1) {
+    ELP_LOAD_FP(gx.c0, C::g2frob(1, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(1, 0, 1, i_));
+    ELP_LOAD_FP(gy.c0, C::g2frob(1, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(1, 1, 1, i_));
+  } else if (n == 2) {
+    ELP_LOAD_FP(gx.c0, C::g2frob(2, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(2, 0, 1, i_));
+    ELP_LOAD_FP(gy.c0, C::g2frob(2, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(2, 1, 1, i_));
   } else {
-    Fp2<C> g;
-    fp2_inv<C>(g, fp2_frob_coeff<C>(n, 2));
-    fp2_mul<C>(r.x, x, g);
-    fp2_inv<C>(g, fp2_frob_coeff<C>(n, 3));
-    fp2_mul<C>(r.y, y, g);
+    ELP_LOAD_FP(gx.c0, C::g2frob(3, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(3, 0, 1, i_));
+    ELP_LOAD_FP(gy.c0, C::g2frob(3, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(3, 1, 1, i_));
   }
+  fp2_mul<C>(r.x, x, gx);
+  fp2_mul<C>(r.y, y, gy);
 }
 
 }  // namespace elp

@@ -140,14 +140,16 @@ ELP_INL i32 elp_balanced30(u32 x) {  // low 30 bits of x as a signed value in [-
   return (i32)(x << 2) >> 2;
 }
 
-// Weak modular reduction: subtracts round(value / p) * p, estimated from the top limb (error < 2^-13), leaving
+// Weak modular reduction: subtracts round(value / p) * p, estimated from the top limbs (error < 2^-9), leaving
 // |value| <= 0.51 p.  Additions never need it (products bound the magnitude); it exists for the few formulas in which a
 // value is carried forward LINEARLY across many steps without passing through a product (Granger-Scott squaring), where
 // the magnitude would otherwise double per step.  ~6 instructions per limb.
 template <class C>
 ELP_INL void fp_reduce_weak(Fp<C>& a) {
   constexpr int NL = C::NL;
-  const i32 q = (i32)(((i64)a.v[NL - 1] * C::QK + ((i64)1 << (C::QS - 1))) >> C::QS);
+  i64 top = a.v[C::QI];
+  if (C::QI + 1 < NL) top += (i64)a.v[C::QI + 1] << ELP_LIMB_BITS;
+  const i32 q = (i32)((top * C::QK + ((i64)1 << (C::QS - 1))) >> C::QS);
   i64 t = 0;
   ELP_UNROLL
   for (int i = 0; i < NL - 1; i++) {

@@ -184,18 +184,23 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
   }
 }
 
-// a^|z| for a in the cyclotomic subgroup
+// a^e (e > 0, 64-bit) for a in the cyclotomic subgroup
 template <class C>
-ELP_HEAVY void fp12_exp_absz(Fp12<C>& r, const Fp12<C>& a) {
+ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e) {
   Fp12<C> acc = a;
   int top = 63;
-  while (!((C::ZABS >> top) & 1)) top--;
+  while (!((e >> top) & 1)) top--;
   ELP_NOUNROLL
   for (int i = top - 1; i >= 0; i--) {
     fp12_cyc_sqr<C>(acc, acc);
-    if ((C::ZABS >> i) & 1) fp12_mul<C>(acc, acc, a);
+    if ((e >> i) & 1) fp12_mul<C>(acc, acc, a);
   }
   r = acc;
+}
+// a^|z| for a in the cyclotomic subgroup
+template <class C>
+ELP_INL void fp12_exp_absz(Fp12<C>& r, const Fp12<C>& a) {
+  fp12_exp_u64<C>(r, a, C::ZABS);
 }
 // a^z (signed z) in the cyclotomic subgroup, where inversion is conjugation
 template <class C>
@@ -213,7 +218,7 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in) {
   fp12_mul<C>(f, t1, t0);      // f^(p^6 - 1)
   fp12_frob<C>(t0, f, 2);
   fp12_mul<C>(f, t0, f);       // ^(p^2 + 1)
-  if (C::IS_BN) {
+  if constexpr (C::IS_BN) {
     // Devegili-Scott-Dahab: (p^4-p^2+1)/r = p^3 + (6z^2+1) p^2 + (-36z^3-18z^2-12z+1) p + (-36z^3-30z^2-18z-2)
     // evaluated with the vectorial addition chain  y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36.
     Fp12<C> fz, fz2, fz3, y0, y1, y2, y3, y4, y5, y6, T0, T1, t;
@@ -250,31 +255,24 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in) {
     fp12_cyc_sqr<C>(T0, T0);
     fp12_mul<C>(r, T0, T1);
   } else {
-    // BLS12: (p^4-p^2+1)/r = ((z-1)^2 (z+p)(z^2+p^2-1))/3 + 1 ; we compute the cube-free multiple
-    // 3*(hard part) = (z-1)^2 (z+p)(z^2+p^2-1) + 3  (gcd(3, r) = 1, so ==1 tests and GT equality are preserved).
+    // BLS12 (Hayashida-Hayasaka-Teruya): (p^4-p^2+1)/r = ((z-1)^2/3) (z+p) (z^2+p^2-1) + 1, evaluated exactly:
+    // a = f^((z-1)/3), a = a^(z-1), b = a^(z+p), c = b^(z^2+p^2-1), result = c * f.
     Fp12<C> a, b, c, t;
-    // a = f^((z-1)^2)
-    fp12_exp_z<C>(t, f);
-    fp12_conj(b, f);
-    fp12_mul<C>(a, t, b);                   // f^(z-1)
+    fp12_exp_u64<C>(a, f, C::ZM1D3_ABS);
+    if (C::Z_NEG) fp12_conj(a, a);          // z - 1 < 0 as well
     fp12_exp_z<C>(t, a);
     fp12_conj(b, a);
-    fp12_mul<C>(a, t, b);                   // f^((z-1)^2)
-    // b = a^(z+p)
+    fp12_mul<C>(a, t, b);                   // a^(z-1)
     fp12_exp_z<C>(t, a);
     fp12_frob<C>(b, a, 1);
-    fp12_mul<C>(b, b, t);
-    // c = b^(z^2 + p^2 - 1)
+    fp12_mul<C>(b, b, t);                   // a^(z+p)
     fp12_exp_z<C>(t, b);
     fp12_exp_z<C>(t, t);
     fp12_frob<C>(c, b, 2);
     fp12_mul<C>(c, c, t);
     fp12_conj(t, b);
-    fp12_mul<C>(c, c, t);
-    // * f^3
-    fp12_cyc_sqr<C>(t, f);
-    fp12_mul<C>(t, t, f);
-    fp12_mul<C>(r, c, t);
+    fp12_mul<C>(c, c, t);                   // b^(z^2+p^2-1)
+    fp12_mul<C>(r, c, f);
   }
 }
 

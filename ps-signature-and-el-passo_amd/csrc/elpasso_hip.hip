@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/elpasso.h"
+#include "elp/params_bls12_381.h"
 #include "elp/params_bn254.h"
 #include "elp/pipeline.h"
 
@@ -380,7 +381,7 @@ int elp_field_bytes(int curve) { return curve == ELP_CURVE_BN254 ? 32 : curve ==
 int elp_init(int curve, int device, elp_ctx** out) {
   if (!out) return ELP_ERR_ARG;
   *out = nullptr;
-  if (curve != ELP_CURVE_BN254) return ELP_ERR_ARG;  // BLS12-381 instantiation: see DESIGN.md (next)
+  if (curve != ELP_CURVE_BN254 && curve != ELP_CURVE_BLS12_381) return ELP_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELP_ERR_NODEVICE;
   if (device < 0 || device >= ndev) return ELP_ERR_ARG;
@@ -470,9 +471,9 @@ static int rebuild_key(elp_ctx* c, const uint8_t* g2_bases_std) {
   return ELP_OK;
 }
 
-int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
+template <class C>
+static int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
                    const uint8_t* YYi, int window_bits) {
-  typedef BN254 C;
   if (!c || nattr < 1 || nattr > 62 || !g || !gg || !XX || !Yi || !YYi) return ELP_ERR_ARG;
   if (window_bits == 0) window_bits = 8;
   if (window_bits < 2 || window_bits > 16) return ELP_ERR_ARG;
@@ -498,10 +499,15 @@ int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, c
   c->have_pk = true;
   return ELP_OK;
 }
+int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
+                   const uint8_t* YYi, int window_bits) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_set_pubkey_t<BN254>(c, nattr, g, gg, XX, Yi, YYi, window_bits) : elp_set_pubkey_t<BLS12_381>(c, nattr, g, gg, XX, Yi, YYi, window_bits);
+}
 
-int elp_set_rp(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
+template <class C>
+static int elp_set_rp_t(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
                const uint8_t* h) {
-  typedef BN254 C;
   if (!c) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
@@ -526,9 +532,14 @@ int elp_set_rp(elp_ctx* c, const uint8_t* service_name, size_t service_len, cons
   }
   return rebuild_key<C>(c, nullptr);
 }
+int elp_set_rp(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
+               const uint8_t* h) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_set_rp_t<BN254>(c, service_name, service_len, authority_pk, g, h) : elp_set_rp_t<BLS12_381>(c, service_name, service_len, authority_pk, g, h);
+}
 
-int elp_set_signer_secret(elp_ctx* c, const uint8_t* X) {
-  typedef BN254 C;
+template <class C>
+static int elp_set_signer_secret_t(elp_ctx* c, const uint8_t* X) {
   if (!c || !X) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
@@ -536,6 +547,10 @@ int elp_set_signer_secret(elp_ctx* c, const uint8_t* X) {
   }
   memcpy(c->h_b1.data() + (size_t)(c->A + 5) * Sizes<C>::G1, X, Sizes<C>::G1);
   return rebuild_key<C>(c, nullptr);
+}
+int elp_set_signer_secret(elp_ctx* c, const uint8_t* X) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_set_signer_secret_t<BN254>(c, X) : elp_set_signer_secret_t<BLS12_381>(c, X);
 }
 
 // ---- generic "copy in, launch, copy out" helper for the host-buffer primitives
@@ -569,9 +584,8 @@ static int run_host(elp_ctx* c, const IoSpec* ins, int nin, void* const* outs, c
   return ELP_OK;
 }
 
-template <int G>
-static int decompress_impl(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
-  typedef BN254 C;
+template <class C, int G>
+static int decompress_impl_t(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
   if (!c || (n && (!wire || !out || !ok))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   IoSpec ins[1] = {{wire, n * (size_t)(G * C::FBYTES)}};
@@ -582,6 +596,11 @@ static int decompress_impl(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* o
                        (uint8_t*)po[1], n);
   });
 }
+template <int G>
+static int decompress_impl(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? decompress_impl_t<BN254, G>(c, n, wire, out, ok) : decompress_impl_t<BLS12_381, G>(c, n, wire, out, ok);
+}
 int elp_g1_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
   return decompress_impl<1>(c, n, wire, out, ok);
 }
@@ -589,9 +608,8 @@ int elp_g2_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, u
   return decompress_impl<2>(c, n, wire, out, ok);
 }
 
-template <int G>
-static int mul_impl(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
-  typedef BN254 C;
+template <class C, int G>
+static int mul_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
   if (!c || (n && (!pts || !ks || !out))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
@@ -603,12 +621,16 @@ static int mul_impl(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks,
                        (u32*)po[0], n);
   });
 }
+template <int G>
+static int mul_impl(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? mul_impl_t<BN254, G>(c, n, pts, ks, out) : mul_impl_t<BLS12_381, G>(c, n, pts, ks, out);
+}
 int elp_g1_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<1>(c, n, p, k, o); }
 int elp_g2_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<2>(c, n, p, k, o); }
 
-template <int G>
-static int add_impl(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-  typedef BN254 C;
+template <class C, int G>
+static int add_impl_t(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   if (!c || (n && (!a || !b || !out))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
@@ -620,12 +642,16 @@ static int add_impl(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, ui
                        (u32*)po[0], n);
   });
 }
+template <int G>
+static int add_impl(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? add_impl_t<BN254, G>(c, n, a, b, out) : add_impl_t<BLS12_381, G>(c, n, a, b, out);
+}
 int elp_g1_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<1>(c, n, a, b, o); }
 int elp_g2_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<2>(c, n, a, b, o); }
 
-template <int G>
-static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
-  typedef BN254 C;
+template <class C, int G>
+static int msm_fixed_impl_t(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
   if (!c || nterms < 1 || (n && (!ids || !ks || !out))) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
@@ -645,6 +671,11 @@ static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, 
                        (const u32*)pi[1], (u32*)po[0], n);
   });
 }
+template <int G>
+static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? msm_fixed_impl_t<BN254, G>(c, n, nterms, ids, ks, out) : msm_fixed_impl_t<BLS12_381, G>(c, n, nterms, ids, ks, out);
+}
 int elp_g1_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
   return msm_fixed_impl<1>(c, n, nt, ids, ks, o);
 }
@@ -652,8 +683,8 @@ int elp_g2_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uin
   return msm_fixed_impl<2>(c, n, nt, ids, ks, o);
 }
 
-int elp_hash_to_g1(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
-  typedef BN254 C;
+template <class C>
+static int elp_hash_to_g1_t(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
   if (!c || (n && (!off || !out))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   uint8_t dummy[4] = {0};
@@ -665,9 +696,13 @@ int elp_hash_to_g1(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* of
                        (u32*)po[0], n);
   });
 }
+int elp_hash_to_g1(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_hash_to_g1_t<BN254>(c, n, msgs, off, out) : elp_hash_to_g1_t<BLS12_381>(c, n, msgs, off, out);
+}
 
-int elp_pairing(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
-  typedef BN254 C;
+template <class C>
+static int elp_pairing_t(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
   if (!c || (n && (!g1 || !g2 || !gt))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   IoSpec ins[2] = {{g1, n * Sizes<C>::G1}, {g2, n * Sizes<C>::G2}};
@@ -678,9 +713,13 @@ int elp_pairing(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint
                        (u32*)po[0], n);
   });
 }
+int elp_pairing(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_pairing_t<BN254>(c, n, g1, g2, gt) : elp_pairing_t<BLS12_381>(c, n, g1, g2, gt);
+}
 
-int elp_pairing_check(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
-  typedef BN254 C;
+template <class C>
+static int elp_pairing_check_t(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
   if (!c || npairs < 1 || npairs > 4 || (n && (!g1 || !g2 || !ok))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   IoSpec ins[2] = {{g1, n * npairs * Sizes<C>::G1}, {g2, n * npairs * Sizes<C>::G2}};
@@ -698,6 +737,10 @@ int elp_pairing_check(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const
     }
   });
 }
+int elp_pairing_check(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_pairing_check_t<BN254>(c, n, npairs, g1, g2, ok) : elp_pairing_check_t<BLS12_381>(c, n, npairs, g1, g2, ok);
+}
 
 // ---- fused batches
 static int popcount_mask(uint64_t m, int A) {
@@ -706,14 +749,17 @@ static int popcount_mask(uint64_t m, int A) {
   return h;
 }
 size_t elp_verify_id_record_size(int curve, int A, int H, int retr) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)verify_id_record_words<BLS12_381>(A, H, retr != 0);
   if (curve != ELP_CURVE_BN254) return 0;
   return 4 * (size_t)verify_id_record_words<BN254>(A, H, retr != 0);
 }
 size_t elp_ps_verify_record_size(int curve, int A) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)(4 * BLS12_381::N + 8 * A);
   if (curve != ELP_CURVE_BN254) return 0;
   return 4 * (size_t)(4 * BN254::N + 8 * A);
 }
 size_t elp_provide_id_record_size(int curve, int A, int H) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)provide_id_record_words<BLS12_381>(A, H);
   if (curve != ELP_CURVE_BN254) return 0;
   return 4 * (size_t)provide_id_record_words<BN254>(A, H);
 }
@@ -728,9 +774,9 @@ static int check_fused(elp_ctx* c, uint64_t mask) {
   return ELP_OK;
 }
 
-int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+template <class C>
+static int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
                             const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  typedef BN254 C;
   int rc = check_fused(c, mask);
   if (rc) return rc;
   if (n == 0) return ELP_OK;
@@ -743,8 +789,13 @@ int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_re
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
-int elp_ps_verify_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
-  typedef BN254 C;
+int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+                            const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_verify_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted) : elp_verify_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+}
+template <class C>
+static int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, 0);
   if (rc) return rc;
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
@@ -754,9 +805,13 @@ int elp_ps_verify_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_re
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
-int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+int elp_ps_verify_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_ps_verify_batch_dev_t<BN254>(c, stream, n, d_records, nattr, d_flags, d_accepted) : elp_ps_verify_batch_dev_t<BLS12_381>(c, stream, n, d_records, nattr, d_flags, d_accepted);
+}
+template <class C>
+static int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
                              const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
-  typedef BN254 C;
   int rc = check_fused(c, mask);
   if (rc) return rc;
   if (n == 0) return ELP_OK;
@@ -767,6 +822,11 @@ int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_r
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
+}
+int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+                             const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted) : elp_provide_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted);
 }
 
 // host-buffer wrappers: stage inputs, call the _dev entry point on the context stream, copy results back
@@ -837,9 +897,9 @@ int elp_ps_verify_batch(elp_ctx* c, size_t n, const uint8_t* records, int nattr,
   return ELP_OK;
 }
 
-int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
+template <class C>
+static int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
                          size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
-  typedef BN254 C;
   int rc = check_fused(c, mask);
   if (rc) return rc;
   if (accepted) *accepted = 0;
@@ -867,6 +927,11 @@ int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t 
   if (accepted) *accepted = cnt;
   return ELP_OK;
 }
+int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
+                         size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_t<BN254>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted) : elp_provide_id_batch_t<BLS12_381>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted);
+}
 
 int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const void* d_records, uint64_t mask, int retr,
                            const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted, float* avg_ms) {
@@ -889,8 +954,8 @@ int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const v
   return ELP_OK;
 }
 
-int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
-  typedef BN254 C;
+template <class C>
+static int elp_bench_op_t(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
   if (!c || !ms || lanes == 0 || op < 0 || op > 19) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf out;
@@ -908,9 +973,13 @@ int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
   (void)hipEventDestroy(e1);
   return ELP_OK;
 }
+int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_bench_op_t<BN254>(c, op, lanes, iters, ms) : elp_bench_op_t<BLS12_381>(c, op, lanes, iters, ms);
+}
 
-int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
-  typedef BN254 C;
+template <class C>
+static int elp_bench_fp_mul_t(elp_ctx* c, size_t lanes, int iters, float* ms) {
   if (!c || !ms || lanes == 0) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf out;
@@ -927,5 +996,9 @@ int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return ELP_OK;
+}
+int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_bench_fp_mul_t<BN254>(c, lanes, iters, ms) : elp_bench_fp_mul_t<BLS12_381>(c, lanes, iters, ms);
 }
 

@@ -22,6 +22,16 @@ GG_BN254 = bytes.fromhex(
     "bd866ad84d3fd1320a")
 
 
+R_BLS12_381 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+# standard BLS12-381 G2 generator (affine x.a | x.b | y.a | y.b, 48-byte little-endian coordinates)
+GG_BLS12_381 = b"".join(int(v, 16).to_bytes(48, "little") for v in (
+    "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8",
+    "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e",
+    "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801",
+    "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be"))
+CURVES = {0: (R_BN254, GG_BN254), 1: (R_BLS12_381, GG_BLS12_381)}
+
+
 def scalar_stream(seed, i, r=R_BN254):
     d = hashlib.sha256(int(seed).to_bytes(8, "little") + int(i).to_bytes(8, "little")).digest()
     return int.from_bytes(d, "little") % r
@@ -60,7 +70,9 @@ class Workload:
     """Key material + RP parameters installed into an elpasso Context, and batch generators on top of it."""
 
     def __init__(self, ctx, nattr, seed=20211, window_bits=0, service=b"service", ad=b"hello"):
-        self.ctx, self.A, self.seed, self.r = ctx, nattr, seed, R_BN254
+        self.ctx, self.A, self.seed = ctx, nattr, seed
+        self.r, gg_const = CURVES[getattr(ctx, "curve", 0)]
+        self.F = ctx.F
         self.service, self.ad = service, ad
         r = self.r
         self.x = scalar_stream(seed, 0, r)
@@ -68,7 +80,7 @@ class Workload:
         pts = ctx.hash_to_g1([b"abc", b"ghi", b"jkl"])
         G1 = ctx.G1
         self.g, self.apk, self.h = pts[:G1], pts[G1:2 * G1], pts[2 * G1:3 * G1]
-        self.gg = GG_BN254
+        self.gg = gg_const
         # key_gen (src/ps-signer.cc:29-55): X = g^x, XX = gg^x, Y_i = g^y_i, YY_i = gg^y_i
         ks = _fr_bytes([self.x] + self.ys)
         g1s = ctx.g1_mul(self.g * (nattr + 1), ks)
@@ -131,16 +143,17 @@ class Workload:
         phi = ctx.g1_msm_fixed([hs], _fr_bytes(e_phi))
         Vk = ctx.g2_msm_fixed([0], _fr_bytes(e_Vk))
         Vphi = ctx.g1_msm_fixed([hs], _fr_bytes(e_Vphi))
-        parts = [g2_wire(kk), g1_wire(phi)]
+        F = self.F
+        parts = [g2_wire(kk, F), g1_wire(phi, F)]
         if with_retrieval:
             E1 = ctx.g1_msm_fixed([geg], _fr_bytes(e_E1))
             E2 = ctx.g1_msm_fixed([apk, hh], _fr_bytes(e_E2))
             VE1 = ctx.g1_msm_fixed([geg], _fr_bytes(e_VE1))
             VE2 = ctx.g1_msm_fixed([apk, hh], _fr_bytes(e_VE2))
-            parts += [g1_wire(E1), g1_wire(E2)]
-        parts += [g2_wire(Vk), g1_wire(Vphi)]
+            parts += [g1_wire(E1, F), g1_wire(E2, F)]
+        parts += [g2_wire(Vk, F), g1_wire(Vphi, F)]
         if with_retrieval:
-            parts += [g1_wire(VE1), g1_wire(VE2)]
+            parts += [g1_wire(VE1, F), g1_wire(VE2, F)]
         recs = bytearray()
         expect = np.ones(N, dtype=np.uint8)
         for i in range(N):
@@ -192,7 +205,7 @@ class Workload:
             keep.append((m, t1, rho0, rho, u))
         Apts = ctx.g1_msm_fixed([0], _fr_bytes(eA))
         Vpts = ctx.g1_msm_fixed([0], _fr_bytes(eV))
-        wa, wv = g1_wire(Apts), g1_wire(Vpts)
+        wa, wv = g1_wire(Apts, self.F), g1_wire(Vpts, self.F)
         G1 = ctx.G1
         recs = bytearray()
         expect = np.ones(n_items, dtype=np.uint8)

@@ -9,7 +9,15 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from oracle.pymodel import BN254, Codec, Mcl, Protocol, scalar_stream  # noqa: E402
+from oracle.pymodel import BLS12_381, BN254, Codec, Mcl, Protocol, scalar_stream  # noqa: E402
+
+# standard BLS12-381 generators (zkcrypto / IETF pairing-friendly-curves draft)
+BLS_G1 = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+          0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+BLS_G2 = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+           0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+          (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+           0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -56,10 +64,11 @@ def hidden_mask(attributes):
 
 def pack_verify_id(m, pr):
     """sig1 | sig2 | phi | [E1 | E2] | k | c | rs | m_revealed   (csrc/elp/pipeline.h verify_id_item)."""
-    out = g1b(pr.sig1) + g1b(pr.sig2) + g1b(pr.phi)
+    n = m.fb
+    out = g1b(pr.sig1, n) + g1b(pr.sig2, n) + g1b(pr.phi, n)
     if pr.has_E:
-        out += g1b(pr.E1) + g1b(pr.E2)
-    out += g2b(pr.k) + fb(pr.c)
+        out += g1b(pr.E1, n) + g1b(pr.E2, n)
+    out += g2b(pr.k, n) + fb(pr.c)
     for r in pr.rs:
         out += fb(r)
     for a in pr.attributes:
@@ -69,14 +78,14 @@ def pack_verify_id(m, pr):
 
 
 def pack_ps_verify(m, cred, all_attributes):
-    out = g1b(cred.sig1) + g1b(cred.sig2)
+    out = g1b(cred.sig1, m.fb) + g1b(cred.sig2, m.fb)
     for a in all_attributes:
         out += fb(m.fr_hash(a.encode() if isinstance(a, str) else bytes(a)))
     return out
 
 
 def pack_provide_id(m, rq, u):
-    out = g1b(rq.A) + fb(rq.c)
+    out = g1b(rq.A, m.fb) + fb(rq.c)
     for r in rq.rs:
         out += fb(r)
     for a in rq.attributes:
@@ -89,11 +98,11 @@ def g1_bases(m, pk, svc=None, g_eg=None, apk=None, h=None, skX=None):
     """0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X."""
     hs = m.hash_to_g1(svc) if svc is not None else None
     pts = [pk.g] + list(pk.Yi) + [hs, g_eg, apk, h, skX]
-    return b"".join(g1b(P) for P in pts)
+    return b"".join(g1b(P, m.fb) for P in pts)
 
 
 def g2_bases(m, pk):
-    return b"".join(g2b(P) for P in [pk.gg, pk.XX] + list(pk.YYi))
+    return b"".join(g2b(P, m.fb) for P in [pk.gg, pk.XX] + list(pk.YYi))
 
 
 _twin = None
@@ -112,7 +121,7 @@ def twin():
             import subprocess
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", so, src])
         _twin = ctypes.CDLL(so)
-        for n in ("twin_bn254_ctx_new",):
+        for n in ("twin_bn254_ctx_new", "twin_bls_ctx_new"):
             getattr(_twin, n).restype = ctypes.c_void_p
     return _twin
 

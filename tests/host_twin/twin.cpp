@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "elp/pipeline.h"
+#include "elp/params_bls12_381.h"
 #include "elp/params_bn254.h"
 
 using namespace elp;
@@ -204,3 +205,4 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
   }
 
 TWIN(BN254, twin_bn254)
+TWIN(BLS12_381, twin_bls)
