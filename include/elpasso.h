@@ -91,6 +91,13 @@ size_t elp_provide_id_record_size(int curve, int nattr, int nhidden);
  * flags[i] = 1 iff the reference would return true; *accepted = number of ones. */
 int elp_verify_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval,
                         const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted);
+/* The same verification straight from the reference's wire messages: msgs = concatenated IdProof::toBufferString() bytes
+ * (src/ps-encoding.cc:451-467; base64 already removed), message i = msgs[msg_off[i] .. msg_off[i+1]).  T-L-V parsing, point
+ * decompression (G?::deserialize, src/ps-encoding.cc:192,224) and Fr::setHashOf of the revealed attributes
+ * (src/ps-verifier.cc:224) all run on the GPU; the hidden pattern is taken per message from its "" placeholders.
+ * Malformed / truncated messages, scalars >= r, or an attribute count different from the key's are rejected (flag 0). */
+int elp_verify_id_wire_batch(elp_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int with_retrieval,
+                             const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted);
 /* PSVerifier::verify (src/ps-verifier.cc:13-35). record i: sig1 | sig2 | m[nattr] */
 int elp_ps_verify_batch(elp_ctx* ctx, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted);
 /* PSSigner::el_passo_provide_id (src/ps-signer.cc:63-146). record i: A | c | rs[H+1] | m[A-H] | u  (u = the nonce that
@@ -104,6 +111,9 @@ int elp_provide_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_
 int elp_verify_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
                             int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
                             void* d_accepted);
+int elp_verify_id_wire_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_msgs, const void* d_msg_off,
+                                 int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
+                                 void* d_accepted);
 int elp_ps_verify_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, int nattr, void* d_flags,
                             void* d_accepted);
 int elp_provide_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,

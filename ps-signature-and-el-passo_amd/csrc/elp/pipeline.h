@@ -205,31 +205,50 @@ ELP_HD constexpr int verify_id_record_words(int A, int H, bool retr) {
   return ((retr ? 5 : 3) * 2 * C::N) + 4 * C::N + 8 * (1 + H + (retr ? 2 : 1) + (A - H));
 }
 
+// Where the fields of one proof come from.  RecordSrc: the fixed-stride std-form record of elp_verify_id_batch.
+// WireSrc (further below): the reference's own T-L-V wire message (IdProof::toBufferString, src/ps-encoding.cc:451-467),
+// with point decompression and attribute hashing done here on the device.
 template <class C>
-ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad,
-                              size_t ad_len) {
+struct RecordSrc {
+  const u32 *rs_, *ms_;
+  u64 mask_;
+  int nrs_, jr_;
+  ELP_HD bool open(const u32* rec, u64 hidden_mask, int A, bool retr, Aff<F1<C>>& sig1, Aff<F1<C>>& sig2, Aff<F1<C>>& phi,
+                   Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
+    int H = 0;
+    for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+    mask_ = hidden_mask;
+    nrs_ = H + (retr ? 2 : 1);
+    jr_ = 0;
+    bool ok = true;
+    const u32* p = rec;
+    ok &= g1_load<C>(sig1, p); p += 2 * C::N;
+    ok &= g1_load<C>(sig2, p); p += 2 * C::N;
+    ok &= g1_load<C>(phi, p);  p += 2 * C::N;
+    if (retr) {
+      ok &= g1_load<C>(E1, p); p += 2 * C::N;
+      ok &= g1_load<C>(E2, p); p += 2 * C::N;
+    }
+    ok &= g2_load<C>(kk, p); p += 4 * C::N;
+    c = scalar_load_w(p); p += 8;
+    rs_ = p; p += 8 * nrs_;
+    ms_ = p;
+    return ok;
+  }
+  ELP_HD int nrs() const { return nrs_; }
+  ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
+  ELP_HD Scalar rs(int j) const { return scalar_load_w(rs_ + 8 * j); }
+  ELP_HD Scalar next_revealed_hash(int) { return scalar_load_w(ms_ + 8 * jr_++); }   // revealed attributes in order
+};
+
+template <class C, class Src>
+ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& sig1, const Aff<F1<C>>& sig2,
+                              const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2, const Aff<F2<C>>& kk, const Scalar& c,
+                              const uint8_t* ad, size_t ad_len) {
   typedef F1<C> G1F;
   typedef F2<C> G2F;
   const int A = key.A;
-  int H = 0;
-  for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
-  const int nrs = H + (retr ? 2 : 1);
-  Aff<G1F> sig1, sig2, phi, E1, E2;
-  Aff<G2F> kk;
-  bool ok = true;
-  const u32* p = rec;
-  ok &= g1_load<C>(sig1, p); p += 2 * C::N;
-  ok &= g1_load<C>(sig2, p); p += 2 * C::N;
-  ok &= g1_load<C>(phi, p);  p += 2 * C::N;
-  if (retr) {
-    ok &= g1_load<C>(E1, p); p += 2 * C::N;
-    ok &= g1_load<C>(E2, p); p += 2 * C::N;
-  }
-  ok &= g2_load<C>(kk, p); p += 4 * C::N;
-  if (!ok) return false;
-  const Scalar c = scalar_load_w(p); p += 8;
-  const u32* rs = p; p += 8 * nrs;
-  const u32* ms = p;
+  const int nrs = src.nrs();
 
   // V_k = k^c * prod_{hidden} YY_j^{r_j} * gg^{r_t} * XX^{1-c}          (src/ps-verifier.cc:72-88)
   // K   = k * prod_{revealed} YY_i^{m_i}                                 (src/ps-verifier.cc:214-229)
@@ -237,7 +256,7 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   // V_E1 = E1^c * g^{r_eps} ; V_E2 = E2^c * y^{r_eps} * h^{r_1}          (src/ps-verifier.cc:99-108)
   Jac<G2F> Vk, K;
   Jac<G1F> Vphi, VE1, VE2;
-  const Scalar r_t = scalar_load_w(rs + 8 * (retr ? nrs - 2 : nrs - 1));
+  const Scalar r_t = src.rs(retr ? nrs - 2 : nrs - 1);
   Scalar one;
   for (int i = 0; i < 8; i++) one.v[i] = 0;
   one.v[0] = 1;
@@ -253,11 +272,11 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   {
     int jh = 0, jr = 0;
     for (int i = 0; i < A; i++) {
-      if ((hidden_mask >> i) & 1) {
-        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, scalar_load_w(rs + 8 * jh));
+      if (src.hidden(i)) {
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, src.rs(jh));
         jh++;
       } else {
-        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(ms + 8 * jr));
+        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
         jr++;
       }
     }
@@ -265,14 +284,14 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
   acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
   jac_mul_var<G1F>(Vphi, phi, c);
-  acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), scalar_load_w(rs));
+  acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), src.rs(0));
   if (retr) {
-    const Scalar r_e = scalar_load_w(rs + 8 * (nrs - 1));
+    const Scalar r_e = src.rs(nrs - 1);
     jac_mul_var<G1F>(VE1, E1, c);
     acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
     jac_mul_var<G1F>(VE2, E2, c);
     acc_fixed_g1<C>(VE2, key, g1_base_apk(key), r_e);
-    acc_fixed_g1<C>(VE2, key, g1_base_h(key), scalar_load_w(rs + 8));
+    acc_fixed_g1<C>(VE2, key, g1_base_h(key), src.rs(1));
   }
 
   // canonical affine forms with one shared inversion
@@ -319,6 +338,141 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
   final_exp<C>(g, f);
   return fp12_is_one(g);
+}
+
+template <class C>
+ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad,
+                              size_t ad_len) {
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk;
+  Scalar c;
+  RecordSrc<C> src;
+  if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
+  return verify_id_core<C, RecordSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
+}
+
+// ---- wire ingest (SURVEY.md section 8f rank 1 + 2): T-L-V parsing, point decompression (one Fp / Fp2 square root each) and
+// Fr::setHashOf of the revealed attributes on the device.  Layout (src/ps-encoding.cc:451-467, Appendix C of SURVEY.md):
+//   01 L sig1 | 01 L sig2 | 02 2L k | 01 L phi | 03 20 c | 06 m (20 r)* | 07 A (len str)* [| 01 L E1 | 01 L E2],  L = FBYTES
+// var = 1 byte below 253, else FD hi lo.  Anything malformed or truncated rejects the item (the reference has undefined
+// behaviour there); scalars must be < r as mcl's Fr::deserialize requires.
+template <class C>
+struct WireSrc {
+  const uint8_t *b_, *rs_, *attr_;   // message, first response, cursor into the string list
+  size_t len_;
+  int nrs_, nattr_, attr_i_;
+  u64 mask_;
+
+  ELP_HD static bool var(const uint8_t* b, size_t len, size_t& off, size_t& v) {
+    if (off >= len) return false;
+    uint8_t f = b[off];
+    if (f < 253) {
+      v = f;
+      off += 1;
+      return true;
+    }
+    if (f == 253 && off + 2 < len) {
+      v = ((size_t)b[off + 1] << 8) | b[off + 2];
+      off += 3;
+      return true;
+    }
+    return false;
+  }
+  ELP_HD static bool elem(const uint8_t* b, size_t len, size_t& off, uint8_t type, size_t want, const uint8_t*& body) {
+    if (off >= len || b[off] != type) return false;
+    off += 1;
+    size_t n;
+    if (!var(b, len, off, n) || n != want || off + n > len) return false;
+    body = b + off;
+    off += n;
+    return true;
+  }
+  ELP_HD static bool scalar_ok(const uint8_t* p, Scalar& s) {
+    s = scalar_load_le(p);
+    return !scalar_geq_r<C>(s);
+  }
+  ELP_HD bool open(const uint8_t* msg, size_t len, int A, bool retr, Aff<F1<C>>& sig1, Aff<F1<C>>& sig2, Aff<F1<C>>& phi,
+                   Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
+    constexpr size_t L = C::FBYTES;
+    b_ = msg;
+    len_ = len;
+    size_t off = 0, n;
+    const uint8_t *p1, *p2, *pk, *pphi, *pc;
+    if (!elem(msg, len, off, 1, L, p1) || !elem(msg, len, off, 1, L, p2) || !elem(msg, len, off, 2, 2 * L, pk) ||
+        !elem(msg, len, off, 1, L, pphi) || !elem(msg, len, off, 3, 32, pc))
+      return false;
+    // FrList
+    if (off >= len || msg[off] != 6) return false;
+    off += 1;
+    if (!var(msg, len, off, n) || n > 64) return false;
+    nrs_ = (int)n;
+    rs_ = msg + off;
+    for (int j = 0; j < nrs_; j++) {
+      size_t l;
+      if (!var(msg, len, off, l) || l != 32 || off + 32 > len) return false;
+      Scalar t;
+      if (!scalar_ok(msg + off, t)) return false;
+      off += 32;
+    }
+    // StrList: record where it starts, derive the hidden mask
+    if (off >= len || msg[off] != 7) return false;
+    off += 1;
+    if (!var(msg, len, off, n) || (int)n != A) return false;   // the reference indexes YYi[i] unchecked; we require the key's count
+    nattr_ = A;
+    attr_ = msg + off;
+    attr_i_ = 0;
+    mask_ = 0;
+    int H = 0;
+    for (int i = 0; i < A; i++) {
+      size_t l;
+      if (!var(msg, len, off, l) || off + l > len) return false;
+      if (l == 0) {
+        mask_ |= 1ull << i;
+        H++;
+      }
+      off += l;
+    }
+    if (nrs_ != H + (retr ? 2 : 1) || H < (retr ? 2 : 1)) return false;
+    if (retr) {
+      const uint8_t *pe1, *pe2;
+      if (!elem(msg, len, off, 1, L, pe1) || !elem(msg, len, off, 1, L, pe2)) return false;   // src/ps-verifier.cc:68-70
+      if (!g1_deserialize<C>(E1, pe1) || !g1_deserialize<C>(E2, pe2)) return false;
+    }
+    if (!scalar_ok(pc, c)) return false;
+    return g1_deserialize<C>(sig1, p1) && g1_deserialize<C>(sig2, p2) && g1_deserialize<C>(phi, pphi) && g2_deserialize<C>(kk, pk);
+  }
+  ELP_HD int nrs() const { return nrs_; }
+  ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
+  ELP_HD Scalar rs(int j) const { return scalar_load_le(rs_ + 33 * (size_t)j + 1); }   // each entry: 20 | 32 bytes
+  // Fr::setHashOf(attributes[i]) for the next revealed attribute i (called with increasing i)
+  ELP_HD Scalar next_revealed_hash(int i) {
+    size_t off = 0, l = 0;
+    const size_t rem = (size_t)(b_ + len_ - attr_);
+    while (attr_i_ <= i) {
+      var(attr_, rem, off, l);     // bounds were validated in open()
+      if (attr_i_ == i) break;
+      off += l;
+      attr_i_++;
+    }
+    Sha256 s;
+    sha256_init(s);
+    sha256_update(s, attr_ + off, l);
+    uint8_t d[32];
+    sha256_final(s, d);
+    attr_ += off + l;
+    attr_i_ = i + 1;
+    return scalar_from_digest<C>(d);
+  }
+};
+
+template <class C>
+ELP_HEAVY bool verify_id_wire_item(const KeyCtx<C>& key, const uint8_t* msg, size_t len, bool retr, const uint8_t* ad, size_t ad_len) {
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk;
+  Scalar c;
+  WireSrc<C> src;
+  if (!src.open(msg, len, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
+  return verify_id_core<C, WireSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,21 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_verify_id(KeyCtx<C> key, const u3
 }
 
 template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_verify_id_wire(KeyCtx<C> key, const uint8_t* msgs, const u32* msg_off, int retr,
+                                                              const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
+                                                              unsigned long long* accepted, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = verify_id_wire_item<C>(key, msgs + msg_off[i], (size_t)(msg_off[i + 1] - msg_off[i]), retr != 0, a, al);
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
+template <class C>
 __global__ void __launch_bounds__(ELP_BLOCK) k_ps_verify(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* flags,
                                                          unsigned long long* accepted, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -795,6 +810,26 @@ int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_re
   return c->curve == ELP_CURVE_BN254 ? elp_verify_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted) : elp_verify_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
 }
 template <class C>
+static int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
+                                          const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  int rc = check_fused(c, 0);
+  if (rc) return rc;
+  if (n == 0) return ELP_OK;
+  hipLaunchKernelGGL((k_verify_id_wire<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+                     (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
+                     (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+int elp_verify_id_wire_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
+                                 const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254
+             ? elp_verify_id_wire_batch_dev_t<BN254>(c, stream, n, d_msgs, d_msg_off, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted)
+             : elp_verify_id_wire_batch_dev_t<BLS12_381>(c, stream, n, d_msgs, d_msg_off, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+}
+
+template <class C>
 static int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, 0);
   if (rc) return rc;
@@ -864,6 +899,35 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
   if (rc) return rc;
   rc = elp_verify_id_batch_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int retr, const uint8_t* ad,
+                             const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
+  int rc = check_fused(c, 0);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!msgs || !msg_off || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf dmsg, dmoff, dad, doff, dfl, dcnt;
+  const void *pad, *poff;
+  HIPCHK(c, dmsg.alloc(msg_off[n]));
+  HIPCHK(c, dmoff.alloc((n + 1) * 4));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  if (msg_off[n]) HIPCHK(c, hipMemcpyAsync(dmsg.p, msgs, msg_off[n], hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dmoff.p, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_verify_id_wire_batch_dev(c, c->stream, n, dmsg.p, dmoff.p, retr, pad, poff, ad_len, dfl.p, dcnt.p);
   if (rc) return rc;
   uint64_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));

@@ -106,6 +106,33 @@ std::vector<bool> PSVerifier::el_passo_verify_id_without_id_retrieval_batch(cons
   m_key->useRp(service_name, nullptr, nullptr, nullptr);
   return verifyIdImpl(proofs, ads, false);
 }
+std::vector<bool> PSVerifier::el_passo_verify_id_wire_batch(const std::vector<PSBuffer>& messages, const std::vector<std::string>& ads,
+                                                            const std::string& service_name, const G1* authority_pk, const G1* g,
+                                                            const G1* h) const {
+  if (ads.size() != messages.size()) throw std::runtime_error("associated data count does not match");
+  const bool retr = authority_pk != nullptr;
+  m_key->useRp(service_name, authority_pk, g, h);
+  std::vector<uint8_t> buf, adbuf;
+  std::vector<uint32_t> moff(1, 0), adoff(1, 0);
+  for (size_t i = 0; i < messages.size(); i++) {
+    put(buf, messages[i].data(), messages[i].size());
+    moff.push_back((uint32_t)buf.size());
+    put(adbuf, (const uint8_t*)ads[i].data(), ads[i].size());
+    adoff.push_back((uint32_t)adbuf.size());
+  }
+  if (buf.empty()) buf.push_back(0);
+  if (adbuf.empty()) adbuf.push_back(0);
+  std::vector<uint8_t> flags(messages.size());
+  uint64_t acc = 0;
+  elpCheck(m_key->ctx(),
+           elp_verify_id_wire_batch(m_key->ctx(), messages.size(), buf.data(), moff.data(), retr ? 1 : 0, adbuf.data(), adoff.data(), 0,
+                                    flags.data(), &acc),
+           "elp_verify_id_wire_batch");
+  std::vector<bool> out(messages.size());
+  for (size_t i = 0; i < messages.size(); i++) out[i] = flags[i] != 0;
+  return out;
+}
+
 bool PSVerifier::el_passo_verify_id(const IdProof& proof, const std::string& associated_data, const std::string& service_name,
                                     const G1& authority_pk, const G1& g, const G1& h) const {
   return el_passo_verify_id_batch({proof}, {associated_data}, service_name, authority_pk, g, h)[0];

@@ -29,6 +29,11 @@ class PSVerifier {
   std::vector<bool> el_passo_verify_id_without_id_retrieval_batch(const std::vector<IdProof>& proofs,
                                                                   const std::vector<std::string>& associated_data,
                                                                   const std::string& service_name) const;
+  // wire messages (IdProof::toBufferString bytes) verified without host-side decoding: T-L-V parsing, point decompression and
+  // attribute hashing run on the GPU (elp_verify_id_wire_batch); the hidden pattern may differ per message
+  std::vector<bool> el_passo_verify_id_wire_batch(const std::vector<PSBuffer>& messages, const std::vector<std::string>& associated_data,
+                                                  const std::string& service_name, const G1* authority_pk = nullptr,
+                                                  const G1* g = nullptr, const G1* h = nullptr) const;
   std::vector<bool> verify_batch(const std::vector<PSCredential>& sigs, const std::vector<std::vector<std::string>>& all_attributes) const;
 
  private:

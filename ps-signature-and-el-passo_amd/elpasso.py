@@ -38,6 +38,10 @@ _SIGS = {
     "elp_provide_id_record_size": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     "elp_verify_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _c.c_int, _u8p, _u8p, _c.c_size_t, _u8p,
                                        _c.POINTER(_c.c_uint64)]),
+    "elp_verify_id_wire_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _c.c_int, _u8p, _u8p, _c.c_size_t, _u8p,
+                                            _c.POINTER(_c.c_uint64)]),
+    "elp_verify_id_wire_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                                _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
     "elp_ps_verify_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_int, _u8p, _c.POINTER(_c.c_uint64)]),
     "elp_provide_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _u8p, _u8p, _c.c_size_t, _u8p, _u8p,
                                         _c.POINTER(_c.c_uint64)]),
@@ -224,6 +228,21 @@ class Context:
         self._chk(self.lib.elp_verify_id_batch(self.h, n, kr[1], hidden_mask, int(with_retrieval), kd[1],
                                                off.ctypes.data if off is not None else None, adl, flags.ctypes.data,
                                                ctypes.byref(cnt)))
+        return flags, cnt.value
+
+    def verify_id_wire_batch(self, messages, with_retrieval, ad):
+        """messages: list of raw IdProof wire messages (bytes, base64 already decoded)."""
+        n = len(messages)
+        moff = np.zeros(n + 1, dtype=np.uint32)
+        for i, m in enumerate(messages):
+            moff[i + 1] = moff[i] + len(m)
+        data, off, adl = self._ad(ad)
+        flags = np.zeros(n, dtype=np.uint8)
+        cnt = ctypes.c_uint64(0)
+        km, kd = _buf(b"".join(bytes(m) for m in messages) or b"\0"), _buf(data or b"\0")
+        self._chk(self.lib.elp_verify_id_wire_batch(self.h, n, km[1], moff.ctypes.data, int(with_retrieval), kd[1],
+                                                    off.ctypes.data if off is not None else None, adl, flags.ctypes.data,
+                                                    ctypes.byref(cnt)))
         return flags, cnt.value
 
     def ps_verify_batch(self, records, nattr):

@@ -103,6 +103,12 @@ static void test_el_passo(size_t n) {
   std::vector<IdProof> batch{prove, bad, prove};
   auto flags = rp.el_passo_verify_id_batch(batch, {"hello", "hello", "nope"}, "service", authority_pk, g, h);
   CHECK(flags.size() == 3 && flags[0] && !flags[1] && !flags[2]);
+  // wire path: messages go to the GPU undecoded
+  std::vector<PSBuffer> wire{prove.toBufferString(), bad.toBufferString(), prove.toBufferString()};
+  auto wflags = rp.el_passo_verify_id_wire_batch(wire, {"hello", "hello", "nope"}, "service", &authority_pk, &g, &h);
+  CHECK(wflags.size() == 3 && wflags[0] && !wflags[1] && !wflags[2]);
+  auto wflags2 = rp.el_passo_verify_id_wire_batch({prove2.toBufferString()}, {"hello"}, "service");
+  CHECK(wflags2[0]);
   // attribute count mismatch throws like the reference (src/ps-requester.cc:31-33)
   bool threw = false;
   try {

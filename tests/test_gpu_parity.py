@@ -314,3 +314,36 @@ def test_synthetic_batch_and_exceptional_cases_vs_oracle(gpu_ctx):
     for i in (0, 13, 64, 110, 129):
         assert L.elpo_provide_id(key, recs[i * rsz:(i + 1) * rsz], mask, b"hello", 5, out) == int(flags[i])
         assert out.raw == sigs[128 * i:128 * i + 128]
+
+
+def test_verify_id_from_wire_messages_golden(gpu_ctx):
+    """Wire ingest on the device: the reference's own base64-decoded IdProof messages (per-message hidden pattern,
+    decompression and attribute hashing on the GPU) must reproduce every golden verdict."""
+    d = load_golden("bn254_oracle_flows.json")
+    total = 0
+    for s in d["scenarios"]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        _set_key(gpu_ctx, pk)
+        groups = {}
+        for p in s["proofs"]:
+            for c in p["cases"]:
+                groups.setdefault(c["svc"], []).append((base64.b64decode(c["proof"]), c["ad"].encode(), c["expect"], c["label"]))
+        for svc, items in groups.items():
+            gpu_ctx.set_rp(svc.encode())
+            raw0 = items[0][0]
+            extra = [(raw0[:cut], items[0][1], False, "cut%d" % cut) for cut in (0, 1, 34, 71, len(raw0) - 1)]
+            items = items + extra
+            flags, cnt = gpu_ctx.verify_id_wire_batch([i[0] for i in items], False, [i[1] for i in items])
+            for f, it in zip(flags, items):
+                assert bool(f) == it[2], (s["name"], svc, it[3])
+            assert cnt == sum(1 for it in items if it[2])
+            total += len(items)
+    assert total > 250
+    w = load_golden("bn254_oracle_with_retrieval.json")
+    for r in w["runs"]:
+        pk = CD.pk_decode(base64.b64decode(r["pk"]))
+        g, apk, h = M.hash_to_g1(r["g_seed"]), M.hash_to_g1(r["authority_pk_seed"]), M.hash_to_g1(r["h_seed"])
+        _set_key(gpu_ctx, pk, svc=r["svc"], g_eg=g, apk=apk, h=h)
+        raw = base64.b64decode(r["proof"])
+        flags, cnt = gpu_ctx.verify_id_wire_batch([raw, raw, raw[:-1]], True, [b"hello", b"hellO", b"hello"])
+        assert list(flags) == [1, 0, 0]

@@ -182,3 +182,37 @@ def test_exceptional_group_law_cases_take_the_exact_path(L):
         rec = recs[i * rsz:(i + 1) * rsz]
         assert O.elpo_verify_id(okey, rec, mask, 1, b"hello", 5) == 1
         assert L.twin_bn254_verify_id(ctypes.c_void_p(h), rec, ctypes.c_uint64(mask), 1, b"hello", 5) == 1, i
+
+
+def test_verify_id_from_wire_messages_golden(L):
+    """Device-side wire ingest (T-L-V parse + decompression + attribute hashing): the reference's own messages, byte for byte."""
+    d = load_golden("bn254_oracle_flows.json")
+    n = 0
+    for s in d["scenarios"][:2] + d["scenarios"][4:]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        ctxs = {}
+        for p in s["proofs"][:2]:
+            for c in p["cases"]:
+                if c["svc"] not in ctxs:
+                    ctxs[c["svc"]] = _ctx(L, pk, svc=c["svc"])
+                raw = base64.b64decode(c["proof"])
+                ad = c["ad"].encode()
+                assert bool(L.twin_bn254_verify_id_wire(ctxs[c["svc"]], raw, len(raw), 0, ad, len(ad))) == c["expect"], (s["name"], c["label"])
+                n += 1
+        # truncations and garbage never crash and never verify
+        raw = base64.b64decode(s["proofs"][0]["cases"][0]["proof"])
+        key = ctxs[s["proofs"][0]["cases"][0]["svc"]]
+        ad = s["proofs"][0]["cases"][0]["ad"].encode()
+        for cut in (0, 1, 2, 33, 70, len(raw) // 2, len(raw) - 1):
+            assert L.twin_bn254_verify_id_wire(key, raw[:cut], cut, 0, ad, len(ad)) == 0
+        assert L.twin_bn254_verify_id_wire(key, raw + b"\x01", len(raw) + 1, 0, ad, len(ad)) in (0, 1)
+        assert L.twin_bn254_verify_id_wire(key, raw, len(raw), 1, ad, len(ad)) == 0       # no E1/E2 in the message
+    assert n > 60
+    w = load_golden("bn254_oracle_with_retrieval.json")
+    g, apk, h = M.hash_to_g1("abc"), M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    for r in w["runs"]:
+        pk = CD.pk_decode(base64.b64decode(r["pk"]))
+        ctx = _ctx(L, pk, svc=r["svc"], g_eg=g, apk=apk, h=h)
+        raw = base64.b64decode(r["proof"])
+        assert L.twin_bn254_verify_id_wire(ctx, raw, len(raw), 1, b"hello", 5) == 1
+        assert L.twin_bn254_verify_id_wire(ctx, raw, len(raw), 1, b"hellO", 5) == 0
