@@ -127,7 +127,7 @@ int elp_time_verify_id_dev(elp_ctx* ctx, void* stream, int reps, size_t n, const
                            void* d_accepted, float* avg_ms);
 /* Base-field multiplication micro-benchmark: every lane runs `iters` dependent Montgomery products; returns ms. */
 int elp_bench_fp_mul(elp_ctx* ctx, size_t lanes, int iters, float* ms);
-/* Per-routine micro-benchmark (op codes in csrc/elpasso_hip.hip, k_bench_op): `iters` dependent applications per lane; ms. */
+/* Per-routine micro-benchmark (op codes in csrc/elpasso_impl.h, k_bench_op): `iters` dependent applications per lane; ms. */
 int elp_bench_op(elp_ctx* ctx, int op, size_t lanes, int iters, float* ms);
 
 #ifdef __cplusplus

@@ -22,15 +22,34 @@ def _newest(paths):
     return t
 
 
+# translation units of libelpasso_hip.so: the two curves compile in parallel (the per-curve units hold the explicit template
+# instantiations of every kernel); per-unit flags: BN254 additionally inlines the Fp6-level routines into Fp12-level leaf
+# functions (+13 % on the verify kernel; on the 14-limb BLS12-381 field it only doubles the compile time).
+HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bls12_381.hip", [])]
+
+
 def build_hip(force=False, verbose=False):
-    src = os.path.join(CSRC, "elpasso_hip.hip")
-    deps = [src, os.path.join(CSRC, "elp"), os.path.join(HERE, "..", "include")]
+    deps = [os.path.join(CSRC, u) for u, _ in HIP_UNITS] + [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elp"),
+                                                           os.path.join(HERE, "..", "include")]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB, src]
+    objdir = os.path.abspath(os.path.join(HERE, "..", "build", "obj"))
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for unit, flags in HIP_UNITS:
+        obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags + ["-c", "-o", obj, os.path.join(CSRC, unit)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

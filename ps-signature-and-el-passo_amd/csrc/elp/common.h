@@ -51,6 +51,17 @@
 #define ELP_FP2 ELP_INL
 #endif
 
+// ELP_FP6: linkage of the Fp6-level routines (fp6_mul, fp6_sqr, fp6_mul_by_01, fp6_mul_by_fp2).  -DELP_FP6_INLINE=1 makes the
+// Fp12-level routines (fp12_mul, fp12_sqr, sparse line product) single leaf functions.
+#ifndef ELP_FP6_INLINE
+#define ELP_FP6_INLINE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !ELP_FP6_INLINE
+#define ELP_FP6 ELP_HEAVY
+#else
+#define ELP_FP6 ELP_INL
+#endif
+
 namespace elp {
 typedef uint32_t u32;
 typedef uint64_t u64;

@@ -205,7 +205,7 @@ ELP_INL void fp6_mul_by_v(Fp6<C>& r, const Fp6<C>& a) {  // (c0,c1,c2) v = (xi c
   r.c0 = t;
 }
 template <class C>
-ELP_HEAVY void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karatsuba, 6 Fp2 mul
+ELP_FP6 void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karatsuba, 6 Fp2 mul
   Fp2<C> t0, t1, t2, s;
   fp2_mul<C>(t0, a.c0, b.c0);
   fp2_mul<C>(t1, a.c1, b.c1);
@@ -222,7 +222,7 @@ ELP_HEAVY void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karats
   r.c2 = r2;
 }
 template <class C>
-ELP_HEAVY void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {  // CH-SQR2: 2 mul + 3 sqr in Fp2
+ELP_FP6 void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {  // CH-SQR2: 2 mul + 3 sqr in Fp2
   Fp2<C> s0, s1, s2, s3, s4;
   fp2_sqr<C>(s0, a.c0);
   fp2_mul<C>(s1, a.c0, a.c1);
@@ -237,7 +237,7 @@ ELP_HEAVY void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {  // CH-SQR2: 2 mul + 3 sqr 
 }
 // a * (b0 + b1 v)
 template <class C>
-ELP_HEAVY void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {  // 5 Fp2 mul
+ELP_FP6 void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {  // 5 Fp2 mul
   Fp2<C> t0, t1, s, r0, r1, r2;
   fp2_mul<C>(t0, a.c0, b0);
   fp2_mul<C>(t1, a.c1, b1);
@@ -252,7 +252,7 @@ ELP_HEAVY void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const
   r.c2 = r2;
 }
 template <class C>
-ELP_HEAVY void fp6_mul_by_fp2(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b) {  // 3 Fp2 mul
+ELP_FP6 void fp6_mul_by_fp2(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b) {  // 3 Fp2 mul
   fp2_mul<C>(r.c0, a.c0, b);
   fp2_mul<C>(r.c1, a.c1, b);
   fp2_mul<C>(r.c2, a.c2, b);

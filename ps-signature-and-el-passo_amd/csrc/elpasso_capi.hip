@@ -1,0 +1,274 @@
+// C-ABI entry points of include/elpasso.h: curve dispatch onto the per-curve instantiations.
+#include "elpasso_impl.h"
+
+extern template int elp_set_pubkey_t<BN254>(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi, int window_bits);
+extern template int elp_set_rp_t<BN254>(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g, const uint8_t* h);
+extern template int elp_set_signer_secret_t<BN254>(elp_ctx* c, const uint8_t* X);
+extern template int decompress_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok);
+extern template int decompress_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok);
+extern template int mul_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int mul_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int add_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+extern template int add_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+extern template int msm_fixed_impl_t<BN254, 1>(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out);
+extern template int msm_fixed_impl_t<BN254, 2>(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out);
+extern template int elp_hash_to_g1_t<BN254>(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out);
+extern template int elp_pairing_t<BN254>(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt);
+extern template int elp_pairing_check_t<BN254>(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok);
+extern template int elp_verify_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template int elp_verify_id_wire_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template int elp_ps_verify_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template int elp_provide_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted);
+extern template int elp_provide_id_batch_t<BN254>(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
+extern template int elp_bench_op_t<BN254>(elp_ctx* c, int op, size_t lanes, int iters, float* ms);
+extern template int elp_bench_fp_mul_t<BN254>(elp_ctx* c, size_t lanes, int iters, float* ms);
+extern template int elp_set_pubkey_t<BLS12_381>(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi, int window_bits);
+extern template int elp_set_rp_t<BLS12_381>(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g, const uint8_t* h);
+extern template int elp_set_signer_secret_t<BLS12_381>(elp_ctx* c, const uint8_t* X);
+extern template int decompress_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok);
+extern template int decompress_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok);
+extern template int mul_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int mul_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int add_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+extern template int add_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+extern template int msm_fixed_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out);
+extern template int msm_fixed_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out);
+extern template int elp_hash_to_g1_t<BLS12_381>(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out);
+extern template int elp_pairing_t<BLS12_381>(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt);
+extern template int elp_pairing_check_t<BLS12_381>(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok);
+extern template int elp_verify_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template int elp_verify_id_wire_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template int elp_ps_verify_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template int elp_provide_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted);
+extern template int elp_provide_id_batch_t<BLS12_381>(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
+extern template int elp_bench_op_t<BLS12_381>(elp_ctx* c, int op, size_t lanes, int iters, float* ms);
+extern template int elp_bench_fp_mul_t<BLS12_381>(elp_ctx* c, size_t lanes, int iters, float* ms);
+
+
+// (definitions below get C linkage from their declarations in include/elpasso.h)
+
+const char* elp_version(void) { return "elpasso-hip 0.1 (gfx950)"; }
+
+int elp_field_bytes(int curve) { return curve == ELP_CURVE_BN254 ? 32 : curve == ELP_CURVE_BLS12_381 ? 48 : 0; }
+
+int elp_init(int curve, int device, elp_ctx** out) {
+  if (!out) return ELP_ERR_ARG;
+  *out = nullptr;
+  if (curve != ELP_CURVE_BN254 && curve != ELP_CURVE_BLS12_381) return ELP_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELP_ERR_NODEVICE;
+  if (device < 0 || device >= ndev) return ELP_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return ELP_ERR_NODEVICE;
+  elp_ctx* c = new elp_ctx();
+  c->curve = curve;
+  c->device = device;
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    return ELP_ERR_HIP;
+  }
+  *out = c;
+  return ELP_OK;
+}
+
+void elp_destroy(elp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_key(c);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* elp_last_error(const elp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
+                   const uint8_t* YYi, int window_bits) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_set_pubkey_t<BN254>(c, nattr, g, gg, XX, Yi, YYi, window_bits) : elp_set_pubkey_t<BLS12_381>(c, nattr, g, gg, XX, Yi, YYi, window_bits);
+}
+int elp_set_rp(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
+               const uint8_t* h) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_set_rp_t<BN254>(c, service_name, service_len, authority_pk, g, h) : elp_set_rp_t<BLS12_381>(c, service_name, service_len, authority_pk, g, h);
+}
+int elp_set_signer_secret(elp_ctx* c, const uint8_t* X) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_set_signer_secret_t<BN254>(c, X) : elp_set_signer_secret_t<BLS12_381>(c, X);
+}
+int elp_g1_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+  return decompress_impl<1>(c, n, wire, out, ok);
+}
+int elp_g2_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+  return decompress_impl<2>(c, n, wire, out, ok);
+}
+int elp_g1_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<1>(c, n, p, k, o); }
+int elp_g2_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<2>(c, n, p, k, o); }
+int elp_g1_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<1>(c, n, a, b, o); }
+int elp_g2_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<2>(c, n, a, b, o); }
+int elp_g1_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
+  return msm_fixed_impl<1>(c, n, nt, ids, ks, o);
+}
+int elp_g2_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
+  return msm_fixed_impl<2>(c, n, nt, ids, ks, o);
+}
+int elp_hash_to_g1(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_hash_to_g1_t<BN254>(c, n, msgs, off, out) : elp_hash_to_g1_t<BLS12_381>(c, n, msgs, off, out);
+}
+int elp_pairing(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_pairing_t<BN254>(c, n, g1, g2, gt) : elp_pairing_t<BLS12_381>(c, n, g1, g2, gt);
+}
+int elp_pairing_check(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_pairing_check_t<BN254>(c, n, npairs, g1, g2, ok) : elp_pairing_check_t<BLS12_381>(c, n, npairs, g1, g2, ok);
+}
+size_t elp_verify_id_record_size(int curve, int A, int H, int retr) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)verify_id_record_words<BLS12_381>(A, H, retr != 0);
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)verify_id_record_words<BN254>(A, H, retr != 0);
+}
+size_t elp_ps_verify_record_size(int curve, int A) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)(4 * BLS12_381::N + 8 * A);
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)(4 * BN254::N + 8 * A);
+}
+size_t elp_provide_id_record_size(int curve, int A, int H) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)provide_id_record_words<BLS12_381>(A, H);
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)provide_id_record_words<BN254>(A, H);
+}
+int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+                            const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_verify_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted) : elp_verify_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+}
+int elp_verify_id_wire_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
+                                 const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254
+             ? elp_verify_id_wire_batch_dev_t<BN254>(c, stream, n, d_msgs, d_msg_off, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted)
+             : elp_verify_id_wire_batch_dev_t<BLS12_381>(c, stream, n, d_msgs, d_msg_off, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+}
+int elp_ps_verify_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_ps_verify_batch_dev_t<BN254>(c, stream, n, d_records, nattr, d_flags, d_accepted) : elp_ps_verify_batch_dev_t<BLS12_381>(c, stream, n, d_records, nattr, d_flags, d_accepted);
+}
+int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+                             const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted) : elp_provide_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted);
+}
+
+int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
+                        const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
+  DevBuf drec, dad, doff, dfl, dcnt;
+  const void *pad, *poff;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_verify_id_batch_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int retr, const uint8_t* ad,
+                             const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
+  int rc = check_fused(c, 0);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!msgs || !msg_off || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf dmsg, dmoff, dad, doff, dfl, dcnt;
+  const void *pad, *poff;
+  HIPCHK(c, dmsg.alloc(msg_off[n]));
+  HIPCHK(c, dmoff.alloc((n + 1) * 4));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  if (msg_off[n]) HIPCHK(c, hipMemcpyAsync(dmsg.p, msgs, msg_off[n], hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dmoff.p, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_verify_id_wire_batch_dev(c, c->stream, n, dmsg.p, dmoff.p, retr, pad, poff, ad_len, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_ps_verify_batch(elp_ctx* c, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted) {
+  int rc = check_fused(c, 0);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_ps_verify_record_size(c->curve, nattr);
+  DevBuf drec, dfl, dcnt;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = elp_ps_verify_batch_dev(c, c->stream, n, drec.p, nattr, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
+                         size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_t<BN254>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted) : elp_provide_id_batch_t<BLS12_381>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted);
+}
+
+int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const void* d_records, uint64_t mask, int retr,
+                           const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted, float* avg_ms) {
+  if (!c || reps < 1 || !avg_ms) return ELP_ERR_ARG;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, (hipStream_t)stream));
+  for (int r = 0; r < reps; r++) {
+    int rc = elp_verify_id_batch_dev(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipEventRecord(e1, (hipStream_t)stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / reps;
+  return ELP_OK;
+}
+int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_bench_op_t<BN254>(c, op, lanes, iters, ms) : elp_bench_op_t<BLS12_381>(c, op, lanes, iters, ms);
+}
+int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_bench_fp_mul_t<BN254>(c, lanes, iters, ms) : elp_bench_fp_mul_t<BLS12_381>(c, lanes, iters, ms);
+}

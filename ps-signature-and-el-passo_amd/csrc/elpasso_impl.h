@@ -1,3 +1,7 @@
+// Kernels, templated host-side implementations and the context of the C-ABI (included by the three translation units
+// elpasso_capi.hip, elpasso_bn254.hip, elpasso_bls12_381.hip; the per-curve units hold the explicit instantiations so that the
+// two curves compile in parallel).
+#pragma once
 // HIP kernels (gfx950 / MI355X) and the C-ABI of include/elpasso.h.
 // One independent item (credential / proof / point) per lane; all arithmetic lives in elp/*.h.
 #include <hip/hip_runtime.h>
@@ -387,32 +391,7 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
 };
 
-// (definitions below get C linkage from their declarations in include/elpasso.h)
-
-const char* elp_version(void) { return "elpasso-hip 0.1 (gfx950)"; }
-
-int elp_field_bytes(int curve) { return curve == ELP_CURVE_BN254 ? 32 : curve == ELP_CURVE_BLS12_381 ? 48 : 0; }
-
-int elp_init(int curve, int device, elp_ctx** out) {
-  if (!out) return ELP_ERR_ARG;
-  *out = nullptr;
-  if (curve != ELP_CURVE_BN254 && curve != ELP_CURVE_BLS12_381) return ELP_ERR_ARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELP_ERR_NODEVICE;
-  if (device < 0 || device >= ndev) return ELP_ERR_ARG;
-  if (hipSetDevice(device) != hipSuccess) return ELP_ERR_NODEVICE;
-  elp_ctx* c = new elp_ctx();
-  c->curve = curve;
-  c->device = device;
-  if (hipStreamCreate(&c->stream) != hipSuccess) {
-    delete c;
-    return ELP_ERR_HIP;
-  }
-  *out = c;
-  return ELP_OK;
-}
-
-static void free_key(elp_ctx* c) {
+static inline void free_key(elp_ctx* c) {
   void** ps[] = {&c->b1, &c->b2, &c->t1, &c->t2, &c->lines};
   for (void** p : ps) {
     if (*p) (void)hipFree(*p);
@@ -420,16 +399,6 @@ static void free_key(elp_ctx* c) {
   }
   c->have_pk = false;
 }
-
-void elp_destroy(elp_ctx* c) {
-  if (!c) return;
-  (void)hipSetDevice(c->device);
-  free_key(c);
-  (void)hipStreamDestroy(c->stream);
-  delete c;
-}
-
-const char* elp_last_error(const elp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 // (re)build every device-side key structure from host copies of the base points
 template <class C>
@@ -487,7 +456,7 @@ static int rebuild_key(elp_ctx* c, const uint8_t* g2_bases_std) {
 }
 
 template <class C>
-static int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
+int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
                    const uint8_t* YYi, int window_bits) {
   if (!c || nattr < 1 || nattr > 62 || !g || !gg || !XX || !Yi || !YYi) return ELP_ERR_ARG;
   if (window_bits == 0) window_bits = 8;
@@ -514,14 +483,9 @@ static int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8
   c->have_pk = true;
   return ELP_OK;
 }
-int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
-                   const uint8_t* YYi, int window_bits) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_set_pubkey_t<BN254>(c, nattr, g, gg, XX, Yi, YYi, window_bits) : elp_set_pubkey_t<BLS12_381>(c, nattr, g, gg, XX, Yi, YYi, window_bits);
-}
 
 template <class C>
-static int elp_set_rp_t(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
+int elp_set_rp_t(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
                const uint8_t* h) {
   if (!c) return ELP_ERR_ARG;
   if (!c->have_pk) {
@@ -547,14 +511,9 @@ static int elp_set_rp_t(elp_ctx* c, const uint8_t* service_name, size_t service_
   }
   return rebuild_key<C>(c, nullptr);
 }
-int elp_set_rp(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g,
-               const uint8_t* h) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_set_rp_t<BN254>(c, service_name, service_len, authority_pk, g, h) : elp_set_rp_t<BLS12_381>(c, service_name, service_len, authority_pk, g, h);
-}
 
 template <class C>
-static int elp_set_signer_secret_t(elp_ctx* c, const uint8_t* X) {
+int elp_set_signer_secret_t(elp_ctx* c, const uint8_t* X) {
   if (!c || !X) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
@@ -562,10 +521,6 @@ static int elp_set_signer_secret_t(elp_ctx* c, const uint8_t* X) {
   }
   memcpy(c->h_b1.data() + (size_t)(c->A + 5) * Sizes<C>::G1, X, Sizes<C>::G1);
   return rebuild_key<C>(c, nullptr);
-}
-int elp_set_signer_secret(elp_ctx* c, const uint8_t* X) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_set_signer_secret_t<BN254>(c, X) : elp_set_signer_secret_t<BLS12_381>(c, X);
 }
 
 // ---- generic "copy in, launch, copy out" helper for the host-buffer primitives
@@ -600,7 +555,7 @@ static int run_host(elp_ctx* c, const IoSpec* ins, int nin, void* const* outs, c
 }
 
 template <class C, int G>
-static int decompress_impl_t(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
+int decompress_impl_t(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
   if (!c || (n && (!wire || !out || !ok))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   IoSpec ins[1] = {{wire, n * (size_t)(G * C::FBYTES)}};
@@ -616,15 +571,9 @@ static int decompress_impl(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* o
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? decompress_impl_t<BN254, G>(c, n, wire, out, ok) : decompress_impl_t<BLS12_381, G>(c, n, wire, out, ok);
 }
-int elp_g1_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
-  return decompress_impl<1>(c, n, wire, out, ok);
-}
-int elp_g2_decompress(elp_ctx* c, size_t n, const uint8_t* wire, uint8_t* out, uint8_t* ok) {
-  return decompress_impl<2>(c, n, wire, out, ok);
-}
 
 template <class C, int G>
-static int mul_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
+int mul_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
   if (!c || (n && (!pts || !ks || !out))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
@@ -641,11 +590,9 @@ static int mul_impl(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks,
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? mul_impl_t<BN254, G>(c, n, pts, ks, out) : mul_impl_t<BLS12_381, G>(c, n, pts, ks, out);
 }
-int elp_g1_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<1>(c, n, p, k, o); }
-int elp_g2_mul(elp_ctx* c, size_t n, const uint8_t* p, const uint8_t* k, uint8_t* o) { return mul_impl<2>(c, n, p, k, o); }
 
 template <class C, int G>
-static int add_impl_t(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+int add_impl_t(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   if (!c || (n && (!a || !b || !out))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
@@ -662,11 +609,9 @@ static int add_impl(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, ui
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? add_impl_t<BN254, G>(c, n, a, b, out) : add_impl_t<BLS12_381, G>(c, n, a, b, out);
 }
-int elp_g1_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<1>(c, n, a, b, o); }
-int elp_g2_add(elp_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* o) { return add_impl<2>(c, n, a, b, o); }
 
 template <class C, int G>
-static int msm_fixed_impl_t(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
+int msm_fixed_impl_t(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
   if (!c || nterms < 1 || (n && (!ids || !ks || !out))) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
@@ -691,15 +636,9 @@ static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, 
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? msm_fixed_impl_t<BN254, G>(c, n, nterms, ids, ks, out) : msm_fixed_impl_t<BLS12_381, G>(c, n, nterms, ids, ks, out);
 }
-int elp_g1_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
-  return msm_fixed_impl<1>(c, n, nt, ids, ks, o);
-}
-int elp_g2_msm_fixed(elp_ctx* c, size_t n, int nt, const int32_t* ids, const uint8_t* ks, uint8_t* o) {
-  return msm_fixed_impl<2>(c, n, nt, ids, ks, o);
-}
 
 template <class C>
-static int elp_hash_to_g1_t(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
+int elp_hash_to_g1_t(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
   if (!c || (n && (!off || !out))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   uint8_t dummy[4] = {0};
@@ -711,13 +650,9 @@ static int elp_hash_to_g1_t(elp_ctx* c, size_t n, const uint8_t* msgs, const uin
                        (u32*)po[0], n);
   });
 }
-int elp_hash_to_g1(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* off, uint8_t* out) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_hash_to_g1_t<BN254>(c, n, msgs, off, out) : elp_hash_to_g1_t<BLS12_381>(c, n, msgs, off, out);
-}
 
 template <class C>
-static int elp_pairing_t(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+int elp_pairing_t(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
   if (!c || (n && (!g1 || !g2 || !gt))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   IoSpec ins[2] = {{g1, n * Sizes<C>::G1}, {g2, n * Sizes<C>::G2}};
@@ -728,13 +663,9 @@ static int elp_pairing_t(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t*
                        (u32*)po[0], n);
   });
 }
-int elp_pairing(elp_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_pairing_t<BN254>(c, n, g1, g2, gt) : elp_pairing_t<BLS12_381>(c, n, g1, g2, gt);
-}
 
 template <class C>
-static int elp_pairing_check_t(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
+int elp_pairing_check_t(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
   if (!c || npairs < 1 || npairs > 4 || (n && (!g1 || !g2 || !ok))) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   IoSpec ins[2] = {{g1, n * npairs * Sizes<C>::G1}, {g2, n * npairs * Sizes<C>::G2}};
@@ -752,34 +683,15 @@ static int elp_pairing_check_t(elp_ctx* c, size_t n, int npairs, const uint8_t* 
     }
   });
 }
-int elp_pairing_check(elp_ctx* c, size_t n, int npairs, const uint8_t* g1, const uint8_t* g2, uint8_t* ok) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_pairing_check_t<BN254>(c, n, npairs, g1, g2, ok) : elp_pairing_check_t<BLS12_381>(c, n, npairs, g1, g2, ok);
-}
 
 // ---- fused batches
-static int popcount_mask(uint64_t m, int A) {
+static inline int popcount_mask(uint64_t m, int A) {
   int h = 0;
   for (int i = 0; i < A; i++) h += (int)((m >> i) & 1);
   return h;
 }
-size_t elp_verify_id_record_size(int curve, int A, int H, int retr) {
-  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)verify_id_record_words<BLS12_381>(A, H, retr != 0);
-  if (curve != ELP_CURVE_BN254) return 0;
-  return 4 * (size_t)verify_id_record_words<BN254>(A, H, retr != 0);
-}
-size_t elp_ps_verify_record_size(int curve, int A) {
-  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)(4 * BLS12_381::N + 8 * A);
-  if (curve != ELP_CURVE_BN254) return 0;
-  return 4 * (size_t)(4 * BN254::N + 8 * A);
-}
-size_t elp_provide_id_record_size(int curve, int A, int H) {
-  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)provide_id_record_words<BLS12_381>(A, H);
-  if (curve != ELP_CURVE_BN254) return 0;
-  return 4 * (size_t)provide_id_record_words<BN254>(A, H);
-}
 
-static int check_fused(elp_ctx* c, uint64_t mask) {
+static inline int check_fused(elp_ctx* c, uint64_t mask) {
   if (!c) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
@@ -790,7 +702,7 @@ static int check_fused(elp_ctx* c, uint64_t mask) {
 }
 
 template <class C>
-static int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
                             const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, mask);
   if (rc) return rc;
@@ -804,13 +716,8 @@ static int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const v
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
-int elp_verify_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
-                            const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_verify_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted) : elp_verify_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
-}
 template <class C>
-static int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
+int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
                                           const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, 0);
   if (rc) return rc;
@@ -821,16 +728,9 @@ static int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, co
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
-int elp_verify_id_wire_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
-                                 const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254
-             ? elp_verify_id_wire_batch_dev_t<BN254>(c, stream, n, d_msgs, d_msg_off, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted)
-             : elp_verify_id_wire_batch_dev_t<BLS12_381>(c, stream, n, d_msgs, d_msg_off, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
-}
 
 template <class C>
-static int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
+int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, 0);
   if (rc) return rc;
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
@@ -840,12 +740,8 @@ static int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const v
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
-int elp_ps_verify_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_ps_verify_batch_dev_t<BN254>(c, stream, n, d_records, nattr, d_flags, d_accepted) : elp_ps_verify_batch_dev_t<BLS12_381>(c, stream, n, d_records, nattr, d_flags, d_accepted);
-}
 template <class C>
-static int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
                              const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, mask);
   if (rc) return rc;
@@ -858,14 +754,9 @@ static int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const 
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
-int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
-                             const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted) : elp_provide_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted);
-}
 
 // host-buffer wrappers: stage inputs, call the _dev entry point on the context stream, copy results back
-static int stage_ad(elp_ctx* c, size_t n, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, DevBuf& dad, DevBuf& doff,
+static inline int stage_ad(elp_ctx* c, size_t n, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, DevBuf& dad, DevBuf& doff,
                     const void** p_ad, const void** p_off) {
   size_t total = ad_off ? ad_off[n] : ad_len;
   HIPCHK(c, dad.alloc(total));
@@ -880,89 +771,8 @@ static int stage_ad(elp_ctx* c, size_t n, const uint8_t* ad, const uint32_t* ad_
   return ELP_OK;
 }
 
-int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
-                        const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
-  int rc = check_fused(c, mask);
-  if (rc) return rc;
-  if (accepted) *accepted = 0;
-  if (n == 0) return ELP_OK;
-  if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
-  DevBuf drec, dad, doff, dfl, dcnt;
-  const void *pad, *poff;
-  HIPCHK(c, drec.alloc(n * rsz));
-  HIPCHK(c, dfl.alloc(n));
-  HIPCHK(c, dcnt.alloc(8));
-  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
-  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
-  rc = elp_verify_id_batch_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, dfl.p, dcnt.p);
-  if (rc) return rc;
-  uint64_t cnt = 0;
-  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (accepted) *accepted = cnt;
-  return ELP_OK;
-}
-
-int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int retr, const uint8_t* ad,
-                             const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
-  int rc = check_fused(c, 0);
-  if (rc) return rc;
-  if (accepted) *accepted = 0;
-  if (n == 0) return ELP_OK;
-  if (!msgs || !msg_off || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  DevBuf dmsg, dmoff, dad, doff, dfl, dcnt;
-  const void *pad, *poff;
-  HIPCHK(c, dmsg.alloc(msg_off[n]));
-  HIPCHK(c, dmoff.alloc((n + 1) * 4));
-  HIPCHK(c, dfl.alloc(n));
-  HIPCHK(c, dcnt.alloc(8));
-  if (msg_off[n]) HIPCHK(c, hipMemcpyAsync(dmsg.p, msgs, msg_off[n], hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dmoff.p, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
-  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
-  rc = elp_verify_id_wire_batch_dev(c, c->stream, n, dmsg.p, dmoff.p, retr, pad, poff, ad_len, dfl.p, dcnt.p);
-  if (rc) return rc;
-  uint64_t cnt = 0;
-  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (accepted) *accepted = cnt;
-  return ELP_OK;
-}
-
-int elp_ps_verify_batch(elp_ctx* c, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted) {
-  int rc = check_fused(c, 0);
-  if (rc) return rc;
-  if (accepted) *accepted = 0;
-  if (n == 0) return ELP_OK;
-  if (!records || !flags) return ELP_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  const size_t rsz = elp_ps_verify_record_size(c->curve, nattr);
-  DevBuf drec, dfl, dcnt;
-  HIPCHK(c, drec.alloc(n * rsz));
-  HIPCHK(c, dfl.alloc(n));
-  HIPCHK(c, dcnt.alloc(8));
-  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
-  rc = elp_ps_verify_batch_dev(c, c->stream, n, drec.p, nattr, dfl.p, dcnt.p);
-  if (rc) return rc;
-  uint64_t cnt = 0;
-  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (accepted) *accepted = cnt;
-  return ELP_OK;
-}
-
 template <class C>
-static int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
+int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
                          size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
   int rc = check_fused(c, mask);
   if (rc) return rc;
@@ -991,35 +801,9 @@ static int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, 
   if (accepted) *accepted = cnt;
   return ELP_OK;
 }
-int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
-                         size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_t<BN254>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted) : elp_provide_id_batch_t<BLS12_381>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted);
-}
-
-int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const void* d_records, uint64_t mask, int retr,
-                           const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted, float* avg_ms) {
-  if (!c || reps < 1 || !avg_ms) return ELP_ERR_ARG;
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
-  HIPCHK(c, hipEventRecord(e0, (hipStream_t)stream));
-  for (int r = 0; r < reps; r++) {
-    int rc = elp_verify_id_batch_dev(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
-    if (rc) return rc;
-  }
-  HIPCHK(c, hipEventRecord(e1, (hipStream_t)stream));
-  HIPCHK(c, hipEventSynchronize(e1));
-  float ms = 0;
-  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *avg_ms = ms / reps;
-  return ELP_OK;
-}
 
 template <class C>
-static int elp_bench_op_t(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
+int elp_bench_op_t(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
   if (!c || !ms || lanes == 0 || op < 0 || op > 19) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf out;
@@ -1037,13 +821,9 @@ static int elp_bench_op_t(elp_ctx* c, int op, size_t lanes, int iters, float* ms
   (void)hipEventDestroy(e1);
   return ELP_OK;
 }
-int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_bench_op_t<BN254>(c, op, lanes, iters, ms) : elp_bench_op_t<BLS12_381>(c, op, lanes, iters, ms);
-}
 
 template <class C>
-static int elp_bench_fp_mul_t(elp_ctx* c, size_t lanes, int iters, float* ms) {
+int elp_bench_fp_mul_t(elp_ctx* c, size_t lanes, int iters, float* ms) {
   if (!c || !ms || lanes == 0) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf out;
@@ -1061,8 +841,6 @@ static int elp_bench_fp_mul_t(elp_ctx* c, size_t lanes, int iters, float* ms) {
   (void)hipEventDestroy(e1);
   return ELP_OK;
 }
-int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
-  if (!c) return ELP_ERR_ARG;
-  return c->curve == ELP_CURVE_BN254 ? elp_bench_fp_mul_t<BN254>(c, lanes, iters, ms) : elp_bench_fp_mul_t<BLS12_381>(c, lanes, iters, ms);
-}
+
+
 
