@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_bench_fp_mul(u32* out, int iters,
 // Per-routine micro-benchmark: every lane runs `iters` dependent applications of one device routine on lane-private data.
 // op: 0 fp_mul 1 fp_sqr 2 fp2_mul 3 fp2_sqr 4 fp6_mul 5 fp12_mul 6 fp12_sqr 7 fp12_cyc_sqr 8 mul_by_line
 //     9 jac_dbl<G1> 10 jac_madd<G1> 11 jac_add<G1> 12 jac_dbl<G2> 13 jac_madd<G2> 14 jac_add<G2> 15 ml_dbl_step 16 ml_add_step
-//     17 fp_inv 18 fp_add 19 fp2_add
+//     17 fp_inv 18 fp_add 19 fp2_add 20 jac_mul_var<G1> 21 jac_mul_var<G2> 22 miller_loop (1 pair) 23 final_exp
 template <class C>
 __global__ void __launch_bounds__(ELP_BLOCK) k_bench_op(int op, u32* out, int iters, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,6 +327,10 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_bench_op(int op, u32* out, int it
       case 15: ml_dbl_step<C>(T, l); T.Z = fp2_add(T.Z, l.c); break;
       case 16: ml_add_step<C>(T, l, x, y); T.Z = fp2_add(T.Z, l.c); break;
       case 17: a = fp_inv<C>(a); break;
+      case 20: { Scalar k; for (int q = 0; q < 8; q++) k.v[q] = (u32)a.v[q] * 2654435761u; k.v[7] &= 0x1fffffff; jac_mul_var<F1<C>>(j1, p1, k); p1.x = j1.X; } break;
+      case 21: { Scalar k; for (int q = 0; q < 8; q++) k.v[q] = (u32)a.v[q] * 2654435761u; k.v[7] &= 0x1fffffff; jac_mul_var<F2<C>>(j2, p2, k); p2.x = j2.X; } break;
+      case 22: miller_loop<C, 1, 0>(f, &p1, &p2, (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0); p1.x = f.c0.c0.c0; break;
+      case 23: final_exp<C>(f, g); g.c0.c0 = f.c1.c1; break;
       case 18: a = fp_add(a, b); b = fp_sub(b, a); break;
       default: x = fp2_add(x, y); y = fp2_sub(y, x); break;
     }
@@ -804,7 +808,7 @@ int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_
 
 template <class C>
 int elp_bench_op_t(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
-  if (!c || !ms || lanes == 0 || op < 0 || op > 19) return ELP_ERR_ARG;
+  if (!c || !ms || lanes == 0 || op < 0 || op > 23) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf out;
   HIPCHK(c, out.alloc(lanes * 4));

@@ -8,15 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 elp = importlib.import_module("ps-signature-and-el-passo_amd")
 OPS = ["fp_mul", "fp_sqr", "fp2_mul", "fp2_sqr", "fp6_mul", "fp12_mul", "fp12_sqr", "fp12_cyc_sqr", "mul_by_line", "jac_dbl<G1>",
        "jac_madd<G1>", "jac_add<G1>", "jac_dbl<G2>", "jac_madd<G2>", "jac_add<G2>", "ml_dbl_step", "ml_add_step", "fp_inv", "fp_add+sub",
-       "fp2_add+sub"]
-MULS = [1, 1, 3, 2, 18, 54, 36, 18, 39, 7, 11, 16, 16, 29, 43, 25, 35, 380, 0, 0]   # Fp products per application (model)
+       "fp2_add+sub", "jac_mul_var<G1>", "jac_mul_var<G2>", "miller_loop 1 pair", "final_exp"]
+MULS = [1, 1, 3, 2, 18, 54, 36, 18, 39, 7, 11, 16, 16, 29, 43, 25, 35, 380, 0, 0, 2970, 7200, 9000, 6000]   # Fp products per application (model)
 ctx = elp.Context()
 ms = ctypes.c_float()
-for waves in (1, 2):
+for waves in (1,):
     lanes = 256 * 4 * 64 * waves
     print("== %d wave(s) per SIMD" % waves)
     for op, name in enumerate(OPS):
-        iters = 20 if name == "fp_inv" else (2000 if MULS[op] <= 3 else 200)
+        iters = 2 if MULS[op] >= 2000 else (20 if name == "fp_inv" else (2000 if MULS[op] <= 3 else 200))
         ctx._chk(ctx.lib.elp_bench_op(ctx.h, op, lanes, iters, ctypes.byref(ms)))
         ns = ms.value * 1e6 / iters          # per application per wave (all SIMDs in parallel)
         cyc = ns * 2.4 / waves               # SIMD cycles per application at 2.4 GHz
