@@ -158,6 +158,11 @@ def main():
             out["bls12_381"] = second_curve(pkg, synth, local_rank, dev, A, H, min(B, 32768), args.window)
         except Exception as e:  # pragma: no cover
             out["bls12_381"] = {"error": str(e)}
+    if rank == 0 and world == 1 and args.curve == "bn254" and not args.no_second_curve:
+        try:
+            out["secondary"] = secondary_workloads(pkg, synth, local_rank, dev, args.window)
+        except Exception as e:  # pragma: no cover
+            out["secondary"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
@@ -190,6 +195,52 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
     res = {"value": B / (ms.value * 1e-3), "unit": "verifications/s", "batch": B, "kernel_ms": float(ms.value),
            "parity_ok": bool((flags == expect).all()) and int(d_cnt.item()) == 3 * int(expect.sum()),
            "algorithmic_bytes_per_item": rsz + 4, "note": "BLS12-381 instantiation: no reference oracle exists; checked against the big-int model in tests"}
+    ctx.close()
+    return res
+
+
+def secondary_workloads(pkg, synth, local_rank, dev, window):
+    """BASELINE.json configs 2 and 3 (parity-test cases, reported for orientation): 4096 PS verifications with 3 attributes and
+    65 536 IdP issuances with 8 attributes (4 hidden), device-resident records, torch events on the launch stream."""
+    import numpy as np
+    import torch
+    res = {}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, reps=3):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
+    wl = synth.Workload(ctx, 3, seed=20211, window_bits=window)
+    n = 4096
+    recs, expect = wl.ps_verify_batch(n)
+    d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)
+    d_fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
+    res["ps_verify_4096x3attrs"] = {"value": n / (ms * 1e-3), "unit": "verifications/s", "kernel_ms": ms,
+                                    "parity_ok": bool((d_fl.cpu().numpy() == expect).all())}
+    ctx.close()
+    ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
+    wl = synth.Workload(ctx, 8, seed=20211, window_bits=window)
+    n = 65536
+    recs, mask, expect = wl.provide_id_batch(n, 4)
+    d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)
+    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    d_fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_sig = torch.zeros(n * 2 * ctx.G1, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ms = timed(lambda: ctx._chk(ctx.lib.elp_provide_id_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), mask, d_ad.data_ptr(), None,
+                                                                  len(wl.ad), d_sig.data_ptr(), d_fl.data_ptr(), d_cnt.data_ptr())))
+    res["provide_id_65536x8attrs"] = {"value": n / (ms * 1e-3), "unit": "issuances/s", "kernel_ms": ms,
+                                      "parity_ok": bool((d_fl.cpu().numpy() == expect).all())}
     ctx.close()
     return res
 

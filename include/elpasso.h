@@ -71,6 +71,11 @@ int elp_g2_add(elp_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8
  * G2 base ids: 0 = gg, 1 = XX, 2+i = YY_i. */
 int elp_g1_msm_fixed(elp_ctx* ctx, size_t n, int nterms, const int32_t* base_ids, const uint8_t* scalars, uint8_t* out);
 int elp_g2_msm_fixed(elp_ctx* ctx, size_t n, int nterms, const int32_t* base_ids, const uint8_t* scalars, uint8_t* out);
+/* Single-output multi-scalar multiplication  out = sum_i scalars[i] * points[i]  over caller-supplied points (Pippenger bucket
+ * method: LDS counting sort by window digit, bucket sums, shuffle/LDS scan reductions).  No call in the reference corresponds to
+ * it (mcl's mulVec is unused there); it is the general MSM operator and the building block of aggregated verification. */
+int elp_g1_msm(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
+int elp_g2_msm(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
 /* hashAndMapToG1 (src/ps-verifier.cc:94; BN254: mcl's Shallue-van de Woestijne map). msgs concatenated, offsets[n+1]. */
 int elp_hash_to_g1(elp_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, uint8_t* out);
 /* pairing(GT&, G1, G2) (src/ps-verifier.cc:32-33) */

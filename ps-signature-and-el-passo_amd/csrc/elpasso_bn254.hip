@@ -22,3 +22,5 @@ template int elp_provide_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t 
 template int elp_provide_id_batch_t<BN254>(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
 template int elp_bench_op_t<BN254>(elp_ctx* c, int op, size_t lanes, int iters, float* ms);
 template int elp_bench_fp_mul_t<BN254>(elp_ctx* c, size_t lanes, int iters, float* ms);
+template int msm_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+template int msm_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);

@@ -1,6 +1,10 @@
 // C-ABI entry points of include/elpasso.h: curve dispatch onto the per-curve instantiations.
 #include "elpasso_impl.h"
 
+extern template int msm_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int msm_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int msm_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int msm_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
 extern template int elp_set_pubkey_t<BN254>(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi, int window_bits);
 extern template int elp_set_rp_t<BN254>(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g, const uint8_t* h);
 extern template int elp_set_signer_secret_t<BN254>(elp_ctx* c, const uint8_t* X);
@@ -271,4 +275,13 @@ int elp_bench_op(elp_ctx* c, int op, size_t lanes, int iters, float* ms) {
 int elp_bench_fp_mul(elp_ctx* c, size_t lanes, int iters, float* ms) {
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? elp_bench_fp_mul_t<BN254>(c, lanes, iters, ms) : elp_bench_fp_mul_t<BLS12_381>(c, lanes, iters, ms);
+}
+
+int elp_g1_msm(elp_ctx* c, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? msm_impl_t<BN254, 1>(c, n, points, scalars, out) : msm_impl_t<BLS12_381, 1>(c, n, points, scalars, out);
+}
+int elp_g2_msm(elp_ctx* c, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? msm_impl_t<BN254, 2>(c, n, points, scalars, out) : msm_impl_t<BLS12_381, 2>(c, n, points, scalars, out);
 }

@@ -215,6 +215,134 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_pairing_check(const u32* g1, cons
   okf[i] = ok;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Single-output multi-scalar multiplication  sum_i k_i * P_i  (Pippenger bucket method, 8-bit windows).
+// The reference has no equivalent call (mcl's mulVec is unused); it is the general MSM operator of this library and the
+// building block of aggregated verification.
+//   k_msm_prepare : std affine points -> Montgomery affine (validated), one lane per point
+//   k_msm_buckets : one 256-thread workgroup per (window, slice of <= 8192 points): LDS histogram of the window's digits
+//                   (byte w of each scalar), shfl-based exclusive scan, LDS counting sort of the slice's indices by digit, then
+//                   lane b sums the points of bucket b (no elliptic-curve atomics, no divergence inside the additions)
+//   k_msm_reduce  : per window: slices combined, then sum_b b*B_b as a suffix scan + tree reduction through LDS
+//   k_msm_final   : Horner over the 32 windows, normalisation, one std affine point out
+#define ELP_MSM_SLICE 8192
+#define ELP_MSM_TPB 256
+
+template <class C, int G>
+__global__ void __launch_bounds__(ELP_BLOCK) k_msm_prepare(const u32* pts, void* out, int* bad, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (G == 1) {
+    Aff<F1<C>> p;
+    if (!g1_load<C>(p, pts + i * 2 * C::N)) {
+      aff_set_inf(p);
+      atomicAdd(bad, 1);
+    }
+    ((Aff<F1<C>>*)out)[i] = p;
+  } else {
+    Aff<F2<C>> p;
+    if (!g2_load<C>(p, pts + i * 4 * C::N)) {
+      aff_set_inf(p);
+      atomicAdd(bad, 1);
+    }
+    ((Aff<F2<C>>*)out)[i] = p;
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(ELP_MSM_TPB) k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
+                                                             Jac<F>* partial) {
+  __shared__ unsigned cnt[256];
+  __shared__ unsigned start[256];
+  __shared__ unsigned wave_tot[4];
+  __shared__ unsigned short idx[ELP_MSM_SLICE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = blockIdx.x / S, s = blockIdx.x % S;
+  const size_t lo = n * (size_t)s / S, hi = n * (size_t)(s + 1) / S;
+  const int M = (int)(hi - lo);
+  cnt[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < M; j += ELP_MSM_TPB) {
+    unsigned d = scalars[(lo + j) * 32 + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) atomicAdd(&cnt[d], 1u);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the 256 bucket counts: wave-level inclusive scan with shuffles, wave totals through LDS
+  unsigned c0 = cnt[tid], x = c0;
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wave_tot[wv] = x;
+  __syncthreads();
+  unsigned base = 0;
+  for (int k = 0; k < wv; k++) base += wave_tot[k];
+  const unsigned my_start = base + x - c0;
+  start[tid] = my_start;
+  __syncthreads();
+  cnt[tid] = my_start;   // becomes the scatter cursor
+  __syncthreads();
+  for (int j = tid; j < M; j += ELP_MSM_TPB) {
+    unsigned d = scalars[(lo + j) * 32 + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)j;
+  }
+  __syncthreads();
+  Jac<F> acc;
+  jac_set_inf(acc);
+  const unsigned t1 = start[tid] + c0;
+  for (unsigned t = start[tid]; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
+  partial[(size_t)blockIdx.x * 256 + tid] = acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(ELP_MSM_TPB) k_msm_reduce(const Jac<F>* partial, int S, Jac<F>* win) {
+  __shared__ Jac<F> sh[256];
+  const int tid = threadIdx.x, w = blockIdx.x;
+  Jac<F> acc = partial[((size_t)w * S) * 256 + tid];
+  for (int s = 1; s < S; s++) jac_add<F>(acc, acc, partial[((size_t)w * S + s) * 256 + tid]);
+  // suffix scan: acc_b = sum_{j >= b} B_j
+  for (int d = 1; d < 256; d <<= 1) {
+    sh[tid] = acc;
+    __syncthreads();
+    if (tid + d < 256) jac_add<F>(acc, acc, sh[tid + d]);
+    __syncthreads();
+  }
+  if (tid == 0) jac_set_inf(acc);          // sum_b b*B_b = sum_{b>=1} S_b
+  for (int d = 128; d >= 1; d >>= 1) {
+    sh[tid] = acc;
+    __syncthreads();
+    if (tid < d) jac_add<F>(acc, acc, sh[tid + d]);
+    __syncthreads();
+  }
+  if (tid == 0) win[w] = acc;
+}
+
+template <class C, int G>
+__global__ void __launch_bounds__(ELP_BLOCK) k_msm_final(const void* win_, u32* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (G == 1) {
+    const Jac<F1<C>>* win = (const Jac<F1<C>>*)win_;
+    Jac<F1<C>> r = win[31];
+    for (int w = 30; w >= 0; w--) {
+      for (int k = 0; k < 8; k++) jac_dbl<F1<C>>(r, r);
+      jac_add<F1<C>>(r, r, win[w]);
+    }
+    Aff<F1<C>> a;
+    jac_to_aff<F1<C>>(a, r);
+    g1_store<C>(out, a);
+  } else {
+    const Jac<F2<C>>* win = (const Jac<F2<C>>*)win_;
+    Jac<F2<C>> r = win[31];
+    for (int w = 30; w >= 0; w--) {
+      for (int k = 0; k < 8; k++) jac_dbl<F2<C>>(r, r);
+      jac_add<F2<C>>(r, r, win[w]);
+    }
+    Aff<F2<C>> a;
+    jac_to_aff<F2<C>>(a, r);
+    g2_store<C>(out, a);
+  }
+}
+
 // ---- setup kernels
 template <class F>
 __global__ void __launch_bounds__(ELP_BLOCK) k_window_bases(const Aff<F>* bases, int nb, int W, int nwin, Aff<F>* bj) {
@@ -639,6 +767,54 @@ template <int G>
 static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, const uint8_t* ks, uint8_t* out) {
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? msm_fixed_impl_t<BN254, G>(c, n, nterms, ids, ks, out) : msm_fixed_impl_t<BLS12_381, G>(c, n, nterms, ids, ks, out);
+}
+
+template <class C, int G>
+int msm_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
+  if (!c || !out || (n && (!pts || !ks))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t P = G == 1 ? Sizes<C>::G1 : Sizes<C>::G2;
+  const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
+  const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
+  if (n == 0) {
+    memset(out, 0, P);
+    return ELP_OK;
+  }
+  const int S = (int)((n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE);
+  DevBuf dpts, dks, daff, dpart, dwin, dbad, dout;
+  HIPCHK(c, dpts.alloc(n * P));
+  HIPCHK(c, dks.alloc(n * 32));
+  HIPCHK(c, daff.alloc(n * AFF));
+  HIPCHK(c, dpart.alloc((size_t)32 * S * 256 * JAC));
+  HIPCHK(c, dwin.alloc(32 * JAC));
+  HIPCHK(c, dbad.alloc(4));
+  HIPCHK(c, dout.alloc(P));
+  HIPCHK(c, hipMemcpyAsync(dpts.p, pts, n * P, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dks.p, ks, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dbad.p, 0, 4, c->stream));
+  hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)dpts.p, daff.p, (int*)dbad.p, n);
+  if (G == 1) {
+    typedef F1<C> F;
+    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, c->stream, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, S,
+                       (Jac<F>*)dpart.p);
+    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, c->stream, (const Jac<F>*)dpart.p, S, (Jac<F>*)dwin.p);
+  } else {
+    typedef F2<C> F;
+    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, c->stream, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, S,
+                       (Jac<F>*)dpart.p);
+    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, c->stream, (const Jac<F>*)dpart.p, S, (Jac<F>*)dwin.p);
+  }
+  hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, c->stream, (const void*)dwin.p, (u32*)dout.p);
+  HIPCHK(c, hipGetLastError());
+  int hbad = 0;
+  HIPCHK(c, hipMemcpyAsync(&hbad, dbad.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out, dout.p, P, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (hbad) {
+    c->err = "an input point is not a valid curve point";
+    return ELP_ERR_POINT;
+  }
+  return ELP_OK;
 }
 
 template <class C>

@@ -30,6 +30,8 @@ _SIGS = {
     "elp_g2_add": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_g1_msm_fixed": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
     "elp_g2_msm_fixed": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
+    "elp_g1_msm": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_g2_msm": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_hash_to_g1": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_pairing": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_pairing_check": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
@@ -185,6 +187,19 @@ class Context:
 
     def g2_msm_fixed(self, base_ids, scalars):
         return self._msm(self.lib.elp_g2_msm_fixed, base_ids, scalars, self.G2)
+
+    def g1_msm(self, pts, ks):
+        """sum_i ks[i] * pts[i] (single output, Pippenger)."""
+        out = np.zeros(self.G1, dtype=np.uint8)
+        ka, kb = _buf(pts), _buf(ks)
+        self._chk(self.lib.elp_g1_msm(self.h, len(pts) // self.G1, ka[1], kb[1], out.ctypes.data))
+        return out.tobytes()
+
+    def g2_msm(self, pts, ks):
+        out = np.zeros(self.G2, dtype=np.uint8)
+        ka, kb = _buf(pts), _buf(ks)
+        self._chk(self.lib.elp_g2_msm(self.h, len(pts) // self.G2, ka[1], kb[1], out.ctypes.data))
+        return out.tobytes()
 
     def hash_to_g1(self, msgs):
         off = np.zeros(len(msgs) + 1, dtype=np.uint32)

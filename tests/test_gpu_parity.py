@@ -347,3 +347,50 @@ def test_verify_id_from_wire_messages_golden(gpu_ctx):
         raw = base64.b64decode(r["proof"])
         flags, cnt = gpu_ctx.verify_id_wire_batch([raw, raw, raw[:-1]], True, [b"hello", b"hellO", b"hello"])
         assert list(flags) == [1, 0, 0]
+
+
+def test_pippenger_msm_vs_oracle(gpu_ctx):
+    """Single-output MSM (LDS counting sort + bucket sums + scan reductions) against the oracle's plain sum of products."""
+    import ctypes
+    from elp_testlib import oracle
+    L = oracle()
+    rnd = random.Random(21)
+    pk = _pk0()
+    g, gg = pk.g, pk.gg
+
+    def ref(mulfn, addfn, sz, pts, ks):
+        acc, o = bytes(sz), ctypes.create_string_buffer(sz)
+        for i in range(len(ks) // 32):
+            assert mulfn(pts[i * sz:(i + 1) * sz], ks[32 * i:32 * i + 32], o)
+            t = o.raw
+            assert addfn(acc, t, o)
+            acc = o.raw
+        return acc
+
+    for n in (1, 2, 63, 300):
+        base_k = [rnd.randrange(M.r) for _ in range(n)]
+        pts = gpu_ctx.g1_mul(g1b(g) * n, b"".join(fb(k) for k in base_k))        # n distinct points
+        ks = [rnd.randrange(M.r) for _ in range(n)]
+        if n > 2:
+            ks[0], ks[1] = 0, M.r - 1
+            pts = pts[:128] + pts[64:128] + pts[192:]                              # duplicate point: P + P inside a bucket when digits agree
+            ks[2] = ks[1]
+        ksb = b"".join(fb(k) for k in ks)
+        assert gpu_ctx.g1_msm(pts, ksb) == ref(L.elpo_g1_mul, L.elpo_g1_add, 64, pts, ksb), n
+    n = 40
+    pts = gpu_ctx.g2_mul(g2b(gg) * n, b"".join(fb(rnd.randrange(M.r)) for _ in range(n)))
+    ksb = b"".join(fb(rnd.randrange(M.r)) for _ in range(n))
+    assert gpu_ctx.g2_msm(pts, ksb) == ref(L.elpo_g2_mul, L.elpo_g2_add, 128, pts, ksb)
+    # larger n across several slices: compare with the library's own per-item products summed through the MSM identity
+    n = 20000
+    kk = np.frombuffer(np.random.RandomState(3).bytes(n * 32), dtype=np.uint8).copy()
+    kk[31::32] &= 0x0f
+    kk = kk.tobytes()
+    pts = gpu_ctx.g1_mul(g1b(g) * n, kk)                                          # P_i = a_i g
+    total = 0
+    ks = [rnd.randrange(M.r) for _ in range(n)]
+    for i in range(n):
+        total = (total + int.from_bytes(kk[32 * i:32 * i + 32], "little") * ks[i]) % M.r
+    want = gpu_ctx.g1_mul(g1b(g), fb(total))
+    assert gpu_ctx.g1_msm(pts, b"".join(fb(k) for k in ks)) == want
+    assert gpu_ctx.g1_msm(b"", b"") == bytes(64)
