@@ -284,6 +284,203 @@ ELP_HEAVY void jac_mul_var(Jac<F>& r, const Aff<F>& p, const Scalar& k) {
   r = acc;
 }
 
+// ---- GLV / GLS scalar decomposition (constants from tools/glv.py): k -> D signed sub-scalars with sum_i k_i lam^i == k (mod r).
+// c_j = round(k * G_j / 2^256), k_i = [i == 0] k - sum_j c_j B_ji, all modulo 2^(32 NW) (the true values are far smaller).
+template <class C>
+ELP_INL Scalar scalar_mod_r(Scalar k) {   // k mod r for any 256-bit k (r > 2^253: at most 7 subtractions)
+  ELP_NOUNROLL
+  for (int it = 0; it < 8; it++) {
+    u64 br = 0;
+    u32 d[8];
+    for (int i = 0; i < 8; i++) {
+      u64 t = (u64)k.v[i] - C::rmod(i) - br;
+      d[i] = (u32)t;
+      br = (t >> 32) & 1;
+    }
+    if (br) break;
+    for (int i = 0; i < 8; i++) k.v[i] = d[i];
+  }
+  return k;
+}
+template <int D, int NG, int NW, class GL>
+ELP_HEAVY void lattice_split(const Scalar& k, u32 (*mag)[NW], bool* neg, GL lat) {
+  u32 c[D][NW];
+  for (int j = 0; j < D; j++) {
+    u32 prod[8 + NG + 1];
+    for (int i = 0; i < 8 + NG + 1; i++) prod[i] = 0;
+    for (int a = 0; a < 8; a++) {
+      u64 carry = 0;
+      for (int b = 0; b < NG; b++) {
+        u64 t = (u64)k.v[a] * lat.g(j, b) + prod[a + b] + carry;
+        prod[a + b] = (u32)t;
+        carry = t >> 32;
+      }
+      prod[a + NG] = (u32)carry;
+    }
+    u64 t = (u64)prod[7] + 0x80000000u;   // + 2^255 (rounding)
+    u64 carry = t >> 32;
+    for (int i = 8; i < 8 + NG + 1 && carry; i++) {
+      t = (u64)prod[i] + carry;
+      prod[i] = (u32)t;
+      carry = t >> 32;
+    }
+    for (int l = 0; l < NW; l++) c[j][l] = (8 + l < 8 + NG + 1) ? prod[8 + l] : 0;
+  }
+  for (int i = 0; i < D; i++) {
+    u32 acc[NW];
+    for (int l = 0; l < NW; l++) acc[l] = (i == 0 && l < 8) ? k.v[l] : 0;
+    for (int j = 0; j < D; j++) {
+      u32 t[NW];
+      for (int l = 0; l < NW; l++) t[l] = 0;
+      for (int a = 0; a < NW; a++) {
+        u64 carry = 0;
+        for (int b = 0; a + b < NW; b++) {
+          u64 x = (u64)c[j][a] * lat.b(j, i, b) + t[a + b] + carry;
+          t[a + b] = (u32)x;
+          carry = x >> 32;
+        }
+      }
+      const bool add = lat.gneg(j) != lat.bneg(j, i);   // product c_j * B_ji negative -> subtracting it adds
+      u64 cy = add ? 0 : 1;
+      for (int l = 0; l < NW; l++) {
+        u64 x = (u64)acc[l] + (add ? t[l] : ~t[l]) + cy;
+        acc[l] = (u32)x;
+        cy = x >> 32;
+      }
+    }
+    neg[i] = (acc[NW - 1] >> 31) != 0;
+    if (neg[i]) {
+      u64 cy = 1;
+      for (int l = 0; l < NW; l++) {
+        u64 x = (u64)(~acc[l]) + cy;
+        acc[l] = (u32)x;
+        cy = x >> 32;
+      }
+    }
+    for (int l = 0; l < NW; l++) mag[i][l] = acc[l];
+  }
+}
+template <class C>
+struct Glv1Lat {
+  ELP_HD u32 g(int j, int l) const { return C::glv1_g(j, l); }
+  ELP_HD bool gneg(int j) const { return C::glv1_gneg(j); }
+  ELP_HD u32 b(int j, int i, int l) const { return C::glv1_b(j, i, l); }
+  ELP_HD bool bneg(int j, int i) const { return C::glv1_bneg(j, i); }
+};
+template <class C>
+struct Gls2Lat {
+  ELP_HD u32 g(int j, int l) const { return C::gls2_g(j, l); }
+  ELP_HD bool gneg(int j) const { return C::gls2_gneg(j); }
+  ELP_HD u32 b(int j, int i, int l) const { return C::gls2_b(j, i, l); }
+  ELP_HD bool bneg(int j, int i) const { return C::gls2_bneg(j, i); }
+};
+template <int NW>
+ELP_INL int limbs_window(const u32* m, int bit, int w) {
+  int limb = bit >> 5, sh = bit & 31;
+  u64 t = m[limb];
+  if (limb + 1 < NW) t |= (u64)m[limb + 1] << 32;
+  return (int)((t >> sh) & ((1u << w) - 1));
+}
+
+// [k]P for P in the order-r subgroup of G1: k = k1 + k2 lam with phi(x, y) = (beta x, y) = [lam](x, y); one shared chain of
+// 132 doublings, two table additions per 4-bit window (the second through phi).
+template <class C>
+ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in) {
+  typedef F1<C> F;
+  Jac<F> tbl[16];
+  jac_set_inf(tbl[0]);
+  jac_from_aff(tbl[1], p);
+  ELP_NOUNROLL
+  for (int i = 2; i < 16; i++) {
+    if (i & 1)
+      jac_madd<F>(tbl[i], tbl[i - 1], p);
+    else
+      jac_dbl<F>(tbl[i], tbl[i >> 1]);
+  }
+  u32 m[2][5];
+  bool neg[2];
+  lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());
+  Fp<C> beta;
+  ELP_LOAD_FP(beta, C::glv_beta(i_));
+  Jac<F> acc;
+  jac_set_inf(acc);
+  ELP_NOUNROLL
+  for (int w = 32; w >= 0; w--) {
+    if (w != 32) {
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+    }
+    Jac<F> t = tbl[limbs_window<5>(m[0], 4 * w, 4)];
+    if (neg[0]) t.Y = fp_neg(t.Y);
+    jac_add<F>(acc, acc, t);
+    t = tbl[limbs_window<5>(m[1], 4 * w, 4)];
+    t.X = fp_mul<C>(t.X, beta);
+    if (neg[1]) t.Y = fp_neg(t.Y);
+    jac_add<F>(acc, acc, t);
+  }
+  r = acc;
+}
+
+// [k]Q for Q in the order-r subgroup of G2: k = k0 + k1 lam + k2 lam^2 + k3 lam^3 with psi(Q) = [lam]Q, lam = p mod r
+// (psi = twist o Frobenius o untwist); 68 shared doublings, four table additions per 4-bit window.
+template <class C>
+ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in) {
+  typedef F2<C> F;
+  Jac<F> tbl[16];
+  jac_set_inf(tbl[0]);
+  jac_from_aff(tbl[1], p);
+  ELP_NOUNROLL
+  for (int i = 2; i < 16; i++) {
+    if (i & 1)
+      jac_madd<F>(tbl[i], tbl[i - 1], p);
+    else
+      jac_dbl<F>(tbl[i], tbl[i >> 1]);
+  }
+  u32 m[4][3];
+  bool neg[4];
+  lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());
+  Jac<F> acc;
+  jac_set_inf(acc);
+  ELP_NOUNROLL
+  for (int w = 16; w >= 0; w--) {
+    if (w != 16) {
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+      jac_dbl<F>(acc, acc);
+    }
+    ELP_NOUNROLL
+    for (int j = 0; j < 4; j++) {
+      Jac<F> t = tbl[limbs_window<3>(m[j], 4 * w, 4)];
+      if (j != 0 && !jac_is_inf(t)) {   // psi^j in Jacobian coordinates: (conj^j X * gx_j, conj^j Y * gy_j, conj^j Z)
+        Fp2<C> gx, gy;
+        if (j == 1) {
+          ELP_LOAD_FP(gx.c0, C::g2frob(1, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(1, 0, 1, i_));
+          ELP_LOAD_FP(gy.c0, C::g2frob(1, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(1, 1, 1, i_));
+        } else if (j == 2) {
+          ELP_LOAD_FP(gx.c0, C::g2frob(2, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(2, 0, 1, i_));
+          ELP_LOAD_FP(gy.c0, C::g2frob(2, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(2, 1, 1, i_));
+        } else {
+          ELP_LOAD_FP(gx.c0, C::g2frob(3, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(3, 0, 1, i_));
+          ELP_LOAD_FP(gy.c0, C::g2frob(3, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(3, 1, 1, i_));
+        }
+        if (j & 1) {
+          t.X = fp2_conj(t.X);
+          t.Y = fp2_conj(t.Y);
+          t.Z = fp2_conj(t.Z);
+        }
+        fp2_mul<C>(t.X, t.X, gx);
+        fp2_mul<C>(t.Y, t.Y, gy);
+      }
+      if (neg[j]) t.Y = fp2_neg(t.Y);
+      jac_add<F>(acc, acc, t);
+    }
+  }
+  r = acc;
+}
+
 // Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,
 // j = 0 .. ceil(256/W)-1.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
 template <class F>

@@ -267,7 +267,7 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
     cred = scalar_sub_mod_r<C>(cred, rr);
   }
   const Scalar one_minus_c = scalar_sub_mod_r<C>(one, cred);
-  jac_mul_var<G2F>(Vk, kk, c);
+  g2_mul_gls<C>(Vk, kk, c);      // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
   jac_from_aff(K, kk);
   {
     int jh = 0, jr = 0;
@@ -283,13 +283,13 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
   }
   acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
   acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
-  jac_mul_var<G1F>(Vphi, phi, c);
+  g1_mul_glv<C>(Vphi, phi, c);
   acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), src.rs(0));
   if (retr) {
     const Scalar r_e = src.rs(nrs - 1);
-    jac_mul_var<G1F>(VE1, E1, c);
+    g1_mul_glv<C>(VE1, E1, c);
     acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
-    jac_mul_var<G1F>(VE2, E2, c);
+    g1_mul_glv<C>(VE2, E2, c);
     acc_fixed_g1<C>(VE2, key, g1_base_apk(key), r_e);
     acc_fixed_g1<C>(VE2, key, g1_base_h(key), src.rs(1));
   }
@@ -525,7 +525,7 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
   const Scalar u = scalar_load_w(p);
   // V = A^c * g^{r_0} * prod_{hidden} Y_i^{r_j}                           (src/ps-signer.cc:82-94)
   Jac<G1F> V, Ap;
-  jac_mul_var<G1F>(V, Ac, c);
+  g1_mul_glv<C>(V, Ac, c);
   acc_fixed_g1<C>(V, key, G1_BASE_G, scalar_load_w(rs));
   jac_from_aff(Ap, Ac);
   {
@@ -556,7 +556,7 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
   jac_madd<G1F>(Ap, Ap, key.b1[g1_base_skx(key)]);
   Aff<G1F> aAp;
   jac_to_aff<G1F>(aAp, Ap);
-  jac_mul_var<G1F>(s2, aAp, u);
+  g1_mul_glv<C>(s2, aAp, u);
   Fp<C> z[2], zi[2];
   z[0] = s1.Z;
   z[1] = s2.Z;

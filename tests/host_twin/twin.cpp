@@ -76,6 +76,24 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     g2_store<C>(o, r);                                                                                                 \
     return 1;                                                                                                          \
   }                                                                                                                    \
+  int pfx##_g1_mul_glv(const u32* P, const u32* k, u32* o) {                                                           \
+    Aff<F1<C>> p, r;                                                                                                   \
+    if (!g1_load<C>(p, P)) return 0;                                                                                   \
+    Jac<F1<C>> j;                                                                                                      \
+    g1_mul_glv<C>(j, p, scalar_load_w(k));                                                                             \
+    jac_to_aff<F1<C>>(r, j);                                                                                           \
+    g1_store<C>(o, r);                                                                                                 \
+    return 1;                                                                                                          \
+  }                                                                                                                    \
+  int pfx##_g2_mul_gls(const u32* P, const u32* k, u32* o) {                                                           \
+    Aff<F2<C>> p, r;                                                                                                   \
+    if (!g2_load<C>(p, P)) return 0;                                                                                   \
+    Jac<F2<C>> j;                                                                                                      \
+    g2_mul_gls<C>(j, p, scalar_load_w(k));                                                                             \
+    jac_to_aff<F2<C>>(r, j);                                                                                           \
+    g2_store<C>(o, r);                                                                                                 \
+    return 1;                                                                                                          \
+  }                                                                                                                    \
   int pfx##_g1_add(const u32* P, const u32* Q, u32* o) {                                                               \
     Aff<F1<C>> p, q, r;                                                                                                \
     if (!g1_load<C>(p, P) || !g1_load<C>(q, Q)) return 0;                                                              \

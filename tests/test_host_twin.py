@@ -216,3 +216,17 @@ def test_verify_id_from_wire_messages_golden(L):
         raw = base64.b64decode(r["proof"])
         assert L.twin_bn254_verify_id_wire(ctx, raw, len(raw), 1, b"hello", 5) == 1
         assert L.twin_bn254_verify_id_wire(ctx, raw, len(raw), 1, b"hellO", 5) == 0
+
+
+def test_glv_gls_scalar_multiplication(L):
+    """Endomorphism-accelerated variable-base multiplication ([k]P through phi / psi) equals plain scalar multiplication."""
+    rnd = random.Random(3)
+    d = load_golden("bn254_oracle_flows.json")
+    pk = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
+    P, Q = G.g1_mul(pk.g, 777), G.g2_mul(pk.gg, 999)
+    o, o2 = ctypes.create_string_buffer(64), ctypes.create_string_buffer(128)
+    ks = [0, 1, 2, 15, 16, M.r - 1, M.r, M.r + 1, 2**256 - 1, (M.r - 1) // 2] + [rnd.randrange(M.r) for _ in range(10)]
+    for k in ks:
+        assert L.twin_bn254_g1_mul_glv(g1b(P), fb(k), o) and g1u(o.raw) == G.g1_mul(P, k)
+        assert L.twin_bn254_g2_mul_gls(g2b(Q), fb(k), o2) and g2u(o2.raw) == G.g2_mul(Q, k)
+    assert L.twin_bn254_g1_mul_glv(bytes(64), fb(5), o) and g1u(o.raw) is None
