@@ -35,6 +35,16 @@ struct StdFp {  // canonical integer in [0, p) (or any N-word integer before ran
   u32 w[C::N];
 };
 
+// -DELP_BOUND_CHECK (host twin only): every limb-wise operation is redone in 64 bits and asserted to fit int32, and every
+// product asserts that its column sums cannot overflow the signed 64-bit accumulator.
+#if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#include <assert.h>
+#include <stdlib.h>
+#define ELP_ASSERT_I32(x) assert((x) >= -2147483647LL - 1 && (x) <= 2147483647LL)
+#else
+#define ELP_ASSERT_I32(x) ((void)0)
+#endif
+
 constexpr i32 ELP_LIMB_BITS = 30;
 constexpr i32 ELP_LIMB_HALF = 1 << 29;
 constexpr u32 ELP_LIMB_MASK = (1u << 30) - 1;
@@ -93,7 +103,10 @@ template <class C>
 ELP_INL Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] + b.v[i];
+  for (int i = 0; i < C::NL; i++) {
+    ELP_ASSERT_I32((i64)a.v[i] + (i64)b.v[i]);
+    r.v[i] = a.v[i] + b.v[i];
+  }
   fp_carry(r);
   return r;
 }
@@ -101,7 +114,10 @@ template <class C>
 ELP_INL Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] - b.v[i];
+  for (int i = 0; i < C::NL; i++) {
+    ELP_ASSERT_I32((i64)a.v[i] - (i64)b.v[i]);
+    r.v[i] = a.v[i] - b.v[i];
+  }
   fp_carry(r);
   return r;
 }
@@ -116,7 +132,10 @@ template <class C>
 ELP_INL Fp<C> fp_dbl(const Fp<C>& a) {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] * 2;
+  for (int i = 0; i < C::NL; i++) {
+    ELP_ASSERT_I32((i64)a.v[i] * 2);
+    r.v[i] = a.v[i] * 2;
+  }
   fp_carry(r);
   return r;
 }
@@ -125,14 +144,20 @@ template <class C>
 ELP_INL Fp<C> fp_add_lazy(const Fp<C>& a, const Fp<C>& b) {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] + b.v[i];
+  for (int i = 0; i < C::NL; i++) {
+    ELP_ASSERT_I32((i64)a.v[i] + (i64)b.v[i]);
+    r.v[i] = a.v[i] + b.v[i];
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp<C> fp_sub_lazy(const Fp<C>& a, const Fp<C>& b) {
   Fp<C> r;
   ELP_UNROLL
-  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i] - b.v[i];
+  for (int i = 0; i < C::NL; i++) {
+    ELP_ASSERT_I32((i64)a.v[i] - (i64)b.v[i]);
+    r.v[i] = a.v[i] - b.v[i];
+  }
   return r;
 }
 
@@ -168,6 +193,18 @@ ELP_INL void fp_reduce_weak(Fp<C>& a) {
 template <class C>
 ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
   constexpr int NL = C::NL;
+#if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+  {
+    long double ma = 0, mb = 0;
+    for (int i = 0; i < NL - 1; i++) {
+      if (llabs((long long)a.v[i]) > ma) ma = llabs((long long)a.v[i]);
+      if (llabs((long long)b.v[i]) > mb) mb = llabs((long long)b.v[i]);
+    }
+    // worst column: NL products of the operands + NL products m_i p_j (|m_i| <= 2^29, |p_j| <= 2^29) + carry-in
+    assert(ma * mb * NL + (long double)NL * 288230376151711744.0L + 1.0e18L < 9223372036854775807.0L);
+    assert(llabs((long long)a.v[NL - 1]) < (1LL << 29) && llabs((long long)b.v[NL - 1]) < (1LL << 29));
+  }
+#endif
   i32 m[NL];
   Fp<C> r;
   i64 acc = 0;

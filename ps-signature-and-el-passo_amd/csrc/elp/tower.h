@@ -79,6 +79,34 @@ ELP_INL Fp2<C> fp2_select(bool c, const Fp2<C>& a, const Fp2<C>& b) {
   r.c1 = fp_select(c, a.c1, b.c1);
   return r;
 }
+// lazy (carry-free) variants; results must be carried (fp2_carry) before they are stored or multiplied on both sides
+template <class C>
+ELP_INL Fp2<C> fp2_add_lazy(const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  r.c0 = fp_add_lazy(a.c0, b.c0);
+  r.c1 = fp_add_lazy(a.c1, b.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_sub_lazy(const Fp2<C>& a, const Fp2<C>& b) {
+  Fp2<C> r;
+  r.c0 = fp_sub_lazy(a.c0, b.c0);
+  r.c1 = fp_sub_lazy(a.c1, b.c1);
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_carry(Fp2<C> a) {
+  fp_carry(a.c0);
+  fp_carry(a.c1);
+  return a;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_mul_xi_lazy(const Fp2<C>& a) {   // input carried, output limbs <= 2^30
+  Fp2<C> r;
+  r.c0 = fp_sub_lazy(a.c0, a.c1);
+  r.c1 = fp_add_lazy(a.c0, a.c1);
+  return r;
+}
 // (a0 + a1 i)(1 + i) = (a0 - a1) + (a0 + a1) i
 template <class C>
 ELP_INL Fp2<C> fp2_mul_xi(const Fp2<C>& a) {
@@ -91,14 +119,20 @@ template <class C>
 ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // Karatsuba, 3 Fp mul
   Fp<C> t0 = fp_mul<C>(a.c0, b.c0);
   Fp<C> t1 = fp_mul<C>(a.c1, b.c1);
-  Fp<C> s = fp_mul<C>(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+  // one operand of a product may be a lazy two-term sum when 9 limbs are summed per column (BN254); with 14 limbs
+  // (BLS12-381) the accumulator has no room for it
+  Fp<C> sa = (C::NL <= 9) ? fp_add_lazy(a.c0, a.c1) : fp_add(a.c0, a.c1);
+  Fp<C> s = fp_mul<C>(sa, fp_add(b.c0, b.c1));
   r.c0 = fp_sub(t0, t1);
-  r.c1 = fp_sub(fp_sub(s, t0), t1);
+  Fp<C> u = fp_sub_lazy(fp_sub_lazy(s, t0), t1);   // three carried terms: |limb| < 1.5 * 2^30
+  fp_carry(u);
+  r.c1 = u;
 }
 template <class C>
 ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul
   Fp<C> t = fp_mul<C>(a.c0, a.c1);
-  Fp<C> u = fp_mul<C>(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1));
+  Fp<C> sa = (C::NL <= 9) ? fp_add_lazy(a.c0, a.c1) : fp_add(a.c0, a.c1);
+  Fp<C> u = fp_mul<C>(sa, fp_sub(a.c0, a.c1));
   r.c0 = u;
   r.c1 = fp_dbl(t);
 }
@@ -211,12 +245,13 @@ ELP_FP6 void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karatsub
   fp2_mul<C>(t1, a.c1, b.c1);
   fp2_mul<C>(t2, a.c2, b.c2);
   Fp2<C> r0, r1, r2;
+  // post-additions: chains of up to three carried terms are summed lazily and carried once
   fp2_mul<C>(s, fp2_add(a.c1, a.c2), fp2_add(b.c1, b.c2));
-  r0 = fp2_add(t0, fp2_mul_xi(fp2_sub(fp2_sub(s, t1), t2)));
+  r0 = fp2_carry(fp2_add_lazy(t0, fp2_mul_xi_lazy(fp2_carry(fp2_sub_lazy(fp2_sub_lazy(s, t1), t2)))));
   fp2_mul<C>(s, fp2_add(a.c0, a.c1), fp2_add(b.c0, b.c1));
-  r1 = fp2_add(fp2_sub(fp2_sub(s, t0), t1), fp2_mul_xi(t2));
+  r1 = fp2_carry(fp2_add_lazy(fp2_carry(fp2_sub_lazy(fp2_sub_lazy(s, t0), t1)), fp2_mul_xi_lazy(t2)));
   fp2_mul<C>(s, fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2));
-  r2 = fp2_add(fp2_sub(fp2_sub(s, t0), t2), t1);
+  r2 = fp2_carry(fp2_add_lazy(fp2_carry(fp2_sub_lazy(fp2_sub_lazy(s, t0), t2)), t1));
   r.c0 = r0;
   r.c1 = r1;
   r.c2 = r2;
