@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU per step")
     ap.add_argument("--attrs", type=int, default=8)
     ap.add_argument("--hidden", type=int, default=4)
-    ap.add_argument("--window", type=int, default=12, help="fixed-base window bits of the key tables (library default 8)")
+    ap.add_argument("--window", type=int, default=16, help="fixed-base window bits of the key tables (library default 8)")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(1536, 48 x cores))")
