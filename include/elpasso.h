@@ -103,6 +103,16 @@ int elp_verify_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t
  * Malformed / truncated messages, scalars >= r, or an attribute count different from the key's are rejected (flag 0). */
 int elp_verify_id_wire_batch(elp_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int with_retrieval,
                              const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted);
+/* Aggregated variant of elp_verify_id_batch (no counterpart in the reference).  The NIZK half runs per
+ * item as usual; the signature checks of the items that pass it are combined with verifier-chosen 128-bit multipliers d_i
+ * (SHA-256(seed32 || le64(i)), seed32 = 32 fresh random bytes per batch):
+ *     prod_i e(d_i sig1_i, K_i) * e(-sum_i d_i sig2_i, gg) == 1
+ * i.e. one Miller loop per item, a Pippenger MSM for sum d_i sig2_i, ONE final exponentiation per batch.  If the batch equation
+ * fails the items are re-verified one by one inside the same call, so flags[] are the reference's verdicts either way (a wrong
+ * accept requires a 2^-128 event).  *batch_equation_held reports which path produced them. */
+int elp_verify_id_batch_aggregated(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval,
+                                   const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, const uint8_t* seed32, uint8_t* flags,
+                                   uint64_t* accepted, int* batch_equation_held);
 /* PSVerifier::verify (src/ps-verifier.cc:13-35). record i: sig1 | sig2 | m[nattr] */
 int elp_ps_verify_batch(elp_ctx* ctx, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted);
 /* PSSigner::el_passo_provide_id (src/ps-signer.cc:63-146). record i: A | c | rs[H+1] | m[A-H] | u  (u = the nonce that
@@ -119,6 +129,9 @@ int elp_verify_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_
 int elp_verify_id_wire_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_msgs, const void* d_msg_off,
                                  int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
                                  void* d_accepted);
+int elp_verify_id_batch_aggregated_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
+                                       int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len,
+                                       const uint8_t* seed32 /* host */, void* d_flags, void* d_accepted);
 int elp_ps_verify_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, int nattr, void* d_flags,
                             void* d_accepted);
 int elp_provide_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,

@@ -257,7 +257,7 @@ ELP_INL bool scalar_is_zero(const Scalar& k) {
 // Variable-base scalar multiplication: fixed 4-bit windows, uniform control flow across lanes
 // (64 x (4 dbl + 1 table add)); the per-lane table lives in private memory.
 template <class F>
-ELP_HEAVY void jac_mul_var(Jac<F>& r, const Aff<F>& p, const Scalar& k) {
+ELP_HEAVY void jac_mul_var(Jac<F>& r, const Aff<F>& p, const Scalar& k, int nwin = 64) {   // nwin 4-bit windows (scalar < 2^(4 nwin))
   Jac<F> tbl[16];
   jac_set_inf(tbl[0]);
   jac_from_aff(tbl[1], p);
@@ -271,8 +271,8 @@ ELP_HEAVY void jac_mul_var(Jac<F>& r, const Aff<F>& p, const Scalar& k) {
   Jac<F> acc;
   jac_set_inf(acc);
   ELP_NOUNROLL
-  for (int w = 63; w >= 0; w--) {
-    if (w != 63) {
+  for (int w = nwin - 1; w >= 0; w--) {
+    if (w != nwin - 1) {
       jac_dbl<F>(acc, acc);
       jac_dbl<F>(acc, acc);
       jac_dbl<F>(acc, acc);

@@ -241,10 +241,11 @@ struct RecordSrc {
   ELP_HD Scalar next_revealed_hash(int) { return scalar_load_w(ms_ + 8 * jr_++); }   // revealed attributes in order
 };
 
+// NIZK half of VerifyID: recomputes V_k, V_phi, (V_E1, V_E2), the challenge, and K (returned in affine form for the pairing).
 template <class C, class Src>
-ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& sig1, const Aff<F1<C>>& sig2,
-                              const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2, const Aff<F2<C>>& kk, const Scalar& c,
-                              const uint8_t* ad, size_t ad_len) {
+ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& phi, const Aff<F1<C>>& E1,
+                              const Aff<F1<C>>& E2, const Aff<F2<C>>& kk, const Scalar& c, const uint8_t* ad, size_t ad_len,
+                              Aff<F2<C>>& aK) {
   typedef F1<C> G1F;
   typedef F2<C> G2F;
   const int A = key.A;
@@ -303,7 +304,7 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
   z2[0] = Vk.Z;
   z2[1] = K.Z;
   batch_zinv<C, 3, 2>(zi1, z1, zi2, z2);
-  Aff<G2F> aVk, aK;
+  Aff<G2F> aVk;
   Aff<G1F> aVphi, aVE1, aVE2;
   jac_to_aff_with_zinv<G2F>(aVk, Vk, zi2[0]);
   jac_to_aff_with_zinv<G2F>(aK, K, zi2[1]);
@@ -327,10 +328,13 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
     transcript_g1<C>(t, aVE2);
   }
   const Scalar c2 = transcript_challenge<C>(t, ad, ad_len);
-  if (!scalar_eq(c2, c)) return false;
+  return scalar_eq(c2, c);
+}
 
-  // e(sig1, K) == e(sig2, gg)  <=>  e(sig1, K) * e(-sig2, gg) == 1       (src/ps-verifier.cc:133-137)
-  Aff<G1F> nsig2;
+// Signature half: e(sig1, K) == e(sig2, gg)  <=>  e(sig1, K) * e(-sig2, gg) == 1       (src/ps-verifier.cc:133-137)
+template <class C>
+ELP_HEAVY bool ps_pairing_check(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, const Aff<F1<C>>& sig2, const Aff<F2<C>>& aK) {
+  Aff<F1<C>> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
   Fp12<C> f, g;
@@ -338,6 +342,57 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
   final_exp<C>(g, f);
   return fp12_is_one(g);
+}
+
+template <class C, class Src>
+ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& sig1, const Aff<F1<C>>& sig2,
+                              const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2, const Aff<F2<C>>& kk, const Scalar& c,
+                              const uint8_t* ad, size_t ad_len) {
+  Aff<F2<C>> aK;
+  if (!verify_id_nizk<C, Src>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
+  return ps_pairing_check<C>(key, sig1, sig2, aK);
+}
+
+// Aggregated (random-linear-combination) verification, SURVEY.md section 8f rank 4.  For the items that pass the NIZK half,
+//     prod_i [ e(sig1_i, K_i) e(-sig2_i, gg) ]^{d_i} == 1   <=>   prod_i e(d_i sig1_i, K_i) * e(-sum_i d_i sig2_i, gg) == 1
+// with verifier-chosen 128-bit d_i: ONE final exponentiation and ONE Miller loop against gg for the whole batch; sum d_i sig2_i is
+// a Pippenger MSM.  This per-item part returns the item's Miller value f_i = f(d_i sig1_i, K_i) (1 for rejected items), its
+// multiplier d_i and a copy of sig2_i.  If the batch equation fails, the caller falls back to the per-item check, so verdicts
+// stay exact; a wrong accept needs a 2^-128 event.
+ELP_HD inline Scalar agg_multiplier(const uint8_t seed[32], u64 index) {
+  Sha256 s;
+  sha256_init(s);
+  sha256_update(s, seed, 32);
+  for (int i = 0; i < 8; i++) sha256_put(s, (uint8_t)(index >> (8 * i)));
+  uint8_t d[32];
+  sha256_final(s, d);
+  Scalar k;
+  for (int i = 0; i < 8; i++) k.v[i] = 0;
+  for (int i = 0; i < 4; i++) k.v[i] = (u32)d[4 * i] | ((u32)d[4 * i + 1] << 8) | ((u32)d[4 * i + 2] << 16) | ((u32)d[4 * i + 3] << 24);
+  k.v[3] |= 0x80000000u;   // exactly 128 bits, never zero
+  return k;
+}
+template <class C>
+ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
+                                  const uint8_t* seed, u64 index, Fp12<C>& f, u32* delta_out, u32* sig2_out) {
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk, aK;
+  Scalar c;
+  RecordSrc<C> src;
+  fp12_set_one(f);
+  for (int i = 0; i < 8; i++) delta_out[i] = 0;
+  for (int i = 0; i < 2 * C::N; i++) sig2_out[i] = 0;
+  if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
+  if (!verify_id_nizk<C, RecordSrc<C>>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
+  const Scalar d = agg_multiplier(seed, index);
+  Jac<F1<C>> P;
+  jac_mul_var<F1<C>>(P, sig1, d, 32);
+  Aff<F1<C>> aP;
+  jac_to_aff<F1<C>>(aP, P);
+  miller_loop<C, 1, 0>(f, &aP, &aK, (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0);
+  for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
+  g1_store<C>(sig2_out, sig2);
+  return true;
 }
 
 template <class C>

@@ -1,6 +1,8 @@
 // C-ABI entry points of include/elpasso.h: curve dispatch onto the per-curve instantiations.
 #include "elpasso_impl.h"
 
+extern template int elp_verify_id_batch_aggregated_dev_t<BN254>(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags, void* d_accepted);
+extern template int elp_verify_id_batch_aggregated_dev_t<BLS12_381>(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags, void* d_accepted);
 extern template int msm_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
 extern template int msm_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
 extern template int msm_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
@@ -78,6 +80,8 @@ void elp_destroy(elp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   free_key(c);
+  if (c->agg_ws) (void)hipFree(c->agg_ws);
+  if (c->agg_ok) (void)hipFree(c->agg_ok);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -284,4 +288,46 @@ int elp_g1_msm(elp_ctx* c, size_t n, const uint8_t* points, const uint8_t* scala
 int elp_g2_msm(elp_ctx* c, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out) {
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? msm_impl_t<BN254, 2>(c, n, points, scalars, out) : msm_impl_t<BLS12_381, 2>(c, n, points, scalars, out);
+}
+
+int elp_verify_id_batch_aggregated_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+                                       const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254
+             ? elp_verify_id_batch_aggregated_dev_t<BN254>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, seed32, d_flags, d_accepted)
+             : elp_verify_id_batch_aggregated_dev_t<BLS12_381>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, seed32, d_flags,
+                                                               d_accepted);
+}
+
+int elp_verify_id_batch_aggregated(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
+                                   const uint32_t* ad_off, size_t ad_len, const uint8_t* seed32, uint8_t* flags, uint64_t* accepted,
+                                   int* batch_equation_held) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (accepted) *accepted = 0;
+  if (batch_equation_held) *batch_equation_held = 1;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags || !seed32 || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
+  DevBuf drec, dad, doff, dfl, dcnt;
+  const void *pad, *poff;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_verify_id_batch_aggregated_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, seed32, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  int held = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&held, c->agg_ok, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (accepted) *accepted = cnt;
+  if (batch_equation_held) *batch_equation_held = held;
+  return ELP_OK;
 }

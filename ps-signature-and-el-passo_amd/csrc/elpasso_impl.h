@@ -343,6 +343,93 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_msm_final(const void* win_, u32* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Aggregated VerifyID: k_verify_id_agg does the NIZK half and one Miller loop per item and multiplies
+// the 64 Miller values of its wave through LDS; k_fp12_reduce shrinks the per-wave products; the Pippenger kernels above give
+// sum d_i sig2_i; k_agg_final closes the batch equation with one more Miller loop and ONE final exponentiation; k_agg_finish
+// publishes the verdicts, re-verifying every item individually only when the batch equation failed.
+struct AggSeed {
+  uint8_t b[32];
+};
+
+template <class C>
+__device__ __forceinline__ void wave_fp12_product(Fp12<C>& f, Fp12<C>* sh) {   // sh: 64 entries in LDS; result valid in lane 0
+  const int lane = threadIdx.x & 63;
+  for (int d = 32; d >= 1; d >>= 1) {
+    sh[lane] = f;
+    __syncthreads();
+    if (lane < d) fp12_mul<C>(f, f, sh[lane + d]);
+    __syncthreads();
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_verify_id_agg(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+                                                             const uint8_t* ad, const u32* ad_off, u32 ad_len, AggSeed seed,
+                                                             uint8_t* nizk_flags, u32* deltas, u32* sig2s, Fp12<C>* wave_prod, size_t n) {
+  __shared__ Fp12<C> sh[ELP_BLOCK];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fp12<C> f;
+  fp12_set_one(f);
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    bool ok = verify_id_agg_item<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al, seed.b, (u64)i, f, deltas + i * 8,
+                                    sig2s + i * (size_t)(2 * C::N));
+    nizk_flags[i] = ok ? 1 : 0;
+  }
+  wave_fp12_product<C>(f, sh);
+  if (threadIdx.x == 0) wave_prod[blockIdx.x] = f;
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_fp12_reduce(const Fp12<C>* in, size_t n, Fp12<C>* out) {
+  __shared__ Fp12<C> sh[ELP_BLOCK];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fp12<C> f;
+  if (i < n)
+    f = in[i];
+  else
+    fp12_set_one(f);
+  wave_fp12_product<C>(f, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = f;
+}
+
+// F * f(-S2, gg) -> final exponentiation -> *agg_ok = (result == 1).  One lane.
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_agg_final(KeyCtx<C> key, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Aff<F1<C>> s2, ns2;
+  bool ok = g1_load<C>(s2, s2_std);
+  aff_neg(ns2, s2);
+  if (aff_is_inf(s2)) aff_set_inf(ns2);
+  Fp12<C> f, g;
+  const LineCoef<C>* lines[1] = {key.gg_lines};
+  miller_loop<C, 0, 1>(f, (const Aff<F1<C>>*)0, (const Aff<F2<C>>*)0, &ns2, lines);
+  fp12_mul<C>(f, f, F[0]);
+  final_exp<C>(g, f);
+  *agg_ok = (ok && fp12_is_one(g)) ? 1 : 0;
+}
+
+// verdicts: the NIZK flags when the batch equation held, otherwise the exact per-item verification (rare, slow path)
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_agg_finish(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+                                                          const uint8_t* ad, const u32* ad_off, u32 ad_len, const uint8_t* nizk_flags,
+                                                          const int* agg_ok, uint8_t* flags, unsigned long long* accepted, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    ok = nizk_flags[i] != 0;
+    if (ok && *agg_ok == 0) {
+      const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+      size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+      ok = verify_id_item<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al);
+    }
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
 // ---- setup kernels
 template <class F>
 __global__ void __launch_bounds__(ELP_BLOCK) k_window_bases(const Aff<F>* bases, int nb, int W, int nwin, Aff<F>* bj) {
@@ -486,6 +573,10 @@ struct elp_ctx {
   void* lines = nullptr;
   std::vector<uint8_t> h_b1;  // host mirror of the G1 base words (std form) so set_rp / set_signer_secret can rebuild
   bool have_pk = false;
+  // workspace of the aggregated verification (grown on demand, reused across calls)
+  void* agg_ws = nullptr;
+  size_t agg_ws_bytes = 0;
+  int* agg_ok = nullptr;      // device flag of the last aggregated batch
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -878,6 +969,95 @@ static inline int check_fused(elp_ctx* c, uint64_t mask) {
     return ELP_ERR_STATE;
   }
   if (c->A < 64 && (mask >> c->A) != 0) return ELP_ERR_ARG;
+  return ELP_OK;
+}
+
+// Pippenger launch sequence over device buffers (points std affine, 32-byte scalars); `ws` needs msm_ws_bytes() bytes.
+template <class C, int G>
+static size_t msm_ws_bytes(size_t n) {
+  const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
+  const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
+  const size_t S = (n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE;
+  return ((n * AFF + 255) & ~(size_t)255) + ((32 * S * 256 * JAC + 255) & ~(size_t)255) + ((32 * JAC + 255) & ~(size_t)255) + 256;
+}
+template <class C, int G>
+static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws) {
+  const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
+  const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
+  const int S = (int)((n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE);
+  uint8_t* aff = ws;
+  uint8_t* part = aff + ((n * AFF + 255) & ~(size_t)255);
+  uint8_t* win = part + (((size_t)32 * S * 256 * JAC + 255) & ~(size_t)255);
+  int* bad = (int*)(win + ((32 * JAC + 255) & ~(size_t)255));
+  (void)hipMemsetAsync(bad, 0, 4, stream);
+  hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, (const u32*)d_pts_std, (void*)aff, bad, n);
+  if (G == 1) {
+    typedef F1<C> F;
+    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
+    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+  } else {
+    typedef F2<C> F;
+    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
+    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+  }
+  hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
+}
+
+template <class C>
+int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr,
+                                         const void* d_ad, const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags,
+                                         void* d_accepted) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (!seed32) return ELP_ERR_ARG;
+  if (n == 0) return ELP_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = popcount_mask(mask, c->A);
+  if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;
+  const int words = verify_id_record_words<C>(c->A, H, retr != 0);
+  const size_t nw = grid_for(n);                       // waves = per-wave Miller products
+  const size_t nw2 = grid_for(nw);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_flags = 0, o_delta = al(n), o_sig2 = o_delta + al(n * 32), o_f1 = o_sig2 + al(n * Sizes<C>::G1),
+               o_f2 = o_f1 + al(nw * sizeof(Fp12<C>)), o_f3 = o_f2 + al(nw2 * sizeof(Fp12<C>)), o_s2 = o_f3 + al(sizeof(Fp12<C>)),
+               o_msm = o_s2 + al(Sizes<C>::G1), total = o_msm + msm_ws_bytes<C, 1>(n);
+  if (c->agg_ws_bytes < total) {
+    HIPCHK(c, hipStreamSynchronize(stream));
+    if (c->agg_ws) (void)hipFree(c->agg_ws);
+    c->agg_ws = nullptr;
+    c->agg_ws_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->agg_ws, total));
+    c->agg_ws_bytes = total;
+  }
+  if (!c->agg_ok) HIPCHK(c, hipMalloc((void**)&c->agg_ok, 256));
+  uint8_t* ws = (uint8_t*)c->agg_ws;
+  AggSeed seed;
+  memcpy(seed.b, seed32, 32);
+  KeyCtx<C> key = make_key<C>(c);
+  hipLaunchKernelGGL((k_verify_id_agg<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
+                     (Fp12<C>*)(ws + o_f1), n);
+  // product of the per-wave Miller values: nw -> nw2 -> 1
+  hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nw2), dim3(ELP_BLOCK), 0, stream, (const Fp12<C>*)(ws + o_f1), nw, (Fp12<C>*)(ws + o_f2));
+  const Fp12<C>* F = (const Fp12<C>*)(ws + o_f2);
+  size_t left = nw2;
+  uint8_t *cur = ws + o_f2, *nxt = ws + o_f1;   // ping-pong (o_f1 is free again after the first reduction)
+  while (left > 1) {
+    size_t nl = grid_for(left);
+    hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nl), dim3(ELP_BLOCK), 0, stream, (const Fp12<C>*)cur, left, (Fp12<C>*)nxt);
+    uint8_t* t = cur;
+    cur = nxt;
+    nxt = t;
+    left = nl;
+  }
+  F = (const Fp12<C>*)cur;
+  // S2 = sum d_i sig2_i
+  msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm);
+  hipLaunchKernelGGL((k_agg_final<C>), dim3(1), dim3(ELP_BLOCK), 0, stream, key, F, (const u32*)(ws + o_s2), c->agg_ok);
+  hipLaunchKernelGGL((k_agg_finish<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (const uint8_t*)(ws + o_flags), (const int*)c->agg_ok,
+                     (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
 

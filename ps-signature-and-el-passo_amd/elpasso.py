@@ -44,6 +44,10 @@ _SIGS = {
                                             _c.POINTER(_c.c_uint64)]),
     "elp_verify_id_wire_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                                 _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
+    "elp_verify_id_batch_aggregated": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _c.c_int, _u8p, _u8p, _c.c_size_t, _u8p, _u8p,
+                                                  _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_int)]),
+    "elp_verify_id_batch_aggregated_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p,
+                                                      _c.c_void_p, _c.c_size_t, _u8p, _c.c_void_p, _c.c_void_p]),
     "elp_ps_verify_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_int, _u8p, _c.POINTER(_c.c_uint64)]),
     "elp_provide_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _u8p, _u8p, _c.c_size_t, _u8p, _u8p,
                                         _c.POINTER(_c.c_uint64)]),
@@ -244,6 +248,20 @@ class Context:
                                                off.ctypes.data if off is not None else None, adl, flags.ctypes.data,
                                                ctypes.byref(cnt)))
         return flags, cnt.value
+
+    def verify_id_batch_aggregated(self, records, hidden_mask, with_retrieval, ad, seed):
+        """Returns (flags, accepted, batch_equation_held)."""
+        H = bin(hidden_mask).count("1")
+        rsz = self.lib.elp_verify_id_record_size(self.curve, self.A, H, int(with_retrieval))
+        n = len(records) // rsz
+        data, off, adl = self._ad(ad)
+        flags = np.zeros(n, dtype=np.uint8)
+        cnt, held = ctypes.c_uint64(0), ctypes.c_int(0)
+        kr, kd, ks = _buf(records), _buf(data or b"\0"), _buf(seed)
+        self._chk(self.lib.elp_verify_id_batch_aggregated(self.h, n, kr[1], hidden_mask, int(with_retrieval), kd[1],
+                                                          off.ctypes.data if off is not None else None, adl, ks[1], flags.ctypes.data,
+                                                          ctypes.byref(cnt), ctypes.byref(held)))
+        return flags, cnt.value, bool(held.value)
 
     def verify_id_wire_batch(self, messages, with_retrieval, ad):
         """messages: list of raw IdProof wire messages (bytes, base64 already decoded)."""
