@@ -119,3 +119,45 @@ def test_synthetic_batch_expectation(bls_ctx):
         pr = IdProof(pts[0], pts[1], k, pts[2], sc[0], sc[1:1 + H + 2], attrs, pts[3], pts[4], True)
         assert [M.fr_hash(a) for a in attrs[H:]] == sc[1 + H + 2:]
         assert PR.verify_id(pk, pr, b"hello", b"service", g1u(wl.apk, N), g1u(wl.g, N), g1u(wl.h, N)) == bool(flags[i])
+
+
+def test_msm_wire_and_aggregated_paths_on_bls(bls_ctx):
+    """The wider entry points on the BLS12-381 instantiation: Pippenger MSM vs the model's sum of products, wire ingest of a
+    model-encoded proof, aggregated verification vs the per-item verdicts."""
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    from oracle.pymodel import Codec
+    rnd = random.Random(4)
+    n = 70
+    ks = [rnd.randrange(M.r) for _ in range(n)]
+    bs = [rnd.randrange(1, 1 << 40) for _ in range(n)]
+    pts = bls_ctx.g1_mul(g1b(BLS_G1, N) * n, b"".join(fb(b) for b in bs))
+    total = sum(k * b for k, b in zip(ks, bs)) % M.r
+    assert g1u(bls_ctx.g1_msm(pts, b"".join(fb(k) for k in ks)), N) == G.g1_mul(BLS_G1, total)
+    pts2 = bls_ctx.g2_mul(g2b(BLS_G2, N) * 20, b"".join(fb(b) for b in bs[:20]))
+    total2 = sum(k * b for k, b in zip(ks[:20], bs[:20])) % M.r
+    assert g2u(bls_ctx.g2_msm(pts2, b"".join(fb(k) for k in ks[:20])), N) == G.g2_mul(BLS_G2, total2)
+    A, H, m = 4, 2, 200
+    wl = synth.Workload(bls_ctx, A)
+    recs, mask, expect = wl.verify_id_batch(m, H, corrupt_every=11, corrupt_at=4)
+    flags, cnt = bls_ctx.verify_id_batch(recs, mask, True, b"hello")
+    assert (flags == expect).all()
+    fl2, cnt2, held = bls_ctx.verify_id_batch_aggregated(recs, mask, True, b"hello", bytes(32))
+    assert held and (fl2 == expect).all() and cnt2 == cnt
+    rsz = len(recs) // m
+    r = bytearray(recs)
+    r[3 * rsz:3 * rsz + 96] = r[5 * rsz:5 * rsz + 96]        # foreign sig1: passes the NIZK, fails the pairing
+    fl3, cnt3, held = bls_ctx.verify_id_batch_aggregated(bytes(r), mask, True, b"hello", bytes(32))
+    ref, _ = bls_ctx.verify_id_batch(bytes(r), mask, True, b"hello")
+    assert not held and (fl3 == ref).all() and ref[3] == 0
+    # wire path: re-encode record 0 as the reference's T-L-V message through the model's codec
+    from oracle.pymodel import IdProof
+    from elp_testlib import ib
+    rec = recs[:rsz]
+    p = [g1u(rec[96 * j:96 * j + 96], N) for j in range(5)]
+    k = g2u(rec[480:672], N)
+    sc = [ib(rec[672 + 32 * j:704 + 32 * j]) for j in range(1 + H + 2 + (A - H))]
+    attrs = [b""] * H + wl.attributes(0)[H:]
+    pr = IdProof(p[0], p[1], k, p[2], sc[0], sc[1:1 + H + 2], attrs, p[3], p[4], True)
+    wire = Codec(M).proof_encode(pr)
+    fl4, _ = bls_ctx.verify_id_wire_batch([wire, wire[:-1]], True, b"hello")
+    assert list(fl4) == [1, 0]
