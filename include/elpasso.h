@@ -121,6 +121,25 @@ int elp_ps_verify_batch(elp_ctx* ctx, size_t n, const uint8_t* records, int natt
 int elp_provide_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, const uint8_t* ad,
                          const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
 
+/* ---- user side in batch ---------------------------------------------------------------
+ * The reference's requester draws its randomness with Fr::setByCSPRNG; here it is an input, in the reference's draw order,
+ * so a batch is reproducible (load generators, test-vector production) and comparable with the oracle bit for bit.
+ * Scalars are 32-byte little-endian values < r; m[i] = Fr::setHashOf(attribute i) for ALL attributes. */
+size_t elp_request_id_record_size(int curve, int nattr, int nhidden);
+size_t elp_request_id_out_size(int curve, int nhidden);
+size_t elp_prove_id_record_size(int curve, int nattr, int nhidden, int with_retrieval);
+/* PSRequester::el_passo_request_id (src/ps-requester.cc:19-99).  record i: m[A] | t | rho_0 | rho[H]
+ * requests[i] = A | c | rs[H+1]  (the head of the elp_provide_id_batch record: append m_revealed and the nonce u to issue). */
+int elp_request_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, const uint8_t* ad,
+                         const uint32_t* ad_off, size_t ad_len, uint8_t* requests);
+/* PSRequester::el_passo_prove_id / _without_id_retrieval (src/ps-requester.cc:150-432), credential randomisation included
+ * (:163-170).  record i: sig1 | sig2 | m[A] | t | r | [eps] | rho[H] | rho_t | [rho_eps]   ([..] only with retrieval).
+ * proofs[i] is the elp_verify_id_batch record (elp_verify_id_record_size bytes): prover output = verifier input.
+ * flags[i] = 0 (proof zeroed) when the credential points are not on the curve or attribute 0 (and 1) is not hidden. */
+int elp_prove_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval,
+                       const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* proofs, uint8_t* flags,
+                       uint64_t* produced);
+
 /* Same fused batches over DEVICE buffers, asynchronous on `stream` (hipStream_t; NULL = default stream).  Nothing is
  * copied or synchronised; *d_accepted (uint64 in device memory) is atomically incremented. */
 int elp_verify_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
@@ -137,6 +156,11 @@ int elp_ps_verify_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_
 int elp_provide_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
                              const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags,
                              void* d_accepted);
+int elp_request_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
+                             const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_requests);
+int elp_prove_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
+                           int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_proofs,
+                           void* d_flags, void* d_accepted);
 
 /* ---- measurement helpers ---------------------------------------------------------------------------------------- */
 /* Times `reps` launches of the verify_id kernel with HIP events on `stream`; returns the average ms per launch. */

@@ -65,4 +65,7 @@
 namespace elp {
 typedef uint32_t u32;
 typedef uint64_t u64;
+// scalar-field (Fr) Montgomery parameters of a curve; specialised in params_<curve>.h
+template <class C>
+struct FrOf;
 }  // namespace elp

@@ -625,6 +625,219 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// User side in batch.  Randomness is an input (the reference draws it with setByCSPRNG), in the
+// reference's draw order, so outputs are reproducible and can be compared with the oracle bit for bit.
+
+// rho - secret * c  (mod r): the Schnorr responses (src/ps-requester.cc:80-85,280-294); Fr as a second Montgomery field
+template <class C>
+ELP_HEAVY Scalar fr_response(const Scalar& rho, const Scalar& secret, const Scalar& c) {
+  typedef typename FrOf<C>::type R;
+  StdFp<R> a, b;
+  for (int i = 0; i < 8; i++) {
+    a.w[i] = secret.v[i];
+    b.w[i] = c.v[i];
+  }
+  StdFp<R> t = fp_to_std<R>(fp_mul<R>(fp_from_std<R>(a), fp_from_std<R>(b)));
+  Scalar prod;
+  for (int i = 0; i < 8; i++) prod.v[i] = t.w[i];
+  return scalar_sub_mod_r<C>(scalar_mod_r<C>(rho), prod);
+}
+
+// EL PASSO RequestID (src/ps-requester.cc:19-99).  Record: m[A] | t1 | rho0 | rho[H]     (m = Fr::setHashOf(attribute), all A)
+// Output: A | c | rs[H+1]   (the first part of the provide_id record: append m_revealed and the IdP nonce to issue)
+template <class C>
+ELP_HD constexpr int request_id_record_words(int A, int H) { return 8 * (A + 2 + H); }
+template <class C>
+ELP_HD constexpr int request_id_out_words(int H) { return 2 * C::N + 8 * (2 + H); }
+template <class C>
+ELP_HEAVY void request_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, const uint8_t* ad, size_t ad_len, u32* out) {
+  typedef F1<C> G1F;
+  const int A = key.A;
+  const u32* ms = rec;
+  const Scalar t1 = scalar_load_w(rec + 8 * A), rho0 = scalar_load_w(rec + 8 * (A + 1));
+  const u32* rhos = rec + 8 * (A + 2);
+  Jac<G1F> Ac, V;
+  jac_set_inf(Ac);
+  jac_set_inf(V);
+  acc_fixed_g1<C>(Ac, key, G1_BASE_G, t1);                       // A = g^t prod Y_i^{m_i}
+  acc_fixed_g1<C>(V, key, G1_BASE_G, rho0);                      // V = g^rho0 prod Y_i^{rho_i}
+  int j = 0;
+  for (int i = 0; i < A; i++)
+    if ((hidden_mask >> i) & 1) {
+      acc_fixed_g1<C>(Ac, key, G1_BASE_Y0 + i, scalar_load_w(ms + 8 * i));
+      acc_fixed_g1<C>(V, key, G1_BASE_Y0 + i, scalar_load_w(rhos + 8 * j));
+      j++;
+    }
+  Fp<C> z[2], zi[2];
+  z[0] = Ac.Z;
+  z[1] = V.Z;
+  batch_zinv<C, 2, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
+  Aff<G1F> aA, aV;
+  jac_to_aff_with_zinv<G1F>(aA, Ac, zi[0]);
+  jac_to_aff_with_zinv<G1F>(aV, V, zi[1]);
+  Transcript t;
+  transcript_init(t);
+  transcript_g1<C>(t, aA);
+  transcript_g1<C>(t, aV);
+  const Scalar c = transcript_challenge<C>(t, ad, ad_len);
+  g1_store<C>(out, aA);
+  u32* o = out + 2 * C::N;
+  for (int i = 0; i < 8; i++) o[i] = c.v[i];
+  o += 8;
+  Scalar r0 = fr_response<C>(rho0, t1, c);
+  for (int i = 0; i < 8; i++) o[i] = r0.v[i];
+  o += 8;
+  j = 0;
+  for (int i = 0; i < A; i++)
+    if ((hidden_mask >> i) & 1) {
+      Scalar r = fr_response<C>(scalar_load_w(rhos + 8 * j), scalar_load_w(ms + 8 * i), c);
+      for (int q = 0; q < 8; q++) o[q] = r.v[q];
+      o += 8;
+      j++;
+    }
+}
+
+// EL PASSO ProveID (src/ps-requester.cc:150-310, :312-432).  Record: sig1 | sig2 | m[A] | t | r | [eps] | rho[H] | rho_t | [rho_e]
+// Output: the verify_id record  sig1' | sig2' | phi | [E1 | E2] | k | c | rs | m_revealed  -- prover output = verifier input.
+template <class C>
+ELP_HD constexpr int prove_id_record_words(int A, int H, bool retr) { return 4 * C::N + 8 * (A + 2 + (retr ? 1 : 0) + H + 1 + (retr ? 1 : 0)); }
+template <class C>
+ELP_HEAVY bool prove_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
+                             u32* out) {
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  const int A = key.A;
+  int H = 0;
+  for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+  const int out_words = verify_id_record_words<C>(A, H, retr);
+  for (int i = 0; i < out_words; i++) out[i] = 0;
+  Aff<G1F> sig1, sig2;
+  if (!g1_load<C>(sig1, rec) || !g1_load<C>(sig2, rec + 2 * C::N)) return false;
+  if (!(hidden_mask & 1) || (retr && !(hidden_mask & 2))) return false;   // attribute 0 (and 1) must be hidden, SURVEY.md section 3D
+  const u32* ms = rec + 4 * C::N;
+  const u32* p = ms + 8 * A;
+  const Scalar t = scalar_load_w(p), rr = scalar_load_w(p + 8);
+  p += 16;
+  Scalar eps;
+  for (int i = 0; i < 8; i++) eps.v[i] = 0;
+  if (retr) {
+    eps = scalar_load_w(p);
+    p += 8;
+  }
+  const u32* rhos = p;
+  const Scalar rho_t = scalar_load_w(p + 8 * H);
+  Scalar rho_e = eps;
+  if (retr) rho_e = scalar_load_w(p + 8 * (H + 1));
+  // randomised signature (sig1^r, (sig2 sig1^t)^r)                        src/ps-requester.cc:163-170
+  Jac<G1F> s1, s2, tmp;
+  g1_mul_glv<C>(s1, sig1, rr);
+  g1_mul_glv<C>(tmp, sig1, t);
+  jac_madd<G1F>(tmp, tmp, sig2);
+  Aff<G1F> atmp;
+  jac_to_aff<G1F>(atmp, tmp);
+  g1_mul_glv<C>(s2, atmp, rr);
+  // phi, E1, E2 and the commitments                                        :172-187, :227-261
+  Jac<G1F> phi, E1, E2, Vphi, VE1, VE2;
+  jac_set_inf(phi); jac_set_inf(E1); jac_set_inf(E2); jac_set_inf(Vphi); jac_set_inf(VE1); jac_set_inf(VE2);
+  acc_fixed_g1<C>(phi, key, g1_base_hs(key), scalar_load_w(ms));
+  acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), scalar_load_w(rhos));
+  if (retr) {
+    acc_fixed_g1<C>(E1, key, g1_base_geg(key), eps);
+    acc_fixed_g1<C>(E2, key, g1_base_apk(key), eps);
+    acc_fixed_g1<C>(E2, key, g1_base_h(key), scalar_load_w(ms + 8));
+    acc_fixed_g1<C>(VE1, key, g1_base_geg(key), rho_e);
+    acc_fixed_g1<C>(VE2, key, g1_base_apk(key), rho_e);
+    acc_fixed_g1<C>(VE2, key, g1_base_h(key), scalar_load_w(rhos + 8));
+  }
+  // k = XX prod YY_j^{m_j} gg^t ; V_k = XX prod YY_j^{rho_j} gg^{rho_t}     :189-204, :227-246
+  Jac<G2F> kk, Vk;
+  jac_from_aff(kk, key.b2[G2_BASE_XX]);
+  jac_from_aff(Vk, key.b2[G2_BASE_XX]);
+  {
+    int j = 0;
+    for (int i = 0; i < A; i++)
+      if ((hidden_mask >> i) & 1) {
+        acc_fixed_g2<C>(kk, key, G2_BASE_YY0 + i, scalar_load_w(ms + 8 * i));
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, scalar_load_w(rhos + 8 * j));
+        j++;
+      }
+  }
+  acc_fixed_g2<C>(kk, key, G2_BASE_GG, t);
+  acc_fixed_g2<C>(Vk, key, G2_BASE_GG, rho_t);
+  // affine forms with one inversion
+  Fp<C> z1[8], zi1[8];
+  Fp2<C> z2[2], zi2[2];
+  z1[0] = s1.Z; z1[1] = s2.Z; z1[2] = phi.Z; z1[3] = Vphi.Z;
+  z1[4] = retr ? E1.Z : fp_one<C>(); z1[5] = retr ? E2.Z : fp_one<C>(); z1[6] = retr ? VE1.Z : fp_one<C>(); z1[7] = retr ? VE2.Z : fp_one<C>();
+  z2[0] = kk.Z;
+  z2[1] = Vk.Z;
+  batch_zinv<C, 8, 2>(zi1, z1, zi2, z2);
+  Aff<G1F> a1, a2, aphi, aVphi, aE1, aE2, aVE1, aVE2;
+  Aff<G2F> ak, aVk;
+  jac_to_aff_with_zinv<G1F>(a1, s1, zi1[0]);
+  jac_to_aff_with_zinv<G1F>(a2, s2, zi1[1]);
+  jac_to_aff_with_zinv<G1F>(aphi, phi, zi1[2]);
+  jac_to_aff_with_zinv<G1F>(aVphi, Vphi, zi1[3]);
+  jac_to_aff_with_zinv<G2F>(ak, kk, zi2[0]);
+  jac_to_aff_with_zinv<G2F>(aVk, Vk, zi2[1]);
+  Transcript tr;
+  transcript_init(tr);
+  transcript_g2<C>(tr, ak);
+  transcript_g1<C>(tr, aphi);
+  if (retr) {
+    jac_to_aff_with_zinv<G1F>(aE1, E1, zi1[4]);
+    jac_to_aff_with_zinv<G1F>(aE2, E2, zi1[5]);
+    jac_to_aff_with_zinv<G1F>(aVE1, VE1, zi1[6]);
+    jac_to_aff_with_zinv<G1F>(aVE2, VE2, zi1[7]);
+    transcript_g1<C>(tr, aE1);
+    transcript_g1<C>(tr, aE2);
+  }
+  transcript_g2<C>(tr, aVk);
+  transcript_g1<C>(tr, aVphi);
+  if (retr) {
+    transcript_g1<C>(tr, aVE1);
+    transcript_g1<C>(tr, aVE2);
+  }
+  const Scalar c = transcript_challenge<C>(tr, ad, ad_len);
+  // emit the verifier's record
+  u32* o = out;
+  g1_store<C>(o, a1); o += 2 * C::N;
+  g1_store<C>(o, a2); o += 2 * C::N;
+  g1_store<C>(o, aphi); o += 2 * C::N;
+  if (retr) {
+    g1_store<C>(o, aE1); o += 2 * C::N;
+    g1_store<C>(o, aE2); o += 2 * C::N;
+  }
+  g2_store<C>(o, ak); o += 4 * C::N;
+  for (int i = 0; i < 8; i++) o[i] = c.v[i];
+  o += 8;
+  {
+    int j = 0;
+    for (int i = 0; i < A; i++)
+      if ((hidden_mask >> i) & 1) {
+        Scalar r = fr_response<C>(scalar_load_w(rhos + 8 * j), scalar_load_w(ms + 8 * i), c);
+        for (int q = 0; q < 8; q++) o[q] = r.v[q];
+        o += 8;
+        j++;
+      }
+  }
+  Scalar r = fr_response<C>(rho_t, t, c);
+  for (int q = 0; q < 8; q++) o[q] = r.v[q];
+  o += 8;
+  if (retr) {
+    r = fr_response<C>(rho_e, eps, c);
+    for (int q = 0; q < 8; q++) o[q] = r.v[q];
+    o += 8;
+  }
+  for (int i = 0; i < A; i++)
+    if (!((hidden_mask >> i) & 1)) {
+      for (int q = 0; q < 8; q++) o[q] = ms[8 * i + q];
+      o += 8;
+    }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Setup helpers
 
 // entry (j, d) of the fixed-base table of `base`:  d * 2^(W j) * base, d = 1..2^W-1; one call fills entries

@@ -24,6 +24,8 @@ extern template int elp_pairing_check_t<BN254>(elp_ctx* c, size_t n, int npairs,
 extern template int elp_verify_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template int elp_verify_id_wire_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template int elp_ps_verify_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template int elp_prove_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_proofs, void* d_flags, void* d_accepted);
+extern template int elp_request_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_requests);
 extern template int elp_provide_id_batch_dev_t<BN254>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted);
 extern template int elp_provide_id_batch_t<BN254>(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
 extern template int elp_bench_op_t<BN254>(elp_ctx* c, int op, size_t lanes, int iters, float* ms);
@@ -45,6 +47,8 @@ extern template int elp_pairing_check_t<BLS12_381>(elp_ctx* c, size_t n, int npa
 extern template int elp_verify_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template int elp_verify_id_wire_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template int elp_ps_verify_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template int elp_prove_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_proofs, void* d_flags, void* d_accepted);
+extern template int elp_request_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_requests);
 extern template int elp_provide_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted);
 extern template int elp_provide_id_batch_t<BLS12_381>(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted);
 extern template int elp_bench_op_t<BLS12_381>(elp_ctx* c, int op, size_t lanes, int iters, float* ms);
@@ -134,6 +138,20 @@ size_t elp_verify_id_record_size(int curve, int A, int H, int retr) {
   if (curve != ELP_CURVE_BN254) return 0;
   return 4 * (size_t)verify_id_record_words<BN254>(A, H, retr != 0);
 }
+size_t elp_prove_id_record_size(int curve, int A, int H, int retr) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)prove_id_record_words<BLS12_381>(A, H, retr != 0);
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)prove_id_record_words<BN254>(A, H, retr != 0);
+}
+size_t elp_request_id_record_size(int curve, int A, int H) {
+  if (curve != ELP_CURVE_BLS12_381 && curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)request_id_record_words<BN254>(A, H);
+}
+size_t elp_request_id_out_size(int curve, int H) {
+  if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)request_id_out_words<BLS12_381>(H);
+  if (curve != ELP_CURVE_BN254) return 0;
+  return 4 * (size_t)request_id_out_words<BN254>(H);
+}
 size_t elp_ps_verify_record_size(int curve, int A) {
   if (curve == ELP_CURVE_BLS12_381) return 4 * (size_t)(4 * BLS12_381::N + 8 * A);
   if (curve != ELP_CURVE_BN254) return 0;
@@ -191,6 +209,74 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (accepted) *accepted = cnt;
+  return ELP_OK;
+}
+
+int elp_prove_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+                           const void* d_ad_off, size_t ad_len, void* d_proofs, void* d_flags, void* d_accepted) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254
+             ? elp_prove_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_proofs, d_flags, d_accepted)
+             : elp_prove_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_proofs, d_flags, d_accepted);
+}
+int elp_request_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+                             const void* d_ad_off, size_t ad_len, void* d_requests) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? elp_request_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_requests)
+                                     : elp_request_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_requests);
+}
+
+// user side, host buffers
+int elp_prove_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad, const uint32_t* ad_off,
+                       size_t ad_len, uint8_t* proofs, uint8_t* flags, uint64_t* produced) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (produced) *produced = 0;
+  if (n == 0) return ELP_OK;
+  if (!records || !flags || !proofs || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = popcount_mask(mask, c->A);
+  const size_t rsz = elp_prove_id_record_size(c->curve, c->A, H, retr), osz = elp_verify_id_record_size(c->curve, c->A, H, retr);
+  DevBuf drec, dad, doff, dfl, dcnt, dout;
+  const void *pad, *poff;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dfl.alloc(n));
+  HIPCHK(c, dcnt.alloc(8));
+  HIPCHK(c, dout.alloc(n * osz));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_prove_id_batch_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, dout.p, dfl.p, dcnt.p);
+  if (rc) return rc;
+  uint64_t cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(proofs, dout.p, n * osz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (produced) *produced = cnt;
+  return ELP_OK;
+}
+int elp_request_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
+                         size_t ad_len, uint8_t* requests) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (n == 0) return ELP_OK;
+  if (!records || !requests || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = popcount_mask(mask, c->A);
+  const size_t rsz = elp_request_id_record_size(c->curve, c->A, H), osz = elp_request_id_out_size(c->curve, H);
+  DevBuf drec, dad, doff, dout;
+  const void *pad, *poff;
+  HIPCHK(c, drec.alloc(n * rsz));
+  HIPCHK(c, dout.alloc(n * osz));
+  HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
+  if (rc) return rc;
+  rc = elp_request_id_batch_dev(c, c->stream, n, drec.p, mask, pad, poff, ad_len, dout.p);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(requests, dout.p, n * osz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return ELP_OK;
 }
 

@@ -85,6 +85,31 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_provide_id(KeyCtx<C> key, const u
   count_accept(ok, accepted);
 }
 
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_prove_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
+                                                        const u32* ad_off, u32 ad_len, u32* out, int out_words, uint8_t* flags,
+                                                        unsigned long long* accepted, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = prove_id_item<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al, out + i * (size_t)out_words);
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) k_request_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
+                                                          const u32* ad_off, u32 ad_len, u32* out, int out_words, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+  size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+  request_id_item<C>(key, recs + i * (size_t)rec_words, mask, a, al, out + i * (size_t)out_words);
+}
+
 template <class C, int G>  // G = 1: G1, 2: G2
 __global__ void __launch_bounds__(ELP_BLOCK) k_decompress(const uint8_t* wire, u32* out, uint8_t* okf, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1111,6 +1136,35 @@ int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d
   hipLaunchKernelGGL((k_provide_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
                      (const u32*)d_records, words, (u64)mask, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (u32*)d_sigs,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+
+template <class C>
+int elp_prove_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
+                             const void* d_ad_off, size_t ad_len, void* d_proofs, void* d_flags, void* d_accepted) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (n == 0) return ELP_OK;
+  const int H = popcount_mask(mask, c->A);
+  if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;
+  hipLaunchKernelGGL((k_prove_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+                     (const u32*)d_records, prove_id_record_words<C>(c->A, H, retr != 0), (u64)mask, retr, (const uint8_t*)d_ad,
+                     (const u32*)d_ad_off, (u32)ad_len, (u32*)d_proofs, verify_id_record_words<C>(c->A, H, retr != 0),
+                     (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+template <class C>
+int elp_request_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
+                               const void* d_ad_off, size_t ad_len, void* d_requests) {
+  int rc = check_fused(c, mask);
+  if (rc) return rc;
+  if (n == 0) return ELP_OK;
+  const int H = popcount_mask(mask, c->A);
+  hipLaunchKernelGGL((k_request_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+                     (const u32*)d_records, request_id_record_words<C>(c->A, H), (u64)mask, (const uint8_t*)d_ad,
+                     (const u32*)d_ad_off, (u32)ad_len, (u32*)d_requests, request_id_out_words<C>(H), n);
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }

@@ -51,6 +51,16 @@ _SIGS = {
     "elp_ps_verify_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_int, _u8p, _c.POINTER(_c.c_uint64)]),
     "elp_provide_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _u8p, _u8p, _c.c_size_t, _u8p, _u8p,
                                         _c.POINTER(_c.c_uint64)]),
+    "elp_request_id_record_size": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    "elp_request_id_out_size": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "elp_prove_id_record_size": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "elp_request_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _u8p, _u8p, _c.c_size_t, _u8p]),
+    "elp_prove_id_batch": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _c.c_uint64, _c.c_int, _u8p, _u8p, _c.c_size_t, _u8p, _u8p,
+                                      _c.POINTER(_c.c_uint64)]),
+    "elp_request_id_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_void_p, _c.c_void_p,
+                                            _c.c_size_t, _c.c_void_p]),
+    "elp_prove_id_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p,
+                                          _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "elp_verify_id_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p]),
     "elp_ps_verify_batch_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
@@ -286,6 +296,37 @@ class Context:
         kr = _buf(records)
         self._chk(self.lib.elp_ps_verify_batch(self.h, n, kr[1], nattr, flags.ctypes.data, ctypes.byref(cnt)))
         return flags, cnt.value
+
+    def request_id_batch(self, records, hidden_mask, ad):
+        """PSRequester::el_passo_request_id in batch; records: m[A] | t | rho_0 | rho[H] -> A | c | rs[H+1] per item."""
+        H = bin(hidden_mask).count("1")
+        rsz = self.lib.elp_request_id_record_size(self.curve, self.A, H)
+        osz = self.lib.elp_request_id_out_size(self.curve, H)
+        n = len(records) // rsz
+        assert n * rsz == len(records), "record size mismatch"
+        data, off, adl = self._ad(ad)
+        out = np.zeros(n * osz, dtype=np.uint8)
+        kr, kd = _buf(records), _buf(data or b"\0")
+        self._chk(self.lib.elp_request_id_batch(self.h, n, kr[1], hidden_mask, kd[1], off.ctypes.data if off is not None else None,
+                                                adl, out.ctypes.data))
+        return out.tobytes()
+
+    def prove_id_batch(self, records, hidden_mask, with_retrieval, ad):
+        """PSRequester::el_passo_prove_id in batch; returns (verify_id records, flags, produced)."""
+        H = bin(hidden_mask).count("1")
+        rsz = self.lib.elp_prove_id_record_size(self.curve, self.A, H, int(with_retrieval))
+        osz = self.lib.elp_verify_id_record_size(self.curve, self.A, H, int(with_retrieval))
+        n = len(records) // rsz
+        assert n * rsz == len(records), "record size mismatch"
+        data, off, adl = self._ad(ad)
+        flags = np.zeros(n, dtype=np.uint8)
+        out = np.zeros(n * osz, dtype=np.uint8)
+        cnt = ctypes.c_uint64(0)
+        kr, kd = _buf(records), _buf(data or b"\0")
+        self._chk(self.lib.elp_prove_id_batch(self.h, n, kr[1], hidden_mask, int(with_retrieval), kd[1],
+                                              off.ctypes.data if off is not None else None, adl, out.ctypes.data, flags.ctypes.data,
+                                              ctypes.byref(cnt)))
+        return out.tobytes(), flags, cnt.value
 
     def provide_id_batch(self, records, hidden_mask, ad):
         H = bin(hidden_mask).count("1")

@@ -173,6 +173,31 @@ class Workload:
         return bytes(recs), (1 << H) - 1, expect
 
     # ---------------------------------------------------------------------------------------------------------
+    def prove_id_batch(self, n_items, nhidden, first_item=0, with_retrieval=True):
+        """Input records of elp_prove_id_batch: valid credentials (g^u, g^(u (x + sum y_i m_i))) + the prover's randomness
+        in the reference's draw order (src/ps-requester.cc:150-310).  Returns (records, hidden_mask)."""
+        ctx, A, H, r = self.ctx, self.A, nhidden, self.r
+        e, tails = [], []
+        for n in range(first_item, first_item + n_items):
+            m = [fr_set_hash_of(a, r) for a in self.attributes(n)]
+            u, *rnd = self._fresh(1 + 2 + (1 if with_retrieval else 0) + H + 1 + (1 if with_retrieval else 0))
+            full = (self.x + sum(y * mi for y, mi in zip(self.ys, m))) % r
+            e += [u, u * full % r]
+            tails.append(_fr_bytes(m + rnd))
+        sig = ctx.g1_msm_fixed([0], _fr_bytes(e))
+        G1 = ctx.G1
+        return b"".join(sig[2 * i * G1:(2 * i + 2) * G1] + tails[i] for i in range(n_items)), (1 << H) - 1
+
+    def request_id_batch(self, n_items, nhidden, first_item=0):
+        """Input records of elp_request_id_batch: m[A] | t | rho_0 | rho[H].  Returns (records, hidden_mask)."""
+        r = self.r
+        out = []
+        for n in range(first_item, first_item + n_items):
+            m = [fr_set_hash_of(a, r) for a in self.attributes(n)]
+            out.append(_fr_bytes(m + self._fresh(2 + nhidden)))
+        return b"".join(out), (1 << nhidden) - 1
+
+    # ---------------------------------------------------------------------------------------------------------
     def ps_verify_batch(self, n_items, first_item=0, corrupt_every=97, corrupt_at=13):
         """PS signatures on all-plaintext attributes: sigma = (g^u, g^(u (x + sum y_i m_i)))."""
         ctx, r = self.ctx, self.r

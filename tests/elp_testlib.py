@@ -94,6 +94,16 @@ def pack_provide_id(m, rq, u):
     return out + fb(u)
 
 
+def pack_request_id(m, attrs, rnd):
+    """m[A] | t | rho_0 | rho[H]   (csrc/elp/pipeline.h request_id_item); rnd in the order Protocol.request_id draws it."""
+    return b"".join(fb(m.fr_hash(bytes(a))) for a, _ in attrs) + b"".join(fb(x) for x in rnd)
+
+
+def pack_prove_id(m, cred, attrs, rnd):
+    """sig1 | sig2 | m[A] | t | r | [eps] | rho[H] | rho_t | [rho_eps]   (csrc/elp/pipeline.h prove_id_item)."""
+    return g1b(cred.sig1, m.fb) + g1b(cred.sig2, m.fb) + b"".join(fb(m.fr_hash(bytes(a))) for a, _ in attrs) + b"".join(fb(x) for x in rnd)
+
+
 def g1_bases(m, pk, svc=None, g_eg=None, apk=None, h=None, skX=None):
     """0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X."""
     hs = m.hash_to_g1(svc) if svc is not None else None

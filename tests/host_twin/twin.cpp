@@ -217,6 +217,12 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
   int pfx##_verify_id_wire(void* c, const uint8_t* msg, size_t len, int retr, const uint8_t* ad, size_t adlen) {          \
     return verify_id_wire_item<C>(((TwinCtx<C>*)c)->key, msg, len, retr != 0, ad, adlen) ? 1 : 0;                      \
   }                                                                                                                    \
+  int pfx##_prove_id(void* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen, u32* out) {      \
+    return prove_id_item<C>(((TwinCtx<C>*)c)->key, rec, mask, retr != 0, ad, adlen, out) ? 1 : 0;                      \
+  }                                                                                                                    \
+  void pfx##_request_id(void* c, const u32* rec, uint64_t mask, const uint8_t* ad, size_t adlen, u32* out) {             \
+    request_id_item<C>(((TwinCtx<C>*)c)->key, rec, mask, ad, adlen, out);                                              \
+  }                                                                                                                    \
   int pfx##_ps_verify(void* c, const u32* rec, int nattr) {                                                            \
     return ps_verify_item<C>(((TwinCtx<C>*)c)->key, rec, nattr) ? 1 : 0;                                               \
   }                                                                                                                    \

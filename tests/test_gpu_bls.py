@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from elp_testlib import (BLS12_381, BLS_G1, BLS_G2, Mcl, Protocol, fb, g1b, g1u, g2b, g2u, hidden_mask, pack_provide_id, pack_ps_verify,
+from elp_testlib import (BLS12_381, BLS_G1, BLS_G2, Mcl, Protocol, fb, g1b, g1u, g2b, g2u, hidden_mask, pack_provide_id, pack_prove_id, pack_ps_verify, pack_request_id,
                          pack_verify_id, scalar_stream)
 
 pytestmark = pytest.mark.gpu
@@ -92,9 +92,17 @@ def test_protocol_flows_vs_model(bls_ctx):
     flags, cnt = bls_ctx.verify_id_batch(recs, hidden_mask(pr.attributes), True, [b"sess", b"sess", b"sess", b"sesS"])
     assert list(flags) == [1, 0, 0, 0]
     assert PR.verify_id(pk, pr, b"sess", b"service", apk, g, h) and not PR.verify_id(pk, bad, b"sess", b"service", apk, g, h)
+    # user side on the device: same randomness -> the model's request and proof, byte for byte
+    rq_rnd = [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)]
+    got = bls_ctx.request_id_batch(pack_request_id(M, attrs, rq_rnd), 3, b"ad")
+    assert got == g1b(rq.A, N) + fb(rq.c) + b"".join(fb(x) for x in rq.rs)
+    proofs, pfl, pc = bls_ctx.prove_id_batch(pack_prove_id(M, cred, attrs, rnd), 3, True, b"sess")
+    assert pc == 1 and proofs == pack_verify_id(M, pr)
     pr2 = PR.prove_id(pk, cred, attrs, b"sess", b"service", None, None, None, rnd[:2] + rnd[3:3 + H + 1], with_retrieval=False)
     flags, cnt = bls_ctx.verify_id_batch(pack_verify_id(M, pr2), hidden_mask(pr2.attributes), False, b"sess")
     assert list(flags) == [1] and PR.verify_id_noretr(pk, pr2, b"sess", b"service")
+    proofs, pfl, pc = bls_ctx.prove_id_batch(pack_prove_id(M, cred, attrs, rnd[:2] + rnd[3:3 + H + 1]), 3, False, b"sess")
+    assert pc == 1 and proofs == pack_verify_id(M, pr2)
 
 
 def test_synthetic_batch_expectation(bls_ctx):

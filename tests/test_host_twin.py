@@ -230,3 +230,35 @@ def test_glv_gls_scalar_multiplication(L):
         assert L.twin_bn254_g1_mul_glv(g1b(P), fb(k), o) and g1u(o.raw) == G.g1_mul(P, k)
         assert L.twin_bn254_g2_mul_gls(g2b(Q), fb(k), o2) and g2u(o2.raw) == G.g2_mul(Q, k)
     assert L.twin_bn254_g1_mul_glv(bytes(64), fb(5), o) and g1u(o.raw) is None
+
+
+def test_batch_prover_items_bit_exact_vs_model(L):
+    """request_id_item / prove_id_item (user side on the device) against the oracle model with the same injected randomness:
+    byte-identical outputs, and the prover's output record is accepted by the verifier item."""
+    seed, A, H = 31337, 4, 2
+    d = load_golden("bn254_oracle_flows.json")
+    gg = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"])).gg
+    g = M.hash_to_g1("abc")
+    pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    ctx = _ctx(L, pk, svc="service", g_eg=g, apk=apk, h=h, skX=skX)
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    ms = [M.fr_hash(a) for a, _ in attrs]
+    mask = ctypes.c_uint64(0b0011)
+    rnd = [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)]
+    rq, t1 = PR.request_id(pk, attrs, b"ad1", rnd)
+    out = ctypes.create_string_buffer(64 + 32 * (2 + H))
+    L.twin_bn254_request_id(ctx, b"".join(fb(x) for x in ms + rnd), mask, b"ad1", 3, out)
+    assert out.raw == g1b(rq.A) + fb(rq.c) + b"".join(fb(x) for x in rq.rs)
+    cred = PR.unblind(PR.provide_id(pk, skX, rq, b"ad1", scalar_stream(seed, 99, M.r)), t1)
+    for retr in (1, 0):
+        rnd = [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)]
+        use = rnd if retr else rnd[:2] + rnd[3:3 + H + 1]
+        want = PR.prove_id(pk, cred, attrs, b"sess", b"service", apk if retr else None, g, h, use, with_retrieval=bool(retr))
+        rec = g1b(cred.sig1) + g1b(cred.sig2) + b"".join(fb(x) for x in ms + use)
+        o = ctypes.create_string_buffer(len(pack_verify_id(M, want)))
+        assert L.twin_bn254_prove_id(ctx, rec, mask, retr, b"sess", 4, o) == 1
+        assert o.raw == pack_verify_id(M, want)
+        assert L.twin_bn254_verify_id(ctx, o.raw, mask, retr, b"sess", 4) == 1
+    # attribute 0 must be hidden
+    assert L.twin_bn254_prove_id(ctx, rec, ctypes.c_uint64(0b0110), 0, b"sess", 4, o) == 0

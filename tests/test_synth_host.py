@@ -53,3 +53,24 @@ def test_ps_verify_and_provide_id_workloads():
             # unblinding is impossible without t1, but the blinded pair must satisfy e(s1, XX * prod...) structure:
             assert out.raw != bytes(128)
     assert got == list(expect)
+
+
+def test_prover_workload_credentials_are_valid_signatures():
+    """synth.prove_id_batch hands the batch prover real credentials: each (sig1, sig2) verifies as a PS signature on the item's
+    attributes under the oracle, and the record carries A + 2 + [1] + H + 1 + [1] scalars < r after the two points."""
+    L = oracle()
+    ctx = OracleBackedCtx()
+    A, H = 4, 2
+    wl = synth.Workload(ctx, A)
+    key = ctx.key_handle()
+    for retr in (True, False):
+        recs, mask = wl.prove_id_batch(3, H, first_item=5, with_retrieval=retr)
+        assert mask == 3
+        rsz = 128 + 32 * (A + 2 + H + 1 + (2 if retr else 0))
+        assert len(recs) == 3 * rsz
+        for i in range(3):
+            r = recs[i * rsz:(i + 1) * rsz]
+            assert L.elpo_ps_verify(key, r[:128 + 32 * A], A) == 1
+            assert all(int.from_bytes(r[128 + 32 * j:160 + 32 * j], "little") < M.r for j in range((rsz - 128) // 32))
+    recs, mask = wl.request_id_batch(3, H)
+    assert len(recs) == 3 * 32 * (A + 2 + H)
