@@ -1,3 +1,2 @@
-set -x
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "user_side or prover_to_verifier or provide_id" 2>&1 | tail -15
-timeout 900 python -m pytest tests/test_gpu_bls.py -x -q -m gpu -k "protocol_flows" 2>&1 | tail -15
+W=16 python tests/gpu_probe5.py 2>&1 | grep "B= *65536\|B= *16384\|B= *262144"
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -4

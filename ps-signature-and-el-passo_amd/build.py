@@ -42,7 +42,8 @@ def build_hip(force=False, verbose=False):
     for unit, flags in HIP_UNITS:
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags + ["-c", "-o", obj, os.path.join(CSRC, unit)]
+        extra = os.environ.get("ELP_EXTRA_FLAGS_" + unit.split(".")[0].upper(), "").split()     # experiments only
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags + extra + ["-c", "-o", obj, os.path.join(CSRC, unit)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -65,6 +65,15 @@
 namespace elp {
 typedef uint32_t u32;
 typedef uint64_t u64;
+// Per-lane "hot slot": ELP_HOT_WORDS 32-bit words of LDS that a kernel hands to the device routines (KeyCtx::hot) for the one
+// accumulator that is read and written by every step of a long loop (Miller value, exponentiation accumulator, point accumulator).
+// Routines take it through generic references, so the same code runs on private memory when the slot is absent (host twin, hot == 0)
+// or too small for the type.  4 resident waves x 64 lanes x 432 B = 108 KB of the CU's 160 KB.
+constexpr int ELP_HOT_WORDS = 108;
+template <class T>
+ELP_INL T* hot_as(u32* hot) {
+  return (hot != nullptr && sizeof(T) <= (size_t)ELP_HOT_WORDS * 4) ? reinterpret_cast<T*>(hot) : nullptr;
+}
 // scalar-field (Fr) Montgomery parameters of a curve; specialised in params_<curve>.h
 template <class C>
 struct FrOf;

@@ -385,7 +385,7 @@ ELP_INL int limbs_window(const u32* m, int bit, int w) {
 // [k]P for P in the order-r subgroup of G1: k = k1 + k2 lam with phi(x, y) = (beta x, y) = [lam](x, y); one shared chain of
 // 132 doublings, two table additions per 4-bit window (the second through phi).
 template <class C>
-ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in) {
+ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in, u32* hot = nullptr) {
   typedef F1<C> F;
   Jac<F> tbl[16];
   jac_set_inf(tbl[0]);
@@ -402,7 +402,9 @@ ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in
   lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());
   Fp<C> beta;
   ELP_LOAD_FP(beta, C::glv_beta(i_));
-  Jac<F> acc;
+  Jac<F> acc_priv;
+  Jac<F>* ah = hot_as<Jac<F>>(hot);
+  Jac<F>& acc = ah ? *ah : acc_priv;
   jac_set_inf(acc);
   ELP_NOUNROLL
   for (int w = 32; w >= 0; w--) {
@@ -426,7 +428,7 @@ ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in
 // [k]Q for Q in the order-r subgroup of G2: k = k0 + k1 lam + k2 lam^2 + k3 lam^3 with psi(Q) = [lam]Q, lam = p mod r
 // (psi = twist o Frobenius o untwist); 68 shared doublings, four table additions per 4-bit window.
 template <class C>
-ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in) {
+ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in, u32* hot = nullptr) {
   typedef F2<C> F;
   Jac<F> tbl[16];
   jac_set_inf(tbl[0]);
@@ -441,7 +443,9 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
   u32 m[4][3];
   bool neg[4];
   lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());
-  Jac<F> acc;
+  Jac<F> acc_priv;
+  Jac<F>* ah = hot_as<Jac<F>>(hot);
+  Jac<F>& acc = ah ? *ah : acc_priv;
   jac_set_inf(acc);
   ELP_NOUNROLL
   for (int w = 16; w >= 0; w--) {
@@ -484,19 +488,20 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
 // Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,
 // j = 0 .. ceil(256/W)-1.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
 template <class F>
-ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scalar& k) {
+ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scalar& k, u32* hot = nullptr) {
   const int nwin = (256 + W - 1) / W;
   const int per = (1 << W) - 1;
+  Jac<F>* ah = hot_as<Jac<F>>(hot);   // the running sum lives in the hot slot while the windows are added (table entries are read in place)
+  Jac<F>& a = ah ? *ah : acc;
+  if (ah) a = acc;
   ELP_NOUNROLL
   for (int j = 0; j < nwin; j++) {
     int bit = j * W;
     int w = (bit + W <= 256) ? W : 256 - bit;
     int d = scalar_window(k, bit, w);
-    if (d != 0) {
-      Aff<F> e = table[(size_t)j * per + (d - 1)];
-      jac_madd<F>(acc, acc, e);
-    }
+    if (d != 0) jac_madd<F>(a, a, table[(size_t)j * per + (d - 1)]);
   }
+  if (ah) acc = a;
 }
 
 // psi^n = twist o Frobenius^n o untwist on G2 (affine): (x, y) -> (conj^n(x) g_x, conj^n(y) g_y), constants per twist type

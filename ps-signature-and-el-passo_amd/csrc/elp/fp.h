@@ -45,6 +45,15 @@ struct StdFp {  // canonical integer in [0, p) (or any N-word integer before ran
 #define ELP_ASSERT_I32(x) ((void)0)
 #endif
 
+// -DELP_COUNT_OPS (host twin only, tools/count_ops.py): counts Montgomery products / squares so the VALU roofline of a kernel
+// can be stated in modular multiplications per item.
+#if defined(ELP_COUNT_OPS) && !defined(__HIP_DEVICE_COMPILE__)
+inline unsigned long long elp_op_counts[2] = {0, 0};
+#define ELP_COUNT_OP(i) (elp_op_counts[i]++)
+#else
+#define ELP_COUNT_OP(i) ((void)0)
+#endif
+
 constexpr i32 ELP_LIMB_BITS = 30;
 constexpr i32 ELP_LIMB_HALF = 1 << 29;
 constexpr u32 ELP_LIMB_MASK = (1u << 30) - 1;
@@ -193,6 +202,7 @@ ELP_INL void fp_reduce_weak(Fp<C>& a) {
 template <class C>
 ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
   constexpr int NL = C::NL;
+  ELP_COUNT_OP(0);
 #if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
   {
     long double ma = 0, mb = 0;
@@ -236,6 +246,7 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
 template <class C>
 ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
   constexpr int NL = C::NL;
+  ELP_COUNT_OP(1);
   i32 m[NL];
   Fp<C> r;
   i64 acc = 0;

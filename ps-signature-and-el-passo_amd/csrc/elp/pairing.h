@@ -186,8 +186,11 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
 
 // a^e (e > 0, 64-bit) for a in the cyclotomic subgroup
 template <class C>
-ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e) {
-  Fp12<C> acc = a;
+ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = nullptr) {
+  Fp12<C> acc_priv;
+  Fp12<C>* ah = hot_as<Fp12<C>>(hot);
+  Fp12<C>& acc = ah ? *ah : acc_priv;
+  acc = a;
   int top = 63;
   while (!((e >> top) & 1)) top--;
   ELP_NOUNROLL
@@ -199,19 +202,20 @@ ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e) {
 }
 // a^|z| for a in the cyclotomic subgroup
 template <class C>
-ELP_INL void fp12_exp_absz(Fp12<C>& r, const Fp12<C>& a) {
-  fp12_exp_u64<C>(r, a, C::ZABS);
+ELP_INL void fp12_exp_absz(Fp12<C>& r, const Fp12<C>& a, u32* hot = nullptr) {
+  fp12_exp_u64<C>(r, a, C::ZABS, hot);
 }
 // a^z (signed z) in the cyclotomic subgroup, where inversion is conjugation
 template <class C>
-ELP_INL void fp12_exp_z(Fp12<C>& r, const Fp12<C>& a) {
-  fp12_exp_absz<C>(r, a);
+ELP_INL void fp12_exp_z(Fp12<C>& r, const Fp12<C>& a, u32* hot = nullptr) {
+  fp12_exp_absz<C>(r, a, hot);
   if (C::Z_NEG) fp12_conj(r, r);
 }
 
 // f^((p^12 - 1)/r): easy part (p^6 - 1)(p^2 + 1), then the hard part (p^4 - p^2 + 1)/r.
+// `hot` may hold f_in itself: it is consumed by the first two statements and reused as the accumulator of the exponentiations.
 template <class C>
-ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in) {
+ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
   Fp12<C> f, t0, t1;
   fp12_inv<C>(t0, f_in);
   fp12_conj(t1, f_in);
@@ -222,9 +226,9 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in) {
     // Devegili-Scott-Dahab: (p^4-p^2+1)/r = p^3 + (6z^2+1) p^2 + (-36z^3-18z^2-12z+1) p + (-36z^3-30z^2-18z-2)
     // evaluated with the vectorial addition chain  y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36.
     Fp12<C> fz, fz2, fz3, y0, y1, y2, y3, y4, y5, y6, T0, T1, t;
-    fp12_exp_z<C>(fz, f);
-    fp12_exp_z<C>(fz2, fz);
-    fp12_exp_z<C>(fz3, fz2);
+    fp12_exp_z<C>(fz, f, hot);
+    fp12_exp_z<C>(fz2, fz, hot);
+    fp12_exp_z<C>(fz3, fz2, hot);
     fp12_frob<C>(y0, f, 1);
     fp12_frob<C>(t, f, 2);
     fp12_mul<C>(y0, y0, t);
@@ -258,16 +262,16 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in) {
     // BLS12 (Hayashida-Hayasaka-Teruya): (p^4-p^2+1)/r = ((z-1)^2/3) (z+p) (z^2+p^2-1) + 1, evaluated exactly:
     // a = f^((z-1)/3), a = a^(z-1), b = a^(z+p), c = b^(z^2+p^2-1), result = c * f.
     Fp12<C> a, b, c, t;
-    fp12_exp_u64<C>(a, f, C::ZM1D3_ABS);
+    fp12_exp_u64<C>(a, f, C::ZM1D3_ABS, hot);
     if (C::Z_NEG) fp12_conj(a, a);          // z - 1 < 0 as well
-    fp12_exp_z<C>(t, a);
+    fp12_exp_z<C>(t, a, hot);
     fp12_conj(b, a);
     fp12_mul<C>(a, t, b);                   // a^(z-1)
-    fp12_exp_z<C>(t, a);
+    fp12_exp_z<C>(t, a, hot);
     fp12_frob<C>(b, a, 1);
     fp12_mul<C>(b, b, t);                   // a^(z+p)
-    fp12_exp_z<C>(t, b);
-    fp12_exp_z<C>(t, t);
+    fp12_exp_z<C>(t, b, hot);
+    fp12_exp_z<C>(t, t, hot);
     fp12_frob<C>(c, b, 2);
     fp12_mul<C>(c, c, t);
     fp12_conj(t, b);

@@ -36,6 +36,7 @@ struct KeyCtx {
   const Aff<F1<C>>* b1;           // G1 bases (affine):  0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X (signer secret)
   const Aff<F2<C>>* b2;           // G2 bases (affine):  0 = gg, 1 = XX, 2+i = YY_i
   const LineCoef<C>* gg_lines;    // precomputed Miller lines of gg
+  u32* hot = nullptr;             // this lane's LDS hot slot (ELP_HOT_WORDS words) or null, see common.h
 };
 enum { G1_BASE_G = 0, G1_BASE_Y0 = 1 };
 enum { G2_BASE_GG = 0, G2_BASE_XX = 1, G2_BASE_YY0 = 2 };
@@ -131,11 +132,11 @@ ELP_HEAVY void gt_store(u32* w, const Fp12<C>& f) {  // order: c0.c0, c0.c1, c0.
 // ---- fixed-base accumulation against the key tables
 template <class C>
 ELP_INL void acc_fixed_g1(Jac<F1<C>>& acc, const KeyCtx<C>& k, int base, const Scalar& s) {
-  jac_acc_fixed<F1<C>>(acc, k.t1 + (size_t)base * k.nwin * k.per, k.W, s);
+  jac_acc_fixed<F1<C>>(acc, k.t1 + (size_t)base * k.nwin * k.per, k.W, s, k.hot);
 }
 template <class C>
 ELP_INL void acc_fixed_g2(Jac<F2<C>>& acc, const KeyCtx<C>& k, int base, const Scalar& s) {
-  jac_acc_fixed<F2<C>>(acc, k.t2 + (size_t)base * k.nwin * k.per, k.W, s);
+  jac_acc_fixed<F2<C>>(acc, k.t2 + (size_t)base * k.nwin * k.per, k.W, s, k.hot);
 }
 
 // 1/Z for several Jacobian Z's with ONE base-field inversion (Montgomery's trick); Z == 0 entries are skipped.
@@ -268,7 +269,7 @@ ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const A
     cred = scalar_sub_mod_r<C>(cred, rr);
   }
   const Scalar one_minus_c = scalar_sub_mod_r<C>(one, cred);
-  g2_mul_gls<C>(Vk, kk, c);      // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
+  g2_mul_gls<C>(Vk, kk, c, key.hot);      // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
   jac_from_aff(K, kk);
   {
     int jh = 0, jr = 0;
@@ -284,13 +285,13 @@ ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const A
   }
   acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
   acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
-  g1_mul_glv<C>(Vphi, phi, c);
+  g1_mul_glv<C>(Vphi, phi, c, key.hot);
   acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), src.rs(0));
   if (retr) {
     const Scalar r_e = src.rs(nrs - 1);
-    g1_mul_glv<C>(VE1, E1, c);
+    g1_mul_glv<C>(VE1, E1, c, key.hot);
     acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
-    g1_mul_glv<C>(VE2, E2, c);
+    g1_mul_glv<C>(VE2, E2, c, key.hot);
     acc_fixed_g1<C>(VE2, key, g1_base_apk(key), r_e);
     acc_fixed_g1<C>(VE2, key, g1_base_h(key), src.rs(1));
   }
@@ -337,10 +338,12 @@ ELP_HEAVY bool ps_pairing_check(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, co
   Aff<F1<C>> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
-  Fp12<C> f, g;
+  Fp12<C> f_priv, g;
+  Fp12<C>* fh = hot_as<Fp12<C>>(key.hot);
+  Fp12<C>& f = fh ? *fh : f_priv;
   const LineCoef<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
-  final_exp<C>(g, f);
+  final_exp<C>(g, f, key.hot);
   return fp12_is_one(g);
 }
 
@@ -549,10 +552,12 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   Aff<G1F> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
-  Fp12<C> f, g;
+  Fp12<C> f_priv, g;
+  Fp12<C>* fh = hot_as<Fp12<C>>(key.hot);
+  Fp12<C>& f = fh ? *fh : f_priv;
   const LineCoef<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
-  final_exp<C>(g, f);
+  final_exp<C>(g, f, key.hot);
   return fp12_is_one(g);
 }
 
@@ -580,7 +585,7 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
   const Scalar u = scalar_load_w(p);
   // V = A^c * g^{r_0} * prod_{hidden} Y_i^{r_j}                           (src/ps-signer.cc:82-94)
   Jac<G1F> V, Ap;
-  g1_mul_glv<C>(V, Ac, c);
+  g1_mul_glv<C>(V, Ac, c, key.hot);
   acc_fixed_g1<C>(V, key, G1_BASE_G, scalar_load_w(rs));
   jac_from_aff(Ap, Ac);
   {
@@ -611,7 +616,7 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
   jac_madd<G1F>(Ap, Ap, key.b1[g1_base_skx(key)]);
   Aff<G1F> aAp;
   jac_to_aff<G1F>(aAp, Ap);
-  g1_mul_glv<C>(s2, aAp, u);
+  g1_mul_glv<C>(s2, aAp, u, key.hot);
   Fp<C> z[2], zi[2];
   z[0] = s1.Z;
   z[1] = s2.Z;
@@ -730,12 +735,12 @@ ELP_HEAVY bool prove_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_ma
   if (retr) rho_e = scalar_load_w(p + 8 * (H + 1));
   // randomised signature (sig1^r, (sig2 sig1^t)^r)                        src/ps-requester.cc:163-170
   Jac<G1F> s1, s2, tmp;
-  g1_mul_glv<C>(s1, sig1, rr);
-  g1_mul_glv<C>(tmp, sig1, t);
+  g1_mul_glv<C>(s1, sig1, rr, key.hot);
+  g1_mul_glv<C>(tmp, sig1, t, key.hot);
   jac_madd<G1F>(tmp, tmp, sig2);
   Aff<G1F> atmp;
   jac_to_aff<G1F>(atmp, tmp);
-  g1_mul_glv<C>(s2, atmp, rr);
+  g1_mul_glv<C>(s2, atmp, rr, key.hot);
   // phi, E1, E2 and the commitments                                        :172-187, :227-261
   Jac<G1F> phi, E1, E2, Vphi, VE1, VE2;
   jac_set_inf(phi); jac_set_inf(E1); jac_set_inf(E2); jac_set_inf(Vphi); jac_set_inf(VE1); jac_set_inf(VE2);

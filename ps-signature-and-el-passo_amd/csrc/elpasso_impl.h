@@ -22,6 +22,16 @@ using namespace elp;
 // kernels
 // ------------------------------------------------------------------------------------------------------------
 #define ELP_BLOCK 64
+// register budget of every kernel and (through the attributor) of the device functions they share: ELP_WAVES_PER_EU resident waves per SIMD
+#ifdef ELP_WAVES_PER_EU
+#define ELP_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK, ELP_WAVES_PER_EU)
+#else
+#define ELP_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK)
+#endif
+// gives every lane of the (one-wave) workgroup its LDS hot slot, see elp/common.h
+#define ELP_HOT_SETUP(key)                                                                   \
+  __shared__ __attribute__((aligned(16))) u32 elp_hot_lds[ELP_BLOCK * elp::ELP_HOT_WORDS]; \
+  (key).hot = elp_hot_lds + threadIdx.x * elp::ELP_HOT_WORDS
 
 __device__ __forceinline__ void count_accept(bool ok, unsigned long long* counter) {
   unsigned long long b = __ballot(ok);
@@ -29,9 +39,10 @@ __device__ __forceinline__ void count_accept(bool ok, unsigned long long* counte
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_verify_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+__global__ void ELP_LAUNCH_BOUNDS k_verify_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
                                                          const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
                                                          unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -44,9 +55,10 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_verify_id(KeyCtx<C> key, const u3
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_verify_id_wire(KeyCtx<C> key, const uint8_t* msgs, const u32* msg_off, int retr,
+__global__ void ELP_LAUNCH_BOUNDS k_verify_id_wire(KeyCtx<C> key, const uint8_t* msgs, const u32* msg_off, int retr,
                                                               const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
                                                               unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -59,8 +71,9 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_verify_id_wire(KeyCtx<C> key, con
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_ps_verify(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* flags,
+__global__ void ELP_LAUNCH_BOUNDS k_ps_verify(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* flags,
                                                          unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -71,9 +84,10 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_ps_verify(KeyCtx<C> key, const u3
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_provide_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
+__global__ void ELP_LAUNCH_BOUNDS k_provide_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
                                                           const u32* ad_off, u32 ad_len, u32* sigs, uint8_t* flags,
                                                           unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -86,9 +100,10 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_provide_id(KeyCtx<C> key, const u
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_prove_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
+__global__ void ELP_LAUNCH_BOUNDS k_prove_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
                                                         const u32* ad_off, u32 ad_len, u32* out, int out_words, uint8_t* flags,
                                                         unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -101,8 +116,9 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_prove_id(KeyCtx<C> key, const u32
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_request_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
+__global__ void ELP_LAUNCH_BOUNDS k_request_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
                                                           const u32* ad_off, u32 ad_len, u32* out, int out_words, size_t n) {
+  ELP_HOT_SETUP(key);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
@@ -111,7 +127,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_request_id(KeyCtx<C> key, const u
 }
 
 template <class C, int G>  // G = 1: G1, 2: G2
-__global__ void __launch_bounds__(ELP_BLOCK) k_decompress(const uint8_t* wire, u32* out, uint8_t* okf, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_decompress(const uint8_t* wire, u32* out, uint8_t* okf, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (G == 1) {
@@ -130,7 +146,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_decompress(const uint8_t* wire, u
 }
 
 template <class C, int G>
-__global__ void __launch_bounds__(ELP_BLOCK) k_mul(const u32* pts, const u32* ks, u32* out, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_mul(const u32* pts, const u32* ks, u32* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (G == 1) {
@@ -151,7 +167,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_mul(const u32* pts, const u32* ks
 }
 
 template <class C, int G>
-__global__ void __launch_bounds__(ELP_BLOCK) k_add(const u32* a, const u32* b, u32* out, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_add(const u32* a, const u32* b, u32* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (G == 1) {
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_add(const u32* a, const u32* b, u
 }
 
 template <class C, int G>
-__global__ void __launch_bounds__(ELP_BLOCK) k_msm_fixed(KeyCtx<C> key, int nterms, const int* base_ids, const u32* ks, u32* out,
+__global__ void ELP_LAUNCH_BOUNDS k_msm_fixed(KeyCtx<C> key, int nterms, const int* base_ids, const u32* ks, u32* out,
                                                          size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -198,7 +214,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_msm_fixed(KeyCtx<C> key, int nter
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_hash_to_g1(const uint8_t* msgs, const u32* off, u32* out, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_hash_to_g1(const uint8_t* msgs, const u32* off, u32* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Aff<F1<C>> p;
@@ -207,7 +223,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_hash_to_g1(const uint8_t* msgs, c
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_pairing(const u32* g1, const u32* g2, u32* gt, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_pairing(const u32* g1, const u32* g2, u32* gt, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Aff<F1<C>> p;
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_pairing(const u32* g1, const u32*
 }
 
 template <class C, int NP>
-__global__ void __launch_bounds__(ELP_BLOCK) k_pairing_check(const u32* g1, const u32* g2, uint8_t* okf, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_pairing_check(const u32* g1, const u32* g2, uint8_t* okf, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Aff<F1<C>> p[NP];
@@ -254,7 +270,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_pairing_check(const u32* g1, cons
 #define ELP_MSM_TPB 256
 
 template <class C, int G>
-__global__ void __launch_bounds__(ELP_BLOCK) k_msm_prepare(const u32* pts, void* out, int* bad, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_msm_prepare(const u32* pts, void* out, int* bad, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (G == 1) {
@@ -343,7 +359,7 @@ __global__ void __launch_bounds__(ELP_MSM_TPB) k_msm_reduce(const Jac<F>* partia
 }
 
 template <class C, int G>
-__global__ void __launch_bounds__(ELP_BLOCK) k_msm_final(const void* win_, u32* out) {
+__global__ void ELP_LAUNCH_BOUNDS k_msm_final(const void* win_, u32* out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   if (G == 1) {
     const Jac<F1<C>>* win = (const Jac<F1<C>>*)win_;
@@ -389,9 +405,10 @@ __device__ __forceinline__ void wave_fp12_product(Fp12<C>& f, Fp12<C>* sh) {   /
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_verify_id_agg(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+__global__ void ELP_LAUNCH_BOUNDS k_verify_id_agg(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
                                                              const uint8_t* ad, const u32* ad_off, u32 ad_len, AggSeed seed,
                                                              uint8_t* nizk_flags, u32* deltas, u32* sig2s, Fp12<C>* wave_prod, size_t n) {
+  ELP_HOT_SETUP(key);
   __shared__ Fp12<C> sh[ELP_BLOCK];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   Fp12<C> f;
@@ -408,7 +425,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_verify_id_agg(KeyCtx<C> key, cons
 }
 
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_fp12_reduce(const Fp12<C>* in, size_t n, Fp12<C>* out) {
+__global__ void ELP_LAUNCH_BOUNDS k_fp12_reduce(const Fp12<C>* in, size_t n, Fp12<C>* out) {
   __shared__ Fp12<C> sh[ELP_BLOCK];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   Fp12<C> f;
@@ -422,7 +439,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_fp12_reduce(const Fp12<C>* in, si
 
 // F * f(-S2, gg) -> final exponentiation -> *agg_ok = (result == 1).  One lane.
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_agg_final(KeyCtx<C> key, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
+__global__ void ELP_LAUNCH_BOUNDS k_agg_final(KeyCtx<C> key, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   Aff<F1<C>> s2, ns2;
   bool ok = g1_load<C>(s2, s2_std);
@@ -438,7 +455,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_agg_final(KeyCtx<C> key, const Fp
 
 // verdicts: the NIZK flags when the batch equation held, otherwise the exact per-item verification (rare, slow path)
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_agg_finish(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+__global__ void ELP_LAUNCH_BOUNDS k_agg_finish(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
                                                           const uint8_t* ad, const u32* ad_off, u32 ad_len, const uint8_t* nizk_flags,
                                                           const int* agg_ok, uint8_t* flags, unsigned long long* accepted, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,7 +474,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_agg_finish(KeyCtx<C> key, const u
 
 // ---- setup kernels
 template <class F>
-__global__ void __launch_bounds__(ELP_BLOCK) k_window_bases(const Aff<F>* bases, int nb, int W, int nwin, Aff<F>* bj) {
+__global__ void ELP_LAUNCH_BOUNDS k_window_bases(const Aff<F>* bases, int nb, int W, int nwin, Aff<F>* bj) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   if (aff_is_inf(bases[b])) {
@@ -467,7 +484,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_window_bases(const Aff<F>* bases,
   table_window_bases<F>(bj + (size_t)b * nwin, bases[b], W, nwin);
 }
 template <class F>
-__global__ void __launch_bounds__(ELP_BLOCK) k_table_fill(Aff<F>* tbl, const Aff<F>* bj, int nb, int nwin, int per, int chunk) {
+__global__ void ELP_LAUNCH_BOUNDS k_table_fill(Aff<F>* tbl, const Aff<F>* bj, int nb, int nwin, int per, int chunk) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int nchunk = (per + chunk - 1) / chunk;
   size_t total = (size_t)nb * nwin * nchunk;
@@ -485,11 +502,11 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_table_fill(Aff<F>* tbl, const Aff
   table_fill_chunk<F>(win, base, d0, cnt);
 }
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_lines(const Aff<F2<C>>* gg, LineCoef<C>* out) {
+__global__ void ELP_LAUNCH_BOUNDS k_lines(const Aff<F2<C>>* gg, LineCoef<C>* out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) ml_precompute<C>(out, gg[0]);
 }
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_load_bases(const u32* g1w, int n1, const u32* g2w, int n2, Aff<F1<C>>* b1, Aff<F2<C>>* b2, int* bad) {
+__global__ void ELP_LAUNCH_BOUNDS k_load_bases(const u32* g1w, int n1, const u32* g2w, int n2, Aff<F1<C>>* b1, Aff<F2<C>>* b2, int* bad) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n1) {
     if (!g1_load<C>(b1[t], g1w + (size_t)t * 2 * C::N)) {
@@ -505,7 +522,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_load_bases(const u32* g1w, int n1
   }
 }
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_bench_fp_mul(u32* out, int iters, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_bench_fp_mul(u32* out, int iters, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fp<C> a, b;
@@ -529,7 +546,7 @@ __global__ void __launch_bounds__(ELP_BLOCK) k_bench_fp_mul(u32* out, int iters,
 //     9 jac_dbl<G1> 10 jac_madd<G1> 11 jac_add<G1> 12 jac_dbl<G2> 13 jac_madd<G2> 14 jac_add<G2> 15 ml_dbl_step 16 ml_add_step
 //     17 fp_inv 18 fp_add 19 fp2_add 20 jac_mul_var<G1> 21 jac_mul_var<G2> 22 miller_loop (1 pair) 23 final_exp
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK) k_bench_op(int op, u32* out, int iters, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_bench_op(int op, u32* out, int iters, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fp<C> a = fp_one<C>(), b;

@@ -12,10 +12,14 @@ OPS = ["fp_mul", "fp_sqr", "fp2_mul", "fp2_sqr", "fp6_mul", "fp12_mul", "fp12_sq
 MULS = [1, 1, 3, 2, 18, 54, 36, 18, 39, 7, 11, 16, 16, 29, 43, 25, 35, 380, 0, 0, 2970, 7200, 9000, 6000]   # Fp products per application (model)
 ctx = elp.Context()
 ms = ctypes.c_float()
-for waves in (1,):
+import os
+SEL = [int(x) for x in os.environ.get('OPS', ','.join(str(i) for i in range(24))).split(',')]
+for waves in [int(x) for x in os.environ.get('WAVES','1').split(',')]:
     lanes = 256 * 4 * 64 * waves
     print("== %d wave(s) per SIMD" % waves)
     for op, name in enumerate(OPS):
+        if op not in SEL:
+            continue
         iters = 2 if MULS[op] >= 2000 else (20 if name == "fp_inv" else (2000 if MULS[op] <= 3 else 200))
         ctx._chk(ctx.lib.elp_bench_op(ctx.h, op, lanes, iters, ctypes.byref(ms)))
         ns = ms.value * 1e6 / iters          # per application per wave (all SIMDs in parallel)

@@ -17,6 +17,7 @@ struct TwinCtx {
   std::vector<Aff<F1<C>>> t1, b1;
   std::vector<Aff<F2<C>>> t2, b2;
   std::vector<LineCoef<C>> lines;
+  std::vector<u32> hot;   // stands in for the lane's LDS hot slot so the aliasing rules of KeyCtx::hot are exercised on the host
 };
 
 template <class F>
@@ -208,6 +209,8 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     c->key.b1 = c->b1.data();                                                                                          \
     c->key.b2 = c->b2.data();                                                                                          \
     c->key.gg_lines = c->lines.data();                                                                                 \
+    c->hot.assign(ELP_HOT_WORDS, 0xdeadbeefu);                                                                         \
+    c->key.hot = getenv("ELP_TWIN_NO_HOT") ? nullptr : c->hot.data();                                                  \
     return c;                                                                                                          \
   }                                                                                                                    \
   void pfx##_ctx_free(void* c) { delete (TwinCtx<C>*)c; }                                                              \
@@ -233,3 +236,11 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
 
 TWIN(BN254, twin_bn254)
 TWIN(BLS12_381, twin_bls)
+
+#ifdef ELP_COUNT_OPS
+extern "C" void twin_op_counts(unsigned long long* out, int reset) {
+  out[0] = elp::elp_op_counts[0];
+  out[1] = elp::elp_op_counts[1];
+  if (reset) elp::elp_op_counts[0] = elp::elp_op_counts[1] = 0;
+}
+#endif
