@@ -408,8 +408,9 @@ template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_verify_id_agg(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
                                                              const uint8_t* ad, const u32* ad_off, u32 ad_len, AggSeed seed,
                                                              uint8_t* nizk_flags, u32* deltas, u32* sig2s, Fp12<C>* wave_prod, size_t n) {
-  ELP_HOT_SETUP(key);
-  __shared__ Fp12<C> sh[ELP_BLOCK];
+  __shared__ __attribute__((aligned(16))) Fp12<C> sh[ELP_BLOCK];
+  static_assert(sizeof(Fp12<C>) >= (size_t)elp::ELP_HOT_WORDS * 4, "hot slot must fit an Fp12 entry");
+  key.hot = reinterpret_cast<u32*>(&sh[threadIdx.x]);   // the lane's entry of the product buffer doubles as its hot slot until the reduction
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   Fp12<C> f;
   fp12_set_one(f);
