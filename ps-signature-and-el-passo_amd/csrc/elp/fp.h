@@ -94,6 +94,10 @@ ELP_INL Fp<C> fp_select(bool c, const Fp<C>& a, const Fp<C>& b) {  // c ? a : b
   return r;
 }
 
+ELP_INL i32 elp_balanced30(u32 x) {  // low 30 bits of x as a signed value in [-2^29, 2^29)
+  return (i32)(x << 2) >> 2;
+}
+
 // One parallel carry pass: every limb below the top keeps its balanced low 30 bits and receives the carry of its lower
 // neighbour; no dependency chain.  Any int32 input; for |limb| <= 2^31 - 1 the output is |limb| <= 2^29 + 2.
 template <class C>
@@ -108,6 +112,21 @@ ELP_INL void fp_carry(Fp<C>& a) {
   for (int i = 1; i < C::NL; i++) a.v[i] += c[i - 1];
 }
 
+// Same pass for inputs known to satisfy |limb| < 2^31 - 2^29 (sums or differences of two carried values, doubled carried
+// values): round(a / 2^30) = (a + 2^29) >> 30 cannot overflow, the balanced low part is one signed bit-field extract.
+template <class C>
+ELP_INL void fp_carry_fast(Fp<C>& a) {
+  i32 c[C::NL];
+  ELP_UNROLL
+  for (int i = 0; i < C::NL - 1; i++) {
+    ELP_ASSERT_I32((i64)a.v[i] + (i64)ELP_LIMB_HALF);
+    c[i] = (a.v[i] + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
+    a.v[i] = elp_balanced30((u32)a.v[i]);
+  }
+  ELP_UNROLL
+  for (int i = 1; i < C::NL; i++) a.v[i] += c[i - 1];
+}
+
 template <class C>
 ELP_INL Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
   Fp<C> r;
@@ -116,7 +135,7 @@ ELP_INL Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
     ELP_ASSERT_I32((i64)a.v[i] + (i64)b.v[i]);
     r.v[i] = a.v[i] + b.v[i];
   }
-  fp_carry(r);
+  fp_carry_fast(r);
   return r;
 }
 template <class C>
@@ -127,7 +146,7 @@ ELP_INL Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
     ELP_ASSERT_I32((i64)a.v[i] - (i64)b.v[i]);
     r.v[i] = a.v[i] - b.v[i];
   }
-  fp_carry(r);
+  fp_carry_fast(r);
   return r;
 }
 template <class C>
@@ -145,7 +164,7 @@ ELP_INL Fp<C> fp_dbl(const Fp<C>& a) {
     ELP_ASSERT_I32((i64)a.v[i] * 2);
     r.v[i] = a.v[i] * 2;
   }
-  fp_carry(r);
+  fp_carry_fast(r);
   return r;
 }
 // lazy variants: no carry pass (caller guarantees the result feeds at most one side of a product, or carries later)
@@ -170,9 +189,6 @@ ELP_INL Fp<C> fp_sub_lazy(const Fp<C>& a, const Fp<C>& b) {
   return r;
 }
 
-ELP_INL i32 elp_balanced30(u32 x) {  // low 30 bits of x as a signed value in [-2^29, 2^29)
-  return (i32)(x << 2) >> 2;
-}
 
 // Weak modular reduction: subtracts round(value / p) * p, estimated from the top limbs (error < 2^-9), leaving
 // |value| <= 0.51 p.  Additions never need it (products bound the magnitude); it exists for the few formulas in which a
@@ -234,9 +250,8 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
     ELP_UNROLL
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
-    i32 lo = elp_balanced30((u32)acc);
-    r.v[k - NL] = lo;
-    acc = (acc - lo) >> ELP_LIMB_BITS;
+    r.v[k - NL] = elp_balanced30((u32)acc);
+    acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;               // = (acc - balanced low part) >> 30
   }
   r.v[NL - 1] = (i32)acc;
   return r;
@@ -266,9 +281,8 @@ ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
     } else {
       ELP_UNROLL
       for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
-      i32 lo = elp_balanced30((u32)acc);
-      r.v[k - NL] = lo;
-      acc = (acc - lo) >> ELP_LIMB_BITS;
+      r.v[k - NL] = elp_balanced30((u32)acc);
+      acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
     }
   }
   r.v[NL - 1] = (i32)acc;
