@@ -30,8 +30,11 @@ def main():
     ap.add_argument("--window", type=int, default=16, help="fixed-base window bits of the key tables (library default 8)")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(1536, 48 x cores))")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_second_curve, args.cpu_sample = True, 0
 
     import numpy as np
     import torch
@@ -172,7 +175,7 @@ def main():
             out["bls12_381"] = second_curve(pkg, synth, local_rank, dev, A, H, min(B, 32768), args.window)
         except Exception as e:  # pragma: no cover
             out["bls12_381"] = {"error": str(e)}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         # aggregated (random-linear-combination) variant: reported beside, never instead of, `value`.  Its single-lane tail (one Miller
         # loop + one final exponentiation per batch, ~14 ms) is not overlapped yet, so it only pays off on larger batches: measured on
         # the resident batch and on the same records tiled x4 (262 144 items), each against the per-item kernel at the same size.

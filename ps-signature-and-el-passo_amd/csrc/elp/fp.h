@@ -48,7 +48,7 @@ struct StdFp {  // canonical integer in [0, p) (or any N-word integer before ran
 // -DELP_COUNT_OPS (host twin only, tools/count_ops.py): counts Montgomery products / squares so the VALU roofline of a kernel
 // can be stated in modular multiplications per item.
 #if defined(ELP_COUNT_OPS) && !defined(__HIP_DEVICE_COMPILE__)
-inline unsigned long long elp_op_counts[2] = {0, 0};
+inline unsigned long long elp_op_counts[3] = {0, 0, 0};   // fp_mul, fp_sqr, fp_mul_pair
 #define ELP_COUNT_OP(i) (elp_op_counts[i]++)
 #else
 #define ELP_COUNT_OP(i) ((void)0)
@@ -252,6 +252,60 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
     r.v[k - NL] = elp_balanced30((u32)acc);
     acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;               // = (acc - balanced low part) >> 30
+  }
+  r.v[NL - 1] = (i32)acc;
+  return r;
+}
+
+// Montgomery reduction of a two-term inner product: (a*b + c*d) * R^-1 (mod p) with ONE reduction (243 multiply-adds instead of
+// 324 for two products), the shape of both components of an Fp2 product.  All four operands must be carried (|limb| <= 2^29 + 2):
+// a column then holds 2 NL operand products + NL products m_i p_j, which fits the signed 64-bit accumulator only for NL <= 9.
+template <class C>
+ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
+  constexpr int NL = C::NL;
+  static_assert(NL <= 9, "two-product columns overflow the 64-bit accumulator for longer fields");
+  ELP_COUNT_OP(2);
+#if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+  {
+    long double mab = 0, mcd = 0, ma = 0, mb = 0, mc = 0, md = 0;
+    for (int i = 0; i < NL - 1; i++) {
+      if (llabs((long long)a.v[i]) > ma) ma = llabs((long long)a.v[i]);
+      if (llabs((long long)b.v[i]) > mb) mb = llabs((long long)b.v[i]);
+      if (llabs((long long)c.v[i]) > mc) mc = llabs((long long)c.v[i]);
+      if (llabs((long long)d.v[i]) > md) md = llabs((long long)d.v[i]);
+    }
+    mab = ma * mb;
+    mcd = mc * md;
+    assert((mab + mcd) * NL + (long double)NL * 288230376151711744.0L + 1.0e18L < 9223372036854775807.0L);
+    assert(llabs((long long)a.v[NL - 1]) < (1LL << 29) && llabs((long long)b.v[NL - 1]) < (1LL << 29));
+    assert(llabs((long long)c.v[NL - 1]) < (1LL << 29) && llabs((long long)d.v[NL - 1]) < (1LL << 29));
+  }
+#endif
+  i32 m[NL];
+  Fp<C> r;
+  i64 acc = 0;
+  ELP_UNROLL
+  for (int k = 0; k < NL; k++) {
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)c.v[i] * d.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i < k; i++) acc += (i64)m[i] * C::modl(k - i);
+    m[k] = elp_balanced30((u32)acc * C::INV30);
+    acc += (i64)m[k] * C::modl(0);
+    acc >>= ELP_LIMB_BITS;
+  }
+  ELP_UNROLL
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)c.v[i] * d.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
+    r.v[k - NL] = elp_balanced30((u32)acc);
+    acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
   }
   r.v[NL - 1] = (i32)acc;
   return r;

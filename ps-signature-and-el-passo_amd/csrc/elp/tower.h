@@ -116,7 +116,17 @@ ELP_INL Fp2<C> fp2_mul_xi(const Fp2<C>& a) {
   return r;
 }
 template <class C>
-ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // Karatsuba, 3 Fp mul
+ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands carried
+  if constexpr (C::NL <= 9) {
+    // schoolbook with one reduction per component: the same 486 multiply-adds as Karatsuba with three reductions, but no operand
+    // sums, no output differences and no carry passes
+    Fp<C> c0 = fp_mul_pair<C>(a.c0, b.c0, fp_neg(a.c1), b.c1);
+    Fp<C> c1 = fp_mul_pair<C>(a.c0, b.c1, a.c1, b.c0);
+    r.c0 = c0;
+    r.c1 = c1;
+    return;
+  }
+  // Karatsuba, 3 Fp mul
   Fp<C> t0 = fp_mul<C>(a.c0, b.c0);
   Fp<C> t1 = fp_mul<C>(a.c1, b.c1);
   // one operand of a product may be a lazy two-term sum when 9 limbs are summed per column (BN254); with 14 limbs

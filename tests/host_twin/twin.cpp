@@ -241,6 +241,7 @@ TWIN(BLS12_381, twin_bls)
 extern "C" void twin_op_counts(unsigned long long* out, int reset) {
   out[0] = elp::elp_op_counts[0];
   out[1] = elp::elp_op_counts[1];
-  if (reset) elp::elp_op_counts[0] = elp::elp_op_counts[1] = 0;
+  out[2] = elp::elp_op_counts[2];
+  if (reset) elp::elp_op_counts[0] = elp::elp_op_counts[1] = elp::elp_op_counts[2] = 0;
 }
 #endif
