@@ -144,17 +144,19 @@ def main():
             ctx._chk(ctx.lib.elp_bench_fp_mul(ctx.h, lanes, iters, ctypes.byref(fm)))
             peak = lanes * iters * 2 / (fm.value * 1e-3)
             vb = {"fp_mul_peak_per_s": peak, "unit": "modmul/s",
-                  "note": "peak = Montgomery products/s of the fp_mul micro-benchmark (same limb code, 8 waves/SIMD); achieved = products per "
-                          "verification (profiles/op_counts.json, counted on the host twin of the kernel code) x verifications/s of k_verify_id"}
+                  "note": "peak = Montgomery products/s of the fp_mul micro-benchmark (same limb code, 8 waves/SIMD; 162 multiply-adds each); achieved = "
+                          "multiply-adds per verification / 162 (profiles/op_counts.json, counted on the host twin of the kernel code) x "
+                          "verifications/s of k_verify_id"}
             oc = os.path.join(ROOT, "profiles", "op_counts.json")
             if os.path.exists(oc) and args.curve == "bn254" and A == 8 and H == 4:
                 try:
                     ops = json.load(open(oc))["verify_id"]
                     w = args.window or 8
                     key = "W%d" % w if ("W%d" % w) in ops else "W16"
-                    per_item = ops[key]["fp_mul"] + ops[key]["fp_sqr"]
+                    per_item = ops[key]["fp_mul_equivalents"]      # multiply-adds / 162
                     ach = per_item * B / (kern_ms * 1e-3)
-                    vb.update({"products_per_verification": per_item, "achieved": ach, "frac": ach / peak})
+                    vb.update({"fp_mul_equivalents_per_verification": per_item, "multiply_adds_per_verification": ops[key]["multiply_adds"],
+                               "achieved": ach, "frac": ach / peak})
                 except Exception:
                     pass
             out["valu_bound"] = vb

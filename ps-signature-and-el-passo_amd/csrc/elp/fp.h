@@ -27,7 +27,7 @@ typedef int32_t i32;
 typedef int64_t i64;
 
 template <class C>
-struct Fp {  // Montgomery form, signed radix-2^30 limbs
+struct Fp {  // Montgomery form, signed radix-2^LB limbs (C::LB = 29 or 30)
   i32 v[C::NL];
 };
 template <class C>
@@ -54,9 +54,20 @@ inline unsigned long long elp_op_counts[3] = {0, 0, 0};   // fp_mul, fp_sqr, fp_
 #define ELP_COUNT_OP(i) ((void)0)
 #endif
 
-constexpr i32 ELP_LIMB_BITS = 30;
-constexpr i32 ELP_LIMB_HALF = 1 << 29;
-constexpr u32 ELP_LIMB_MASK = (1u << 30) - 1;
+// Keeps a compile-time constant out of the optimiser's sight (in a scalar register on the device): a multiply-add by a modulus limb
+// that happens to be a power of two would otherwise be rewritten into a slower 64-bit shift-and-subtract sequence.
+ELP_INL i32 elp_opaque(i32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(x));
+#else
+  asm("" : "+r"(x));
+#endif
+  return x;
+}
+// limb geometry of a field: C::LB bits per limb (29 for the 9-limb BN254 field, 30 for the 14-limb BLS12-381 field)
+#define ELP_LIMB_BITS (C::LB)
+#define ELP_LIMB_HALF ((i32)1 << (C::LB - 1))
+#define ELP_LIMB_MASK ((((u32)1) << C::LB) - 1)
 
 // load a generated constant: ELP_LOAD_FP(x, C::curve_b(i_))
 #define ELP_LOAD_FP(dst, expr_i)                               \
@@ -94,9 +105,11 @@ ELP_INL Fp<C> fp_select(bool c, const Fp<C>& a, const Fp<C>& b) {  // c ? a : b
   return r;
 }
 
-ELP_INL i32 elp_balanced30(u32 x) {  // low 30 bits of x as a signed value in [-2^29, 2^29)
-  return (i32)(x << 2) >> 2;
+template <int LB>
+ELP_INL i32 elp_balanced(u32 x) {  // low LB bits of x as a signed value in [-2^(LB-1), 2^(LB-1))
+  return (i32)(x << (32 - LB)) >> (32 - LB);
 }
+#define elp_balanced30 elp_balanced<C::LB>
 
 // One parallel carry pass: every limb below the top keeps its balanced low 30 bits and receives the carry of its lower
 // neighbour; no dependency chain.  Any int32 input; for |limb| <= 2^31 - 1 the output is |limb| <= 2^29 + 2.
@@ -227,11 +240,13 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
       if (llabs((long long)b.v[i]) > mb) mb = llabs((long long)b.v[i]);
     }
     // worst column: NL products of the operands + NL products m_i p_j (|m_i| <= 2^29, |p_j| <= 2^29) + carry-in
-    assert(ma * mb * NL + (long double)NL * 288230376151711744.0L + 1.0e18L < 9223372036854775807.0L);
-    assert(llabs((long long)a.v[NL - 1]) < (1LL << 29) && llabs((long long)b.v[NL - 1]) < (1LL << 29));
+    assert(ma * mb * NL + (long double)NL * (long double)((i64)1 << (2 * C::LB - 2)) + 1.0e18L < 9223372036854775807.0L);
+    assert(llabs((long long)a.v[NL - 1]) < (1LL << (C::LB - 1)) && llabs((long long)b.v[NL - 1]) < (1LL << (C::LB - 1)));
   }
 #endif
-  i32 m[NL];
+  i32 m[NL], pl[NL];
+  ELP_UNROLL
+  for (int i = 0; i < NL; i++) pl[i] = elp_opaque(C::modl(i));
   Fp<C> r;
   i64 acc = 0;
   ELP_UNROLL
@@ -239,9 +254,9 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
     ELP_UNROLL
     for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
     ELP_UNROLL
-    for (int i = 0; i < k; i++) acc += (i64)m[i] * C::modl(k - i);
-    m[k] = elp_balanced30((u32)acc * C::INV30);
-    acc += (i64)m[k] * C::modl(0);
+    for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+    m[k] = elp_balanced30((u32)acc * C::INVL);
+    acc += (i64)m[k] * pl[0];
     acc >>= ELP_LIMB_BITS;                                      // exact: the low 30 bits are zero now
   }
   ELP_UNROLL
@@ -249,7 +264,7 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
     ELP_UNROLL
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
     r.v[k - NL] = elp_balanced30((u32)acc);
     acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;               // = (acc - balanced low part) >> 30
   }
@@ -263,7 +278,7 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
 template <class C>
 ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
   constexpr int NL = C::NL;
-  static_assert(NL <= 9, "two-product columns overflow the 64-bit accumulator for longer fields");
+  static_assert(C::HEADROOM >= 3, "two-product columns overflow the 64-bit accumulator of this field");
   ELP_COUNT_OP(2);
 #if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
   {
@@ -276,12 +291,14 @@ ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
     }
     mab = ma * mb;
     mcd = mc * md;
-    assert((mab + mcd) * NL + (long double)NL * 288230376151711744.0L + 1.0e18L < 9223372036854775807.0L);
-    assert(llabs((long long)a.v[NL - 1]) < (1LL << 29) && llabs((long long)b.v[NL - 1]) < (1LL << 29));
-    assert(llabs((long long)c.v[NL - 1]) < (1LL << 29) && llabs((long long)d.v[NL - 1]) < (1LL << 29));
+    assert((mab + mcd) * NL + (long double)NL * (long double)((i64)1 << (2 * C::LB - 2)) + 1.0e18L < 9223372036854775807.0L);
+    assert(llabs((long long)a.v[NL - 1]) < (1LL << (C::LB - 1)) && llabs((long long)b.v[NL - 1]) < (1LL << (C::LB - 1)));
+    assert(llabs((long long)c.v[NL - 1]) < (1LL << (C::LB - 1)) && llabs((long long)d.v[NL - 1]) < (1LL << (C::LB - 1)));
   }
 #endif
-  i32 m[NL];
+  i32 m[NL], pl[NL];
+  ELP_UNROLL
+  for (int i = 0; i < NL; i++) pl[i] = elp_opaque(C::modl(i));
   Fp<C> r;
   i64 acc = 0;
   ELP_UNROLL
@@ -291,9 +308,9 @@ ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
     ELP_UNROLL
     for (int i = 0; i <= k; i++) acc += (i64)c.v[i] * d.v[k - i];
     ELP_UNROLL
-    for (int i = 0; i < k; i++) acc += (i64)m[i] * C::modl(k - i);
-    m[k] = elp_balanced30((u32)acc * C::INV30);
-    acc += (i64)m[k] * C::modl(0);
+    for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+    m[k] = elp_balanced30((u32)acc * C::INVL);
+    acc += (i64)m[k] * pl[0];
     acc >>= ELP_LIMB_BITS;
   }
   ELP_UNROLL
@@ -303,7 +320,7 @@ ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
     ELP_UNROLL
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)c.v[i] * d.v[k - i];
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
     r.v[k - NL] = elp_balanced30((u32)acc);
     acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
   }
@@ -316,7 +333,9 @@ template <class C>
 ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
   constexpr int NL = C::NL;
   ELP_COUNT_OP(1);
-  i32 m[NL];
+  i32 m[NL], pl[NL];
+  ELP_UNROLL
+  for (int i = 0; i < NL; i++) pl[i] = elp_opaque(C::modl(i));
   Fp<C> r;
   i64 acc = 0;
   ELP_UNROLL
@@ -328,13 +347,13 @@ ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
     if ((k & 1) == 0) acc += (i64)a.v[k / 2] * a.v[k / 2];
     if (k < NL) {
       ELP_UNROLL
-      for (int i = 0; i < k; i++) acc += (i64)m[i] * C::modl(k - i);
-      m[k] = elp_balanced30((u32)acc * C::INV30);
-      acc += (i64)m[k] * C::modl(0);
+      for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+      m[k] = elp_balanced30((u32)acc * C::INVL);
+      acc += (i64)m[k] * pl[0];
       acc >>= ELP_LIMB_BITS;
     } else {
       ELP_UNROLL
-      for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C::modl(k - i);
+      for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
       r.v[k - NL] = elp_balanced30((u32)acc);
       acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
     }
@@ -397,11 +416,11 @@ ELP_HEAVY StdFp<C> fp_to_std(const Fp<C>& a) {
     t.v[NL - 1] += C::modl(NL - 1) + c;
   }
   StdFp<C> s;
-  for (int j = 0; j < C::N; j++) {  // pack 30-bit digits into 32-bit words
-    int bit = 32 * j, li = bit / 30, sh = bit % 30;
+  for (int j = 0; j < C::N; j++) {  // pack LB-bit digits into 32-bit words
+    int bit = 32 * j, li = bit / C::LB, sh = bit % C::LB;
     u64 x = (u64)(u32)t.v[li] >> sh;
-    int have = 30 - sh;
-    for (int k = li + 1; have < 32 && k < NL; k++, have += 30) x |= (u64)(u32)t.v[k] << have;
+    int have = C::LB - sh;
+    for (int k = li + 1; have < 32 && k < NL; k++, have += C::LB) x |= (u64)(u32)t.v[k] << have;
     s.w[j] = (u32)x;
   }
   return s;
@@ -411,11 +430,11 @@ template <class C>
 ELP_HEAVY Fp<C> fp_from_std(const StdFp<C>& s) {
   constexpr int NL = C::NL;
   Fp<C> t;
-  for (int i = 0; i < NL; i++) {  // unpack into unsigned 30-bit digits
-    int bit = 30 * i, wi = bit >> 5, sh = bit & 31;
+  for (int i = 0; i < NL; i++) {  // unpack into unsigned LB-bit digits
+    int bit = C::LB * i, wi = bit >> 5, sh = bit & 31;
     u64 x = 0;
     if (wi < C::N) x = (u64)s.w[wi] >> sh;
-    if (wi + 1 < C::N && sh > 2) x |= (u64)s.w[wi + 1] << (32 - sh);
+    if (wi + 1 < C::N && sh > 32 - C::LB) x |= (u64)s.w[wi + 1] << (32 - sh);
     t.v[i] = (i32)((u32)x & ELP_LIMB_MASK);
   }
   fp_carry(t);  // balance the digits

@@ -101,6 +101,17 @@ ELP_INL Fp2<C> fp2_carry(Fp2<C> a) {
   return a;
 }
 template <class C>
+ELP_INL Fp2<C> fp2_carry_fast(Fp2<C> a) {   // |limb| < 2^31 - 2^(LB-1): lazy sums of up to six carried values at LB = 29
+  fp_carry_fast(a.c0);
+  fp_carry_fast(a.c1);
+  return a;
+}
+// Fields with C::HEADROOM >= 14 (BN254 at 29-bit limbs): a product accepts operands whose limb magnitudes, in units of a carried
+// limb, satisfy A*B <= 13 (fp_mul) or A*B + C*D <= 13 (fp_mul_pair), so the formulas below add and subtract without carrying and
+// carry each result once.  int32 limbs hold lazy sums of up to seven carried values.
+template <class C>
+ELP_HD constexpr bool fp_roomy() { return C::HEADROOM >= 14; }
+template <class C>
 ELP_INL Fp2<C> fp2_mul_xi_lazy(const Fp2<C>& a) {   // input carried, output limbs <= 2^30
   Fp2<C> r;
   r.c0 = fp_sub_lazy(a.c0, a.c1);
@@ -117,7 +128,7 @@ ELP_INL Fp2<C> fp2_mul_xi(const Fp2<C>& a) {
 }
 template <class C>
 ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands carried
-  if constexpr (C::NL <= 9) {
+  if constexpr (C::HEADROOM >= 3) {
     // schoolbook with one reduction per component: the same 486 multiply-adds as Karatsuba with three reductions, but no operand
     // sums, no output differences and no carry passes
     Fp<C> c0 = fp_mul_pair<C>(a.c0, b.c0, fp_neg(a.c1), b.c1);
@@ -131,7 +142,7 @@ ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands
   Fp<C> t1 = fp_mul<C>(a.c1, b.c1);
   // one operand of a product may be a lazy two-term sum when 9 limbs are summed per column (BN254); with 14 limbs
   // (BLS12-381) the accumulator has no room for it
-  Fp<C> sa = (C::NL <= 9) ? fp_add_lazy(a.c0, a.c1) : fp_add(a.c0, a.c1);
+  Fp<C> sa = (C::HEADROOM >= 3) ? fp_add_lazy(a.c0, a.c1) : fp_add(a.c0, a.c1);
   Fp<C> s = fp_mul<C>(sa, fp_add(b.c0, b.c1));
   r.c0 = fp_sub(t0, t1);
   Fp<C> u = fp_sub_lazy(fp_sub_lazy(s, t0), t1);   // three carried terms: |limb| < 1.5 * 2^30
@@ -139,9 +150,16 @@ ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands
   r.c1 = u;
 }
 template <class C>
-ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul
+ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul; operand carried
+  if constexpr (fp_roomy<C>()) {
+    Fp<C> c0 = fp_mul<C>(fp_add_lazy(a.c0, a.c1), fp_sub_lazy(a.c0, a.c1));   // 2 x 2
+    Fp<C> c1 = fp_mul<C>(fp_add_lazy(a.c0, a.c0), a.c1);                       // 2 x 1
+    r.c0 = c0;
+    r.c1 = c1;
+    return;
+  }
   Fp<C> t = fp_mul<C>(a.c0, a.c1);
-  Fp<C> sa = (C::NL <= 9) ? fp_add_lazy(a.c0, a.c1) : fp_add(a.c0, a.c1);
+  Fp<C> sa = (C::HEADROOM >= 3) ? fp_add_lazy(a.c0, a.c1) : fp_add(a.c0, a.c1);
   Fp<C> u = fp_mul<C>(sa, fp_sub(a.c0, a.c1));
   r.c0 = u;
   r.c1 = fp_dbl(t);
@@ -249,7 +267,23 @@ ELP_INL void fp6_mul_by_v(Fp6<C>& r, const Fp6<C>& a) {  // (c0,c1,c2) v = (xi c
   r.c0 = t;
 }
 template <class C>
-ELP_FP6 void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karatsuba, 6 Fp2 mul
+ELP_FP6 void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {  // Karatsuba, 6 Fp2 mul; operands carried
+  if constexpr (fp_roomy<C>()) {
+    Fp2<C> t0, t1, t2, s, r0, r1, r2;
+    fp2_mul<C>(t0, a.c0, b.c0);
+    fp2_mul<C>(t1, a.c1, b.c1);
+    fp2_mul<C>(t2, a.c2, b.c2);
+    fp2_mul<C>(s, fp2_add_lazy(a.c1, a.c2), fp2_add_lazy(b.c1, b.c2));                                    // (2 x 2) + (2 x 2)
+    r0 = fp2_carry(fp2_add_lazy(t0, fp2_mul_xi_lazy(fp2_sub_lazy(fp2_sub_lazy(s, t1), t2))));             // 1 + 2 * 3 = 7
+    fp2_mul<C>(s, fp2_add_lazy(a.c0, a.c1), fp2_add_lazy(b.c0, b.c1));
+    r1 = fp2_carry_fast(fp2_add_lazy(fp2_sub_lazy(fp2_sub_lazy(s, t0), t1), fp2_mul_xi_lazy(t2)));        // 3 + 2
+    fp2_mul<C>(s, fp2_add_lazy(a.c0, a.c2), fp2_add_lazy(b.c0, b.c2));
+    r2 = fp2_carry_fast(fp2_add_lazy(fp2_sub_lazy(fp2_sub_lazy(s, t0), t2), t1));                         // 4
+    r.c0 = r0;
+    r.c1 = r1;
+    r.c2 = r2;
+    return;
+  }
   Fp2<C> t0, t1, t2, s;
   fp2_mul<C>(t0, a.c0, b.c0);
   fp2_mul<C>(t1, a.c1, b.c1);
@@ -282,7 +316,22 @@ ELP_FP6 void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {  // CH-SQR2: 2 mul + 3 sqr in
 }
 // a * (b0 + b1 v)
 template <class C>
-ELP_FP6 void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {  // 5 Fp2 mul
+ELP_FP6 void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {  // 5 Fp2 mul; operands carried
+  if constexpr (fp_roomy<C>()) {
+    Fp2<C> t0, t1, s, r0, r1, r2;
+    fp2_mul<C>(t0, a.c0, b0);
+    fp2_mul<C>(t1, a.c1, b1);
+    fp2_mul<C>(s, fp2_add_lazy(a.c1, a.c2), b1);                                                  // 2 x 1
+    r0 = fp2_carry_fast(fp2_add_lazy(t0, fp2_mul_xi_lazy(fp2_sub_lazy(s, t1))));                  // 1 + 2 * 2
+    fp2_mul<C>(s, fp2_add_lazy(a.c0, a.c1), fp2_add_lazy(b0, b1));                                // 2 x 2
+    r1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s, t0), t1));                                   // 3
+    fp2_mul<C>(s, a.c2, b0);
+    r2 = fp2_carry_fast(fp2_add_lazy(s, t1));                                                     // 2
+    r.c0 = r0;
+    r.c1 = r1;
+    r.c2 = r2;
+    return;
+  }
   Fp2<C> t0, t1, s, r0, r1, r2;
   fp2_mul<C>(t0, a.c0, b0);
   fp2_mul<C>(t1, a.c1, b1);
@@ -353,6 +402,21 @@ ELP_INL bool fp12_eq(const Fp12<C>& a, const Fp12<C>& b) {
 }
 template <class C>
 ELP_HEAVY void fp12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {  // 3 Fp6 mul
+  if constexpr (fp_roomy<C>()) {
+    Fp6<C> t0, t1, s, u;
+    fp6_mul<C>(t0, a.c0, b.c0);
+    fp6_mul<C>(t1, a.c1, b.c1);
+    fp6_add(s, a.c0, a.c1);               // carried: fp6_mul sums its operands lazily once more
+    fp6_add(u, b.c0, b.c1);
+    fp6_mul<C>(s, s, u);
+    r.c1.c0 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s.c0, t0.c0), t1.c0));
+    r.c1.c1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s.c1, t0.c1), t1.c1));
+    r.c1.c2 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s.c2, t0.c2), t1.c2));
+    r.c0.c0 = fp2_carry_fast(fp2_add_lazy(t0.c0, fp2_mul_xi_lazy(t1.c2)));      // t0 + v t1
+    r.c0.c1 = fp2_carry_fast(fp2_add_lazy(t0.c1, t1.c0));
+    r.c0.c2 = fp2_carry_fast(fp2_add_lazy(t0.c2, t1.c1));
+    return;
+  }
   Fp6<C> t0, t1, s, u;
   fp6_mul<C>(t0, a.c0, b.c0);
   fp6_mul<C>(t1, a.c1, b.c1);
@@ -366,6 +430,25 @@ ELP_HEAVY void fp12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {  // 3 
 }
 template <class C>
 ELP_HEAVY void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {  // complex squaring, 2 Fp6 mul
+  if constexpr (fp_roomy<C>()) {
+    Fp6<C> t, s, u;
+    fp6_mul<C>(t, a.c0, a.c1);                                                   // a0 a1
+    fp6_add(s, a.c0, a.c1);                                                       // a0 + a1, carried
+    u.c0 = fp2_carry_fast(fp2_add_lazy(a.c0.c0, fp2_mul_xi_lazy(a.c1.c2)));       // a0 + v a1, carried
+    u.c1 = fp2_add(a.c0.c1, a.c1.c0);
+    u.c2 = fp2_add(a.c0.c2, a.c1.c1);
+    fp6_mul<C>(s, s, u);                                                          // a0^2 + v a1^2 + (1+v) a0 a1
+    Fp2<C> r00 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s.c0, t.c0), fp2_mul_xi_lazy(t.c2)));   // s - t - v t: 1 + 1 + 2
+    Fp2<C> r01 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s.c1, t.c1), t.c0));
+    Fp2<C> r02 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(s.c2, t.c2), t.c1));
+    r.c0.c0 = r00;
+    r.c0.c1 = r01;
+    r.c0.c2 = r02;
+    r.c1.c0 = fp2_dbl(t.c0);
+    r.c1.c1 = fp2_dbl(t.c1);
+    r.c1.c2 = fp2_dbl(t.c2);
+    return;
+  }
   Fp6<C> t, s, u;
   fp6_mul<C>(t, a.c0, a.c1);           // a0 a1
   fp6_add(s, a.c0, a.c1);               // a0 + a1
@@ -418,6 +501,20 @@ ELP_HEAVY void fp12_frob(Fp12<C>& r, const Fp12<C>& a, int n) {
 //  M-type twist: line = a + b w^2 + c w^3 -> c0 = (a,b,0), c1 = (0,c,0)      ("014")
 template <class C>
 ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c) {
+  if constexpr (fp_roomy<C>() && C::TWIST_D) {
+    Fp6<C> t0, t1, t2, s;
+    fp6_mul_by_fp2<C>(t0, f.c0, a);          // f0 * a
+    fp6_mul_by_01<C>(t1, f.c1, b, c);        // f1 * (b + c v)
+    fp6_add(s, f.c0, f.c1);                  // carried
+    fp6_mul_by_01<C>(t2, s, fp2_add(a, b), c);
+    f.c1.c0 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(t2.c0, t0.c0), t1.c0));
+    f.c1.c1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(t2.c1, t0.c1), t1.c1));
+    f.c1.c2 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(t2.c2, t0.c2), t1.c2));
+    f.c0.c0 = fp2_carry_fast(fp2_add_lazy(t0.c0, fp2_mul_xi_lazy(t1.c2)));      // t0 + v t1
+    f.c0.c1 = fp2_carry_fast(fp2_add_lazy(t0.c1, t1.c0));
+    f.c0.c2 = fp2_carry_fast(fp2_add_lazy(t0.c2, t1.c1));
+    return;
+  }
   if (C::TWIST_D) {
     Fp6<C> t0, t1, t2, s;
     fp6_mul_by_fp2<C>(t0, f.c0, a);          // f0 * a

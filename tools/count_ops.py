@@ -34,9 +34,9 @@ def build():
 
 
 def counts(L):
-    c = (ctypes.c_ulonglong * 2)()
+    c = (ctypes.c_ulonglong * 3)()
     L.twin_op_counts(c, 1)
-    return int(c[0]), int(c[1])
+    return int(c[0]), int(c[1]), int(c[2])
 
 
 def main():
@@ -65,20 +65,25 @@ def main():
         # windows: ceil(256 / W); linear through the two measured points (32 and 64 windows)
         n8, n4 = 32, 64
         out = []
-        for j in range(2):
+        for j in range(3):
             y8, y4 = per_w[8][i][j], per_w[4][i][j]
             slope = (y4 - y8) / (n4 - n8)
             out.append(y8 + slope * ((256 + W - 1) // W - n8))
         return out
 
     for name, i in (("verify_id", 0), ("prove_id", 1)):
-        res[name] = {"config": "BN254, 8 attributes, 4 hidden, id-retrieval", "W8": {"fp_mul": per_w[8][i][0], "fp_sqr": per_w[8][i][1]},
-                     "W4": {"fp_mul": per_w[4][i][0], "fp_sqr": per_w[4][i][1]}}
+        def entry(m, s, pr, extrapolated=False):
+            # multiply-adds (v_mad_i64_i32) of the 9-limb routines: product 81 + reduction 81; square 45 + 81; pair 2 x 81 + 81
+            e = {"fp_mul": round(m), "fp_sqr": round(s), "fp_mul_pair": round(pr), "multiply_adds": round(162 * m + 126 * s + 243 * pr),
+                 "fp_mul_equivalents": round(m + 126 / 162 * s + 1.5 * pr)}
+            if extrapolated:
+                e["extrapolated"] = True
+            return e
+        res[name] = {"config": "BN254, 8 attributes, 4 hidden, id-retrieval", "W8": entry(*per_w[8][i]), "W4": entry(*per_w[4][i])}
         for W in (12, 16):
-            m, s = extrapolate(i, W)
-            res[name]["W%d" % W] = {"fp_mul": round(m), "fp_sqr": round(s), "extrapolated": True}
-    res["note"] = ("Montgomery products per item counted on the host twin (same template code as the kernels).  One fp_sqr costs about "
-                   "0.6 fp_mul in VALU work (the symmetric half of the columns is shared); modmul_equiv = fp_mul + fp_sqr.")
+            res[name]["W%d" % W] = entry(*extrapolate(i, W), extrapolated=True)
+    res["note"] = ("Calls per item of the three Montgomery routines, counted on the host twin (same template code as the kernels), and the "
+                   "multiply-add instructions they stand for; fp_mul_equivalents = multiply_adds / 162.")
     path = os.path.join(ROOT, "profiles", "op_counts.json")
     with open(path, "w") as f:
         json.dump(res, f, indent=1)
