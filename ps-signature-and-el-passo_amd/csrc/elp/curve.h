@@ -16,6 +16,14 @@ struct F1 {
   ELP_INL static T add(const T& a, const T& b) { return fp_add(a, b); }
   ELP_INL static T sub(const T& a, const T& b) { return fp_sub(a, b); }
   ELP_INL static T dbl(const T& a) { return fp_dbl(a); }
+  // lazy forms (no carry pass) where the field has the headroom for them, the carried forms otherwise; carry() closes a lazy chain
+  ELP_INL static T addl(const T& a, const T& b) { return fp_roomy<C>() ? fp_add_lazy(a, b) : fp_add(a, b); }
+  ELP_INL static T subl(const T& a, const T& b) { return fp_roomy<C>() ? fp_sub_lazy(a, b) : fp_sub(a, b); }
+  ELP_INL static T dbll(const T& a) { return fp_roomy<C>() ? fp_add_lazy(a, a) : fp_dbl(a); }
+  ELP_INL static T carry(T a) {
+    if (fp_roomy<C>()) fp_carry_fast(a);
+    return a;
+  }
   ELP_INL static T neg(const T& a) { return fp_neg(a); }
   ELP_INL static bool is_zero(const T& a) { return fp_is_zero<C>(a); }
   ELP_INL static bool is_zero_exact(const T& a) { return fp_is_zero_exact(a); }
@@ -39,6 +47,10 @@ struct F2 {
   ELP_INL static T add(const T& a, const T& b) { return fp2_add(a, b); }
   ELP_INL static T sub(const T& a, const T& b) { return fp2_sub(a, b); }
   ELP_INL static T dbl(const T& a) { return fp2_dbl(a); }
+  ELP_INL static T addl(const T& a, const T& b) { return fp_roomy<C>() ? fp2_add_lazy(a, b) : fp2_add(a, b); }
+  ELP_INL static T subl(const T& a, const T& b) { return fp_roomy<C>() ? fp2_sub_lazy(a, b) : fp2_sub(a, b); }
+  ELP_INL static T dbll(const T& a) { return fp_roomy<C>() ? fp2_add_lazy(a, a) : fp2_dbl(a); }
+  ELP_INL static T carry(const T& a) { return fp_roomy<C>() ? fp2_carry_fast(a) : a; }
   ELP_INL static T neg(const T& a) { return fp2_neg(a); }
   ELP_INL static bool is_zero(const T& a) { return fp2_is_zero(a); }
   ELP_INL static bool is_zero_exact(const T& a) { return fp2_is_zero_exact(a); }
@@ -116,21 +128,25 @@ ELP_HEAVY bool aff_on_curve(const Aff<F>& p) {
   return F::eq(l, r);
 }
 
-// dbl-2009-l (a = 0): 2M + 5S
+// dbl-2009-l (a = 0) with the two squaring tricks undone (a square costs 0.9 products here and the tricks cost carried sums):
+// A = X^2, B = Y^2, C = B^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Y3 = E (D - X3) - 8 C, Z3 = 2 Y Z.   3M + 4S.
+// Operands and results carried; the comments give limb magnitudes in carried units where sums stay lazy (roomy fields).
 template <class F>
 ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
   typedef typename F::T T;
   T A = F::sqr(p.X);
   T B = F::sqr(p.Y);
   T Cc = F::sqr(B);
-  T D = F::sub(F::sub(F::sqr(F::add(p.X, B)), A), Cc);
-  D = F::dbl(D);
-  T E = F::add(F::dbl(A), A);
+  T D = F::mul(F::dbll(F::dbll(p.X)), B);                      // 4 x 1
+  T E = F::carry(F::addl(F::dbll(A), A));                      // 3 -> 1 (squared next)
   T Fq = F::sqr(E);
-  T Z3 = F::dbl(F::mul(p.Y, p.Z));
-  T X3 = F::sub(Fq, F::dbl(D));
-  T C8 = F::dbl(F::dbl(F::dbl(Cc)));
-  r.Y = F::sub(F::mul(E, F::sub(D, X3)), C8);
+  T Z3 = F::mul(F::dbll(p.Y), p.Z);                            // 2 x 1
+  T X3 = F::carry(F::subl(Fq, F::dbll(D)));                    // 3 -> 1
+  T C4 = F::dbll(F::dbll(Cc));                                 // 4
+  T Y3 = F::mul(E, F::subl(D, X3));                            // 1 x 2
+  Y3 = F::carry(F::subl(Y3, C4));                              // 5 -> 1
+  Y3 = F::carry(F::subl(Y3, C4));
+  r.Y = Y3;
   r.X = X3;
   r.Z = Z3;  // Y == 0 never happens on prime-order curves; Z == 0 stays 0
 }
@@ -155,24 +171,24 @@ ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   T Z1Z1 = F::sqr(p.Z);
   T U2 = F::mul(q.x, Z1Z1);
   T S2 = F::mul(F::mul(q.y, p.Z), Z1Z1);
-  T H = F::sub(U2, p.X);
-  T rr = F::sub(S2, p.Y);
+  T H = F::carry(F::subl(U2, p.X));                            // 2 -> 1 (squared next)
+  T rr = F::subl(S2, p.Y);                                     // 2
   T HH = F::sqr(H);
   if (F::is_zero_exact(HH)) {            // H == 0 (mod p): same x-coordinate
-    if (F::is_zero_exact(F::sqr(rr))) {  // and same y: doubling
+    if (F::is_zero_exact(F::sqr(F::carry(rr)))) {  // and same y: doubling
       jac_dbl<F>(r, p);
     } else {
       jac_set_inf(r);
     }
     return;
   }
-  rr = F::dbl(rr);
-  T I = F::dbl(F::dbl(HH));
-  T J = F::mul(H, I);
+  rr = F::carry(F::dbll(rr));                                  // 4 -> 1
+  T I = F::dbll(F::dbll(HH));                                  // 4
+  T J = F::mul(H, I);                                          // 1 x 4
   T V = F::mul(p.X, I);
-  T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));
-  T Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::dbl(F::mul(p.Y, J)));
-  T Z3 = F::sub(F::sub(F::sqr(F::add(p.Z, H)), Z1Z1), HH);
+  T X3 = F::carry(F::subl(F::subl(F::sqr(rr), J), F::dbll(V)));             // 4 -> 1
+  T Y3 = F::carry(F::subl(F::mul(rr, F::subl(V, X3)), F::dbll(F::mul(p.Y, J))));   // 1 x 2; 3 -> 1
+  T Z3 = F::mul(F::dbll(p.Z), H);                              // (Z + H)^2 - Z^2 - H^2 = 2 Z H
   r.X = X3;
   r.Y = Y3;
   r.Z = Z3;
@@ -196,23 +212,23 @@ ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   T U2 = F::mul(q.X, Z1Z1);
   T S1 = F::mul(F::mul(p.Y, q.Z), Z2Z2);
   T S2 = F::mul(F::mul(q.Y, p.Z), Z1Z1);
-  T H = F::sub(U2, U1);
-  T rr = F::sub(S2, S1);
-  T I = F::sqr(F::dbl(H));
+  T H = F::subl(U2, U1);                                       // 2
+  T rr = F::subl(S2, S1);                                      // 2
+  T I = F::sqr(F::carry(F::dbll(H)));                          // (2H)^2, operand 4 -> 1
   if (F::is_zero_exact(I)) {             // H == 0 (mod p), see jac_madd
-    if (F::is_zero_exact(F::sqr(rr))) {
+    if (F::is_zero_exact(F::sqr(F::carry(rr)))) {
       jac_dbl<F>(r, p);
     } else {
       jac_set_inf(r);
     }
     return;
   }
-  rr = F::dbl(rr);
-  T J = F::mul(H, I);
+  rr = F::carry(F::dbll(rr));                                  // 4 -> 1
+  T J = F::mul(H, I);                                          // 2 x 1
   T V = F::mul(U1, I);
-  T X3 = F::sub(F::sub(F::sqr(rr), J), F::dbl(V));
-  T Y3 = F::sub(F::mul(rr, F::sub(V, X3)), F::dbl(F::mul(S1, J)));
-  T Z3 = F::mul(F::sub(F::sub(F::sqr(F::add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+  T X3 = F::carry(F::subl(F::subl(F::sqr(rr), J), F::dbll(V)));             // 4 -> 1
+  T Y3 = F::carry(F::subl(F::mul(rr, F::subl(V, X3)), F::dbll(F::mul(S1, J))));   // 1 x 2; 3 -> 1
+  T Z3 = F::mul(F::mul(F::dbll(p.Z), q.Z), H);                 // ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H = 2 Z1 Z2 H; 1 x 2
   r.X = X3;
   r.Y = Y3;
   r.Z = Z3;

@@ -30,6 +30,30 @@ ELP_HEAVY void ml_dbl_step(G2Proj<C>& T, LineCoef<C>& l) {
   Fp<C> inv2;
   ELP_LOAD_FP(inv2, C::inv2(i_));
   Fp2<C> A, B, Cz, E, Fq, G, H, J, t;
+  if constexpr (fp_roomy<C>()) {
+    // same formulas, sums left lazy (limb magnitudes in carried units in the comments); T stays carried, the line coefficients are
+    // handed on lazily (a, b: 3; c: 2), which the sparse product in ml_apply_line is sized for
+    fp2_mul<C>(A, T.X, T.Y);
+    A = fp2_mul_fp(A, inv2);
+    fp2_sqr<C>(B, T.Y);
+    fp2_sqr<C>(Cz, T.Z);
+    fp2_mul<C>(E, Cz, fp2_twist_3b<C>());
+    Fq = fp2_add_lazy(fp2_add_lazy(E, E), E);                                  // 3
+    G = fp2_mul_fp(fp2_add_lazy(B, Fq), inv2);                                 // 4 x 1
+    fp2_sqr<C>(H, fp2_add(T.Y, T.Z));                                          // squared: carried
+    H = fp2_sub_lazy(fp2_sub_lazy(H, B), Cz);                                  // 3
+    fp2_sqr<C>(J, T.X);
+    l.a = H;
+    l.b = fp2_neg(fp2_add_lazy(fp2_add_lazy(J, J), J));                        // 3
+    l.c = fp2_sub_lazy(B, E);                                                  // 2
+    fp2_mul<C>(T.X, A, fp2_sub_lazy(B, Fq));                                   // 1 x 4
+    fp2_sqr<C>(t, G);
+    Fp2<C> E2;
+    fp2_sqr<C>(E2, E);
+    T.Y = fp2_carry_fast(fp2_sub_lazy(t, fp2_add_lazy(fp2_add_lazy(E2, E2), E2)));   // 4 -> 1
+    fp2_mul<C>(T.Z, B, H);                                                     // 1 x 3
+    return;
+  }
   fp2_mul<C>(A, T.X, T.Y);
   A = fp2_mul_fp(A, inv2);
   fp2_sqr<C>(B, T.Y);
@@ -55,6 +79,29 @@ ELP_HEAVY void ml_dbl_step(G2Proj<C>& T, LineCoef<C>& l) {
 template <class C>
 ELP_HEAVY void ml_add_step(G2Proj<C>& T, LineCoef<C>& l, const Fp2<C>& xq, const Fp2<C>& yq) {
   Fp2<C> theta, mu, t, Cc, D, E, Fq, G, H;
+  if constexpr (fp_roomy<C>()) {
+    fp2_mul<C>(t, yq, T.Z);
+    theta = fp2_sub(T.Y, t);                                                   // squared below: carried
+    fp2_mul<C>(t, xq, T.Z);
+    mu = fp2_sub(T.X, t);
+    l.a = mu;
+    l.b = fp2_neg(theta);
+    fp2_mul<C>(t, theta, xq);
+    fp2_mul<C>(Cc, mu, yq);
+    l.c = fp2_sub_lazy(t, Cc);                                                 // 2
+    fp2_sqr<C>(Cc, theta);
+    fp2_sqr<C>(D, mu);
+    fp2_mul<C>(E, mu, D);
+    fp2_mul<C>(Fq, T.Z, Cc);
+    fp2_mul<C>(G, T.X, D);
+    H = fp2_sub_lazy(fp2_add_lazy(E, Fq), fp2_add_lazy(G, G));                 // 4
+    fp2_mul<C>(T.X, mu, H);                                                    // 1 x 4
+    fp2_mul<C>(t, theta, fp2_sub_lazy(G, H));                                  // 1 x 5
+    fp2_mul<C>(Cc, E, T.Y);
+    T.Y = fp2_carry_fast(fp2_sub_lazy(t, Cc));                                 // 2 -> 1
+    fp2_mul<C>(T.Z, T.Z, E);
+    return;
+  }
   fp2_mul<C>(t, yq, T.Z);
   theta = fp2_sub(T.Y, t);
   fp2_mul<C>(t, xq, T.Z);
