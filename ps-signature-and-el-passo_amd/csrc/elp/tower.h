@@ -546,6 +546,47 @@ ELP_HEAVY void fp12_cyc_sqr(Fp12<C>& r, const Fp12<C>& a) {
   // view Fp12 as three Fp4 = Fp2[s]/(s^2 - xi):  (g0 + g1 s) with pairs (c0.c0,c1.c1), (c1.c0,c0.c2), (c0.c1,c1.c2)
   const Fp2<C>&z0 = a.c0.c0, &z4 = a.c0.c1, &z3 = a.c0.c2, &z2 = a.c1.c0, &z1 = a.c1.c1, &z5 = a.c1.c2;
   Fp2<C> t0, t1, t2, t3, t4, t5, tmp;
+  if constexpr (fp_roomy<C>()) {
+    // per Fp4 block: A0 = z0^2 + xi z1^2 and A1 = 2 z0 z1 carried once each (3 -> 1), then 3 A -+ 2 z summed lazily (5) straight
+    // into the weak reduction, which accepts any int32 limbs and returns carried ones
+    Fp2<C> n[6];
+    const Fp2<C>* za[3] = {&z0, &z2, &z4};
+    const Fp2<C>* zb[3] = {&z1, &z3, &z5};
+    ELP_UNROLL
+    for (int k = 0; k < 3; k++) {
+      fp2_sqr<C>(t0, *za[k]);
+      fp2_sqr<C>(t1, *zb[k]);
+      fp2_sqr<C>(tmp, fp2_add(*za[k], *zb[k]));
+      Fp2<C> A1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(tmp, t0), t1));        // 2 za zb
+      Fp2<C> A0 = fp2_carry_fast(fp2_add_lazy(t0, fp2_mul_xi_lazy(t1)));          // za^2 + xi zb^2
+      n[2 * k] = A0;
+      n[2 * k + 1] = A1;
+    }
+    // A = (n0, n1) from (z0, z1); B = (n2, n3) from (z2, z3); Cq = (n4, n5) from (z4, z5)
+    auto three_minus = [](const Fp2<C>& A, const Fp2<C>& z) {   // 3 A - 2 z
+      return fp2_sub_lazy(fp2_add_lazy(fp2_add_lazy(A, A), A), fp2_add_lazy(z, z));
+    };
+    auto three_plus = [](const Fp2<C>& A, const Fp2<C>& z) {    // 3 A + 2 z
+      return fp2_add_lazy(fp2_add_lazy(fp2_add_lazy(A, A), A), fp2_add_lazy(z, z));
+    };
+    Fp2<C> o0 = three_minus(n[0], z0);                 // z0' = 3 A0 - 2 z0
+    Fp2<C> o1 = three_plus(n[1], z1);                  // z1' = 3 A1 + 2 z1
+    Fp2<C> xc1 = fp2_carry_fast(fp2_mul_xi_lazy(n[5]));
+    Fp2<C> o2 = three_plus(xc1, z2);                   // z2' = 3 xi C1 + 2 z2
+    Fp2<C> o3 = three_minus(n[4], z3);                 // z3' = 3 C0 - 2 z3
+    Fp2<C> o4 = three_minus(n[2], z4);                 // z4' = 3 B0 - 2 z4
+    Fp2<C> o5 = three_plus(n[3], z5);                  // z5' = 3 B1 + 2 z5
+    fp_reduce_weak(o0.c0); fp_reduce_weak(o0.c1); fp_reduce_weak(o1.c0); fp_reduce_weak(o1.c1);
+    fp_reduce_weak(o2.c0); fp_reduce_weak(o2.c1); fp_reduce_weak(o3.c0); fp_reduce_weak(o3.c1);
+    fp_reduce_weak(o4.c0); fp_reduce_weak(o4.c1); fp_reduce_weak(o5.c0); fp_reduce_weak(o5.c1);
+    r.c0.c0 = o0;
+    r.c0.c1 = o4;
+    r.c0.c2 = o3;
+    r.c1.c0 = o2;
+    r.c1.c1 = o1;
+    r.c1.c2 = o5;
+    return;
+  }
   // (z0 + z1 s)^2 = (z0^2 + xi z1^2) + 2 z0 z1 s
   fp2_sqr<C>(t0, z0);
   fp2_sqr<C>(t1, z1);
