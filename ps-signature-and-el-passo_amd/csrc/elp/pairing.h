@@ -26,7 +26,7 @@ ELP_INL Fp2<C> fp2_twist_3b() {
 
 // Tangent line at T and T <- 2T.   line = 2YZ * y_P  -  3X^2 * x_P  +  (Y^2 - 3b'Z^2)
 template <class C>
-ELP_HEAVY void ml_dbl_step(G2Proj<C>& T, LineCoef<C>& l) {
+ELP_INL void ml_dbl_step_inl(G2Proj<C>& T, LineCoef<C>& l) {
   Fp<C> inv2;
   ELP_LOAD_FP(inv2, C::inv2(i_));
   Fp2<C> A, B, Cz, E, Fq, G, H, J, t;
@@ -75,9 +75,14 @@ ELP_HEAVY void ml_dbl_step(G2Proj<C>& T, LineCoef<C>& l) {
   fp2_mul<C>(T.Z, B, H);
 }
 
+template <class C>
+ELP_HEAVY void ml_dbl_step(G2Proj<C>& T, LineCoef<C>& l) {
+  ml_dbl_step_inl<C>(T, l);
+}
+
 // Chord through T and Q (affine) and T <- T + Q.   line = mu * y_P - theta * x_P + (theta x_Q - mu y_Q)
 template <class C>
-ELP_HEAVY void ml_add_step(G2Proj<C>& T, LineCoef<C>& l, const Fp2<C>& xq, const Fp2<C>& yq) {
+ELP_INL void ml_add_step_inl(G2Proj<C>& T, LineCoef<C>& l, const Fp2<C>& xq, const Fp2<C>& yq) {
   Fp2<C> theta, mu, t, Cc, D, E, Fq, G, H;
   if constexpr (fp_roomy<C>()) {
     fp2_mul<C>(t, yq, T.Z);
@@ -124,14 +129,25 @@ ELP_HEAVY void ml_add_step(G2Proj<C>& T, LineCoef<C>& l, const Fp2<C>& xq, const
   fp2_mul<C>(T.Z, T.Z, E);
 }
 
+// f <- f * line(P).  One leaf routine (evaluation at P and the sparse product together): a separate wrapper around the product would
+// be a non-leaf function and save / restore its callee-saved registers on every call.
 template <class C>
-ELP_HEAVY void ml_apply_line(Fp12<C>& f, const LineCoef<C>& l, const Fp<C>& xp, const Fp<C>& yp) {
+ELP_HEAVY void ml_add_step(G2Proj<C>& T, LineCoef<C>& l, const Fp2<C>& xq, const Fp2<C>& yq) {
+  ml_add_step_inl<C>(T, l, xq, yq);
+}
+
+template <class C>
+ELP_INL void ml_apply_line_inl(Fp12<C>& f, const LineCoef<C>& l, const Fp<C>& xp, const Fp<C>& yp) {
   Fp2<C> a = fp2_mul_fp(l.a, yp);
   Fp2<C> b = fp2_mul_fp(l.b, xp);
   if (C::TWIST_D)
-    fp12_mul_by_line<C>(f, a, b, l.c);
+    fp12_mul_by_line_inl<C>(f, a, b, l.c);
   else
-    fp12_mul_by_line<C>(f, l.c, b, a);
+    fp12_mul_by_line_inl<C>(f, l.c, b, a);
+}
+template <class C>
+ELP_HEAVY void ml_apply_line(Fp12<C>& f, const LineCoef<C>& l, const Fp<C>& xp, const Fp<C>& yp) {
+  ml_apply_line_inl<C>(f, l, xp, yp);
 }
 
 // number of line coefficients produced for one fixed G2 argument
@@ -187,26 +203,36 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
   fp12_set_one(f);
   LineCoef<C> l;
   int n = 0;
+  // For the verification shape (one variable pair, one pair with precomputed lines) the step routines are inlined into this loop
+  // (FUSE): as separate routines each call saves and restores the callee-saved registers it uses, which was the bulk of the
+  // private-memory traffic of the whole verification.  The half-step loop keeps one copy of each routine per pair kind.  Other
+  // shapes keep the calls (the instances that are handed null pair arrays trip an illegal-instruction bug of the compiler when fused).
+  constexpr bool FUSE = (NV == 1 && NF == 1);
   ELP_NOUNROLL
   for (int i = 0; i < C::ATE_LEN; i++) {
-    if (i != 0) fp12_sqr<C>(f, f);
-    for (int k = 0; k < NV; k++)
-      if (live_v[k]) {
-        ml_dbl_step<C>(T[k], l);
-        ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
-      }
-    for (int k = 0; k < NF; k++)
-      if (live_f[k]) ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
-    n++;
-    int d = C::ate_naf(i);
-    if (d != 0) {
-      for (int k = 0; k < NV; k++)
-        if (live_v[k]) {
-          ml_add_step<C>(T[k], l, qv[k].x, d > 0 ? qv[k].y : nqy[k]);
-          ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+    if (i != 0) {
+      if (FUSE) fp12_sqr_inl<C>(f, f); else fp12_sqr<C>(f, f);
+    }
+    const int d = C::ate_naf(i);
+    ELP_NOUNROLL
+    for (int half = 0; half < 2; half++) {          // 0: doubling step, 1: addition step (only for a non-zero digit)
+      if (half == 1 && d == 0) break;
+      ELP_UNROLL
+      for (int k = 0; k < NV; k++) {
+        if (!live_v[k]) continue;
+        if (half == 0) {
+          if (FUSE) ml_dbl_step_inl<C>(T[k], l); else ml_dbl_step<C>(T[k], l);
+        } else {
+          const Fp2<C> yq = fp2_select(d > 0, qv[k].y, nqy[k]);   // by value: no select between a private and a generic pointer
+          if (FUSE) ml_add_step_inl<C>(T[k], l, qv[k].x, yq); else ml_add_step<C>(T[k], l, qv[k].x, yq);
         }
-      for (int k = 0; k < NF; k++)
-        if (live_f[k]) ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+        if (FUSE) ml_apply_line_inl<C>(f, l, pv[k].x, pv[k].y); else ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+      }
+      ELP_UNROLL
+      for (int k = 0; k < NF; k++) {
+        if (!live_f[k]) continue;
+        if (FUSE) ml_apply_line_inl<C>(f, lines[k][n], pf[k].x, pf[k].y); else ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+      }
       n++;
     }
   }

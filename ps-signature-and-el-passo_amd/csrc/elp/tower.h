@@ -429,7 +429,7 @@ ELP_HEAVY void fp12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {  // 3 
   fp6_add(r.c0, t0, t1);
 }
 template <class C>
-ELP_HEAVY void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {  // complex squaring, 2 Fp6 mul
+ELP_INL void fp12_sqr_inl(Fp12<C>& r, const Fp12<C>& a) {  // complex squaring, 2 Fp6 mul
   if constexpr (fp_roomy<C>()) {
     Fp6<C> t, s, u;
     fp6_mul<C>(t, a.c0, a.c1);                                                   // a0 a1
@@ -459,6 +459,10 @@ ELP_HEAVY void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {  // complex squaring, 2 
   fp6_mul_by_v(u, t);
   fp6_sub(r.c0, s, u);
   fp6_add(r.c1, t, t);
+}
+template <class C>
+ELP_HEAVY void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {
+  fp12_sqr_inl<C>(r, a);
 }
 template <class C>
 ELP_INL void fp12_conj(Fp12<C>& r, const Fp12<C>& a) {  // a^(p^6)
@@ -500,7 +504,7 @@ ELP_HEAVY void fp12_frob(Fp12<C>& r, const Fp12<C>& a, int n) {
 //  D-type twist: line = a + b w + c w^3   -> c0 = (a,0,0), c1 = (b,c,0)      ("034")
 //  M-type twist: line = a + b w^2 + c w^3 -> c0 = (a,b,0), c1 = (0,c,0)      ("014")
 template <class C>
-ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c) {
+ELP_INL void fp12_mul_by_line_inl(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c) {
   if constexpr (fp_roomy<C>() && C::TWIST_D) {
     Fp6<C> t0, t1, t2, s;
     fp6_mul_by_fp2<C>(t0, f.c0, a);          // f0 * a
@@ -538,6 +542,11 @@ ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, co
     fp6_mul_by_v(t1, t1);
     fp6_add(f.c0, t0, t1);
   }
+}
+
+template <class C>
+ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c) {
+  fp12_mul_by_line_inl<C>(f, a, b, c);
 }
 
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final exponentiation).

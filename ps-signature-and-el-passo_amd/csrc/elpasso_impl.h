@@ -25,8 +25,10 @@ using namespace elp;
 // register budget of every kernel and (through the attributor) of the device functions they share: ELP_WAVES_PER_EU resident waves per SIMD
 #ifdef ELP_WAVES_PER_EU
 #define ELP_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK, ELP_WAVES_PER_EU)
+#define ELP_MSM_LAUNCH_BOUNDS __launch_bounds__(ELP_MSM_TPB, ELP_WAVES_PER_EU)
 #else
 #define ELP_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK)
+#define ELP_MSM_LAUNCH_BOUNDS __launch_bounds__(ELP_MSM_TPB)
 #endif
 // gives every lane of the (one-wave) workgroup its LDS hot slot, see elp/common.h
 #define ELP_HOT_SETUP(key)                                                                   \
@@ -291,7 +293,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_prepare(const u32* pts, void* out, int* 
 }
 
 template <class F>
-__global__ void __launch_bounds__(ELP_MSM_TPB) k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
+__global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
                                                              Jac<F>* partial) {
   __shared__ unsigned cnt[256];
   __shared__ unsigned start[256];
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(ELP_MSM_TPB) k_msm_buckets(const Aff<F>* pts, 
 }
 
 template <class F>
-__global__ void __launch_bounds__(ELP_MSM_TPB) k_msm_reduce(const Jac<F>* partial, int S, Jac<F>* win) {
+__global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S, Jac<F>* win) {
   __shared__ Jac<F> sh[256];
   const int tid = threadIdx.x, w = blockIdx.x;
   Jac<F> acc = partial[((size_t)w * S) * 256 + tid];
