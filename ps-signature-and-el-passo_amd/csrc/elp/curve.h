@@ -156,7 +156,7 @@ ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
 // ((kp * lp + m p)/R with m = -kl p exactly), while H != 0 (mod p) gives H^2 != 0.  So no modular reduction or
 // comparison is needed on the hot path.
 template <class F>
-ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
+ELP_INL void jac_madd_inl(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   typedef typename F::T T;
   if (aff_is_inf(q)) {
     r = p;
@@ -192,6 +192,11 @@ ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   r.X = X3;
   r.Y = Y3;
   r.Z = Z3;
+}
+
+template <class F>
+ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
+  jac_madd_inl<F>(r, p, q);
 }
 
 // add-2007-bl: Jacobian + Jacobian, 11M + 5S
@@ -515,7 +520,13 @@ ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scal
     int bit = j * W;
     int w = (bit + W <= 256) ? W : 256 - bit;
     int d = scalar_window(k, bit, w);
-    if (d != 0) jac_madd<F>(a, a, table[(size_t)j * per + (d - 1)]);
+    if (d != 0) {
+      // the mixed addition is part of this loop for the Fp2 group (as a routine of its own it saves and restores ~170 registers per call)
+      if (sizeof(typename F::T) > sizeof(Fp<typename F::Curve>))
+        jac_madd_inl<F>(a, a, table[(size_t)j * per + (d - 1)]);
+      else
+        jac_madd<F>(a, a, table[(size_t)j * per + (d - 1)]);
+    }
   }
   if (ah) acc = a;
 }
