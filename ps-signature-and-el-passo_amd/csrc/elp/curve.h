@@ -132,7 +132,9 @@ ELP_HEAVY bool aff_on_curve(const Aff<F>& p) {
 // A = X^2, B = Y^2, C = B^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Y3 = E (D - X3) - 8 C, Z3 = 2 Y Z.   3M + 4S.
 // Operands and results carried; the comments give limb magnitudes in carried units where sums stay lazy (roomy fields).
 template <class F>
-ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p);
+template <class F>
+ELP_INL void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
   typedef typename F::T T;
   T A = F::sqr(p.X);
   T B = F::sqr(p.Y);
@@ -149,6 +151,11 @@ ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
   r.Y = Y3;
   r.X = X3;
   r.Z = Z3;  // Y == 0 never happens on prime-order curves; Z == 0 stays 0
+}
+
+template <class F>
+ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+  jac_dbl_inl<F>(r, p);
 }
 
 // madd-2007-bl: Jacobian + affine, 7M + 4S, exceptional cases included.  The test "H == 0 (mod p)" (P == +-Q) is free in
@@ -201,7 +208,7 @@ ELP_HEAVY void jac_madd(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
 
 // add-2007-bl: Jacobian + Jacobian, 11M + 5S
 template <class F>
-ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+ELP_INL void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   typedef typename F::T T;
   if (jac_is_inf(q)) {
     r = p;
@@ -237,6 +244,11 @@ ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   r.X = X3;
   r.Y = Y3;
   r.Z = Z3;
+}
+
+template <class F>
+ELP_HEAVY void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+  jac_add_inl<F>(r, p, q);
 }
 
 // Jacobian -> affine given zinv = 1/Z (or anything when Z == 0)
@@ -423,25 +435,23 @@ ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in
   lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());
   Fp<C> beta;
   ELP_LOAD_FP(beta, C::glv_beta(i_));
-  Jac<F> acc_priv;
-  Jac<F>* ah = hot_as<Jac<F>>(hot);
-  Jac<F>& acc = ah ? *ah : acc_priv;
+  // the running point stays in registers: doubling and addition are inlined into the loop (one copy each)
+  (void)hot;
+  Jac<F> acc;
   jac_set_inf(acc);
   ELP_NOUNROLL
   for (int w = 32; w >= 0; w--) {
     if (w != 32) {
-      jac_dbl<F>(acc, acc);
-      jac_dbl<F>(acc, acc);
-      jac_dbl<F>(acc, acc);
-      jac_dbl<F>(acc, acc);
+      ELP_NOUNROLL
+      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
     }
-    Jac<F> t = tbl[limbs_window<5>(m[0], 4 * w, 4)];
-    if (neg[0]) t.Y = fp_neg(t.Y);
-    jac_add<F>(acc, acc, t);
-    t = tbl[limbs_window<5>(m[1], 4 * w, 4)];
-    t.X = fp_mul<C>(t.X, beta);
-    if (neg[1]) t.Y = fp_neg(t.Y);
-    jac_add<F>(acc, acc, t);
+    ELP_NOUNROLL
+    for (int j = 0; j < 2; j++) {
+      Jac<F> t = tbl[limbs_window<5>(m[j], 4 * w, 4)];
+      if (j == 1) t.X = fp_mul<C>(t.X, beta);
+      if (neg[j]) t.Y = fp_neg(t.Y);
+      jac_add_inl<F>(acc, acc, t);
+    }
   }
   r = acc;
 }
@@ -464,17 +474,14 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
   u32 m[4][3];
   bool neg[4];
   lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());
-  Jac<F> acc_priv;
-  Jac<F>* ah = hot_as<Jac<F>>(hot);
-  Jac<F>& acc = ah ? *ah : acc_priv;
+  (void)hot;
+  Jac<F> acc;              // in registers: doubling and addition are inlined into the loop (one copy each)
   jac_set_inf(acc);
   ELP_NOUNROLL
   for (int w = 16; w >= 0; w--) {
     if (w != 16) {
-      jac_dbl<F>(acc, acc);
-      jac_dbl<F>(acc, acc);
-      jac_dbl<F>(acc, acc);
-      jac_dbl<F>(acc, acc);
+      ELP_NOUNROLL
+      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
     }
     ELP_NOUNROLL
     for (int j = 0; j < 4; j++) {
@@ -500,7 +507,7 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
         fp2_mul<C>(t.Y, t.Y, gy);
       }
       if (neg[j]) t.Y = fp2_neg(t.Y);
-      jac_add<F>(acc, acc, t);
+      jac_add_inl<F>(acc, acc, t);
     }
   }
   r = acc;
