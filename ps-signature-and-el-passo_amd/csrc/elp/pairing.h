@@ -268,7 +268,7 @@ ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = null
   while (!((e >> top) & 1)) top--;
   ELP_NOUNROLL
   for (int i = top - 1; i >= 0; i--) {
-    fp12_cyc_sqr<C>(acc, acc);
+    fp12_cyc_sqr<C>(acc, acc);     // stays a call: with the squaring inlined and the accumulator in registers the loop spills more than it saves
     if ((e >> i) & 1) fp12_mul<C>(acc, acc, a);
   }
   r = acc;

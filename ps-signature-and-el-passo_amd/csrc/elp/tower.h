@@ -551,7 +551,7 @@ ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, co
 
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final exponentiation).
 template <class C>
-ELP_HEAVY void fp12_cyc_sqr(Fp12<C>& r, const Fp12<C>& a) {
+ELP_INL void fp12_cyc_sqr_inl(Fp12<C>& r, const Fp12<C>& a) {
   // view Fp12 as three Fp4 = Fp2[s]/(s^2 - xi):  (g0 + g1 s) with pairs (c0.c0,c1.c1), (c1.c0,c0.c2), (c0.c1,c1.c2)
   const Fp2<C>&z0 = a.c0.c0, &z4 = a.c0.c1, &z3 = a.c0.c2, &z2 = a.c1.c0, &z1 = a.c1.c1, &z5 = a.c1.c2;
   Fp2<C> t0, t1, t2, t3, t4, t5, tmp;
@@ -637,6 +637,11 @@ ELP_HEAVY void fp12_cyc_sqr(Fp12<C>& r, const Fp12<C>& a) {
   r.c1.c0 = n2;
   r.c1.c1 = n1;
   r.c1.c2 = n5;
+}
+
+template <class C>
+ELP_HEAVY void fp12_cyc_sqr(Fp12<C>& r, const Fp12<C>& a) {
+  fp12_cyc_sqr_inl<C>(r, a);
 }
 
 }  // namespace elp
