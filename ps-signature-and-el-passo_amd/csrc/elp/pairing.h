@@ -206,8 +206,9 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
   // For the verification shape (one variable pair, one pair with precomputed lines) the step routines are inlined into this loop
   // (FUSE): as separate routines each call saves and restores the callee-saved registers it uses, which was the bulk of the
   // private-memory traffic of the whole verification.  The half-step loop keeps one copy of each routine per pair kind.  Other
-  // shapes keep the calls (the instances that are handed null pair arrays trip an illegal-instruction bug of the compiler when fused).
-  constexpr bool FUSE = (NV == 1 && NF == 1);
+  // shapes keep the calls.  Callers of a fused shape pass real pointers for arrays it does not read: constant null arguments
+  // propagated into the fused body trip an illegal-instruction bug of the compiler.
+  constexpr bool FUSE = (NV == 1 && NF <= 1);
   ELP_NOUNROLL
   for (int i = 0; i < C::ATE_LEN; i++) {
     if (i != 0) {

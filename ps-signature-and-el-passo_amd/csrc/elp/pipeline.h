@@ -394,7 +394,8 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   jac_to_aff<F1<C>>(aP, P);
   Fp12<C>* fh = hot_as<Fp12<C>>(key.hot);
   Fp12<C>& fm = fh ? *fh : f;
-  miller_loop<C, 1, 0>(fm, &aP, &aK, (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0);
+  const LineCoef<C>* no_lines[1] = {key.gg_lines};          // never read (no fixed pair); real pointers keep the fused loop compilable
+  miller_loop<C, 1, 0>(fm, &aP, &aK, &aP, no_lines);
   if (fh) f = fm;
   for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
   g1_store<C>(sig2_out, sig2);
