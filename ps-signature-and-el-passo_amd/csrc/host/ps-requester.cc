@@ -197,3 +197,73 @@ IdProof PSRequester::el_passo_prove_id_without_id_retrieval(const PSCredential& 
                                                             const std::string& associated_data, const std::string& service_name) const {
   return proveImpl(sig, attributes, associated_data, service_name, nullptr, nullptr, nullptr);
 }
+
+std::vector<IdProof> PSRequester::el_passo_prove_id_batch(const std::vector<PSCredential>& sigs,
+                                                          const std::vector<std::vector<std::tuple<std::string, bool>>>& attributes,
+                                                          const std::vector<std::string>& ads, const std::string& service,
+                                                          const G1* apk, const G1* g, const G1* h) const {
+  const size_t n = sigs.size(), A = m_pk.Yi.size();
+  if (attributes.size() != n || ads.size() != n) throw std::runtime_error("batch sizes do not match");
+  std::vector<IdProof> out(n);
+  if (n == 0) return out;
+  const bool retr = apk != nullptr;
+  m_key->useRp(service, apk, g, h);
+  uint64_t mask = 0;
+  for (size_t i = 0; i < attributes[0].size() && i < 64; i++)
+    if (std::get<1>(attributes[0][i])) mask |= (uint64_t)1 << i;
+  const size_t H = (size_t)__builtin_popcountll(mask);
+  if (!(mask & 1)) throw std::runtime_error("attribute 0 must be hidden");
+  if (retr && !(mask & 2)) throw std::runtime_error("attributes 0 and 1 must be hidden for id retrieval");
+  std::vector<uint8_t> recs, adbuf;
+  std::vector<uint32_t> adoff(1, 0);
+  auto put = [](std::vector<uint8_t>& v, const uint8_t* p, size_t len) { v.insert(v.end(), p, p + len); };
+  for (size_t u = 0; u < n; u++) {
+    if (attributes[u].size() != A) throw std::runtime_error("attribute size does not match");
+    for (size_t i = 0; i < A; i++)
+      if (std::get<1>(attributes[u][i]) != (((mask >> i) & 1) != 0)) throw std::runtime_error("hidden pattern differs inside the batch");
+    put(recs, sigs[u].sig1.b, 64);
+    put(recs, sigs[u].sig2.b, 64);
+    for (size_t i = 0; i < A; i++) {
+      Fr m;
+      m.setHashOf(std::get<0>(attributes[u][i]));
+      put(recs, m.b, 32);
+    }
+    const size_t ndraw = 2 + (retr ? 1 : 0) + H + 1 + (retr ? 1 : 0);
+    for (size_t j = 0; j < ndraw; j++) {
+      Fr x = draw();
+      put(recs, x.b, 32);
+    }
+    put(adbuf, (const uint8_t*)ads[u].data(), ads[u].size());
+    adoff.push_back((uint32_t)adbuf.size());
+  }
+  if (adbuf.empty()) adbuf.push_back(0);
+  const size_t osz = elp_verify_id_record_size(ELP_CURVE_BN254, (int)A, (int)H, retr ? 1 : 0);
+  std::vector<uint8_t> proofs(n * osz), flags(n);
+  uint64_t produced = 0;
+  elpCheck(m_key->ctx(),
+           elp_prove_id_batch(m_key->ctx(), n, recs.data(), mask, retr ? 1 : 0, adbuf.data(), adoff.data(), 0, proofs.data(), flags.data(),
+                              &produced),
+           "elp_prove_id_batch");
+  for (size_t u = 0; u < n; u++) {
+    if (!flags[u]) throw std::runtime_error("credential is not a pair of curve points");
+    const uint8_t* p = proofs.data() + u * osz;
+    IdProof& pr = out[u];
+    auto take = [&p](uint8_t* dst, size_t len) { memcpy(dst, p, len); p += len; };
+    take(pr.sig1.b, 64);
+    take(pr.sig2.b, 64);
+    take(pr.phi.b, 64);
+    if (retr) {
+      G1 e1, e2;
+      take(e1.b, 64);
+      take(e2.b, 64);
+      pr.E1 = e1;
+      pr.E2 = e2;
+    }
+    take(pr.k.b, 128);
+    take(pr.c.b, 32);
+    pr.rs.resize(H + (retr ? 2 : 1));
+    for (Fr& r : pr.rs) take(r.b, 32);
+    for (const auto& a : attributes[u]) pr.attributes.push_back(std::get<1>(a) ? std::string() : std::get<0>(a));
+  }
+  return out;
+}

@@ -25,6 +25,13 @@ class PSRequester {
   IdProof el_passo_prove_id_without_id_retrieval(const PSCredential& sig, const std::vector<std::tuple<std::string, bool>> attributes,
                                                  const std::string& associated_data, const std::string& service_name) const;
 
+  // ---- added: the proofs of many users against one RP in one launch (elp_prove_id_batch).  All items share the hidden pattern of
+  // `attributes[0]`; randomness is drawn per item in the reference's order (t, r, [eps], rho_j, rho_t, [rho_eps]).
+  std::vector<IdProof> el_passo_prove_id_batch(const std::vector<PSCredential>& sigs,
+                                               const std::vector<std::vector<std::tuple<std::string, bool>>>& attributes,
+                                               const std::vector<std::string>& associated_data, const std::string& service_name,
+                                               const G1* authority_pk, const G1* g, const G1* h) const;
+
   // ---- RNG seam for reproducible tests: when set, random scalars are taken from this list (in draw order) instead of the CSPRNG
   void set_random_source(const std::vector<Fr>& values);
 

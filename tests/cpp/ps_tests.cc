@@ -5,6 +5,7 @@
 #include <ps-signer.h>
 #include <ps-verifier.h>
 
+#include <algorithm>
 #include <chrono>
 #include <iostream>
 
@@ -109,6 +110,38 @@ static void test_el_passo(size_t n) {
   CHECK(wflags.size() == 3 && wflags[0] && !wflags[1] && !wflags[2]);
   auto wflags2 = rp.el_passo_verify_id_wire_batch({prove2.toBufferString()}, {"hello"}, "service");
   CHECK(wflags2[0]);
+  // batch prover: the same randomness through the single-item method and through the batch launch gives identical messages, and
+  // the batch verifier accepts them under their own associated data only
+  {
+    const size_t H = (size_t)std::count_if(attributes.begin(), attributes.end(), [](const auto& a) { return std::get<1>(a); });
+    for (int retr = 1; retr >= 0; retr--) {
+      std::vector<Fr> rnd;
+      for (size_t i = 0; i < 3 * (2 + H + 1 + 2 * (size_t)retr); i++) {
+        Fr x;
+        x.setByCSPRNG();
+        rnd.push_back(x);
+      }
+      std::vector<std::string> ads{"a0", "a1", "a2"};
+      user.set_random_source(rnd);
+      std::vector<IdProof> single;
+      for (int u = 0; u < 3; u++)
+        single.push_back(retr ? user.el_passo_prove_id(ub, attributes, ads[u], "service", authority_pk, g, h)
+                              : user.el_passo_prove_id_without_id_retrieval(ub, attributes, ads[u], "service"));
+      user.set_random_source(rnd);
+      auto many = user.el_passo_prove_id_batch({ub, ub, ub}, {attributes, attributes, attributes}, ads, "service",
+                                               retr ? &authority_pk : nullptr, retr ? &g : nullptr, retr ? &h : nullptr);
+      user.set_random_source({});
+      CHECK(many.size() == 3);
+      for (int u = 0; u < 3 && u < (int)many.size(); u++)
+        CHECK(many[u].toBufferString().toBase64() == single[u].toBufferString().toBase64());
+      auto vf = retr ? rp.el_passo_verify_id_batch(many, ads, "service", authority_pk, g, h)
+                     : rp.el_passo_verify_id_without_id_retrieval_batch(many, ads, "service");
+      CHECK(vf.size() == 3 && vf[0] && vf[1] && vf[2]);
+      auto vf2 = retr ? rp.el_passo_verify_id_batch(many, {"a0", "a0", "a0"}, "service", authority_pk, g, h)
+                      : rp.el_passo_verify_id_without_id_retrieval_batch(many, {"a0", "a0", "a0"}, "service");
+      CHECK(vf2[0] && !vf2[1] && !vf2[2]);
+    }
+  }
   // attribute count mismatch throws like the reference (src/ps-requester.cc:31-33)
   bool threw = false;
   try {

@@ -4,7 +4,7 @@ import importlib
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 elp = importlib.import_module("ps-signature-and-el-passo_amd")
 OPS = ["fp_mul", "fp_sqr", "fp2_mul", "fp2_sqr", "fp6_mul", "fp12_mul", "fp12_sqr", "fp12_cyc_sqr", "mul_by_line", "jac_dbl<G1>",
        "jac_madd<G1>", "jac_add<G1>", "jac_dbl<G2>", "jac_madd<G2>", "jac_add<G2>", "ml_dbl_step", "ml_add_step", "fp_inv", "fp_add+sub",

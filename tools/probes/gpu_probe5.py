@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 elp = importlib.import_module("ps-signature-and-el-passo_amd")
 synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
 W = int(os.environ.get("W", "8"))
