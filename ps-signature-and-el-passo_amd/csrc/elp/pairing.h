@@ -208,7 +208,7 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
   // private-memory traffic of the whole verification.  The half-step loop keeps one copy of each routine per pair kind.  Other
   // shapes keep the calls.  Callers of a fused shape pass real pointers for arrays it does not read: constant null arguments
   // propagated into the fused body trip an illegal-instruction bug of the compiler.
-  constexpr bool FUSE = (NV == 1 && NF <= 1);
+  constexpr bool FUSE = (NV == 1 && NF <= 1) && fp_roomy<C>();   // 9-limb field only: for 13 limbs it doubles the compile time for ~2 %
   ELP_NOUNROLL
   for (int i = 0; i < C::ATE_LEN; i++) {
     if (i != 0) {
