@@ -298,6 +298,18 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
                                                                   len(wl.ad), d_sig.data_ptr(), d_fl.data_ptr(), d_cnt.data_ptr())))
     res["provide_id_65536x8attrs"] = {"value": n / (ms * 1e-3), "unit": "issuances/s", "kernel_ms": ms,
                                       "parity_ok": bool((d_fl.cpu().numpy() == expect).all())}
+    # wire ingest: the same kind of proofs as undecoded IdProof messages -- T-L-V parse, point decompression
+    # and attribute hashing run inside the kernel
+    nw = 65536
+    vrecs, vmask, vexpect = wl.verify_id_batch(nw, 4, with_retrieval=True)
+    msgs, moff = wl.wire_messages(vrecs, nw, 4, with_retrieval=True)
+    d_msg = torch.from_numpy(np.frombuffer(msgs, dtype=np.uint8).copy()).to(dev)
+    d_off = torch.from_numpy(moff.view(np.int32).copy()).to(dev)
+    d_wfl = torch.zeros(nw, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_wire_batch_dev(ctx.h, stream, nw, d_msg.data_ptr(), d_off.data_ptr(), 1, d_ad.data_ptr(),
+                                                                      None, len(wl.ad), d_wfl.data_ptr(), d_cnt.data_ptr())))
+    res["verify_id_wire_65536x8attrs"] = {"value": nw / (ms * 1e-3), "unit": "verifications/s", "kernel_ms": ms,
+                                          "bytes_per_message": len(msgs) / nw, "parity_ok": bool((d_wfl.cpu().numpy() == vexpect).all())}
     # user side: batch prover, its output fed straight to the batch verifier
     recs, mask = wl.prove_id_batch(n, 4, with_retrieval=True)
     d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)

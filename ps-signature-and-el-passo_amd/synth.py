@@ -173,6 +173,45 @@ class Workload:
         return bytes(recs), (1 << H) - 1, expect
 
     # ---------------------------------------------------------------------------------------------------------
+    def wire_messages(self, recs, n_items, nhidden, first_item=0, with_retrieval=True):
+        """The same proofs as IdProof::toBufferString() messages (src/ps-encoding.cc:451-467: T-L-V, compressed points, attribute
+        strings with "" for hidden ones).  Returns (bytes, uint32 offsets[n+1]) for elp_verify_id_wire_batch."""
+        A, H, F = self.A, nhidden, self.F
+        G1, G2 = 2 * F, 4 * F
+        rsz = len(recs) // n_items
+        a = np.frombuffer(recs, dtype=np.uint8).reshape(n_items, rsz)
+        o = 0
+        sig1 = g1_wire(a[:, o:o + G1].tobytes(), F); o += G1
+        sig2 = g1_wire(a[:, o:o + G1].tobytes(), F); o += G1
+        phi = g1_wire(a[:, o:o + G1].tobytes(), F); o += G1
+        if with_retrieval:
+            E1 = g1_wire(a[:, o:o + G1].tobytes(), F); o += G1
+            E2 = g1_wire(a[:, o:o + G1].tobytes(), F); o += G1
+        kk = g2_wire(a[:, o:o + G2].tobytes(), F); o += G2
+        c = a[:, o:o + 32]; o += 32
+        nrs = H + (2 if with_retrieval else 1)
+        rs = a[:, o:o + 32 * nrs]
+        hdr1, hdr2 = bytes([1, F]), bytes([2, 2 * F])
+        out, off = bytearray(), np.zeros(n_items + 1, dtype=np.uint32)
+        for i in range(n_items):
+            out += hdr1 + sig1[i].tobytes() + hdr1 + sig2[i].tobytes() + hdr2 + kk[i].tobytes() + hdr1 + phi[i].tobytes()
+            out += bytes([3, 32]) + c[i].tobytes() + bytes([6, nrs])
+            r = rs[i].tobytes()
+            for j in range(nrs):
+                out += bytes([32]) + r[32 * j:32 * j + 32]
+            out += bytes([7, A])
+            for j, s in enumerate(self.attributes(first_item + i)):
+                if j < H:
+                    out.append(0)
+                else:
+                    out.append(len(s))
+                    out += s
+            if with_retrieval:
+                out += hdr1 + E1[i].tobytes() + hdr1 + E2[i].tobytes()
+            off[i + 1] = len(out)
+        return bytes(out), off
+
+    # ---------------------------------------------------------------------------------------------------------
     def prove_id_batch(self, n_items, nhidden, first_item=0, with_retrieval=True):
         """Input records of elp_prove_id_batch: valid credentials (g^u, g^(u (x + sum y_i m_i))) + the prover's randomness
         in the reference's draw order (src/ps-requester.cc:150-310).  Returns (records, hidden_mask)."""

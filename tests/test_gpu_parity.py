@@ -574,3 +574,34 @@ def test_prover_to_verifier_pipeline_at_size(gpu_ctx):
     assert vcnt == n
     vflags, vcnt = gpu_ctx.verify_id_batch(proofs, mask, True, b"hellp")
     assert vcnt == 0
+
+
+def test_prover_irregular_pattern_and_sixteen_attributes(gpu_ctx):
+    """Batch prover with a non-contiguous hidden pattern and with the 16-attribute key of BASELINE.json config 5: proofs equal the
+    oracle's byte for byte and verify; the wire form of the same proofs is accepted by the wire entry point."""
+    seed = 4711
+    g, gg = M.hash_to_g1("abc"), _pk0().gg
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    for A, hidden in ((6, (0, 1, 3, 5)), (16, (0, 1, 2, 3, 7, 9, 12, 15))):
+        pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+        _set_key(gpu_ctx, pk, svc="service", g_eg=g, apk=apk, h=h, skX=skX, W=4)
+        H = len(hidden)
+        mask = sum(1 << i for i in hidden)
+        n = 3
+        attrs = [[(("v%d.%d" % (i, u)).encode() * (1 + (i % 3)), i in hidden) for i in range(A)] for u in range(n)]
+        creds = []
+        for u in range(n):
+            rnd = [scalar_stream(seed, 100 + 32 * u + j, M.r) for j in range(2 + H)]
+            rq, t1 = PR.request_id(pk, attrs[u], b"ad", rnd)
+            creds.append(PR.unblind(PR.provide_id(pk, skX, rq, b"ad", scalar_stream(seed, 900 + u, M.r)), t1))
+        rnds = [[scalar_stream(seed, 2000 + 64 * u + j, M.r) for j in range(3 + H + 2)] for u in range(n)]
+        want = [PR.prove_id(pk, creds[u], attrs[u], b"sid%d" % u, b"service", apk, g, h, rnds[u]) for u in range(n)]
+        sids = [b"sid%d" % u for u in range(n)]
+        proofs, flags, cnt = gpu_ctx.prove_id_batch(b"".join(pack_prove_id(M, creds[u], attrs[u], rnds[u]) for u in range(n)), mask, True, sids)
+        assert cnt == n and proofs == b"".join(pack_verify_id(M, w) for w in want)
+        vflags, vcnt = gpu_ctx.verify_id_batch(proofs, mask, True, sids)
+        assert vcnt == n
+        wflags, wcnt = gpu_ctx.verify_id_wire_batch([CD.proof_encode(w) for w in want], True, sids)
+        assert wcnt == n and wflags.all()
+        wflags, wcnt = gpu_ctx.verify_id_wire_batch([CD.proof_encode(w) for w in want], True, b"sid0")
+        assert list(wflags) == [1, 0, 0]

@@ -74,3 +74,26 @@ def test_prover_workload_credentials_are_valid_signatures():
             assert all(int.from_bytes(r[128 + 32 * j:160 + 32 * j], "little") < M.r for j in range((rsz - 128) // 32))
     recs, mask = wl.request_id_batch(3, H)
     assert len(recs) == 3 * 32 * (A + 2 + H)
+
+
+def test_wire_messages_decode_to_the_same_proofs():
+    """synth.wire_messages re-encodes the record batch as IdProof wire messages: the oracle's codec reads them back with the same
+    points, scalars and attribute strings, and the oracle verifies the decoded proofs with the expected verdicts."""
+    from elp_testlib import Codec, Protocol, g1u, g2u, ib
+    L = oracle()
+    ctx = OracleBackedCtx()
+    A, H, n = 4, 2, 4
+    wl = synth.Workload(ctx, A)
+    for retr in (True, False):
+        recs, mask, expect = wl.verify_id_batch(n, H, first_item=3, with_retrieval=retr, corrupt_every=2, corrupt_at=1)
+        msgs, off = wl.wire_messages(recs, n, H, first_item=3, with_retrieval=retr)
+        assert len(off) == n + 1 and off[-1] == len(msgs)
+        rsz = len(recs) // n
+        cd = Codec(M)
+        for i in range(n):
+            pr = cd.proof_decode(msgs[off[i]:off[i + 1]])
+            r = recs[i * rsz:(i + 1) * rsz]
+            assert pr.sig1 == g1u(r[0:64]) and pr.sig2 == g1u(r[64:128]) and pr.phi == g1u(r[128:192])
+            o = 320 if retr else 192
+            assert pr.k == g2u(r[o:o + 128]) and pr.c == ib(r[o + 128:o + 160]) and pr.has_E == retr
+            assert [bytes(a) for a in pr.attributes] == [b""] * H + wl.attributes(3 + i)[H:]
