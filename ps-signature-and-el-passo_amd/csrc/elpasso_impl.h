@@ -31,9 +31,13 @@ using namespace elp;
 #define ELP_MSM_LAUNCH_BOUNDS __launch_bounds__(ELP_MSM_TPB)
 #endif
 // gives every lane of the (one-wave) workgroup its LDS hot slot, see elp/common.h
+#ifdef ELP_NO_HOT   /* experiments: no LDS hot slot (KeyCtx::hot stays null) */
+#define ELP_HOT_SETUP(key) (void)0
+#else
 #define ELP_HOT_SETUP(key)                                                                   \
   __shared__ __attribute__((aligned(16))) u32 elp_hot_lds[ELP_BLOCK * elp::ELP_HOT_WORDS]; \
   (key).hot = elp_hot_lds + threadIdx.x * elp::ELP_HOT_WORDS
+#endif
 
 __device__ __forceinline__ void count_accept(bool ok, unsigned long long* counter) {
   unsigned long long b = __ballot(ok);
