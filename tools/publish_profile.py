@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Copies the evidence collected by tools/profile_round.sh (gpurun_out/prof_<tag>/) into profiles/ under the round's names, keeping
+only the rows of the dominant kernel from the per-dispatch tables, and refreshes profiles/hbm_traffic.json (read by bench.py)."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles")
+shutil.copy(f"{src}/bench_n1.json", f"{dst}/{tag}_bench_n1.json")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/{tag}_bench_under_rocprof.json")
+shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")
+shutil.copy(f"{src}/summary.json", f"{dst}/{tag}_summary.json")
+
+
+def filt(inp, out):
+    rows = list(csv.reader(open(inp)))
+    ki = rows[0].index("Kernel_Name")
+    keep = [rows[0]] + [r for r in rows[1:] if "k_verify_id<elp::BN254>" in r[ki]]
+    csv.writer(open(out, "w", newline="")).writerows(keep)
+
+
+filt(f"{src}/trace/{tag}_kernel_trace.csv", f"{dst}/{tag}_kernel_trace_k_verify_id.csv")
+filt(f"{src}/pmc_a/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_a_k_verify_id.csv")
+filt(f"{src}/pmc_b/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_b_k_verify_id.csv")
+s = json.load(open(f"{src}/summary.json"))
+h = {"kernel": "k_verify_id<BN254>", "items_per_launch": s["k_verify_id"]["grid"],
+     "build": "round-1 final (29-bit limbs, single-reduction Fp2 products, lazy sums, LDS hot slot, fused loops, W=16)",
+     "FETCH_SIZE_KiB": s["pmc_per_launch"]["FETCH_SIZE"], "WRITE_SIZE_KiB": s["pmc_per_launch"]["WRITE_SIZE"],
+     "k_verify_id_bytes_per_launch": s["k_verify_id_bytes_per_launch"],
+     "k_verify_id_bytes_per_launch_uncorrected": s["k_verify_id_bytes_per_launch_uncorrected"], "l2_hit_rate": s["l2_hit_rate"],
+     "note": "separate --pmc passes (tools/profile_round.sh, bench.py --headline-only so every launch has the headline size); FETCH_SIZE "
+             "doubled per MI355X_MICROARCH.md; the traffic is per-lane private (scratch) memory of temporaries, call frames and "
+             "callee-saved registers, not input data (52.7 MB algorithmic per launch)"}
+json.dump(h, open(f"{dst}/hbm_traffic.json", "w"), indent=1)
+print(json.dumps(s["pmc_per_launch"], indent=1))
