@@ -118,6 +118,24 @@ def g2_bases(m, pk):
 _twin = None
 
 
+def build_twin(so, flags):
+    """g++ build of tests/host_twin/twin.cpp: one object per curve, compiled in parallel, linked into `so`."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "host_twin", "twin.cpp")
+    inc = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc")
+    objs, procs = [], []
+    for part in (1, 2):
+        obj = "%s.part%d.o" % (so, part)
+        objs.append(obj)
+        procs.append(subprocess.Popen(["g++", "-std=c++17", "-fPIC", "-DTWIN_PART=%d" % part, "-I", inc] + list(flags) + ["-c", "-o", obj, src]))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("host twin build failed")
+    subprocess.check_call(["g++", "-shared", "-o", so] + objs)
+    for o in objs:
+        os.remove(o)
+
+
 def twin():
     """Host (g++) build of the device headers — test-only library, built on demand."""
     global _twin
@@ -128,8 +146,7 @@ def twin():
         newest = max(os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(inc) for f in fs if f.endswith(".h"))
         newest = max(newest, os.path.getmtime(src))
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
-            import subprocess
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", so, src])
+            build_twin(so, ["-O2"])
         _twin = ctypes.CDLL(so)
         for n in ("twin_bn254_ctx_new", "twin_bls_ctx_new"):
             getattr(_twin, n).restype = ctypes.c_void_p

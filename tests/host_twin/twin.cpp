@@ -234,10 +234,15 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
   }                                                                                                                    \
   }
 
+// TWIN_PART selects one curve so the two halves can be compiled in parallel (tests/elp_testlib.py); default: both
+#if !defined(TWIN_PART) || TWIN_PART == 1
 TWIN(BN254, twin_bn254)
+#endif
+#if !defined(TWIN_PART) || TWIN_PART == 2
 TWIN(BLS12_381, twin_bls)
+#endif
 
-#ifdef ELP_COUNT_OPS
+#if defined(ELP_COUNT_OPS) && (!defined(TWIN_PART) || TWIN_PART == 1)
 extern "C" void twin_op_counts(unsigned long long* out, int reset) {
   out[0] = elp::elp_op_counts[0];
   out[1] = elp::elp_op_counts[1];

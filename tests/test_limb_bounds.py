@@ -11,9 +11,7 @@ from elp_testlib import ROOT
 
 def test_flows_stay_within_limb_bounds(tmp_path):
     so = os.path.join(str(tmp_path), "libtwin_chk.so")
-    inc = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-DELP_BOUND_CHECK", "-I", inc, "-o", so,
-                           os.path.join(ROOT, "tests", "host_twin", "twin.cpp")])
+    elp_testlib.build_twin(so, ["-O1", "-DELP_BOUND_CHECK"])
     L = ctypes.CDLL(so)
     L.twin_bn254_ctx_new.restype = ctypes.c_void_p
     L.twin_bls_ctx_new.restype = ctypes.c_void_p
