@@ -185,6 +185,9 @@ ELP_HEAVY void ml_precompute(LineCoef<C>* out, const Aff<F2<C>>& q) {
 
 // f = prod_i f_{s,Q_i}(P_i) over NV pairs with run-time Q and NF pairs whose lines were precomputed.
 // Pairs with P or Q at infinity contribute 1 (e(O, Q) = e(P, O) = 1).
+#ifndef ELP_MILLER_REG_ON
+#define ELP_MILLER_REG_ON 1
+#endif
 template <class C, int NV, int NF>
 ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* qv, const Aff<F1<C>>* pf,
                            const LineCoef<C>* const* lines) {
@@ -200,7 +203,6 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
     nqy[k] = fp2_neg(qv[k].y);
   }
   for (int k = 0; k < NF; k++) live_f[k] = !aff_is_inf(pf[k]);
-  fp12_set_one(f);
   LineCoef<C> l;
   int n = 0;
   // For the verification shape (one variable pair, one pair with precomputed lines) the step routines are inlined into this loop
@@ -209,10 +211,14 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
   // shapes keep the calls.  Callers of a fused shape pass real pointers for arrays it does not read: constant null arguments
   // propagated into the fused body trip an illegal-instruction bug of the compiler.
   constexpr bool FUSE = (NV == 1 && NF <= 1) && fp_roomy<C>();   // 9-limb field only: for 13 limbs it doubles the compile time for ~2 %
+  constexpr bool MREG = FUSE && (ELP_MILLER_REG_ON != 0);         // the Miller value stays in registers through the fused loop (+1-2 %)
+  Fp12<C> fr;
+  Fp12<C>& fw = MREG ? fr : f;
+  fp12_set_one(fw);
   ELP_NOUNROLL
   for (int i = 0; i < C::ATE_LEN; i++) {
     if (i != 0) {
-      if (FUSE) fp12_sqr_inl<C>(f, f); else fp12_sqr<C>(f, f);
+      if (FUSE) fp12_sqr_inl<C>(fw, fw); else fp12_sqr<C>(f, f);
     }
     const int d = C::ate_naf(i);
     ELP_NOUNROLL
@@ -227,16 +233,17 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
           const Fp2<C> yq = fp2_select(d > 0, qv[k].y, nqy[k]);   // by value: no select between a private and a generic pointer
           if (FUSE) ml_add_step_inl<C>(T[k], l, qv[k].x, yq); else ml_add_step<C>(T[k], l, qv[k].x, yq);
         }
-        if (FUSE) ml_apply_line_inl<C>(f, l, pv[k].x, pv[k].y); else ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
+        if (FUSE) ml_apply_line_inl<C>(fw, l, pv[k].x, pv[k].y); else ml_apply_line<C>(f, l, pv[k].x, pv[k].y);
       }
       ELP_UNROLL
       for (int k = 0; k < NF; k++) {
         if (!live_f[k]) continue;
-        if (FUSE) ml_apply_line_inl<C>(f, lines[k][n], pf[k].x, pf[k].y); else ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+        if (FUSE) ml_apply_line_inl<C>(fw, lines[k][n], pf[k].x, pf[k].y); else ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
       }
       n++;
     }
   }
+  if (MREG) f = fr;
   if (C::Z_NEG) fp12_conj(f, f);
   if (C::IS_BN) {
     for (int k = 0; k < NV; k++)
