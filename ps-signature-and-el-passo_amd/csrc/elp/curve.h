@@ -13,6 +13,10 @@ struct F1 {
   typedef C Curve;
   ELP_INL static T mul(const T& a, const T& b) { return fp_mul<C>(a, b); }
   ELP_INL static T sqr(const T& a) { return fp_sqr<C>(a); }
+  ELP_INL static T mul_pair(const T& a, const T& b, const T& c, const T& d) {   // a*b + c*d
+    if constexpr (C::HEADROOM >= 3) return fp_mul_pair<C>(a, b, c, d);
+    else return fp_add(fp_mul<C>(a, b), fp_mul<C>(c, d));
+  }
   ELP_INL static T add(const T& a, const T& b) { return fp_add(a, b); }
   ELP_INL static T sub(const T& a, const T& b) { return fp_sub(a, b); }
   ELP_INL static T dbl(const T& a) { return fp_dbl(a); }
@@ -44,6 +48,11 @@ struct F2 {
   typedef C Curve;
   ELP_INL static T mul(const T& a, const T& b) { return fp2_mulv<C>(a, b); }
   ELP_INL static T sqr(const T& a) { return fp2_sqrv<C>(a); }
+  ELP_INL static T mul_pair(const T& a, const T& b, const T& c, const T& d) {   // a*b + c*d
+    T r;
+    fp2_mul_pair<C>(r, a, b, c, d);
+    return r;
+  }
   ELP_INL static T add(const T& a, const T& b) { return fp2_add(a, b); }
   ELP_INL static T sub(const T& a, const T& b) { return fp2_sub(a, b); }
   ELP_INL static T dbl(const T& a) { return fp2_dbl(a); }
@@ -128,8 +137,8 @@ ELP_HEAVY bool aff_on_curve(const Aff<F>& p) {
   return F::eq(l, r);
 }
 
-// dbl-2009-l (a = 0) with the two squaring tricks undone (a square costs 0.9 products here and the tricks cost carried sums):
-// A = X^2, B = Y^2, C = B^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Y3 = E (D - X3) - 8 C, Z3 = 2 Y Z.   3M + 4S.
+// dbl-2009-l (a = 0) with the two squaring tricks undone (a square costs 0.9 products here and the tricks cost carried sums) and
+// Y3 as one inner product:  A = X^2, B = Y^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Y3 = E (D - X3) - (4B)(2B), Z3 = 2 Y Z.
 // Operands and results carried; the comments give limb magnitudes in carried units where sums stay lazy (roomy fields).
 template <class F>
 ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p);
@@ -138,16 +147,13 @@ ELP_INL void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
   typedef typename F::T T;
   T A = F::sqr(p.X);
   T B = F::sqr(p.Y);
-  T Cc = F::sqr(B);
   T D = F::mul(F::dbll(F::dbll(p.X)), B);                      // 4 x 1
   T E = F::carry(F::addl(F::dbll(A), A));                      // 3 -> 1 (squared next)
   T Fq = F::sqr(E);
   T Z3 = F::mul(F::dbll(p.Y), p.Z);                            // 2 x 1
   T X3 = F::carry(F::subl(Fq, F::dbll(D)));                    // 3 -> 1
-  T C4 = F::dbll(F::dbll(Cc));                                 // 4
-  T Y3 = F::mul(E, F::subl(D, X3));                            // 1 x 2
-  Y3 = F::carry(F::subl(Y3, C4));                              // 5 -> 1
-  Y3 = F::carry(F::subl(Y3, C4));
+  T B4 = F::carry(F::dbll(F::dbll(B)));                        // 4 -> 1
+  T Y3 = F::mul_pair(E, F::subl(D, X3), F::neg(B4), F::dbll(B));   // E (D - X3) - (4B)(2B): 1 x 2 + 1 x 2, one reduction, no C = B^2
   r.Y = Y3;
   r.X = X3;
   r.Z = Z3;  // Y == 0 never happens on prime-order curves; Z == 0 stays 0
@@ -194,7 +200,7 @@ ELP_INL void jac_madd_inl(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   T J = F::mul(H, I);                                          // 1 x 4
   T V = F::mul(p.X, I);
   T X3 = F::carry(F::subl(F::subl(F::sqr(rr), J), F::dbll(V)));             // 4 -> 1
-  T Y3 = F::carry(F::subl(F::mul(rr, F::subl(V, X3)), F::dbll(F::mul(p.Y, J))));   // 1 x 2; 3 -> 1
+  T Y3 = F::mul_pair(rr, F::subl(V, X3), F::neg(F::dbll(p.Y)), J);   // rr (V - X3) - 2 Y1 J: 1 x 2 + 2 x 1, one reduction
   T Z3 = F::mul(F::dbll(p.Z), H);                              // (Z + H)^2 - Z^2 - H^2 = 2 Z H
   r.X = X3;
   r.Y = Y3;
@@ -239,7 +245,7 @@ ELP_INL void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
   T J = F::mul(H, I);                                          // 2 x 1
   T V = F::mul(U1, I);
   T X3 = F::carry(F::subl(F::subl(F::sqr(rr), J), F::dbll(V)));             // 4 -> 1
-  T Y3 = F::carry(F::subl(F::mul(rr, F::subl(V, X3)), F::dbll(F::mul(S1, J))));   // 1 x 2; 3 -> 1
+  T Y3 = F::mul_pair(rr, F::subl(V, X3), F::neg(F::dbll(S1)), J);   // rr (V - X3) - 2 S1 J, one reduction
   T Z3 = F::mul(F::mul(F::dbll(p.Z), q.Z), H);                 // ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H = 2 Z1 Z2 H; 1 x 2
   r.X = X3;
   r.Y = Y3;

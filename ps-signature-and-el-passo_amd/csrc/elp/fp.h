@@ -48,7 +48,7 @@ struct StdFp {  // canonical integer in [0, p) (or any N-word integer before ran
 // -DELP_COUNT_OPS (host twin only, tools/count_ops.py): counts Montgomery products / squares so the VALU roofline of a kernel
 // can be stated in modular multiplications per item.
 #if defined(ELP_COUNT_OPS) && !defined(__HIP_DEVICE_COMPILE__)
-inline unsigned long long elp_op_counts[3] = {0, 0, 0};   // fp_mul, fp_sqr, fp_mul_pair
+inline unsigned long long elp_op_counts[4] = {0, 0, 0, 0};   // fp_mul, fp_sqr, fp_mul_pair, fp_mul_quad
 #define ELP_COUNT_OP(i) (elp_op_counts[i]++)
 #else
 #define ELP_COUNT_OP(i) ((void)0)
@@ -319,6 +319,68 @@ ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
     ELP_UNROLL
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)c.v[i] * d.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
+    r.v[k - NL] = elp_balanced30((u32)acc);
+    acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
+  }
+  r.v[NL - 1] = (i32)acc;
+  return r;
+}
+
+// Four-term inner product with one reduction: (a*b + c*d + e*f + g*h) * R^-1 (mod p), 405 multiply-adds.  Both components of an
+// Fp2 inner product x*y + z*w have this shape.  Needs the headroom of the 29-bit field: sum of the four operand-magnitude products
+// <= 13 (asserted under ELP_BOUND_CHECK).
+template <class C>
+ELP_FPMUL Fp<C> fp_mul_quad(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d, Fp<C> e, Fp<C> f, Fp<C> g, Fp<C> h) {
+  constexpr int NL = C::NL;
+  static_assert(C::HEADROOM >= 14, "four-product columns need the 29-bit field");
+  ELP_COUNT_OP(3);
+#if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+  {
+    const Fp<C>* ops[8] = {&a, &b, &c, &d, &e, &f, &g, &h};
+    long double mx[8];
+    for (int q = 0; q < 8; q++) {
+      mx[q] = 0;
+      for (int i = 0; i < NL - 1; i++)
+        if (llabs((long long)ops[q]->v[i]) > mx[q]) mx[q] = llabs((long long)ops[q]->v[i]);
+      assert(llabs((long long)ops[q]->v[NL - 1]) < (1LL << (C::LB - 1)));
+    }
+    assert((mx[0] * mx[1] + mx[2] * mx[3] + mx[4] * mx[5] + mx[6] * mx[7]) * NL + (long double)NL * (long double)((i64)1 << (2 * C::LB - 2)) + 1.0e18L <
+           9223372036854775807.0L);
+  }
+#endif
+  i32 m[NL], pl[NL];
+  ELP_UNROLL
+  for (int i = 0; i < NL; i++) pl[i] = elp_opaque(C::modl(i));
+  Fp<C> r;
+  i64 acc = 0;
+  ELP_UNROLL
+  for (int k = 0; k < NL; k++) {
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)c.v[i] * d.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)e.v[i] * f.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i <= k; i++) acc += (i64)g.v[i] * h.v[k - i];
+    ELP_UNROLL
+    for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+    m[k] = elp_balanced30((u32)acc * C::INVL);
+    acc += (i64)m[k] * pl[0];
+    acc >>= ELP_LIMB_BITS;
+  }
+  ELP_UNROLL
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)c.v[i] * d.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)e.v[i] * f.v[k - i];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) acc += (i64)g.v[i] * h.v[k - i];
     ELP_UNROLL
     for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
     r.v[k - NL] = elp_balanced30((u32)acc);

@@ -149,6 +149,21 @@ ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands
   fp_carry(u);
   r.c1 = u;
 }
+// r = a*b + c*d in Fp2: one reduction per component where the field has the headroom (operand magnitudes as for fp_mul_quad)
+template <class C>
+ELP_FP2 void fp2_mul_pair(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c, const Fp2<C>& d) {
+  if constexpr (fp_roomy<C>()) {
+    Fp<C> c0 = fp_mul_quad<C>(a.c0, b.c0, fp_neg(a.c1), b.c1, c.c0, d.c0, fp_neg(c.c1), d.c1);
+    Fp<C> c1 = fp_mul_quad<C>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0);
+    r.c0 = c0;
+    r.c1 = c1;
+  } else {
+    Fp2<C> t, u;
+    fp2_mul<C>(t, a, b);
+    fp2_mul<C>(u, c, d);
+    r = fp2_add(t, u);
+  }
+}
 template <class C>
 ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul; operand carried
   if constexpr (fp_roomy<C>()) {

@@ -247,6 +247,7 @@ extern "C" void twin_op_counts(unsigned long long* out, int reset) {
   out[0] = elp::elp_op_counts[0];
   out[1] = elp::elp_op_counts[1];
   out[2] = elp::elp_op_counts[2];
-  if (reset) elp::elp_op_counts[0] = elp::elp_op_counts[1] = elp::elp_op_counts[2] = 0;
+  out[3] = elp::elp_op_counts[3];
+  if (reset) elp::elp_op_counts[0] = elp::elp_op_counts[1] = elp::elp_op_counts[2] = elp::elp_op_counts[3] = 0;
 }
 #endif

@@ -34,9 +34,9 @@ def build():
 
 
 def counts(L):
-    c = (ctypes.c_ulonglong * 3)()
+    c = (ctypes.c_ulonglong * 4)()
     L.twin_op_counts(c, 1)
-    return int(c[0]), int(c[1]), int(c[2])
+    return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
 
 def main():
@@ -65,17 +65,17 @@ def main():
         # windows: ceil(256 / W); linear through the two measured points (32 and 64 windows)
         n8, n4 = 32, 64
         out = []
-        for j in range(3):
+        for j in range(4):
             y8, y4 = per_w[8][i][j], per_w[4][i][j]
             slope = (y4 - y8) / (n4 - n8)
             out.append(y8 + slope * ((256 + W - 1) // W - n8))
         return out
 
     for name, i in (("verify_id", 0), ("prove_id", 1)):
-        def entry(m, s, pr, extrapolated=False):
-            # multiply-adds (v_mad_i64_i32) of the 9-limb routines: product 81 + reduction 81; square 45 + 81; pair 2 x 81 + 81
-            e = {"fp_mul": round(m), "fp_sqr": round(s), "fp_mul_pair": round(pr), "multiply_adds": round(162 * m + 126 * s + 243 * pr),
-                 "fp_mul_equivalents": round(m + 126 / 162 * s + 1.5 * pr)}
+        def entry(m, s, pr, qd, extrapolated=False):
+            # multiply-adds (v_mad_i64_i32) of the 9-limb routines: product 81 + reduction 81; square 45 + 81; pair 2 x 81 + 81; quad 4 x 81 + 81
+            e = {"fp_mul": round(m), "fp_sqr": round(s), "fp_mul_pair": round(pr), "fp_mul_quad": round(qd),
+                 "multiply_adds": round(162 * m + 126 * s + 243 * pr + 405 * qd), "fp_mul_equivalents": round(m + 126 / 162 * s + 1.5 * pr + 2.5 * qd)}
             if extrapolated:
                 e["extrapolated"] = True
             return e
