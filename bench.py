@@ -179,13 +179,14 @@ def main():
             out["bls12_381"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.headline_only:
         # aggregated (random-linear-combination) variant: reported beside, never instead of, `value`.  Its single-lane tail (one Miller
-        # loop + one final exponentiation per batch, ~14 ms) is not overlapped yet, so it only pays off on larger batches: measured on
-        # the resident batch and on the same records tiled x4 (262 144 items), each against the per-item kernel at the same size.
+        # loop + one final exponentiation per batch, ~11 ms) is not overlapped yet, so it only pays off on larger batches: measured on
+        # the resident batch and on the same records tiled x4 and x16 (262 144 / 1 048 576 items), each against the per-item kernel at
+        # the same size.
         try:
             seed_buf = np.frombuffer(bytes((7 * i + 1) & 0xFF for i in range(32)), dtype=np.uint8).copy()
             res = {"note": "elp_verify_id_batch_aggregated_dev: per-item NIZK + one Miller loop, Pippenger MSM of the sig2's, one final "
                            "exponentiation per batch; exact per-item fallback when the batch equation fails"}
-            for tiles in (1, 4):
+            for tiles in (1, 4, 16):
                 nb = B * tiles
                 recs_t = d_rec if tiles == 1 else d_rec.repeat(tiles)
                 fl_t = torch.zeros(nb, dtype=torch.uint8, device=dev)
