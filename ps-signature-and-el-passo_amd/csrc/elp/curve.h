@@ -421,16 +421,32 @@ ELP_INL int limbs_window(const u32* m, int bit, int w) {
   return (int)((t >> sh) & ((1u << w) - 1));
 }
 
+// Signed 4-bit recoding of a sub-scalar magnitude m < 16^NWIN / 4: with K' = m + 0x88...8 (NWIN nibbles), m = sum_i (nib_i(K') - 8) 16^i
+// and every digit lies in [-8, 7], so the table holds 1P .. 8P only (half the table, half the set-up additions).
+template <int NW, int NWIN>
+ELP_INL void limbs_add_eights(u32* m) {
+  u64 cy = 0;
+  for (int l = 0; l < NW; l++) {
+    const int lo = 8 * l;                                   // first nibble of this limb
+    u32 cst = 0;
+    for (int q = 0; q < 8; q++)
+      if (lo + q < NWIN) cst |= 8u << (4 * q);
+    u64 x = (u64)m[l] + cst + cy;
+    m[l] = (u32)x;
+    cy = x >> 32;
+  }
+}
+
 // [k]P for P in the order-r subgroup of G1: k = k1 + k2 lam with phi(x, y) = (beta x, y) = [lam](x, y); one shared chain of
 // 132 doublings, two table additions per 4-bit window (the second through phi).
 template <class C>
 ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in, u32* hot = nullptr) {
   typedef F1<C> F;
-  Jac<F> tbl[16];
+  Jac<F> tbl[9];                     // 0, 1P .. 8P: signed digits, see limbs_add_eights
   jac_set_inf(tbl[0]);
   jac_from_aff(tbl[1], p);
   ELP_NOUNROLL
-  for (int i = 2; i < 16; i++) {
+  for (int i = 2; i < 9; i++) {
     if (i & 1)
       jac_madd<F>(tbl[i], tbl[i - 1], p);
     else
@@ -438,7 +454,9 @@ ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in
   }
   u32 m[2][5];
   bool neg[2];
-  lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());
+  lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());   // |k_i| < 2^129 (tools/glv.py)
+  limbs_add_eights<5, 33>(m[0]);
+  limbs_add_eights<5, 33>(m[1]);
   Fp<C> beta;
   ELP_LOAD_FP(beta, C::glv_beta(i_));
   // the running point stays in registers: doubling and addition are inlined into the loop (one copy each)
@@ -453,9 +471,10 @@ ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in
     }
     ELP_NOUNROLL
     for (int j = 0; j < 2; j++) {
-      Jac<F> t = tbl[limbs_window<5>(m[j], 4 * w, 4)];
+      const int dg = limbs_window<5>(m[j], 4 * w, 4) - 8;
+      Jac<F> t = tbl[dg < 0 ? -dg : dg];
       if (j == 1) t.X = fp_mul<C>(t.X, beta);
-      if (neg[j]) t.Y = fp_neg(t.Y);
+      if (neg[j] != (dg < 0)) t.Y = fp_neg(t.Y);
       jac_add_inl<F>(acc, acc, t);
     }
   }
@@ -467,11 +486,11 @@ ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in
 template <class C>
 ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in, u32* hot = nullptr) {
   typedef F2<C> F;
-  Jac<F> tbl[16];
+  Jac<F> tbl[9];                     // 0, 1Q .. 8Q: signed digits
   jac_set_inf(tbl[0]);
   jac_from_aff(tbl[1], p);
   ELP_NOUNROLL
-  for (int i = 2; i < 16; i++) {
+  for (int i = 2; i < 9; i++) {
     if (i & 1)
       jac_madd<F>(tbl[i], tbl[i - 1], p);
     else
@@ -479,7 +498,8 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
   }
   u32 m[4][3];
   bool neg[4];
-  lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());
+  lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());   // |k_i| < 2^66 (tools/glv.py)
+  for (int j = 0; j < 4; j++) limbs_add_eights<3, 17>(m[j]);
   (void)hot;
   Jac<F> acc;              // in registers: doubling and addition are inlined into the loop (one copy each)
   jac_set_inf(acc);
@@ -491,7 +511,8 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
     }
     ELP_NOUNROLL
     for (int j = 0; j < 4; j++) {
-      Jac<F> t = tbl[limbs_window<3>(m[j], 4 * w, 4)];
+      const int dg = limbs_window<3>(m[j], 4 * w, 4) - 8;
+      Jac<F> t = tbl[dg < 0 ? -dg : dg];
       if (j != 0 && !jac_is_inf(t)) {   // psi^j in Jacobian coordinates: (conj^j X * gx_j, conj^j Y * gy_j, conj^j Z)
         Fp2<C> gx, gy;
         if (j == 1) {
@@ -512,7 +533,7 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
         fp2_mul<C>(t.X, t.X, gx);
         fp2_mul<C>(t.Y, t.Y, gy);
       }
-      if (neg[j]) t.Y = fp2_neg(t.Y);
+      if (neg[j] != (dg < 0)) t.Y = fp2_neg(t.Y);
       jac_add_inl<F>(acc, acc, t);
     }
   }

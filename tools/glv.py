@@ -123,6 +123,12 @@ def derive(cv):
         mx1 = max(mx1, max(abs(v) for v in d1.split(k)))
         mx2 = max(mx2, max(abs(v) for v in d2.split(k)))
     assert mx1.bit_length() <= 130 and mx2.bit_length() <= 67, (mx1.bit_length(), mx2.bit_length())
+    # worst case of the round-off (Babai) step: |k_i| <= (1/2 + eps) * sum_j |B_ji| (+ one basis vector for the truncated c_j); the
+    # signed 4-bit recoding on the device (limbs_add_eights) needs k_i + 0x88..8 to fit 33 / 17 nibbles
+    for dec, nib in ((d1, 33), (d2, 17)):
+        for i in range(dec.d):
+            worst = sum(abs(row[i]) for row in dec.B) * 3 // 2 + 1
+            assert worst + (8 * (16 ** nib - 1)) // 15 < 16 ** nib, (nib, worst.bit_length())
     return {"beta": beta, "lam1": lam1, "d1": d1, "lam2": lam2, "d2": d2, "bits1": mx1.bit_length(), "bits2": mx2.bit_length()}
 
 
