@@ -540,6 +540,97 @@ ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in
   r = acc;
 }
 
+// ---- the same multiplications over AFFINE tables 1P .. 8P (mixed additions: 11 / 29 instead of 16 / 43 products).  The caller builds
+// the multiples of several points with jac_multiples8 and makes them affine with ONE shared inversion (verify_id_nizk).
+template <class F>
+ELP_HEAVY void jac_multiples8(Jac<F>* t, const Aff<F>& p) {   // t[i] = (i + 1) P
+  jac_from_aff(t[0], p);
+  jac_dbl<F>(t[1], t[0]);
+  jac_madd<F>(t[2], t[1], p);
+  jac_dbl<F>(t[3], t[1]);
+  jac_madd<F>(t[4], t[3], p);
+  jac_dbl<F>(t[5], t[2]);
+  jac_madd<F>(t[6], t[5], p);
+  jac_dbl<F>(t[7], t[3]);
+}
+template <class C>
+ELP_HEAVY void g1_mul_glv_tab(Jac<F1<C>>& r, const Aff<F1<C>>* tab, const Scalar& k_in) {
+  typedef F1<C> F;
+  u32 m[2][5];
+  bool neg[2];
+  lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());
+  limbs_add_eights<5, 33>(m[0]);
+  limbs_add_eights<5, 33>(m[1]);
+  Fp<C> beta;
+  ELP_LOAD_FP(beta, C::glv_beta(i_));
+  Jac<F> acc;
+  jac_set_inf(acc);
+  ELP_NOUNROLL
+  for (int w = 32; w >= 0; w--) {
+    if (w != 32) {
+      ELP_NOUNROLL
+      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
+    }
+    ELP_NOUNROLL
+    for (int j = 0; j < 2; j++) {
+      const int dg = limbs_window<5>(m[j], 4 * w, 4) - 8;
+      if (dg == 0) continue;
+      Aff<F> t = tab[(dg < 0 ? -dg : dg) - 1];
+      if (aff_is_inf(t)) continue;
+      if (j == 1) t.x = fp_mul<C>(t.x, beta);
+      if (neg[j] != (dg < 0)) t.y = fp_neg(t.y);
+      jac_madd_inl<F>(acc, acc, t);
+    }
+  }
+  r = acc;
+}
+template <class C>
+ELP_HEAVY void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar& k_in) {
+  typedef F2<C> F;
+  u32 m[4][3];
+  bool neg[4];
+  lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());
+  for (int j = 0; j < 4; j++) limbs_add_eights<3, 17>(m[j]);
+  Jac<F> acc;
+  jac_set_inf(acc);
+  ELP_NOUNROLL
+  for (int w = 16; w >= 0; w--) {
+    if (w != 16) {
+      ELP_NOUNROLL
+      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
+    }
+    ELP_NOUNROLL
+    for (int j = 0; j < 4; j++) {
+      const int dg = limbs_window<3>(m[j], 4 * w, 4) - 8;
+      if (dg == 0) continue;
+      Aff<F> t = tab[(dg < 0 ? -dg : dg) - 1];
+      if (aff_is_inf(t)) continue;
+      if (j != 0) {                        // psi^j on an affine point: (conj^j x * gx_j, conj^j y * gy_j)
+        Fp2<C> gx, gy;
+        if (j == 1) {
+          ELP_LOAD_FP(gx.c0, C::g2frob(1, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(1, 0, 1, i_));
+          ELP_LOAD_FP(gy.c0, C::g2frob(1, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(1, 1, 1, i_));
+        } else if (j == 2) {
+          ELP_LOAD_FP(gx.c0, C::g2frob(2, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(2, 0, 1, i_));
+          ELP_LOAD_FP(gy.c0, C::g2frob(2, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(2, 1, 1, i_));
+        } else {
+          ELP_LOAD_FP(gx.c0, C::g2frob(3, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(3, 0, 1, i_));
+          ELP_LOAD_FP(gy.c0, C::g2frob(3, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(3, 1, 1, i_));
+        }
+        if (j & 1) {
+          t.x = fp2_conj(t.x);
+          t.y = fp2_conj(t.y);
+        }
+        fp2_mul<C>(t.x, t.x, gx);
+        fp2_mul<C>(t.y, t.y, gy);
+      }
+      if (neg[j] != (dg < 0)) t.y = fp2_neg(t.y);
+      jac_madd_inl<F>(acc, acc, t);
+    }
+  }
+  r = acc;
+}
+
 // Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,
 // j = 0 .. ceil(256/W)-1.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
 template <class F>

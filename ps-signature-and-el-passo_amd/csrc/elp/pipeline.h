@@ -269,7 +269,34 @@ ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const A
     cred = scalar_sub_mod_r<C>(cred, rr);
   }
   const Scalar one_minus_c = scalar_sub_mod_r<C>(one, cred);
-  g2_mul_gls<C>(Vk, kk, c, key.hot);      // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
+  // The four variable-base terms k^c, phi^c, E1^c, E2^c share the scalar: their tables of small multiples (1P .. 8P) are built in
+  // Jacobian form, made affine with ONE inversion for all 28 entries that need it, and the GLS / GLV loops run on mixed additions.
+  Aff<G2F> tabk[8];
+  Aff<G1F> tab1[3][8];
+  {
+    Jac<G2F> jk[8];
+    Jac<G1F> j1[3][8];
+    jac_multiples8<G2F>(jk, kk);
+    jac_multiples8<G1F>(j1[0], phi);
+    if (retr) {
+      jac_multiples8<G1F>(j1[1], E1);
+      jac_multiples8<G1F>(j1[2], E2);
+    }
+    Fp<C> z1[21], zi1[21];
+    Fp2<C> z2[7], zi2[7];
+    for (int t = 0; t < 3; t++)
+      for (int i = 1; i < 8; i++) z1[7 * t + i - 1] = (t == 0 || retr) ? j1[t][i].Z : fp_one<C>();
+    for (int i = 1; i < 8; i++) z2[i - 1] = jk[i].Z;
+    batch_zinv<C, 21, 7>(zi1, z1, zi2, z2);
+    tabk[0] = kk;
+    for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G2F>(tabk[i], jk[i], zi2[i - 1]);
+    for (int t = 0; t < 3; t++) {
+      if (t != 0 && !retr) continue;
+      tab1[t][0] = t == 0 ? phi : (t == 1 ? E1 : E2);
+      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab1[t][i], j1[t][i], zi1[7 * t + i - 1]);
+    }
+  }
+  g2_mul_gls_tab<C>(Vk, tabk, c);         // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
   jac_from_aff(K, kk);
   {
     int jh = 0, jr = 0;
@@ -285,13 +312,13 @@ ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const A
   }
   acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
   acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
-  g1_mul_glv<C>(Vphi, phi, c, key.hot);
+  g1_mul_glv_tab<C>(Vphi, tab1[0], c);
   acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), src.rs(0));
   if (retr) {
     const Scalar r_e = src.rs(nrs - 1);
-    g1_mul_glv<C>(VE1, E1, c, key.hot);
+    g1_mul_glv_tab<C>(VE1, tab1[1], c);
     acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
-    g1_mul_glv<C>(VE2, E2, c, key.hot);
+    g1_mul_glv_tab<C>(VE2, tab1[2], c);
     acc_fixed_g1<C>(VE2, key, g1_base_apk(key), r_e);
     acc_fixed_g1<C>(VE2, key, g1_base_h(key), src.rs(1));
   }
