@@ -564,6 +564,44 @@ ELP_HEAVY void fp12_mul_by_line(Fp12<C>& f, const Fp2<C>& a, const Fp2<C>& b, co
   fp12_mul_by_line_inl<C>(f, a, b, c);
 }
 
+// f <- f * l1 * l2 for two D-type lines l_i = a_i + b_i w + c_i w^3 (a_i, b_i carried; c_i of magnitude <= 2): the two sparse elements
+// are multiplied first (6 Fp2 products), their product has five non-zero Fp2 coefficients
+//     L0 = (a1 a2 + xi c1 c2,  b1 b2,  b1 c2 + c1 b2),   L1 = (a1 b2 + a2 b1,  a1 c2 + a2 c1,  0)
+// and f * (L0 + L1 w) costs 6 + 5 + 6 Fp2 products: 23 instead of 26 for two sparse products, and one pass over f instead of two.
+template <class C>
+ELP_INL void fp12_mul_by_two_lines_inl(Fp12<C>& f, const Fp2<C>& a1, const Fp2<C>& b1, const Fp2<C>& c1_in, const Fp2<C>& a2,
+                                       const Fp2<C>& b2, const Fp2<C>& c2_in) {
+  static_assert(C::TWIST_D && C::HEADROOM >= 14, "written for the D-type twist over the 29-bit field");
+  const Fp2<C> c1 = fp2_carry_fast(c1_in), c2 = fp2_carry_fast(c2_in);
+  Fp2<C> taa, tbb, tcc, tbc, tab, tac;
+  fp2_mul<C>(taa, a1, a2);
+  fp2_mul<C>(tbb, b1, b2);
+  fp2_mul<C>(tcc, c1, c2);
+  fp2_mul<C>(tbc, fp2_add_lazy(b1, c1), fp2_add_lazy(b2, c2));                   // 2 x 2
+  fp2_mul<C>(tab, fp2_add_lazy(a1, b1), fp2_add_lazy(a2, b2));
+  fp2_mul<C>(tac, fp2_add_lazy(a1, c1), fp2_add_lazy(a2, c2));
+  Fp6<C> L0, L1s;                                                                // L1s = L0 + L1 (for the Karatsuba cross term)
+  L0.c0 = fp2_carry_fast(fp2_add_lazy(taa, fp2_mul_xi_lazy(tcc)));               // 1 + 2
+  L0.c1 = tbb;
+  L0.c2 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(tbc, tbb), tcc));             // 3
+  const Fp2<C> y0 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(tab, taa), tbb));
+  const Fp2<C> y1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(tac, taa), tcc));
+  L1s.c0 = fp2_add(L0.c0, y0);
+  L1s.c1 = fp2_add(L0.c1, y1);
+  L1s.c2 = L0.c2;
+  Fp6<C> t0, t1, t2, s;
+  fp6_mul<C>(t0, f.c0, L0);
+  fp6_mul_by_01<C>(t1, f.c1, y0, y1);
+  fp6_add(s, f.c0, f.c1);
+  fp6_mul<C>(t2, s, L1s);
+  f.c1.c0 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(t2.c0, t0.c0), t1.c0));
+  f.c1.c1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(t2.c1, t0.c1), t1.c1));
+  f.c1.c2 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(t2.c2, t0.c2), t1.c2));
+  f.c0.c0 = fp2_carry_fast(fp2_add_lazy(t0.c0, fp2_mul_xi_lazy(t1.c2)));         // t0 + v t1
+  f.c0.c1 = fp2_carry_fast(fp2_add_lazy(t0.c1, t1.c0));
+  f.c0.c2 = fp2_carry_fast(fp2_add_lazy(t0.c2, t1.c1));
+}
+
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final exponentiation).
 template <class C>
 ELP_INL void fp12_cyc_sqr_inl(Fp12<C>& r, const Fp12<C>& a) {
