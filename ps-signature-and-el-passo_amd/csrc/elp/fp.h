@@ -424,16 +424,25 @@ ELP_FPMUL Fp<C> fp_sqr(Fp<C> a) {
   return r;
 }
 
-// a^e for a public exponent given as N 32-bit words through a constexpr accessor (square-and-multiply, MSB first).
+// a^e for a public exponent given as N 32-bit words through a constexpr accessor: fixed 4-bit windows, MSB first
+// (32 N squarings, at most 8 N + 14 products; 0^e = 0).
 template <class C, class E>
 ELP_HEAVY Fp<C> fp_pow_const(const Fp<C>& a, E expo) {
+  Fp<C> t[16];
+  t[1] = a;
+  ELP_NOUNROLL
+  for (int i = 2; i < 16; i++) t[i] = fp_mul<C>(t[i - 1], a);
   Fp<C> r = fp_one<C>();
   bool started = false;
   ELP_NOUNROLL
-  for (int i = C::N * 32 - 1; i >= 0; i--) {
-    if (started) r = fp_sqr<C>(r);
-    if ((expo(i >> 5) >> (i & 31)) & 1) {
-      r = started ? fp_mul<C>(r, a) : a;
+  for (int i = C::N * 8 - 1; i >= 0; i--) {
+    const int nib = (int)((expo(i >> 3) >> (4 * (i & 7))) & 15);
+    if (started) {
+      ELP_NOUNROLL
+      for (int s = 0; s < 4; s++) r = fp_sqr<C>(r);
+    }
+    if (nib != 0) {
+      r = started ? fp_mul<C>(r, t[nib]) : t[nib];
       started = true;
     }
   }
