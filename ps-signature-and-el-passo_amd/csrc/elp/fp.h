@@ -527,8 +527,115 @@ ELP_INL bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
 }
 
 template <class C>
-ELP_HEAVY Fp<C> fp_inv(const Fp<C>& a) {  // a^(p-2); inv(0) = 0
+ELP_HEAVY Fp<C> fp_inv_pow(const Fp<C>& a) {  // a^(p-2); inv(0) = 0 (the Fermat inversion, kept as a cross-check)
   return fp_pow_const<C>(a, ExpPm2<C>());
+}
+
+// Inversion by Bernstein-Yang division steps ("safegcd", the half-delta variant also used by libsecp256k1's modinv32), in batches of LB
+// steps on the low limbs with a 2x2 transition matrix applied to the full-length (f, g) and (d, e).  Branch-free, so the lanes of a
+// wave stay converged; about a sixth of the cost of the Fermat power.  inv(0) = 0.
+template <class C>
+ELP_HEAVY Fp<C> fp_inv(const Fp<C>& a) {
+  constexpr int NL = C::NL;
+  constexpr int LB = C::LB;
+  const i32 MLB = (i32)ELP_LIMB_MASK;
+  // x = a / R as a plain integer in [0, p), digits in [0, 2^LB), signed top limb
+  Fp<C> one = fp_zero<C>();
+  one.v[0] = 1;
+  Fp<C> gq = fp_mul<C>(a, one);
+  {
+    i32 c = 0;
+    for (int i = 0; i < NL - 1; i++) {
+      i32 x = gq.v[i] + c;
+      c = x >> LB;
+      gq.v[i] = x & MLB;
+    }
+    gq.v[NL - 1] += c;
+    const i32 neg = gq.v[NL - 1] >> 31;                   // all ones when the representative is negative: add p
+    c = 0;
+    for (int i = 0; i < NL - 1; i++) {
+      i32 x = gq.v[i] + (C::modl(i) & neg) + c;
+      c = x >> LB;
+      gq.v[i] = x & MLB;
+    }
+    gq.v[NL - 1] += (C::modl(NL - 1) & neg) + c;
+  }
+  Fp<C> fq, dq = fp_zero<C>(), eq = fp_zero<C>();
+  ELP_LOAD_FP(fq, C::modl(i_));
+  eq.v[0] = 1;
+  i32 zeta = -1;
+  ELP_NOUNROLL
+  for (int it = 0; it < C::INV_ITERS; it++) {
+    // LB division steps on the low limbs
+    u32 u = 1, v = 0, q = 0, r = 1, f = (u32)fq.v[0], g = (u32)gq.v[0];
+    ELP_NOUNROLL
+    for (int s = 0; s < LB; s++) {
+      u32 m1 = (u32)(zeta >> 31);
+      const u32 m2 = 0u - (g & 1u);
+      const u32 x = (f ^ m1) - m1, y = (u ^ m1) - m1, z = (v ^ m1) - m1;
+      g += x & m2;
+      q += y & m2;
+      r += z & m2;
+      m1 &= m2;
+      zeta = (i32)((u32)zeta ^ m1) - 1;
+      f += g & m1;
+      u += q & m1;
+      v += r & m1;
+      g >>= 1;
+      u <<= 1;
+      v <<= 1;
+    }
+    const i32 tu = (i32)u, tv = (i32)v, tq = (i32)q, tr = (i32)r;
+    // (d, e) <- t (d, e) / 2^LB mod p
+    {
+      const i32 sd = dq.v[NL - 1] >> 31, se = eq.v[NL - 1] >> 31;
+      i32 md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+      i64 cd = (i64)tu * dq.v[0] + (i64)tv * eq.v[0];
+      i64 ce = (i64)tq * dq.v[0] + (i64)tr * eq.v[0];
+      md -= (i32)((C::PINVL * (u32)cd + (u32)md) & (u32)MLB);
+      me -= (i32)((C::PINVL * (u32)ce + (u32)me) & (u32)MLB);
+      cd += (i64)C::modl(0) * md;
+      ce += (i64)C::modl(0) * me;
+      cd >>= LB;
+      ce >>= LB;
+      ELP_UNROLL
+      for (int i = 1; i < NL; i++) {
+        cd += (i64)tu * dq.v[i] + (i64)tv * eq.v[i] + (i64)C::modl(i) * md;
+        ce += (i64)tq * dq.v[i] + (i64)tr * eq.v[i] + (i64)C::modl(i) * me;
+        dq.v[i - 1] = (i32)cd & MLB;
+        eq.v[i - 1] = (i32)ce & MLB;
+        cd >>= LB;
+        ce >>= LB;
+      }
+      dq.v[NL - 1] = (i32)cd;
+      eq.v[NL - 1] = (i32)ce;
+    }
+    // (f, g) <- t (f, g) / 2^LB
+    {
+      i64 cf = (i64)tu * fq.v[0] + (i64)tv * gq.v[0];
+      i64 cg = (i64)tq * fq.v[0] + (i64)tr * gq.v[0];
+      cf >>= LB;
+      cg >>= LB;
+      ELP_UNROLL
+      for (int i = 1; i < NL; i++) {
+        cf += (i64)tu * fq.v[i] + (i64)tv * gq.v[i];
+        cg += (i64)tq * fq.v[i] + (i64)tr * gq.v[i];
+        fq.v[i - 1] = (i32)cf & MLB;
+        gq.v[i - 1] = (i32)cg & MLB;
+        cf >>= LB;
+        cg >>= LB;
+      }
+      fq.v[NL - 1] = (i32)cf;
+      gq.v[NL - 1] = (i32)cg;
+    }
+  }
+  // f = +-1 now (or +-p when x = 0, d = 0): d = +-x^-1 in (-2p, p); back to Montgomery form with one product by R^2
+  const i32 sf = fq.v[NL - 1] >> 31;
+  ELP_UNROLL
+  for (int i = 0; i < NL; i++) dq.v[i] = (dq.v[i] ^ sf) - sf;
+  Fp<C> r2;
+  ELP_LOAD_FP(r2, C::r2(i_));
+  return fp_mul<C>(dq, r2);
 }
 // square root for p = 3 (mod 4): returns false if a is not a square
 template <class C>

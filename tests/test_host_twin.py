@@ -262,3 +262,20 @@ def test_batch_prover_items_bit_exact_vs_model(L):
         assert L.twin_bn254_verify_id(ctx, o.raw, mask, retr, b"sess", 4) == 1
     # attribute 0 must be hidden
     assert L.twin_bn254_prove_id(ctx, rec, ctypes.c_uint64(0b0110), 0, b"sess", 4, o) == 0
+
+
+def test_divstep_inversion_against_model_both_curves(L):
+    """fp_inv is the Bernstein-Yang divstep inversion (csrc/elp/fp.h): every result must equal pow(a, -1, p), inv(0) = 0, on both
+    fields, for edge values (0, 1, 2, p-1, p-2, (p+-1)/2, powers of two, values with long runs of ones) and 400 random ones."""
+    from elp_testlib import BLS12_381
+    rnd = random.Random(2024)
+    for pfx, cv, nb in (("twin_bn254", BN254, 32), ("twin_bls", BLS12_381, 48)):
+        p = cv.p
+        inv = getattr(L, pfx + "_fp_inv")
+        o = ctypes.create_string_buffer(nb)
+        vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 29) - 1, 1 << 29, 1 << 30, (1 << 200) % p, (1 << (p.bit_length() - 1)) - 1,
+                (1 << (p.bit_length() - 1)), p - (1 << 100)] + [rnd.randrange(p) for _ in range(400)] + [rnd.randrange(1 << 40) for _ in range(20)]
+        for a in vals:
+            inv(fb(a, nb), o)
+            got = ib(o.raw)
+            assert got == (pow(a, -1, p) if a else 0), (pfx, hex(a))
