@@ -633,6 +633,7 @@ ELP_HEAVY Fp<C> fp_inv(const Fp<C>& a) {
   const i32 sf = fq.v[NL - 1] >> 31;
   ELP_UNROLL
   for (int i = 0; i < NL; i++) dq.v[i] = (dq.v[i] ^ sf) - sf;
+  fp_carry(dq);                                  // digits in [0, 2^LB) -> balanced limbs, as fp_mul expects of its operands
   Fp<C> r2;
   ELP_LOAD_FP(r2, C::r2(i_));
   return fp_mul<C>(dq, r2);
