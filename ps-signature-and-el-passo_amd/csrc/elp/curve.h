@@ -437,111 +437,11 @@ ELP_INL void limbs_add_eights(u32* m) {
   }
 }
 
-// [k]P for P in the order-r subgroup of G1: k = k1 + k2 lam with phi(x, y) = (beta x, y) = [lam](x, y); one shared chain of
-// 132 doublings, two table additions per 4-bit window (the second through phi).
-template <class C>
-ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k_in, u32* hot = nullptr) {
-  typedef F1<C> F;
-  Jac<F> tbl[9];                     // 0, 1P .. 8P: signed digits, see limbs_add_eights
-  jac_set_inf(tbl[0]);
-  jac_from_aff(tbl[1], p);
-  ELP_NOUNROLL
-  for (int i = 2; i < 9; i++) {
-    if (i & 1)
-      jac_madd<F>(tbl[i], tbl[i - 1], p);
-    else
-      jac_dbl<F>(tbl[i], tbl[i >> 1]);
-  }
-  u32 m[2][5];
-  bool neg[2];
-  lattice_split<2, 5, 5>(scalar_mod_r<C>(k_in), m, neg, Glv1Lat<C>());   // |k_i| < 2^129 (tools/glv.py)
-  limbs_add_eights<5, 33>(m[0]);
-  limbs_add_eights<5, 33>(m[1]);
-  Fp<C> beta;
-  ELP_LOAD_FP(beta, C::glv_beta(i_));
-  // the running point stays in registers: doubling and addition are inlined into the loop (one copy each)
-  (void)hot;
-  Jac<F> acc;
-  jac_set_inf(acc);
-  ELP_NOUNROLL
-  for (int w = 32; w >= 0; w--) {
-    if (w != 32) {
-      ELP_NOUNROLL
-      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
-    }
-    ELP_NOUNROLL
-    for (int j = 0; j < 2; j++) {
-      const int dg = limbs_window<5>(m[j], 4 * w, 4) - 8;
-      Jac<F> t = tbl[dg < 0 ? -dg : dg];
-      if (j == 1) t.X = fp_mul<C>(t.X, beta);
-      if (neg[j] != (dg < 0)) t.Y = fp_neg(t.Y);
-      jac_add_inl<F>(acc, acc, t);
-    }
-  }
-  r = acc;
-}
-
-// [k]Q for Q in the order-r subgroup of G2: k = k0 + k1 lam + k2 lam^2 + k3 lam^3 with psi(Q) = [lam]Q, lam = p mod r
-// (psi = twist o Frobenius o untwist); 68 shared doublings, four table additions per 4-bit window.
-template <class C>
-ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k_in, u32* hot = nullptr) {
-  typedef F2<C> F;
-  Jac<F> tbl[9];                     // 0, 1Q .. 8Q: signed digits
-  jac_set_inf(tbl[0]);
-  jac_from_aff(tbl[1], p);
-  ELP_NOUNROLL
-  for (int i = 2; i < 9; i++) {
-    if (i & 1)
-      jac_madd<F>(tbl[i], tbl[i - 1], p);
-    else
-      jac_dbl<F>(tbl[i], tbl[i >> 1]);
-  }
-  u32 m[4][3];
-  bool neg[4];
-  lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());   // |k_i| < 2^66 (tools/glv.py)
-  for (int j = 0; j < 4; j++) limbs_add_eights<3, 17>(m[j]);
-  (void)hot;
-  Jac<F> acc;              // in registers: doubling and addition are inlined into the loop (one copy each)
-  jac_set_inf(acc);
-  ELP_NOUNROLL
-  for (int w = 16; w >= 0; w--) {
-    if (w != 16) {
-      ELP_NOUNROLL
-      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
-    }
-    ELP_NOUNROLL
-    for (int j = 0; j < 4; j++) {
-      const int dg = limbs_window<3>(m[j], 4 * w, 4) - 8;
-      Jac<F> t = tbl[dg < 0 ? -dg : dg];
-      if (j != 0 && !jac_is_inf(t)) {   // psi^j in Jacobian coordinates: (conj^j X * gx_j, conj^j Y * gy_j, conj^j Z)
-        Fp2<C> gx, gy;
-        if (j == 1) {
-          ELP_LOAD_FP(gx.c0, C::g2frob(1, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(1, 0, 1, i_));
-          ELP_LOAD_FP(gy.c0, C::g2frob(1, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(1, 1, 1, i_));
-        } else if (j == 2) {
-          ELP_LOAD_FP(gx.c0, C::g2frob(2, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(2, 0, 1, i_));
-          ELP_LOAD_FP(gy.c0, C::g2frob(2, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(2, 1, 1, i_));
-        } else {
-          ELP_LOAD_FP(gx.c0, C::g2frob(3, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(3, 0, 1, i_));
-          ELP_LOAD_FP(gy.c0, C::g2frob(3, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(3, 1, 1, i_));
-        }
-        if (j & 1) {
-          t.X = fp2_conj(t.X);
-          t.Y = fp2_conj(t.Y);
-          t.Z = fp2_conj(t.Z);
-        }
-        fp2_mul<C>(t.X, t.X, gx);
-        fp2_mul<C>(t.Y, t.Y, gy);
-      }
-      if (neg[j] != (dg < 0)) t.Y = fp2_neg(t.Y);
-      jac_add_inl<F>(acc, acc, t);
-    }
-  }
-  r = acc;
-}
-
-// ---- the same multiplications over AFFINE tables 1P .. 8P (mixed additions: 11 / 29 instead of 16 / 43 products).  The caller builds
-// the multiples of several points with jac_multiples8 and makes them affine with ONE shared inversion (verify_id_nizk).
+// ---- GLV / GLS multiplication over AFFINE tables 1P .. 8P (mixed additions: 11 / 29 instead of 16 / 43 products).
+// [k]P for P in the order-r subgroup of G1: k = k1 + k2 lam with phi(x, y) = (beta x, y) = [lam](x, y); one shared chain of 132 doublings,
+// two table additions per 4-bit window (the second through phi).  [k]Q in G2: k = k0 + k1 lam + k2 lam^2 + k3 lam^3 with psi(Q) = [lam]Q,
+// lam = p mod r (psi = twist o Frobenius o untwist); 68 shared doublings, four table additions per window.  The caller builds the
+// multiples with jac_multiples8 and makes them affine with one shared inversion (g1_mul_glv / g2_mul_gls / verify_id_nizk in pipeline.h).
 template <class F>
 ELP_HEAVY void jac_multiples8(Jac<F>* t, const Aff<F>& p) {   // t[i] = (i + 1) P
   jac_from_aff(t[0], p);

@@ -168,6 +168,37 @@ ELP_HEAVY void batch_zinv(Fp<C>* zi1, const Fp<C>* z1, Fp2<C>* zi2, const Fp2<C>
   }
 }
 
+// One variable-base multiplication on its own: table of multiples, one (division-step) inversion for its seven non-trivial entries,
+// mixed additions in the loop.
+template <class C>
+ELP_HEAVY void g1_mul_glv(Jac<F1<C>>& r, const Aff<F1<C>>& p, const Scalar& k, u32* hot = nullptr) {
+  (void)hot;
+  typedef F1<C> F;
+  Jac<F> jt[8];
+  Aff<F> tab[8];
+  jac_multiples8<F>(jt, p);
+  Fp<C> z[7], zi[7];
+  for (int i = 1; i < 8; i++) z[i - 1] = jt[i].Z;
+  batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
+  tab[0] = p;
+  for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<F>(tab[i], jt[i], zi[i - 1]);
+  g1_mul_glv_tab<C>(r, tab, k);
+}
+template <class C>
+ELP_HEAVY void g2_mul_gls(Jac<F2<C>>& r, const Aff<F2<C>>& p, const Scalar& k, u32* hot = nullptr) {
+  (void)hot;
+  typedef F2<C> F;
+  Jac<F> jt[8];
+  Aff<F> tab[8];
+  jac_multiples8<F>(jt, p);
+  Fp2<C> z[7], zi[7];
+  for (int i = 1; i < 8; i++) z[i - 1] = jt[i].Z;
+  batch_zinv<C, 0, 7>((Fp<C>*)0, (const Fp<C>*)0, zi, z);
+  tab[0] = p;
+  for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<F>(tab[i], jt[i], zi[i - 1]);
+  g2_mul_gls_tab<C>(r, tab, k);
+}
+
 // Fiat-Shamir challenge: Fr::setHashOf( SHA256( hex(part_0) || ... || ad ) )  (SHA-256 applied twice)
 struct Transcript {
   Sha256 s;
