@@ -42,6 +42,12 @@ int elp_init(int curve, int device, elp_ctx** out);
 void elp_destroy(elp_ctx* ctx);
 const char* elp_last_error(const elp_ctx* ctx);
 int elp_field_bytes(int curve);               /* F */
+/* Options.  ELP_OPT_STRICT_SIGNATURE (default 1): el_passo_verify_id rejects proofs whose sig1 is the point at infinity.  The
+ * reference accepts sig1 = sig2 = infinity with a self-made NIZK (src/ps-verifier.cc:133-137 has no isZero test; golden case
+ * "sig_both_zero"), which is a universal forgery since e(O,K) e(O,gg) = 1, although PSVerifier::verify rejects it
+ * (src/ps-verifier.cc:16-18).  Set to 0 for bit-for-bit reference behaviour on that input. */
+enum { ELP_OPT_STRICT_SIGNATURE = 1 };
+int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 
 /* ---- key material (builds fixed-base window tables and the Miller-loop lines of gg in HBM) ------------------ */
@@ -105,7 +111,8 @@ int elp_verify_id_wire_batch(elp_ctx* ctx, size_t n, const uint8_t* msgs, const 
                              const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted);
 /* Aggregated variant of elp_verify_id_batch (no counterpart in the reference).  The NIZK half runs per
  * item as usual; the signature checks of the items that pass it are combined with verifier-chosen 128-bit multipliers d_i
- * (SHA-256(seed32 || le64(i)), seed32 = 32 fresh random bytes per batch):
+ * (SHA-256(seed || le64(i)); seed32 == NULL (recommended): the library draws the 32-byte seed from the OS CSPRNG per call; a
+ * caller-supplied seed32 must point to exactly 32 bytes that no prover can predict before the batch is fixed):
  *     prod_i e(d_i sig1_i, K_i) * e(-sum_i d_i sig2_i, gg) == 1
  * i.e. one Miller loop per item, a Pippenger MSM for sum d_i sig2_i, ONE final exponentiation per batch.  If the batch equation
  * fails the items are re-verified one by one inside the same call, so flags[] are the reference's verdicts either way (a wrong

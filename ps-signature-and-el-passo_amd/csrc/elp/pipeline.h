@@ -37,7 +37,12 @@ struct KeyCtx {
   const Aff<F2<C>>* b2;           // G2 bases (affine):  0 = gg, 1 = XX, 2+i = YY_i
   const LineCoef<C>* gg_lines;    // precomputed Miller lines of gg
   u32* hot = nullptr;             // this lane's LDS hot slot (ELP_HOT_WORDS words) or null, see common.h
+  int flags = 0;                  // KEY_STRICT_SIG: proofs with sig1 == infinity are rejected (PS / EL PASSO require sigma_1 != 1)
 };
+// The reference's el_passo_verify_id accepts sig1 = sig2 = infinity with a self-made NIZK (e(O,K) e(O,gg) = 1: a universal forgery;
+// golden case "sig_both_zero", src/ps-verifier.cc:133-137 has no isZero test although PSVerifier::verify :16-18 has one).  The library
+// rejects it by default (elp_set_option(ELP_OPT_STRICT_SIGNATURE)); reference-compatible behaviour is opt-in.
+enum { KEY_STRICT_SIG = 1 };
 enum { G1_BASE_G = 0, G1_BASE_Y0 = 1 };
 enum { G2_BASE_GG = 0, G2_BASE_XX = 1, G2_BASE_YY0 = 2 };
 template <class C>
@@ -410,6 +415,7 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
                               const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2, const Aff<F2<C>>& kk, const Scalar& c,
                               const uint8_t* ad, size_t ad_len) {
   Aff<F2<C>> aK;
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
   if (!verify_id_nizk<C, Src>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
   return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
@@ -444,6 +450,7 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   for (int i = 0; i < 8; i++) delta_out[i] = 0;
   for (int i = 0; i < 2 * C::N; i++) sig2_out[i] = 0;
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
   if (!verify_id_nizk<C, RecordSrc<C>>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
   const Scalar d = agg_multiplier(seed, index);
   Jac<F1<C>> P;
@@ -563,7 +570,13 @@ struct WireSrc {
   }
   ELP_HD int nrs() const { return nrs_; }
   ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
-  ELP_HD Scalar rs(int j) const { return scalar_load_le(rs_ + 33 * (size_t)j + 1); }   // each entry: 20 | 32 bytes
+  // entry j of the FrList: each entry is var(32) | 32 bytes, where var is normally the single byte 20 but may be the 3-byte form
+  // FD 00 20 (the reference's parseVar accepts both, src/ps-encoding.cc:149-162), so the list is walked (bounds validated in open())
+  ELP_HD Scalar rs(int j) const {
+    const uint8_t* p = rs_;
+    for (int i = 0; i < j; i++) p += (p[0] == 253 ? 3 : 1) + 32;
+    return scalar_load_le(p + (p[0] == 253 ? 3 : 1));
+  }
   // Fr::setHashOf(attributes[i]) for the next revealed attribute i (called with increasing i)
   ELP_HD Scalar next_revealed_hash(int i) {
     size_t off = 0, l = 0;

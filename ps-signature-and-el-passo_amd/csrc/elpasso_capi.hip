@@ -91,6 +91,13 @@ void elp_destroy(elp_ctx* c) {
 }
 
 const char* elp_last_error(const elp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int elp_set_option(elp_ctx* c, int option, int value) {
+  if (!c) return ELP_ERR_ARG;
+  switch (option) {
+    case ELP_OPT_STRICT_SIGNATURE: c->strict_sig = value ? 1 : 0; return ELP_OK;
+    default: return ELP_ERR_ARG;
+  }
+}
 int elp_set_pubkey(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
                    const uint8_t* YYi, int window_bits) {
   if (!c) return ELP_ERR_ARG;
@@ -186,7 +193,7 @@ int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_r
 
 int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
                         const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
@@ -229,7 +236,7 @@ int elp_request_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_r
 // user side, host buffers
 int elp_prove_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad, const uint32_t* ad_off,
                        size_t ad_len, uint8_t* proofs, uint8_t* flags, uint64_t* produced) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
   if (produced) *produced = 0;
   if (n == 0) return ELP_OK;
@@ -282,7 +289,7 @@ int elp_request_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t 
 
 int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int retr, const uint8_t* ad,
                              const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
-  int rc = check_fused(c, 0);
+  int rc = check_fused(c, 0, need_rp(retr));
   if (rc) return rc;
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
@@ -388,12 +395,12 @@ int elp_verify_id_batch_aggregated_dev(elp_ctx* c, void* stream, size_t n, const
 int elp_verify_id_batch_aggregated(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
                                    const uint32_t* ad_off, size_t ad_len, const uint8_t* seed32, uint8_t* flags, uint64_t* accepted,
                                    int* batch_equation_held) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
   if (accepted) *accepted = 0;
   if (batch_equation_held) *batch_equation_held = 1;
   if (n == 0) return ELP_OK;
-  if (!records || !flags || !seed32 || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
   DevBuf drec, dad, doff, dfl, dcnt;

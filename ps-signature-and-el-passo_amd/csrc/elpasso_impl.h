@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/random.h>
 
 #include <string>
 #include <vector>
@@ -624,6 +625,10 @@ struct elp_ctx {
   void* lines = nullptr;
   std::vector<uint8_t> h_b1;  // host mirror of the G1 base words (std form) so set_rp / set_signer_secret can rebuild
   bool have_pk = false;
+  bool rp_set = false;        // elp_set_rp installed H1(service)
+  bool retr_set = false;      // ... and all of g, authority_pk, h (needed by the id-retrieval variants)
+  bool sk_set = false;        // elp_set_signer_secret installed X
+  int strict_sig = 1;         // ELP_OPT_STRICT_SIGNATURE
   // workspace of the aggregated verification (grown on demand, reused across calls)
   void* agg_ws = nullptr;
   size_t agg_ws_bytes = 0;
@@ -653,6 +658,7 @@ static KeyCtx<C> make_key(const elp_ctx* c) {
   k.b1 = (const Aff<F1<C>>*)c->b1;
   k.b2 = (const Aff<F2<C>>*)c->b2;
   k.gg_lines = (const LineCoef<C>*)c->lines;
+  k.flags = c->strict_sig ? KEY_STRICT_SIG : 0;
   return k;
 }
 
@@ -671,7 +677,7 @@ static inline void free_key(elp_ctx* c) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
-  c->have_pk = false;
+  c->have_pk = c->rp_set = c->retr_set = c->sk_set = false;
 }
 
 // (re)build every device-side key structure from host copies of the base points
@@ -783,7 +789,15 @@ int elp_set_rp_t(elp_ctx* c, const uint8_t* service_name, size_t service_len, co
     else
       memset(c->h_b1.data() + (size_t)(A + 2 + i) * G1, 0, G1);
   }
-  return rebuild_key<C>(c, nullptr);
+  c->rp_set = c->retr_set = false;
+  int rc = rebuild_key<C>(c, nullptr);
+  if (rc != ELP_OK) {          // tables and bases may be inconsistent now: the context needs a fresh elp_set_pubkey
+    free_key(c);
+    return rc;
+  }
+  c->rp_set = service_name != nullptr;
+  c->retr_set = c->rp_set && g && authority_pk && h;
+  return ELP_OK;
 }
 
 template <class C>
@@ -794,7 +808,14 @@ int elp_set_signer_secret_t(elp_ctx* c, const uint8_t* X) {
     return ELP_ERR_STATE;
   }
   memcpy(c->h_b1.data() + (size_t)(c->A + 5) * Sizes<C>::G1, X, Sizes<C>::G1);
-  return rebuild_key<C>(c, nullptr);
+  c->sk_set = false;
+  int rc = rebuild_key<C>(c, nullptr);
+  if (rc != ELP_OK) {
+    free_key(c);
+    return rc;
+  }
+  c->sk_set = true;
+  return ELP_OK;
 }
 
 // ---- generic "copy in, launch, copy out" helper for the host-buffer primitives
@@ -1013,15 +1034,30 @@ static inline int popcount_mask(uint64_t m, int A) {
   return h;
 }
 
-static inline int check_fused(elp_ctx* c, uint64_t mask) {
+// what a fused entry point needs besides the public key: without these the bases would silently be the point at infinity
+enum { NEED_RP = 1, NEED_RETR = 2, NEED_SK = 4 };
+static inline int check_fused(elp_ctx* c, uint64_t mask, int need = 0) {
   if (!c) return ELP_ERR_ARG;
   if (!c->have_pk) {
     c->err = "elp_set_pubkey must be called first";
     return ELP_ERR_STATE;
   }
+  if ((need & NEED_RP) && !c->rp_set) {
+    c->err = "elp_set_rp (service name) must be called first";
+    return ELP_ERR_STATE;
+  }
+  if ((need & NEED_RETR) && !c->retr_set) {
+    c->err = "id-retrieval needs elp_set_rp with authority_pk, g and h";
+    return ELP_ERR_STATE;
+  }
+  if ((need & NEED_SK) && !c->sk_set) {
+    c->err = "elp_set_signer_secret must be called first";
+    return ELP_ERR_STATE;
+  }
   if (c->A < 64 && (mask >> c->A) != 0) return ELP_ERR_ARG;
   return ELP_OK;
 }
+static inline int need_rp(int retr) { return NEED_RP | (retr ? NEED_RETR : 0); }
 
 // Pippenger launch sequence over device buffers (points std affine, 32-byte scalars); `ws` needs msm_ws_bytes() bytes.
 template <class C, int G>
@@ -1058,9 +1094,8 @@ template <class C>
 int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr,
                                          const void* d_ad, const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags,
                                          void* d_accepted) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
-  if (!seed32) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int H = popcount_mask(mask, c->A);
@@ -1082,8 +1117,15 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   }
   if (!c->agg_ok) HIPCHK(c, hipMalloc((void**)&c->agg_ok, 256));
   uint8_t* ws = (uint8_t*)c->agg_ws;
+  // The multipliers must be unpredictable to every prover once the batch is fixed: seed32 == NULL (recommended) draws the seed from
+  // the OS CSPRNG here; a caller-supplied seed (tests, reproducible runs) must be 32 fresh random bytes per batch.
   AggSeed seed;
-  memcpy(seed.b, seed32, 32);
+  if (seed32) {
+    memcpy(seed.b, seed32, 32);
+  } else if (getrandom(seed.b, 32, 0) != 32) {
+    c->err = "getrandom failed";
+    return ELP_ERR_STATE;
+  }
   KeyCtx<C> key = make_key<C>(c);
   hipLaunchKernelGGL((k_verify_id_agg<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                      (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
@@ -1115,7 +1157,7 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
 template <class C>
 int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
                             const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
   if (n == 0) return ELP_OK;
   const int H = popcount_mask(mask, c->A);
@@ -1130,7 +1172,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
 template <class C>
 int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
                                           const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  int rc = check_fused(c, 0);
+  int rc = check_fused(c, 0, need_rp(retr));
   if (rc) return rc;
   if (n == 0) return ELP_OK;
   hipLaunchKernelGGL((k_verify_id_wire<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
@@ -1154,7 +1196,7 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
 template <class C>
 int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad,
                              const void* d_ad_off, size_t ad_len, void* d_sigs, void* d_flags, void* d_accepted) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, NEED_SK);
   if (rc) return rc;
   if (n == 0) return ELP_OK;
   const int H = popcount_mask(mask, c->A);
@@ -1169,7 +1211,7 @@ int elp_provide_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d
 template <class C>
 int elp_prove_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
                              const void* d_ad_off, size_t ad_len, void* d_proofs, void* d_flags, void* d_accepted) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
   if (n == 0) return ELP_OK;
   const int H = popcount_mask(mask, c->A);
@@ -1214,7 +1256,7 @@ static inline int stage_ad(elp_ctx* c, size_t n, const uint8_t* ad, const uint32
 template <class C>
 int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
                          size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
-  int rc = check_fused(c, mask);
+  int rc = check_fused(c, mask, NEED_SK);
   if (rc) return rc;
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;

@@ -2,10 +2,14 @@
 
 #include <string.h>
 
+static bool g_strict_signature = true;
+void elpSetStrictSignature(bool strict) { g_strict_signature = strict; }
+
 ElpKey::ElpKey(const PSPubKey& pk, int device, int window_bits) {
   if (pk.Yi.size() != pk.YYi.size() || pk.Yi.empty() || pk.Yi.size() > 62) throw std::runtime_error("ElpKey: bad public key shape");
   nattr_ = pk.Yi.size();
   elpCheck(nullptr, elp_init(ELP_CURVE_BN254, device, &ctx_), "elp_init");
+  elp_set_option(ctx_, ELP_OPT_STRICT_SIGNATURE, g_strict_signature ? 1 : 0);
   std::vector<uint8_t> yi(64 * nattr_), yyi(128 * nattr_);
   for (size_t i = 0; i < nattr_; i++) {
     memcpy(&yi[64 * i], pk.Yi[i].b, 64);

@@ -43,5 +43,9 @@ class ElpKey {
   G1 rp_apk_, rp_g_, rp_h_, sk_X_;
 };
 
+// Process-wide default of ELP_OPT_STRICT_SIGNATURE for contexts created afterwards (library default: strict, i.e. proofs with
+// sig1 == infinity are rejected; false = the reference's behaviour, which accepts sig1 = sig2 = infinity, see include/elpasso.h).
+void elpSetStrictSignature(bool strict);
+
 // hidden-attribute mask of a message's attribute list ("" = hidden)
 uint64_t elpHiddenMask(const std::vector<std::string>& attributes);

@@ -7,8 +7,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// mcl/bls12_381.hpp brings these in transitively and the reference's sources rely on that (std::get at src/ps-requester.cc:54,
+// std::cout in test/*.cc, std::vector / std::optional in src/ps-encoding.h)
+#include <iostream>
+#include <optional>
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <vector>
 
 #include "../../../include/elpasso.h"
 

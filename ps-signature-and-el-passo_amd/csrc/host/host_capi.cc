@@ -48,6 +48,9 @@ int elph_init(int device) {
   });
 }
 
+// verifiers created afterwards reject (1, default) or accept like the reference (0) proofs with sig1 == infinity
+void elph_set_strict_signature(int strict) { elpSetStrictSignature(strict != 0); }
+
 // 1 = accepted, 0 = rejected, -1 = error
 int elph_verify_id_b64(const char* pk_b64, const char* proof_b64, const char* ad, const char* service, int with_retrieval,
                        const char* authority_seed, const char* g_seed, const char* h_seed) {

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("ELP_LIB") or os.path.join(HERE, "csrc", "libelpasso_h
 
 CURVE_BN254 = 0
 CURVE_BLS12_381 = 1
+OPT_STRICT_SIGNATURE = 1
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -18,6 +19,7 @@ _SIGS = {
     "elp_destroy": (None, [_c.c_void_p]),
     "elp_last_error": (_c.c_char_p, [_c.c_void_p]),
     "elp_field_bytes": (_c.c_int, [_c.c_int]),
+    "elp_set_option": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     "elp_version": (_c.c_char_p, []),
     "elp_set_pubkey": (_c.c_int, [_c.c_void_p, _c.c_int, _u8p, _u8p, _u8p, _u8p, _u8p, _c.c_int]),
     "elp_set_rp": (_c.c_int, [_c.c_void_p, _u8p, _c.c_size_t, _u8p, _u8p, _u8p]),
@@ -139,6 +141,10 @@ class Context:
             raise ElpassoError("elpasso error %d: %s" % (rc, self.lib.elp_last_error(self.h).decode()))
 
     # ---- setup
+    def set_strict_signature(self, on):
+        """ELP_OPT_STRICT_SIGNATURE (default on): reject sig1 == infinity in verify_id; off = the reference's behaviour."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_STRICT_SIGNATURE, int(bool(on))))
+
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
         A = len(Yi) // self.G1
         assert len(YYi) == A * self.G2
@@ -259,8 +265,10 @@ class Context:
                                                ctypes.byref(cnt)))
         return flags, cnt.value
 
-    def verify_id_batch_aggregated(self, records, hidden_mask, with_retrieval, ad, seed):
-        """Returns (flags, accepted, batch_equation_held)."""
+    def verify_id_batch_aggregated(self, records, hidden_mask, with_retrieval, ad, seed=None):
+        """Returns (flags, accepted, batch_equation_held).  seed=None: the library draws it from the OS CSPRNG (recommended)."""
+        if seed is not None and len(seed) != 32:
+            raise ValueError("seed must be exactly 32 bytes")
         H = bin(hidden_mask).count("1")
         rsz = self.lib.elp_verify_id_record_size(self.curve, self.A, H, int(with_retrieval))
         n = len(records) // rsz
