@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- EL PASSO RP verifications/s (el_passo_verify_id, 8 attributes, 4 hidden) on N MI355X.
 
-One "step" = one pass of the hot path (the fused verify_id kernel) over one batch of 65 536 synthetic proofs per GPU,
-records already resident in HBM, followed by the RCCL count all-reduce.  Shards are independent (weak scaling).
+One "step" = one pass of the hot path (the fused verify_id kernel) over one batch of synthetic proofs per GPU (records already
+resident in HBM), followed by the RCCL count all-reduce.  Shards are independent (weak scaling).
+  --config 4 (default): 65 536 proofs per GPU, 8 attributes, 4 hidden   (BASELINE.json configs[3], the metric's configuration)
+  --config 5          : 131 072 proofs per GPU, 16 attributes, 4 hidden (BASELINE.json configs[4]: 2^20 proofs over 8 GPUs)
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+
+Launching: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) every process is one rank.  Started plainly as
+`python bench.py --gpus N` with N > 1 it starts N ranks itself -- as a CHILD `python -m torch.distributed.run` process, before
+anything here touches the GPU -- and exits with that child's code.  `--dry-run` exercises the same launch / rendezvous / shard /
+count-reduce / report path on CPU (gloo, no kernel, value = null): it is what tests/test_dist_gloo.py runs in the GPU-less container.
 """
 import argparse
 import ctypes
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,22 +28,113 @@ PKG = "ps-signature-and-el-passo_amd"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def main():
+CONFIGS = {4: {"batch": 65536, "attrs": 8, "hidden": 4}, 5: {"batch": 131072, "attrs": 16, "hidden": 4}}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU per step")
-    ap.add_argument("--attrs", type=int, default=8)
-    ap.add_argument("--hidden", type=int, default=4)
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS), help="BASELINE.json configuration (4 = the metric's, 5 = 16 attributes, 131 072 per rank)")
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (default: the configuration's)")
+    ap.add_argument("--attrs", type=int, default=0)
+    ap.add_argument("--hidden", type=int, default=0)
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launch, shard, count-reduce and report path; no kernel, value = null")
     ap.add_argument("--window", type=int, default=16, help="fixed-base window bits of the key tables (library default 8)")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(1536, 48 x cores))")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    args.batch = args.batch or cfg["batch"]
+    args.attrs = args.attrs or cfg["attrs"]
+    args.hidden = args.hidden or cfg["hidden"]
     if args.headline_only:
         args.no_second_curve, args.cpu_sample = True, 0
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torchrun (this process has not touched the GPU and
+    never will) and hand back its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """The N > 1 control path without a GPU: gloo rendezvous, contiguous shards, barrier-bracketed timed loop, count all-reduce (SUM),
+    max-over-ranks time, one JSON line from rank 0.  No verification runs here (there is no CPU fallback of the kernel): each rank
+    contributes the size of its shard as its "accepted" count, so the reduced total must equal world x batch."""
+    import torch
+    import torch.distributed as dist
+    shard = importlib.import_module(PKG + ".shard")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    first, count = shard.shard_range(world * args.batch, rank, world)
+    cnt = torch.zeros(1, dtype=torch.int64)
+
+    def step():
+        cnt.fill_(count)
+        if world > 1:
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ranks = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "EL PASSO credential verifications/sec (8 attrs)", "value": None, "unit": "verifications/s",
+                          "n_gpus": world, "ranks_seen": int(ranks.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u32", "data": "synthetic", "dry_run": True, "backend": "gloo" if world > 1 else "none",
+                          "config": workload_config(args, world), "reduced_count": int(cnt.item()),
+                          "shard": {"first": first, "count": count}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if int(cnt.item()) == world * args.batch and int(ranks.item()) == world else 4
+
+
+def workload_config(args, world):
+    A, H, B = args.attrs, args.hidden, args.batch
+    return {"workload": "BASELINE.json config %d: batch of %d EL PASSO RP el_passo_verify_id per GPU, %d attributes with %d hidden, id-retrieval, "
+                        "curve %s" % (args.config, B, A, H, "BN254 (the reference's actual mcl default; golden-vector pinned)" if args.curve == "bn254"
+                                      else "BLS12-381 (north-star curve; no reference oracle, model-checked)"),
+            "baseline_config": args.config, "batch_per_gpu": B, "attrs": A, "hidden": H, "curve": args.curve.upper(), "window_bits": args.window or 8,
+            "parallelism": "independent shards x%d + RCCL count all-reduce" % world}
+
+
+def main():
+    args = parse_args()
+    in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_group:
+        sys.exit(launch_ranks(args))
+    if in_group and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        sys.exit(dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))))
 
     import numpy as np
     import torch
@@ -45,8 +145,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        rs = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(rs, op=dist.ReduceOp.SUM)
+        ranks_seen = int(rs.item())
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
@@ -110,11 +214,13 @@ def main():
     kern_ms = float(ms.value)
     algo_bytes_per_item = rsz + 4                   # affine inputs + 4-byte verdict (804 B at A=8, BN254)
     achieved = B * algo_bytes_per_item / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # per-launch HBM bytes from the PMC passes, if recorded
-    if os.path.exists(tf):
+    traffic, traffic_source = None, None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # per-launch HBM bytes from the round's rocprofv3 --pmc passes (not measured in this run)
+    if os.path.exists(tf) and args.config == 4 and args.curve == "bn254":
         try:
-            traffic = json.load(open(tf)).get("k_verify_id_bytes_per_launch")
+            tj = json.load(open(tf))
+            traffic = tj.get("k_verify_id_bytes_per_launch")
+            traffic_source = "profiles/hbm_traffic.json (%s): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the round's separate rocprofv3 --pmc passes over the same command; not re-measured in this run" % tj.get("tag", "round PMC pass")
         except Exception:
             traffic = None
 
@@ -126,15 +232,11 @@ def main():
             "value": value, "unit": "verifications/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "batch of %d EL PASSO RP el_passo_verify_id per GPU, %d attributes with %d hidden, id-retrieval, "
-                                   "curve %s" % (B, A, H, "BN254 (the reference's actual mcl default; golden-vector pinned)" if args.curve == "bn254"
-                                                 else "BLS12-381 (north-star curve; no reference oracle, model-checked)"),
-                       "batch_per_gpu": B, "attrs": A, "hidden": H, "curve": args.curve.upper(), "window_bits": args.window or 8,
-                       "parallelism": "independent shards x%d + RCCL count all-reduce" % world},
+            "config": workload_config(args, world), "ranks_seen": ranks_seen,
             "parity_ok": parity_ok, "accepted": total_accepted, "expected_accepted": int(exp_total.item()),
             "setup_s": t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_verify_id", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_verify_id", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
                          "note": "integer-VALU bound path: see valu_bound"},
         }
         # secondary ceiling: modular multiplications/s of this kernel vs the fp_mul micro-benchmark (same limb code)
@@ -174,9 +276,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(samp, B))
     if rank == 0 and world == 1 and args.curve == "bn254" and not args.no_second_curve:
         try:
-            out["bls12_381"] = second_curve(pkg, synth, local_rank, dev, A, H, min(B, 32768), args.window)
+            out["bls12_381"] = second_curve(pkg, synth, local_rank, dev, A, H, B, args.window)
         except Exception as e:  # pragma: no cover
             out["bls12_381"] = {"error": str(e)}
+    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only:
+        try:   # BASELINE.json config 5 at N = 1: one rank's share (131 072 proofs, 16 attributes) on this GPU
+            out["config5_rank_share"] = other_config(pkg, synth, local_rank, dev, 5, args.window)
+        except Exception as e:  # pragma: no cover
+            out["config5_rank_share"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.headline_only:
         # aggregated (random-linear-combination) variant: reported beside, never instead of, `value`.  Its single-lane tail (one Miller
         # loop + one final exponentiation per batch, ~11 ms) is not overlapped yet, so it only pays off on larger batches: measured on
@@ -253,6 +360,38 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
     res = {"value": B / (ms.value * 1e-3), "unit": "verifications/s", "batch": B, "kernel_ms": float(ms.value),
            "parity_ok": bool((flags == expect).all()) and int(d_cnt.item()) == 3 * int(expect.sum()),
            "algorithmic_bytes_per_item": rsz + 4, "note": "BLS12-381 instantiation: no reference oracle exists; checked against the big-int model in tests"}
+    ctx.close()
+    return res
+
+
+def other_config(pkg, synth, local_rank, dev, config, window):
+    """Another BASELINE.json configuration on this GPU (BN254), device-resident records, HIP-event timing of the kernel."""
+    import numpy as np
+    import torch
+    cfg = CONFIGS[config]
+    A, H, B = cfg["attrs"], cfg["hidden"], cfg["batch"]
+    ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
+    wl = synth.Workload(ctx, A, seed=20211, window_bits=window)
+    recs, mask, expect = wl.verify_id_batch(B, H, with_retrieval=True)
+    d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)
+    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    d_flags = torch.zeros(B, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ms = ctypes.c_float()
+    for reps in (1, 3):
+        d_cnt.zero_()
+        ctx._chk(ctx.lib.elp_time_verify_id_dev(ctx.h, stream, reps, B, d_rec.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(wl.ad),
+                                                d_flags.data_ptr(), d_cnt.data_ptr(), ctypes.byref(ms)))
+    torch.cuda.synchronize()
+    flags = d_flags.cpu().numpy()
+    rsz = len(recs) // B
+    ach = B * (rsz + 4) / (ms.value * 1e-3) / 1e9
+    res = {"workload": "BASELINE.json config %d, one rank's share: %d el_passo_verify_id, %d attributes with %d hidden, id-retrieval, BN254" % (config, B, A, H),
+           "value": B / (ms.value * 1e-3), "unit": "verifications/s", "batch": B, "kernel_ms": float(ms.value),
+           "parity_ok": bool((flags == expect).all()) and int(d_cnt.item()) == 3 * int(expect.sum()),
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_item": rsz + 4}}
     ctx.close()
     return res
 

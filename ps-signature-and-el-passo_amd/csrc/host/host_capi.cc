@@ -119,4 +119,37 @@ int elph_request_id_b64(const char* pk_b64, const char* attrs_spec, const char* 
   });
 }
 
+// PSSigner::key_gen with injected secrets (key_gen_from): generators g, gg are taken from `pk_template_b64`; returns the base64
+// PSPubKey (src/ps-signer.cc:29-55).
+int elph_key_gen_b64(const char* pk_template_b64, const uint8_t* x32, const uint8_t* ys32, size_t nattr, char* out, size_t cap) {
+  return guarded([&] {
+    PSPubKey tpl = PSPubKey::fromBufferString(PSBuffer::fromBase64(pk_template_b64));
+    PSSigner idp(nattr, tpl.g, tpl.gg);
+    Fr x;
+    memcpy(x.b, x32, 32);
+    std::vector<Fr> ys(nattr);
+    for (size_t i = 0; i < nattr; i++) memcpy(ys[i].b, ys32 + 32 * i, 32);
+    return copyOut(idp.key_gen_from(x, ys).toBufferString().toBase64(), out, cap);
+  });
+}
+
+// User-side credential handling with injected randomness (src/ps-requester.cc:19-99,101-113,139-148): el_passo_request_id draws
+// t1, rho_0, rho_j from rand32 and remembers t1; the (blinded) credential is then unblinded with it and re-randomised with the
+// next injected scalar.  Writes the two base64 PSCredentials; returns 0.
+int elph_unblind_randomize_b64(const char* pk_b64, const char* attrs_spec, const char* ad, const uint8_t* rand32, size_t n_rand,
+                               const char* blinded_cred_b64, char* out_unblinded, size_t cap1, char* out_randomized, size_t cap2) {
+  return guarded([&] {
+    PSRequester user(PSPubKey::fromBufferString(PSBuffer::fromBase64(pk_b64)));
+    std::vector<Fr> rnd(n_rand);
+    for (size_t i = 0; i < n_rand; i++) memcpy(rnd[i].b, rand32 + 32 * i, 32);
+    user.set_random_source(rnd);
+    (void)user.el_passo_request_id(parseAttrs(attrs_spec), ad);
+    PSCredential ub = user.unblind_credential(PSCredential::fromBufferString(PSBuffer::fromBase64(blinded_cred_b64)));
+    if (copyOut(ub.toBufferString().toBase64(), out_unblinded, cap1) < 0) return -1;
+    PSCredential rz = user.randomize_credential(ub);
+    if (copyOut(rz.toBufferString().toBase64(), out_randomized, cap2) < 0) return -1;
+    return 0;
+  });
+}
+
 }  // extern "C"

@@ -18,7 +18,31 @@ struct TwinCtx {
   std::vector<Aff<F2<C>>> t2, b2;
   std::vector<LineCoef<C>> lines;
   std::vector<u32> hot;   // stands in for the lane's LDS hot slot so the aliasing rules of KeyCtx::hot are exercised on the host
+  void *t1s = nullptr, *t2s = nullptr;   // sparse (calloc-backed, lazily committed) tables of ctx_new_sparse
+  ~TwinCtx() {
+    free(t1s);
+    free(t2s);
+  }
 };
+
+// one table entry per window for the digits of `k`: entry (j, d_j) = d_j * 2^(W j) * base, exactly what jac_acc_fixed will read
+template <class F>
+static void touch_entries(Aff<F>* base_tbl, const Aff<F>& base, int W, int nwin, int per, const Scalar& k) {
+  if (aff_is_inf(base)) return;
+  std::vector<Aff<F>> bj(nwin);
+  table_window_bases<F>(bj.data(), base, W, nwin);
+  for (int j = 0; j < nwin; j++) {
+    int bit = j * W, w = (bit + W <= 256) ? W : 256 - bit;
+    int d = scalar_window(k, bit, w);
+    if (d == 0) continue;
+    Scalar s;
+    for (int i = 0; i < 8; i++) s.v[i] = 0;
+    s.v[0] = (u32)d;
+    Jac<F> acc;
+    jac_mul_var<F>(acc, bj[j], s);
+    jac_to_aff<F>(base_tbl[(size_t)j * per + (d - 1)], acc);
+  }
+}
 
 template <class F>
 static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& bases, int W, int nwin, int per) {
@@ -212,6 +236,43 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     c->hot.assign(ELP_HOT_WORDS, 0xdeadbeefu);                                                                         \
     c->key.hot = getenv("ELP_TWIN_NO_HOT") ? nullptr : c->hot.data();                                                  \
     return c;                                                                                                          \
+  }                                                                                                                    \
+  /* Tables of ANY window width without building them: zero-filled virtual memory (an all-zero entry reads as infinity) into which   \
+     table_touch() writes exactly the entries one item will read.  Used by tools/count_ops.py to count the W = 16 kernel. */       \
+  void* pfx##_ctx_new_sparse(int A, int W, const u32* g1b, const u32* g2b) {                                           \
+    TwinCtx<C>* c = new TwinCtx<C>();                                                                                  \
+    c->b1.resize(A + 6);                                                                                               \
+    c->b2.resize(A + 2);                                                                                               \
+    for (int i = 0; i < A + 6; i++)                                                                                    \
+      if (!g1_load<C>(c->b1[i], g1b + i * 2 * C::N)) return 0;                                                         \
+    for (int i = 0; i < A + 2; i++)                                                                                    \
+      if (!g2_load<C>(c->b2[i], g2b + i * 4 * C::N)) return 0;                                                         \
+    int nwin = (256 + W - 1) / W, per = (1 << W) - 1;                                                                  \
+    c->t1s = calloc((size_t)(A + 6) * nwin * per, sizeof(Aff<F1<C>>));                                                 \
+    c->t2s = calloc((size_t)(A + 2) * nwin * per, sizeof(Aff<F2<C>>));                                                 \
+    if (!c->t1s || !c->t2s) return 0;                                                                                  \
+    c->lines.resize(ml_num_lines<C>());                                                                                \
+    ml_precompute<C>(c->lines.data(), c->b2[0]);                                                                       \
+    c->key.A = A;                                                                                                      \
+    c->key.W = W;                                                                                                      \
+    c->key.nwin = nwin;                                                                                                \
+    c->key.per = per;                                                                                                  \
+    c->key.t1 = (const Aff<F1<C>>*)c->t1s;                                                                             \
+    c->key.t2 = (const Aff<F2<C>>*)c->t2s;                                                                             \
+    c->key.b1 = c->b1.data();                                                                                          \
+    c->key.b2 = c->b2.data();                                                                                          \
+    c->key.gg_lines = c->lines.data();                                                                                 \
+    c->hot.assign(ELP_HOT_WORDS, 0xdeadbeefu);                                                                         \
+    c->key.hot = c->hot.data();                                                                                        \
+    return c;                                                                                                          \
+  }                                                                                                                    \
+  void pfx##_table_touch(void* cv, int group, int base, const u32* k) {                                                \
+    TwinCtx<C>* c = (TwinCtx<C>*)cv;                                                                                   \
+    const size_t stride = (size_t)c->key.nwin * c->key.per;                                                            \
+    if (group == 1)                                                                                                    \
+      touch_entries<F1<C>>((Aff<F1<C>>*)c->t1s + base * stride, c->b1[base], c->key.W, c->key.nwin, c->key.per, scalar_load_w(k)); \
+    else                                                                                                               \
+      touch_entries<F2<C>>((Aff<F2<C>>*)c->t2s + base * stride, c->b2[base], c->key.W, c->key.nwin, c->key.per, scalar_load_w(k)); \
   }                                                                                                                    \
   void pfx##_ctx_free(void* c) { delete (TwinCtx<C>*)c; }                                                              \
   int pfx##_verify_id(void* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {             \

@@ -70,3 +70,37 @@ def test_two_rank_gloo_count_reduce():
     assert [r[1] for r in res] == [0, 4] and [r[2] for r in res] == [4, 3]
     assert sum(r[3] for r in res) == 5
     assert all(r[4] == 5 for r in res)
+
+
+def _run_bench(*argv, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_starts_the_ranks_dry_run():
+    """`python bench.py --gpus 2` (the driver's command shape, no torchrun around it) must itself start 2 ranks, rendezvous on
+    127.0.0.1, shard the batch, all-reduce the count and have rank 0 print ONE line with n_gpus = 2 -- here on gloo (--dry-run)."""
+    r, out = _run_bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out is not None and out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dry_run"] is True
+    assert out["reduced_count"] == 2 * 65536 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+    r, out = _run_bench("--gpus", "2", "--dry-run", "--config", "5")
+    assert r.returncode == 0 and out["config"]["attrs"] == 16 and out["config"]["batch_per_gpu"] == 131072 and out["reduced_count"] == 2 * 131072
+
+
+def test_bench_without_gpu_fails_loudly_after_spawning():
+    """Without --dry-run there is no CPU path: the spawned ranks must fail (no GPU in this container), and so must the launcher."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    r, out = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and out is None
+    assert "starting 2 ranks" in r.stderr

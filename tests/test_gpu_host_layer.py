@@ -106,3 +106,65 @@ def test_host_prover_bit_exact_vs_oracle(host, retr):
     else:
         assert PR.verify_id_noretr(pk, want, b"sess", b"service")
     assert host.elph_verify_id_b64(pk_b64, out.value, b"sess", b"service", retr, b"ghi", b"abc", b"jkl") == 1
+
+
+def test_key_gen_from_equals_oracle(host):
+    """a8: PSSigner::key_gen (src/ps-signer.cc:29-55) with injected secrets -> wire bytes equal the model's key."""
+    d = load_golden("bn254_oracle_flows.json")
+    for si, A in ((0, 3), (1, 8)):
+        tpl_b64 = d["scenarios"][si]["pk"]
+        tpl = CD.pk_decode(base64.b64decode(tpl_b64))
+        x = scalar_stream(4242, 0, M.r)
+        ys = [scalar_stream(4242, 1 + i, M.r) for i in range(A)]
+        want, _ = PR.key_gen(tpl.g, tpl.gg, x, ys)
+        out = ctypes.create_string_buffer(8192)
+        host.elph_key_gen_b64.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+        n = host.elph_key_gen_b64(tpl_b64.encode(), fb(x), b"".join(fb(y) for y in ys), A, out, 8192)
+        assert n > 0, host.elph_last_error()
+        assert base64.b64decode(out.value) == CD.pk_encode(want)
+
+
+def test_unblind_and_randomize_equal_oracle(host):
+    """a11: PSRequester::unblind_credential / randomize_credential (src/ps-requester.cc:101-113,139-148) on a reference-issued
+    (blinded) credential with the RNG seam: byte-identical to the model; the unblinded one equals the reference's own unblinding
+    only when t1 is the reference's, so here t1 is ours and the model is the comparison."""
+    seed, A, H = 991, 4, 2
+    gg = CD.pk_decode(base64.b64decode(load_golden("bn254_oracle_flows.json")["scenarios"][0]["pk"])).gg
+    g = M.hash_to_g1("abc")
+    x = scalar_stream(seed, 0, M.r)
+    ys = [scalar_stream(seed, 1 + i, M.r) for i in range(A)]
+    pk, skX = PR.key_gen(g, gg, x, ys)
+    pk_b64 = base64.b64encode(CD.pk_encode(pk))
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    spec = " ".join("%s %s" % (a.decode(), "Y" if h else "N") for a, h in attrs).encode()
+    rnd = [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H + 1)]          # t1, rho_0, rho_j, then t of randomize
+    rq, t1 = PR.request_id(pk, attrs, b"ad1", rnd[:2 + H])
+    blinded = PR.provide_id(pk, skX, rq, b"ad1", scalar_stream(seed, 99, M.r))
+    want_ub = PR.unblind(blinded, t1)
+    want_rz = PR.randomize(want_ub, rnd[2 + H])
+    assert PR.ps_verify(pk, want_ub, [a for a, _ in attrs]) and PR.ps_verify(pk, want_rz, [a for a, _ in attrs])
+    o1, o2 = ctypes.create_string_buffer(512), ctypes.create_string_buffer(512)
+    cp, sz = ctypes.c_char_p, ctypes.c_size_t
+    host.elph_unblind_randomize_b64.argtypes = [cp, cp, cp, cp, sz, cp, cp, sz, cp, sz]
+    rc = host.elph_unblind_randomize_b64(pk_b64, spec, b"ad1", b"".join(fb(v) for v in rnd), len(rnd),
+                                         base64.b64encode(CD.cred_encode(blinded)), o1, 512, o2, 512)
+    assert rc == 0, host.elph_last_error()
+    assert base64.b64decode(o1.value) == CD.cred_encode(want_ub)
+    assert base64.b64decode(o2.value) == CD.cred_encode(want_rz)
+
+
+def test_default_strict_signature_through_reference_api(host):
+    """Library default: sig1 == infinity is rejected by el_passo_verify_id (the reference accepts sig1 = sig2 = infinity)."""
+    d = load_golden("bn254_oracle_flows.json")
+    s = d["scenarios"][0]
+    c = next(c for c in s["proofs"][0]["cases"] if c["label"] == "sig_both_zero")
+    o = next(c for c in s["proofs"][0]["cases"] if c["label"] == "original")
+    assert c["expect"] is True
+    args = (s["pk"].encode(), c["proof"].encode(), c["ad"].encode(), c["svc"].encode(), 0, b"", b"", b"")
+    assert host.elph_verify_id_b64(*args) == 1                      # module fixture: reference-compatible mode
+    host.elph_set_strict_signature(1)
+    try:
+        assert host.elph_verify_id_b64(*args) == 0
+        assert host.elph_verify_id_b64(s["pk"].encode(), o["proof"].encode(), o["ad"].encode(), o["svc"].encode(), 0, b"", b"", b"") == 1
+    finally:
+        host.elph_set_strict_signature(0)
