@@ -65,14 +65,59 @@
 namespace elp {
 typedef uint32_t u32;
 typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lane pairs.  A curve-traits class wrapped as Paired<B> selects the TWO-LANES-PER-ITEM layout of the Fp2 tower: lanes 2i and
+// 2i+1 of a wave work on the same item, the even lane holds the real component of every Fp2 value and the odd lane the imaginary one
+// (struct Fp2<C> then has ONE Fp member).  Everything built from Fp2 -- Fp6, Fp12, G2, Miller loop, final exponentiation -- keeps
+// half of its state per lane (an Fp12 value is 54 registers instead of 108 for BN254), so the verification kernels fit 256 registers
+// and run two waves per SIMD; an Fp2 product is one fp_mul_pair per lane after a DPP exchange of the operands with the neighbouring
+// lane (v_mov_b32 quad_perm:[1,0,3,2], no LDS).  Base-field (G1) work does not split this way; the two lanes take different G1 jobs
+// of the item instead (pipeline.h).  Rules for paired code: every branch whose body exchanges data must be taken by both lanes of a
+// pair (conditions computed from Fp2 values go through fp2_is_zero_exact & co., which agree on both lanes by construction).
+template <class B>
+struct Paired : B {};
+template <class C>
+struct PairInfo {
+  static constexpr bool paired = false;
+  typedef C Base;
+};
+template <class B>
+struct PairInfo<Paired<B>> {
+  static constexpr bool paired = true;
+  typedef B Base;
+};
+template <class C>
+ELP_HD constexpr bool is_paired() { return PairInfo<C>::paired; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+ELP_INL bool pair_odd() { return (threadIdx.x & 1u) != 0; }             // workgroups are one-dimensional with an even size
+ELP_INL int32_t pair_swap_i32(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false); }
+#else
+// Host twin (tests only): the two lanes of a pair are two threads; the twin installs the hook that swaps a buffer with the partner
+// thread's (a rendezvous, so a divergence between the lanes of a pair shows up as a hang / mismatch in the CPU tests).
+inline thread_local int elp_pair_parity = 0;
+inline void (*elp_pair_exchange_hook)(void* buf, size_t bytes) = nullptr;
+inline bool pair_odd() { return elp_pair_parity != 0; }
+inline int32_t pair_swap_i32(int32_t v) {
+  elp_pair_exchange_hook(&v, sizeof v);
+  return v;
+}
+#endif
+ELP_INL bool pair_and(bool b) { return b && pair_swap_i32(b ? 1 : 0) != 0; }   // true iff true on both lanes of the pair
+ELP_INL bool pair_or(bool b) { return b || pair_swap_i32(b ? 1 : 0) != 0; }
 // Per-lane "hot slot": ELP_HOT_WORDS 32-bit words of LDS that a kernel hands to the device routines (KeyCtx::hot) for the one
 // accumulator that is read and written by every step of a long loop (Miller value, exponentiation accumulator, point accumulator).
 // Routines take it through generic references, so the same code runs on private memory when the slot is absent (host twin, hot == 0)
 // or too small for the type.  4 resident waves x 64 lanes x 432 B = 108 KB of the CU's 160 KB.
+// Paired kernels run 8 waves per CU with half-size values: 54 words (216 B) per lane, 110 KB per CU.
 constexpr int ELP_HOT_WORDS = 108;
-template <class T>
-ELP_INL T* hot_as(u32* hot) {
-  return (hot != nullptr && sizeof(T) <= (size_t)ELP_HOT_WORDS * 4) ? reinterpret_cast<T*>(hot) : nullptr;
+constexpr int ELP_HOT_WORDS_PAIRED = 54;
+template <class C>
+ELP_HD constexpr int hot_words() { return is_paired<C>() ? ELP_HOT_WORDS_PAIRED : ELP_HOT_WORDS; }
+template <class T, class C>
+ELP_INL T* hot_as(u32* hot) {   // the BN254 Fp12 fills the slot exactly in either layout; smaller accumulators (Jacobian points) fit as well
+  return (hot != nullptr && sizeof(T) <= (size_t)hot_words<C>() * 4) ? reinterpret_cast<T*>(hot) : nullptr;
 }
 // scalar-field (Fr) Montgomery parameters of a curve; specialised in params_<curve>.h
 template <class C>

@@ -537,7 +537,7 @@ template <class F>
 ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scalar& k, u32* hot = nullptr) {
   const int nwin = (256 + W - 1) / W;
   const int per = (1 << W) - 1;
-  Jac<F>* ah = hot_as<Jac<F>>(hot);   // the running sum lives in the hot slot while the windows are added (table entries are read in place)
+  Jac<F>* ah = hot_as<Jac<F>, typename F::Curve>(hot);   // the running sum lives in the hot slot while the windows are added (table entries are read in place)
   Jac<F>& a = ah ? *ah : acc;
   if (ah) a = acc;
   ELP_NOUNROLL

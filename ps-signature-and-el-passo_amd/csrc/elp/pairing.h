@@ -284,7 +284,7 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
 template <class C>
 ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = nullptr) {
   Fp12<C> acc_priv;
-  Fp12<C>* ah = hot_as<Fp12<C>>(hot);
+  Fp12<C>* ah = hot_as<Fp12<C>, C>(hot);
   Fp12<C>& acc = ah ? *ah : acc_priv;
   acc = a;
   int top = 63;

@@ -402,7 +402,7 @@ ELP_HEAVY bool ps_pairing_check(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, co
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
   Fp12<C> f_priv, g;
-  Fp12<C>* fh = hot_as<Fp12<C>>(key.hot);
+  Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& f = fh ? *fh : f_priv;
   const LineCoef<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
@@ -457,7 +457,7 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   jac_mul_var<F1<C>>(P, sig1, d, 32);
   Aff<F1<C>> aP;
   jac_to_aff<F1<C>>(aP, P);
-  Fp12<C>* fh = hot_as<Fp12<C>>(key.hot);
+  Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& fm = fh ? *fh : f;
   const LineCoef<C>* no_lines[1] = {key.gg_lines};          // never read (no fixed pair); real pointers keep the fused loop compilable
   miller_loop<C, 1, 0>(fm, &aP, &aK, &aP, no_lines);
@@ -628,7 +628,7 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
   Fp12<C> f_priv, g;
-  Fp12<C>* fh = hot_as<Fp12<C>>(key.hot);
+  Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& f = fh ? *fh : f_priv;
   const LineCoef<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);

@@ -6,128 +6,273 @@
 namespace elp {
 
 // ------------------------------------------------------------------ Fp2
+// Two layouts (common.h, "Lane pairs"): the plain one keeps both components in the lane; for C = Paired<B> the lane keeps ONE component
+// (even lane: real part, odd lane: imaginary part) and the routines below exchange operands with the partner lane where the algebra
+// couples the components.  Everything above Fp2 is written against these routines only and therefore serves both layouts.
+template <class C, bool P = PairInfo<C>::paired>
+struct Fp2;
 template <class C>
-struct Fp2 {
+struct Fp2<C, false> {
   Fp<C> c0, c1;
 };
+template <class C>
+struct Fp2<C, true> {
+  Fp<C> c;   // this lane's component
+};
+
+// ---- pair primitives on field elements
+template <class C>
+ELP_INL Fp<C> fp_pair_swap(const Fp<C>& a) {   // the partner lane's value
+  Fp<C> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = pair_swap_i32(a.v[i]);
+#else
+  r = a;
+  elp_pair_exchange_hook(&r, sizeof r);
+#endif
+  return r;
+}
+template <class C>
+ELP_INL Fp<C> fp_cneg(bool c, const Fp<C>& a) {   // c ? -a : a
+  const i32 m = c ? -1 : 0;
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = (a.v[i] ^ m) - m;
+  return r;
+}
+// a generated Fp2 constant: this lane's component (paired) or both
+#define ELP_LOAD_FP2(dst, expr_c)                                        \
+  do {                                                                   \
+    if constexpr (is_paired<C>()) {                                      \
+      const bool odd_ = pair_odd();                                      \
+      ELP_UNROLL                                                         \
+      for (int i_ = 0; i_ < C::NL; i_++) {                               \
+        const i32 e0_ = [&](int c_) { return (expr_c); }(0);             \
+        const i32 e1_ = [&](int c_) { return (expr_c); }(1);             \
+        (dst).c.v[i_] = odd_ ? e1_ : e0_;                                \
+      }                                                                  \
+    } else {                                                             \
+      ELP_UNROLL                                                         \
+      for (int i_ = 0; i_ < C::NL; i_++) {                               \
+        (dst).c0.v[i_] = [&](int c_) { return (expr_c); }(0);            \
+        (dst).c1.v[i_] = [&](int c_) { return (expr_c); }(1);            \
+      }                                                                  \
+    }                                                                    \
+  } while (0)
 
 template <class C>
 ELP_INL Fp2<C> fp2_zero() {
   Fp2<C> r;
-  r.c0 = fp_zero<C>();
-  r.c1 = fp_zero<C>();
+  if constexpr (is_paired<C>()) {
+    r.c = fp_zero<C>();
+  } else {
+    r.c0 = fp_zero<C>();
+    r.c1 = fp_zero<C>();
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_one() {
   Fp2<C> r;
-  r.c0 = fp_one<C>();
-  r.c1 = fp_zero<C>();
+  if constexpr (is_paired<C>()) {
+    r.c = fp_select(pair_odd(), fp_zero<C>(), fp_one<C>());
+  } else {
+    r.c0 = fp_one<C>();
+    r.c1 = fp_zero<C>();
+  }
   return r;
 }
 template <class C>
 ELP_INL bool fp2_is_zero(const Fp2<C>& a) {          // modular test (two products)
-  return fp_is_zero<C>(a.c0) && fp_is_zero<C>(a.c1);
+  if constexpr (is_paired<C>()) return pair_and(fp_is_zero<C>(a.c));
+  else return fp_is_zero<C>(a.c0) && fp_is_zero<C>(a.c1);
 }
 template <class C>
 ELP_INL bool fp2_is_zero_exact(const Fp2<C>& a) {    // literal zero limbs
-  return fp_is_zero_exact(a.c0) && fp_is_zero_exact(a.c1);
+  if constexpr (is_paired<C>()) {
+    i32 t = 0;
+    ELP_UNROLL
+    for (int i = 0; i < C::NL; i++) t |= a.c.v[i];
+    t |= pair_swap_i32(t);
+    return t == 0;
+  } else {
+    return fp_is_zero_exact(a.c0) && fp_is_zero_exact(a.c1);
+  }
 }
 template <class C>
+ELP_INL Fp2<C> fp2_sub_lazy(const Fp2<C>& a, const Fp2<C>& b);
+template <class C>
 ELP_INL bool fp2_eq(const Fp2<C>& a, const Fp2<C>& b) {
-  return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1);
+  if constexpr (is_paired<C>()) return fp2_is_zero<C>(fp2_sub_lazy(a, b));
+  else return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1);
 }
+// component-wise operations: ELP_FP2_CW(r, expression in terms of X(a) ...) would hide too much; spelled out instead
 template <class C>
 ELP_INL Fp2<C> fp2_add(const Fp2<C>& a, const Fp2<C>& b) {
   Fp2<C> r;
-  r.c0 = fp_add(a.c0, b.c0);
-  r.c1 = fp_add(a.c1, b.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_add(a.c, b.c);
+  } else {
+    r.c0 = fp_add(a.c0, b.c0);
+    r.c1 = fp_add(a.c1, b.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_sub(const Fp2<C>& a, const Fp2<C>& b) {
   Fp2<C> r;
-  r.c0 = fp_sub(a.c0, b.c0);
-  r.c1 = fp_sub(a.c1, b.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_sub(a.c, b.c);
+  } else {
+    r.c0 = fp_sub(a.c0, b.c0);
+    r.c1 = fp_sub(a.c1, b.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_neg(const Fp2<C>& a) {
   Fp2<C> r;
-  r.c0 = fp_neg(a.c0);
-  r.c1 = fp_neg(a.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_neg(a.c);
+  } else {
+    r.c0 = fp_neg(a.c0);
+    r.c1 = fp_neg(a.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_dbl(const Fp2<C>& a) {
   Fp2<C> r;
-  r.c0 = fp_dbl(a.c0);
-  r.c1 = fp_dbl(a.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_dbl(a.c);
+  } else {
+    r.c0 = fp_dbl(a.c0);
+    r.c1 = fp_dbl(a.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_conj(const Fp2<C>& a) {
   Fp2<C> r;
-  r.c0 = a.c0;
-  r.c1 = fp_neg(a.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_cneg(pair_odd(), a.c);
+  } else {
+    r.c0 = a.c0;
+    r.c1 = fp_neg(a.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_select(bool c, const Fp2<C>& a, const Fp2<C>& b) {
   Fp2<C> r;
-  r.c0 = fp_select(c, a.c0, b.c0);
-  r.c1 = fp_select(c, a.c1, b.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_select(c, a.c, b.c);
+  } else {
+    r.c0 = fp_select(c, a.c0, b.c0);
+    r.c1 = fp_select(c, a.c1, b.c1);
+  }
   return r;
 }
 // lazy (carry-free) variants; results must be carried (fp2_carry) before they are stored or multiplied on both sides
 template <class C>
 ELP_INL Fp2<C> fp2_add_lazy(const Fp2<C>& a, const Fp2<C>& b) {
   Fp2<C> r;
-  r.c0 = fp_add_lazy(a.c0, b.c0);
-  r.c1 = fp_add_lazy(a.c1, b.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_add_lazy(a.c, b.c);
+  } else {
+    r.c0 = fp_add_lazy(a.c0, b.c0);
+    r.c1 = fp_add_lazy(a.c1, b.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_sub_lazy(const Fp2<C>& a, const Fp2<C>& b) {
   Fp2<C> r;
-  r.c0 = fp_sub_lazy(a.c0, b.c0);
-  r.c1 = fp_sub_lazy(a.c1, b.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_sub_lazy(a.c, b.c);
+  } else {
+    r.c0 = fp_sub_lazy(a.c0, b.c0);
+    r.c1 = fp_sub_lazy(a.c1, b.c1);
+  }
   return r;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_carry(Fp2<C> a) {
-  fp_carry(a.c0);
-  fp_carry(a.c1);
+  if constexpr (is_paired<C>()) {
+    fp_carry(a.c);
+  } else {
+    fp_carry(a.c0);
+    fp_carry(a.c1);
+  }
   return a;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_carry_fast(Fp2<C> a) {   // |limb| < 2^31 - 2^(LB-1): lazy sums of up to six carried values at LB = 29
-  fp_carry_fast(a.c0);
-  fp_carry_fast(a.c1);
+  if constexpr (is_paired<C>()) {
+    fp_carry_fast(a.c);
+  } else {
+    fp_carry_fast(a.c0);
+    fp_carry_fast(a.c1);
+  }
   return a;
+}
+template <class C>
+ELP_INL void fp2_reduce_weak(Fp2<C>& a) {
+  if constexpr (is_paired<C>()) {
+    fp_reduce_weak(a.c);
+  } else {
+    fp_reduce_weak(a.c0);
+    fp_reduce_weak(a.c1);
+  }
 }
 // Fields with C::HEADROOM >= 14 (BN254 at 29-bit limbs): a product accepts operands whose limb magnitudes, in units of a carried
 // limb, satisfy A*B <= 13 (fp_mul) or A*B + C*D <= 13 (fp_mul_pair), so the formulas below add and subtract without carrying and
 // carry each result once.  int32 limbs hold lazy sums of up to seven carried values.
 template <class C>
 ELP_HD constexpr bool fp_roomy() { return C::HEADROOM >= 14; }
+// (a0 + a1 i)(1 + i) = (a0 - a1) + (a0 + a1) i.   Paired: own -+ partner (even lane: own - partner, odd lane: own + partner)
 template <class C>
 ELP_INL Fp2<C> fp2_mul_xi_lazy(const Fp2<C>& a) {   // input carried, output limbs <= 2^30
   Fp2<C> r;
-  r.c0 = fp_sub_lazy(a.c0, a.c1);
-  r.c1 = fp_add_lazy(a.c0, a.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_add_lazy(a.c, fp_cneg(!pair_odd(), fp_pair_swap(a.c)));
+  } else {
+    r.c0 = fp_sub_lazy(a.c0, a.c1);
+    r.c1 = fp_add_lazy(a.c0, a.c1);
+  }
   return r;
 }
-// (a0 + a1 i)(1 + i) = (a0 - a1) + (a0 + a1) i
 template <class C>
 ELP_INL Fp2<C> fp2_mul_xi(const Fp2<C>& a) {
   Fp2<C> r;
-  r.c0 = fp_sub(a.c0, a.c1);
-  r.c1 = fp_add(a.c0, a.c1);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_add(a.c, fp_cneg(!pair_odd(), fp_pair_swap(a.c)));
+  } else {
+    r.c0 = fp_sub(a.c0, a.c1);
+    r.c1 = fp_add(a.c0, a.c1);
+  }
   return r;
 }
+// Paired product: with (p, q) the partner's copies of (a, b),
+//    even lane:  a0 b0 - a1 b1 = own_a * own_b + p_a * (-p_b)          odd lane:  a1 b0 + a0 b1 = own_a * p_b + p_a * own_b
+// i.e. ONE two-term inner product per lane, the same instruction stream on both lanes, operands chosen by lane parity.
 template <class C>
 ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands carried
+  if constexpr (is_paired<C>()) {
+    const bool odd = pair_odd();
+    const Fp<C> pa = fp_pair_swap(a.c), pb = fp_pair_swap(b.c);
+    const Fp<C> y = fp_select(odd, pb, b.c);
+    const Fp<C> w = fp_select(odd, b.c, fp_neg(pb));
+    if constexpr (C::HEADROOM >= 3) {
+      r.c = fp_mul_pair<C>(a.c, y, pa, w);
+    } else {
+      Fp<C> t = fp_sub_lazy(fp_mul<C>(a.c, y), fp_neg(fp_mul<C>(pa, w)));
+      fp_carry(t);
+      r.c = t;
+    }
+    return;
+  } else {
   if constexpr (C::HEADROOM >= 3) {
     // schoolbook with one reduction per component: the same 486 multiply-adds as Karatsuba with three reductions, but no operand
     // sums, no output differences and no carry passes
@@ -148,11 +293,17 @@ ELP_FP2 void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {  // operands
   Fp<C> u = fp_sub_lazy(fp_sub_lazy(s, t0), t1);   // three carried terms: |limb| < 1.5 * 2^30
   fp_carry(u);
   r.c1 = u;
+  }
 }
 // r = a*b + c*d in Fp2: one reduction per component where the field has the headroom (operand magnitudes as for fp_mul_quad)
 template <class C>
 ELP_FP2 void fp2_mul_pair(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b, const Fp2<C>& c, const Fp2<C>& d) {
-  if constexpr (fp_roomy<C>()) {
+  if constexpr (is_paired<C>() && fp_roomy<C>()) {
+    const bool odd = pair_odd();
+    const Fp<C> pa = fp_pair_swap(a.c), pb = fp_pair_swap(b.c), pc = fp_pair_swap(c.c), pd = fp_pair_swap(d.c);
+    r.c = fp_mul_quad<C>(a.c, fp_select(odd, pb, b.c), pa, fp_select(odd, b.c, fp_neg(pb)), c.c, fp_select(odd, pd, d.c), pc,
+                         fp_select(odd, d.c, fp_neg(pd)));
+  } else if constexpr (!is_paired<C>() && fp_roomy<C>()) {
     Fp<C> c0 = fp_mul_quad<C>(a.c0, b.c0, fp_neg(a.c1), b.c1, c.c0, d.c0, fp_neg(c.c1), d.c1);
     Fp<C> c1 = fp_mul_quad<C>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0);
     r.c0 = c0;
@@ -164,8 +315,21 @@ ELP_FP2 void fp2_mul_pair(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b, const Fp2
     r = fp2_add(t, u);
   }
 }
+// Paired square: even lane (a0 + a1)(a0 - a1), odd lane (2 a1) a0 -- one product per lane.
 template <class C>
 ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul; operand carried
+  if constexpr (is_paired<C>()) {
+    const bool odd = pair_odd();
+    const Fp<C> pa = fp_pair_swap(a.c);
+    Fp<C> x = fp_add_lazy(a.c, fp_select(odd, a.c, pa));          // a0 + a1 | 2 a1
+    Fp<C> y = fp_select(odd, pa, fp_sub_lazy(a.c, pa));            // a0 - a1 | a0
+    if constexpr (!fp_roomy<C>()) {
+      fp_carry(x);
+      fp_carry(y);
+    }
+    r.c = fp_mul<C>(x, y);
+    return;
+  } else {
   if constexpr (fp_roomy<C>()) {
     Fp<C> c0 = fp_mul<C>(fp_add_lazy(a.c0, a.c1), fp_sub_lazy(a.c0, a.c1));   // 2 x 2
     Fp<C> c1 = fp_mul<C>(fp_add_lazy(a.c0, a.c0), a.c1);                       // 2 x 1
@@ -178,6 +342,7 @@ ELP_FP2 void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {  // 2 Fp mul; operand carried
   Fp<C> u = fp_mul<C>(sa, fp_sub(a.c0, a.c1));
   r.c0 = u;
   r.c1 = fp_dbl(t);
+  }
 }
 template <class C>
 ELP_INL Fp2<C> fp2_mulv(const Fp2<C>& a, const Fp2<C>& b) {
@@ -192,32 +357,85 @@ ELP_INL Fp2<C> fp2_sqrv(const Fp2<C>& a) {
   return r;
 }
 template <class C>
-ELP_INL Fp2<C> fp2_mul_fp(const Fp2<C>& a, const Fp<C>& s) {
+ELP_INL Fp2<C> fp2_mul_fp(const Fp2<C>& a, const Fp<C>& s) {   // s: the same base-field value on both lanes of a pair
   Fp2<C> r;
-  r.c0 = fp_mul<C>(a.c0, s);
-  r.c1 = fp_mul<C>(a.c1, s);
+  if constexpr (is_paired<C>()) {
+    r.c = fp_mul<C>(a.c, s);
+  } else {
+    r.c0 = fp_mul<C>(a.c0, s);
+    r.c1 = fp_mul<C>(a.c1, s);
+  }
+  return r;
+}
+// norm a0^2 + a1^2 (a base-field value; paired: the same on both lanes).  Exactly zero limbs for the literal zero.
+template <class C>
+ELP_INL Fp<C> fp2_norm(const Fp2<C>& a) {
+  if constexpr (is_paired<C>()) {
+    const Fp<C> s = fp_sqr<C>(a.c);
+    return fp_add(s, fp_pair_swap(s));
+  } else {
+    return fp_add(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1));
+  }
+}
+// conj(a) * s for a base-field s (with s = 1 / norm(a): the inverse of a)
+template <class C>
+ELP_INL Fp2<C> fp2_conj_mul_fp(const Fp2<C>& a, const Fp<C>& s) {
+  Fp2<C> r;
+  if constexpr (is_paired<C>()) {
+    r.c = fp_cneg(pair_odd(), fp_mul<C>(a.c, s));
+  } else {
+    r.c0 = fp_mul<C>(a.c0, s);
+    r.c1 = fp_neg(fp_mul<C>(a.c1, s));
+  }
   return r;
 }
 template <class C>
 ELP_HEAVY void fp2_inv(Fp2<C>& r, const Fp2<C>& a) {
-  Fp<C> n = fp_add(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1));
-  Fp<C> ni = fp_inv<C>(n);
-  r.c0 = fp_mul<C>(a.c0, ni);
-  r.c1 = fp_neg(fp_mul<C>(a.c1, ni));
+  r = fp2_conj_mul_fp<C>(a, fp_inv<C>(fp2_norm<C>(a)));
 }
-// Square root in Fp2 for p = 3 (mod 4) ("complex method").  Returns false when a is not a square.
+// ---- moving between the layouts (paired <-> both components in one lane), for the few routines that are not worth pairing
 template <class C>
-ELP_HEAVY bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a) {
+struct Fp2Full {   // both components, plain layout over the SAME field traits
+  Fp<C> c0, c1;
+};
+template <class C>
+ELP_INL Fp2Full<C> fp2_gather(const Fp2<C>& a) {
+  Fp2Full<C> r;
+  if constexpr (is_paired<C>()) {
+    const Fp<C> p = fp_pair_swap(a.c);
+    const bool odd = pair_odd();
+    r.c0 = fp_select(odd, p, a.c);
+    r.c1 = fp_select(odd, a.c, p);
+  } else {
+    r.c0 = a.c0;
+    r.c1 = a.c1;
+  }
+  return r;
+}
+template <class C>
+ELP_INL Fp2<C> fp2_scatter(const Fp<C>& c0, const Fp<C>& c1) {
+  Fp2<C> r;
+  if constexpr (is_paired<C>()) {
+    r.c = fp_select(pair_odd(), c1, c0);
+  } else {
+    r.c0 = c0;
+    r.c1 = c1;
+  }
+  return r;
+}
+// Square root in Fp2 for p = 3 (mod 4) ("complex method").  Returns false when a is not a square.  Paired layout: both lanes run the
+// whole computation on gathered components (decompression only; not on the verification path proper).
+template <class C>
+ELP_HEAVY bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a_in) {
+  const Fp2Full<C> a = fp2_gather<C>(a_in);
   if (fp_is_zero<C>(a.c1)) {
     Fp<C> s;
     if (fp_sqrt<C>(s, a.c0)) {
-      r.c0 = s;
-      r.c1 = fp_zero<C>();
+      r = fp2_scatter<C>(s, fp_zero<C>());
       return true;
     }
     bool ok = fp_sqrt<C>(s, fp_neg(a.c0));
-    r.c0 = fp_zero<C>();
-    r.c1 = s;
+    r = fp2_scatter<C>(fp_zero<C>(), s);
     return ok;
   }
   Fp<C> n;
@@ -231,22 +449,18 @@ ELP_HEAVY bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a) {
     if (!fp_sqrt<C>(x, t)) return false;
   }
   Fp<C> y = fp_mul<C>(a.c1, fp_inv<C>(fp_dbl(x)));
-  r.c0 = x;
-  r.c1 = y;
+  r = fp2_scatter<C>(x, y);
   return true;
 }
 template <class C>
 ELP_INL Fp2<C> fp2_frob_coeff(int n, int k) {  // gamma_{n,k} = xi^(k (p^n - 1)/6), k = 1..5
   Fp2<C> g;
   if (n == 1) {
-    ELP_LOAD_FP(g.c0, C::frob1(k, 0, i_));
-    ELP_LOAD_FP(g.c1, C::frob1(k, 1, i_));
+    ELP_LOAD_FP2(g, C::frob1(k, c_, i_));
   } else if (n == 2) {
-    ELP_LOAD_FP(g.c0, C::frob2(k, 0, i_));
-    ELP_LOAD_FP(g.c1, C::frob2(k, 1, i_));
+    ELP_LOAD_FP2(g, C::frob2(k, c_, i_));
   } else {
-    ELP_LOAD_FP(g.c0, C::frob3(k, 0, i_));
-    ELP_LOAD_FP(g.c1, C::frob3(k, 1, i_));
+    ELP_LOAD_FP2(g, C::frob3(k, c_, i_));
   }
   return g;
 }
@@ -638,9 +852,7 @@ ELP_INL void fp12_cyc_sqr_inl(Fp12<C>& r, const Fp12<C>& a) {
     Fp2<C> o3 = three_minus(n[4], z3);                 // z3' = 3 C0 - 2 z3
     Fp2<C> o4 = three_minus(n[2], z4);                 // z4' = 3 B0 - 2 z4
     Fp2<C> o5 = three_plus(n[3], z5);                  // z5' = 3 B1 + 2 z5
-    fp_reduce_weak(o0.c0); fp_reduce_weak(o0.c1); fp_reduce_weak(o1.c0); fp_reduce_weak(o1.c1);
-    fp_reduce_weak(o2.c0); fp_reduce_weak(o2.c1); fp_reduce_weak(o3.c0); fp_reduce_weak(o3.c1);
-    fp_reduce_weak(o4.c0); fp_reduce_weak(o4.c1); fp_reduce_weak(o5.c0); fp_reduce_weak(o5.c1);
+    fp2_reduce_weak(o0); fp2_reduce_weak(o1); fp2_reduce_weak(o2); fp2_reduce_weak(o3); fp2_reduce_weak(o4); fp2_reduce_weak(o5);
     r.c0.c0 = o0;
     r.c0.c1 = o4;
     r.c0.c2 = o3;
@@ -681,9 +893,7 @@ ELP_INL void fp12_cyc_sqr_inl(Fp12<C>& r, const Fp12<C>& a) {
   (void)t2; (void)t3; (void)t4;
   // every output depends linearly on the matching input coefficient (3 A - 2 z): without a reduction the magnitude
   // would double per squaring (62 consecutive squarings in fp12_exp_absz)
-  fp_reduce_weak(n0.c0); fp_reduce_weak(n0.c1); fp_reduce_weak(n1.c0); fp_reduce_weak(n1.c1);
-  fp_reduce_weak(n2.c0); fp_reduce_weak(n2.c1); fp_reduce_weak(n3.c0); fp_reduce_weak(n3.c1);
-  fp_reduce_weak(n4.c0); fp_reduce_weak(n4.c1); fp_reduce_weak(n5.c0); fp_reduce_weak(n5.c1);
+  fp2_reduce_weak(n0); fp2_reduce_weak(n1); fp2_reduce_weak(n2); fp2_reduce_weak(n3); fp2_reduce_weak(n4); fp2_reduce_weak(n5);
   r.c0.c0 = n0;
   r.c0.c1 = n4;
   r.c0.c2 = n3;
