@@ -25,7 +25,8 @@ def _newest(paths):
 # translation units of libelpasso_hip.so: the two curves compile in parallel (the per-curve units hold the explicit template
 # instantiations of every kernel); per-unit flags: BN254 additionally inlines the Fp6-level routines into Fp12-level leaf
 # functions (+13 % on the verify kernel; on the 14-limb BLS12-381 field it only doubles the compile time).
-HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bls12_381.hip", [])]
+HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_pair.hip", ["-DELP_FP6_INLINE=1"]),
+             ("elpasso_bls12_381.hip", [])]
 
 
 def build_hip(force=False, verbose=False):

@@ -122,4 +122,6 @@ ELP_INL T* hot_as(u32* hot) {   // the BN254 Fp12 fills the slot exactly in eith
 // scalar-field (Fr) Montgomery parameters of a curve; specialised in params_<curve>.h
 template <class C>
 struct FrOf;
+template <class B>
+struct FrOf<Paired<B>> : FrOf<B> {};
 }  // namespace elp

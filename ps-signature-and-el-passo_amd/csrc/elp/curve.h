@@ -6,11 +6,38 @@
 
 namespace elp {
 
-// ---- field-operation adaptors so that the group law is written once for Fp and Fp2
+// limb-for-limb copy between the field types of a curve and of its Paired<> twin (same modulus, same limbs)
+template <class C, class B>
+ELP_INL Fp<C> fp_cast(const Fp<B>& a) {
+  static_assert(C::NL == B::NL && C::LB == B::LB, "same field expected");
+  Fp<C> r;
+  ELP_UNROLL
+  for (int i = 0; i < C::NL; i++) r.v[i] = a.v[i];
+  return r;
+}
+// a plain-layout Fp2 in memory -> the layout of C (paired: this lane's component only)
+template <class C>
+ELP_INL Fp2<C> fp2_from_mem(const Fp2<typename PairInfo<C>::Base>& m) {
+  Fp2<C> r;
+  if constexpr (is_paired<C>()) {
+    r.c = fp_cast<C>(pair_odd() ? m.c1 : m.c0);
+  } else {
+    r = m;
+  }
+  return r;
+}
+
+template <class F>
+struct Aff;
+// ---- field-operation adaptors so that the group law is written once for Fp and Fp2.
+// MemF: the adaptor of the plain (unpaired) layout, in which key tables and bases are kept in HBM whatever layout the kernel computes in.
 template <class C>
 struct F1 {
   typedef Fp<C> T;
   typedef C Curve;
+  typedef F1<typename PairInfo<C>::Base> MemF;
+  static constexpr bool IS_EXT = false;
+  ELP_INL static T from_mem(const typename MemF::T& m) { return fp_cast<C>(m); }
   ELP_INL static T mul(const T& a, const T& b) { return fp_mul<C>(a, b); }
   ELP_INL static T sqr(const T& a) { return fp_sqr<C>(a); }
   ELP_INL static T mul_pair(const T& a, const T& b, const T& c, const T& d) {   // a*b + c*d
@@ -46,6 +73,9 @@ template <class C>
 struct F2 {
   typedef Fp2<C> T;
   typedef C Curve;
+  typedef F2<typename PairInfo<C>::Base> MemF;
+  static constexpr bool IS_EXT = true;
+  ELP_INL static T from_mem(const typename MemF::T& m) { return fp2_from_mem<C>(m); }
   ELP_INL static T mul(const T& a, const T& b) { return fp2_mulv<C>(a, b); }
   ELP_INL static T sqr(const T& a) { return fp2_sqrv<C>(a); }
   ELP_INL static T mul_pair(const T& a, const T& b, const T& c, const T& d) {   // a*b + c*d
@@ -74,8 +104,7 @@ struct F2 {
   ELP_INL static T select(bool c, const T& a, const T& b) { return fp2_select(c, a, b); }
   ELP_INL static T curve_b() {
     T b;
-    ELP_LOAD_FP(b.c0, C::twist_b(0, i_));
-    ELP_LOAD_FP(b.c1, C::twist_b(1, i_));
+    ELP_LOAD_FP2(b, C::twist_b(c_, i_));
     return b;
   }
 };
@@ -89,6 +118,14 @@ struct Jac {  // Jacobian: (X/Z^2, Y/Z^3); Z == 0 encodes infinity
   typename F::T X, Y, Z;
 };
 
+// a table / base entry (plain layout in HBM) -> the kernel's layout
+template <class F>
+ELP_INL Aff<F> aff_from_mem(const Aff<typename F::MemF>& m) {
+  Aff<F> r;
+  r.x = F::from_mem(m.x);
+  r.y = F::from_mem(m.y);
+  return r;
+}
 template <class F>
 ELP_INL bool aff_is_inf(const Aff<F>& p) {
   return F::is_zero_exact(p.x) && F::is_zero_exact(p.y);
@@ -508,14 +545,14 @@ ELP_HEAVY void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar
       if (j != 0) {                        // psi^j on an affine point: (conj^j x * gx_j, conj^j y * gy_j)
         Fp2<C> gx, gy;
         if (j == 1) {
-          ELP_LOAD_FP(gx.c0, C::g2frob(1, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(1, 0, 1, i_));
-          ELP_LOAD_FP(gy.c0, C::g2frob(1, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(1, 1, 1, i_));
+          ELP_LOAD_FP2(gx, C::g2frob(1, 0, c_, i_));
+          ELP_LOAD_FP2(gy, C::g2frob(1, 1, c_, i_));
         } else if (j == 2) {
-          ELP_LOAD_FP(gx.c0, C::g2frob(2, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(2, 0, 1, i_));
-          ELP_LOAD_FP(gy.c0, C::g2frob(2, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(2, 1, 1, i_));
+          ELP_LOAD_FP2(gx, C::g2frob(2, 0, c_, i_));
+          ELP_LOAD_FP2(gy, C::g2frob(2, 1, c_, i_));
         } else {
-          ELP_LOAD_FP(gx.c0, C::g2frob(3, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(3, 0, 1, i_));
-          ELP_LOAD_FP(gy.c0, C::g2frob(3, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(3, 1, 1, i_));
+          ELP_LOAD_FP2(gx, C::g2frob(3, 0, c_, i_));
+          ELP_LOAD_FP2(gy, C::g2frob(3, 1, c_, i_));
         }
         if (j & 1) {
           t.x = fp2_conj(t.x);
@@ -534,7 +571,7 @@ ELP_HEAVY void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar
 // Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,
 // j = 0 .. ceil(256/W)-1.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
 template <class F>
-ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scalar& k, u32* hot = nullptr) {
+ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<typename F::MemF>* table, int W, const Scalar& k, u32* hot = nullptr) {
   const int nwin = (256 + W - 1) / W;
   const int per = (1 << W) - 1;
   Jac<F>* ah = hot_as<Jac<F>, typename F::Curve>(hot);   // the running sum lives in the hot slot while the windows are added (table entries are read in place)
@@ -547,10 +584,12 @@ ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<F>* table, int W, const Scal
     int d = scalar_window(k, bit, w);
     if (d != 0) {
       // the mixed addition is part of this loop for the Fp2 group (as a routine of its own it saves and restores ~170 registers per call)
-      if (sizeof(typename F::T) > sizeof(Fp<typename F::Curve>))
-        jac_madd_inl<F>(a, a, table[(size_t)j * per + (d - 1)]);
-      else
-        jac_madd<F>(a, a, table[(size_t)j * per + (d - 1)]);
+      if constexpr (is_paired<typename F::Curve>()) {
+        const Aff<F> e = aff_from_mem<F>(table[(size_t)j * per + (d - 1)]);
+        if (F::IS_EXT) jac_madd_inl<F>(a, a, e); else jac_madd<F>(a, a, e);
+      } else {
+        if (F::IS_EXT) jac_madd_inl<F>(a, a, table[(size_t)j * per + (d - 1)]); else jac_madd<F>(a, a, table[(size_t)j * per + (d - 1)]);
+      }
     }
   }
   if (ah) acc = a;
@@ -563,14 +602,14 @@ ELP_HEAVY void g2_frob(Aff<F2<C>>& r, const Aff<F2<C>>& q, int n) {
   Fp2<C> y = (n & 1) ? fp2_conj(q.y) : q.y;
   Fp2<C> gx, gy;
   if (n == 1) {
-    ELP_LOAD_FP(gx.c0, C::g2frob(1, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(1, 0, 1, i_));
-    ELP_LOAD_FP(gy.c0, C::g2frob(1, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(1, 1, 1, i_));
+    ELP_LOAD_FP2(gx, C::g2frob(1, 0, c_, i_));
+    ELP_LOAD_FP2(gy, C::g2frob(1, 1, c_, i_));
   } else if (n == 2) {
-    ELP_LOAD_FP(gx.c0, C::g2frob(2, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(2, 0, 1, i_));
-    ELP_LOAD_FP(gy.c0, C::g2frob(2, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(2, 1, 1, i_));
+    ELP_LOAD_FP2(gx, C::g2frob(2, 0, c_, i_));
+    ELP_LOAD_FP2(gy, C::g2frob(2, 1, c_, i_));
   } else {
-    ELP_LOAD_FP(gx.c0, C::g2frob(3, 0, 0, i_)); ELP_LOAD_FP(gx.c1, C::g2frob(3, 0, 1, i_));
-    ELP_LOAD_FP(gy.c0, C::g2frob(3, 1, 0, i_)); ELP_LOAD_FP(gy.c1, C::g2frob(3, 1, 1, i_));
+    ELP_LOAD_FP2(gx, C::g2frob(3, 0, c_, i_));
+    ELP_LOAD_FP2(gy, C::g2frob(3, 1, c_, i_));
   }
   fp2_mul<C>(r.x, x, gx);
   fp2_mul<C>(r.y, y, gy);

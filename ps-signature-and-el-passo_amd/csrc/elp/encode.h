@@ -77,10 +77,50 @@ ELP_HEAVY void g2_serialize(uint8_t* out, const Aff<F2<C>>& p) {
     for (int i = 0; i < 2 * C::FBYTES; i++) out[i] = 0;
     return;
   }
-  StdFp<C> xa = fp_to_std<C>(p.x.c0), xb = fp_to_std<C>(p.x.c1), ya = fp_to_std<C>(p.y.c0);
-  std_store_le<C>(out, xa);
-  std_store_le<C>(out + C::FBYTES, xb);
-  if (ya.w[0] & 1) out[2 * C::FBYTES - 1] |= 0x80;
+  if constexpr (is_paired<C>()) {
+    // each lane canonicalises its own components; the words of the partner's x and the parity of y.a come over by lane exchange, so
+    // both lanes of the pair emit the same bytes
+    const bool odd = pair_odd();
+    StdFp<C> xs = fp_to_std<C>(p.x.c), ys = fp_to_std<C>(p.y.c), xo;
+    for (int i = 0; i < C::N; i++) xo.w[i] = (u32)pair_swap_i32((int32_t)xs.w[i]);
+    const u32 yo = (u32)pair_swap_i32((int32_t)ys.w[0]);
+    std_store_le<C>(out, odd ? xo : xs);
+    std_store_le<C>(out + C::FBYTES, odd ? xs : xo);
+    if ((odd ? yo : ys.w[0]) & 1) out[2 * C::FBYTES - 1] |= 0x80;
+  } else {
+    StdFp<C> xa = fp_to_std<C>(p.x.c0), xb = fp_to_std<C>(p.x.c1), ya = fp_to_std<C>(p.y.c0);
+    std_store_le<C>(out, xa);
+    std_store_le<C>(out + C::FBYTES, xb);
+    if (ya.w[0] & 1) out[2 * C::FBYTES - 1] |= 0x80;
+  }
+}
+// the same wire bytes straight from canonical affine words (x | y for G1, x.a | x.b | y.a | y.b for G2): no field arithmetic.  Used by
+// the paired kernels for the transcript parts that are inputs (k, phi, E1, E2), which every lane can read for itself.
+template <class C>
+ELP_INL void g1_serialize_std(uint8_t* out, const u32* w) {
+  u32 any = 0;
+  for (int i = 0; i < C::N; i++) {
+    const u32 x = w[i];
+    any |= x | w[C::N + i];
+    out[4 * i] = (uint8_t)x;
+    out[4 * i + 1] = (uint8_t)(x >> 8);
+    out[4 * i + 2] = (uint8_t)(x >> 16);
+    out[4 * i + 3] = (uint8_t)(x >> 24);
+  }
+  if (any && (w[C::N] & 1)) out[C::FBYTES - 1] |= 0x80;
+}
+template <class C>
+ELP_INL void g2_serialize_std(uint8_t* out, const u32* w) {
+  u32 any = 0;
+  for (int i = 0; i < 2 * C::N; i++) {
+    const u32 x = w[i];
+    any |= x | w[2 * C::N + i];
+    out[4 * i] = (uint8_t)x;
+    out[4 * i + 1] = (uint8_t)(x >> 8);
+    out[4 * i + 2] = (uint8_t)(x >> 16);
+    out[4 * i + 3] = (uint8_t)(x >> 24);
+  }
+  if (any && (w[2 * C::N] & 1)) out[2 * C::FBYTES - 1] |= 0x80;
 }
 // Decompression; returns false for x >= p or x not on the curve.  (mcl ignores such failures at
 // src/ps-encoding.cc:192,224; we surface them and let the caller reject the item.)
@@ -128,13 +168,11 @@ ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in) {
   tmp[2 * C::FBYTES - 1] &= 0x7f;
   StdFp<C> xa = std_load_le<C>(tmp), xb = std_load_le<C>(tmp + C::FBYTES);
   if (!std_in_range<C>(xa) || !std_in_range<C>(xb)) return false;
-  Fp2<C> x;
-  x.c0 = fp_from_std<C>(xa);
-  x.c1 = fp_from_std<C>(xb);
+  Fp2<C> x = fp2_scatter<C>(fp_from_std<C>(xa), fp_from_std<C>(xb));
   Fp2<C> rhs = fp2_add(fp2_mulv<C>(fp2_sqrv<C>(x), x), F2<C>::curve_b());
   Fp2<C> y;
   if (!fp2_sqrt<C>(y, rhs)) return false;
-  StdFp<C> ya = fp_to_std<C>(y.c0);
+  StdFp<C> ya = fp_to_std<C>(fp2_gather<C>(y).c0);
   if (((ya.w[0] & 1) != 0) != odd) y = fp2_neg(y);
   p.x = x;
   p.y = y;

@@ -19,9 +19,23 @@ struct LineCoef {  // un-evaluated line: (a * y_P, b * x_P, c)
 template <class C>
 ELP_INL Fp2<C> fp2_twist_3b() {
   Fp2<C> b;
-  ELP_LOAD_FP(b.c0, C::twist_3b(0, i_));
-  ELP_LOAD_FP(b.c1, C::twist_3b(1, i_));
+  ELP_LOAD_FP2(b, C::twist_3b(c_, i_));
   return b;
+}
+// precomputed lines are kept in the plain layout in HBM (built once per key by the unpaired set-up kernel)
+template <class C>
+using LineMem = LineCoef<typename PairInfo<C>::Base>;
+template <class C>
+ELP_INL decltype(auto) line_from_mem(const LineMem<C>& m) {   // plain layout: the entry itself (no copy); paired: this lane's components
+  if constexpr (is_paired<C>()) {
+    LineCoef<C> l;
+    l.a = fp2_from_mem<C>(m.a);
+    l.b = fp2_from_mem<C>(m.b);
+    l.c = fp2_from_mem<C>(m.c);
+    return l;
+  } else {
+    return (m);
+  }
 }
 
 // Tangent line at T and T <- 2T.   line = 2YZ * y_P  -  3X^2 * x_P  +  (Y^2 - 3b'Z^2)
@@ -190,7 +204,7 @@ ELP_HEAVY void ml_precompute(LineCoef<C>* out, const Aff<F2<C>>& q) {
 #endif
 template <class C, int NV, int NF>
 ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* qv, const Aff<F1<C>>* pf,
-                           const LineCoef<C>* const* lines) {
+                           const LineMem<C>* const* lines) {
   G2Proj<C> T[NV > 0 ? NV : 1];
   Fp2<C> nqy[NV > 0 ? NV : 1];
   bool live_v[NV > 0 ? NV : 1];
@@ -232,7 +246,7 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
             const Fp2<C> yq = fp2_select(d > 0, qv[0].y, nqy[0]);
             ml_add_step_inl<C>(T[0], l, qv[0].x, yq);
           }
-          const LineCoef<C>& lf = lines[0][n];
+          const LineCoef<C>& lf = line_from_mem<C>(lines[0][n]);
           fp12_mul_by_two_lines_inl<C>(fw, fp2_mul_fp(l.a, pv[0].y), fp2_mul_fp(l.b, pv[0].x), l.c, fp2_mul_fp(lf.a, pf[0].y),
                                        fp2_mul_fp(lf.b, pf[0].x), lf.c);
           n++;
@@ -253,7 +267,7 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
       ELP_UNROLL
       for (int k = 0; k < NF; k++) {
         if (!live_f[k]) continue;
-        if (FUSE) ml_apply_line_inl<C>(fw, lines[k][n], pf[k].x, pf[k].y); else ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
+        if (FUSE) ml_apply_line_inl<C>(fw, line_from_mem<C>(lines[k][n]), pf[k].x, pf[k].y); else ml_apply_line<C>(f, line_from_mem<C>(lines[k][n]), pf[k].x, pf[k].y);
       }
       n++;
     }
@@ -274,8 +288,8 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
       }
     for (int k = 0; k < NF; k++)
       if (live_f[k]) {
-        ml_apply_line<C>(f, lines[k][n], pf[k].x, pf[k].y);
-        ml_apply_line<C>(f, lines[k][n + 1], pf[k].x, pf[k].y);
+        ml_apply_line<C>(f, line_from_mem<C>(lines[k][n]), pf[k].x, pf[k].y);
+        ml_apply_line<C>(f, line_from_mem<C>(lines[k][n + 1]), pf[k].x, pf[k].y);
       }
   }
 }

@@ -31,11 +31,12 @@ struct KeyCtx {
   int A;                          // attributes in the key
   int W;                          // fixed-base window width
   int nwin, per;                  // windows per scalar, entries per window
-  const Aff<F1<C>>* t1;           // G1 tables: base b at t1 + b * nwin * per
-  const Aff<F2<C>>* t2;           // G2 tables
-  const Aff<F1<C>>* b1;           // G1 bases (affine):  0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X (signer secret)
-  const Aff<F2<C>>* b2;           // G2 bases (affine):  0 = gg, 1 = XX, 2+i = YY_i
-  const LineCoef<C>* gg_lines;    // precomputed Miller lines of gg
+  // key material lives in HBM in the PLAIN layout (built by the unpaired set-up kernels) whatever layout C computes in
+  const Aff<typename F1<C>::MemF>* t1;   // G1 tables: base b at t1 + b * nwin * per
+  const Aff<typename F2<C>::MemF>* t2;   // G2 tables
+  const Aff<typename F1<C>::MemF>* b1;   // G1 bases (affine):  0 = g, 1+i = Y_i, A+1 = H1(service), A+2 = g_eg, A+3 = authority_pk, A+4 = h, A+5 = X (signer secret)
+  const Aff<typename F2<C>::MemF>* b2;   // G2 bases (affine):  0 = gg, 1 = XX, 2+i = YY_i
+  const LineMem<C>* gg_lines;            // precomputed Miller lines of gg
   u32* hot = nullptr;             // this lane's LDS hot slot (ELP_HOT_WORDS words) or null, see common.h
   int flags = 0;                  // KEY_STRICT_SIG: proofs with sig1 == infinity are rejected (PS / EL PASSO require sigma_1 != 1)
 };
@@ -93,6 +94,18 @@ ELP_HEAVY bool g1_load(Aff<F1<C>>& p, const u32* w) {
 }
 template <class C>
 ELP_HEAVY bool g2_load(Aff<F2<C>>& p, const u32* w) {
+  if constexpr (is_paired<C>()) {   // each lane takes its own components; validity is agreed on by the pair
+    const int o = pair_odd() ? C::N : 0;
+    StdFp<C> x = fp_load_w<C>(w + o), y = fp_load_w<C>(w + 2 * C::N + o);
+    if (pair_and(std_is_zero(x) && std_is_zero(y))) {
+      aff_set_inf(p);
+      return true;
+    }
+    if (!pair_and(std_in_range<C>(x) && std_in_range<C>(y))) return false;
+    p.x.c = fp_from_std<C>(x);
+    p.y.c = fp_from_std<C>(y);
+    return aff_on_curve<F2<C>>(p);
+  } else {
   StdFp<C> a = fp_load_w<C>(w), b = fp_load_w<C>(w + C::N), c = fp_load_w<C>(w + 2 * C::N), d = fp_load_w<C>(w + 3 * C::N);
   if (std_is_zero(a) && std_is_zero(b) && std_is_zero(c) && std_is_zero(d)) {
     aff_set_inf(p);
@@ -104,6 +117,7 @@ ELP_HEAVY bool g2_load(Aff<F2<C>>& p, const u32* w) {
   p.y.c0 = fp_from_std<C>(c);
   p.y.c1 = fp_from_std<C>(d);
   return aff_on_curve<F2<C>>(p);
+  }
 }
 template <class C>
 ELP_HEAVY void g1_store(u32* w, const Aff<F1<C>>& p) {
@@ -116,6 +130,16 @@ ELP_HEAVY void g1_store(u32* w, const Aff<F1<C>>& p) {
 }
 template <class C>
 ELP_HEAVY void g2_store(u32* w, const Aff<F2<C>>& p) {
+  if constexpr (is_paired<C>()) {   // the two lanes write disjoint halves of the record
+    const int o = pair_odd() ? C::N : 0;
+    if (aff_is_inf(p)) {
+      for (int i = 0; i < C::N; i++) w[o + i] = w[2 * C::N + o + i] = 0;
+      return;
+    }
+    fp_store_w<C>(w + o, fp_to_std<C>(p.x.c));
+    fp_store_w<C>(w + 2 * C::N + o, fp_to_std<C>(p.y.c));
+    return;
+  } else {
   if (aff_is_inf(p)) {
     for (int i = 0; i < 4 * C::N; i++) w[i] = 0;
     return;
@@ -124,13 +148,18 @@ ELP_HEAVY void g2_store(u32* w, const Aff<F2<C>>& p) {
   fp_store_w<C>(w + C::N, fp_to_std<C>(p.x.c1));
   fp_store_w<C>(w + 2 * C::N, fp_to_std<C>(p.y.c0));
   fp_store_w<C>(w + 3 * C::N, fp_to_std<C>(p.y.c1));
+  }
 }
 template <class C>
 ELP_HEAVY void gt_store(u32* w, const Fp12<C>& f) {  // order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (each a, b)
   const Fp2<C>* e[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
   for (int i = 0; i < 6; i++) {
-    fp_store_w<C>(w + (2 * i) * C::N, fp_to_std<C>(e[i]->c0));
-    fp_store_w<C>(w + (2 * i + 1) * C::N, fp_to_std<C>(e[i]->c1));
+    if constexpr (is_paired<C>()) {
+      fp_store_w<C>(w + (2 * i + (pair_odd() ? 1 : 0)) * C::N, fp_to_std<C>(e[i]->c));
+    } else {
+      fp_store_w<C>(w + (2 * i) * C::N, fp_to_std<C>(e[i]->c0));
+      fp_store_w<C>(w + (2 * i + 1) * C::N, fp_to_std<C>(e[i]->c1));
+    }
   }
 }
 
@@ -151,7 +180,7 @@ ELP_HEAVY void batch_zinv(Fp<C>* zi1, const Fp<C>* z1, Fp2<C>* zi2, const Fp2<C>
   Fp<C> v[NT], pre[NT];
   for (int i = 0; i < N1; i++) v[i] = fp_is_zero_exact(z1[i]) ? fp_one<C>() : z1[i];
   for (int i = 0; i < N2; i++) {
-    Fp<C> n = fp_add(fp_sqr<C>(z2[i].c0), fp_sqr<C>(z2[i].c1));   // norm (exactly 0 for the literal zero of infinity)
+    Fp<C> n = fp2_norm<C>(z2[i]);   // norm (exactly 0 for the literal zero of infinity); paired: the same value on both lanes
     v[N1 + i] = fp_is_zero_exact(n) ? fp_one<C>() : n;
   }
   Fp<C> acc = fp_one<C>();
@@ -166,9 +195,7 @@ ELP_HEAVY void batch_zinv(Fp<C>* zi1, const Fp<C>* z1, Fp2<C>* zi2, const Fp2<C>
     if (i < N1) {
       zi1[i] = vi;
     } else {
-      const Fp2<C>& z = z2[i - N1];
-      zi2[i - N1].c0 = fp_mul<C>(z.c0, vi);
-      zi2[i - N1].c1 = fp_neg(fp_mul<C>(z.c1, vi));
+      zi2[i - N1] = fp2_conj_mul_fp<C>(z2[i - N1], vi);
     }
   }
 }
@@ -404,7 +431,7 @@ ELP_HEAVY bool ps_pairing_check(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, co
   Fp12<C> f_priv, g;
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& f = fh ? *fh : f_priv;
-  const LineCoef<C>* lines[1] = {key.gg_lines};
+  const LineMem<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
   final_exp<C>(g, f, key.hot);
   return fp12_is_one(g);
@@ -459,7 +486,7 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   jac_to_aff<F1<C>>(aP, P);
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& fm = fh ? *fh : f;
-  const LineCoef<C>* no_lines[1] = {key.gg_lines};          // never read (no fixed pair); real pointers keep the fused loop compilable
+  const LineMem<C>* no_lines[1] = {key.gg_lines};          // never read (no fixed pair); real pointers keep the fused loop compilable
   miller_loop<C, 1, 0>(fm, &aP, &aK, &aP, no_lines);
   if (fh) f = fm;
   for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
@@ -476,6 +503,181 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   RecordSrc<C> src;
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   return verify_id_core<C, RecordSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// EL PASSO VerifyID in the PAIRED layout (C = Paired<B>, two lanes per proof; common.h "Lane pairs").  Same record, same verdicts.
+//   * everything over Fp2 -- [c]k by GLS, the ten fixed-base G2 terms, K, the Miller loop and the final exponentiation -- is computed by
+//     the pair together, each lane holding one component;
+//   * the G1 work is split by job: the even lane computes V_phi and V_E1, the odd lane V_E2 (same instruction stream, different points,
+//     bases and scalars), so the three GLV multiplications cost the time of two;
+//   * the transcript is hashed by both lanes (identical bytes): inputs are serialised straight from the record words, V_k by
+//     g2_serialize's exchange, the three G1 commitments are swapped between the lanes as wire bytes.
+template <class C>
+ELP_INL Scalar scalar_select(bool c, const Scalar& a, const Scalar& b) {
+  Scalar r;
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+template <class C>
+ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const Aff<F1<C>>& P0,
+                                     const Aff<F1<C>>& P1, const Aff<F2<C>>& kk, const Scalar& c, const uint8_t* ad, size_t ad_len,
+                                     Aff<F2<C>>& aK) {
+  static_assert(is_paired<C>(), "paired layout only");
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  const bool odd = pair_odd();
+  const int A = key.A;
+  int H = 0;
+  for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+  const int nrs = H + (retr ? 2 : 1);
+  const int G1W = 2 * C::N, G2W = 4 * C::N;
+  const u32* w_phi = rec + 2 * G1W;
+  const u32* w_k = rec + (retr ? 5 : 3) * G1W;
+  const u32* w_rs = w_k + G2W + 8;
+  const u32* w_ms = w_rs + 8 * nrs;
+  const Scalar r_t = scalar_load_w(w_rs + 8 * (retr ? nrs - 2 : nrs - 1));
+  const Scalar r_e = scalar_load_w(w_rs + 8 * (nrs - 1));        // used only with retrieval
+  Scalar one;
+  for (int i = 0; i < 8; i++) one.v[i] = 0;
+  one.v[0] = 1;
+  Scalar cred = c;
+  if (scalar_geq_r<C>(cred)) {
+    Scalar rr;
+    for (int i = 0; i < 8; i++) rr.v[i] = C::rmod(i);
+    cred = scalar_sub_mod_r<C>(cred, rr);
+  }
+  const Scalar one_minus_c = scalar_sub_mod_r<C>(one, cred);
+  // tables 1P .. 8P of k (pair), of this lane's first G1 point and (with retrieval) of its second one; ONE inversion per lane
+  Aff<G2F> tabk[8];
+  Aff<G1F> tab0[8], tab1[8];
+  {
+    Jac<G2F> jk[8];
+    Jac<G1F> j0[8], j1[8];
+    jac_multiples8<G2F>(jk, kk);
+    jac_multiples8<G1F>(j0, P0);
+    if (retr) jac_multiples8<G1F>(j1, P1);
+    Fp<C> z1[14], zi1[14];
+    Fp2<C> z2[7], zi2[7];
+    for (int i = 1; i < 8; i++) {
+      z1[i - 1] = j0[i].Z;
+      z1[7 + i - 1] = retr ? j1[i].Z : fp_one<C>();
+      z2[i - 1] = jk[i].Z;
+    }
+    batch_zinv<C, 14, 7>(zi1, z1, zi2, z2);
+    tabk[0] = kk;
+    tab0[0] = P0;
+    tab1[0] = P1;
+    for (int i = 1; i < 8; i++) {
+      jac_to_aff_with_zinv<G2F>(tabk[i], jk[i], zi2[i - 1]);
+      jac_to_aff_with_zinv<G1F>(tab0[i], j0[i], zi1[i - 1]);
+      if (retr) jac_to_aff_with_zinv<G1F>(tab1[i], j1[i], zi1[7 + i - 1]);
+    }
+  }
+  // G2, by the pair:  V_k = k^c prod_{hidden} YY_j^{r_j} gg^{r_t} XX^{1-c},  K = k prod_{revealed} YY_i^{m_i}     (src/ps-verifier.cc:72-88,214-229)
+  Jac<G2F> Vk, K;
+  g2_mul_gls_tab<C>(Vk, tabk, c);
+  jac_from_aff(K, kk);
+  {
+    int jh = 0, jr = 0;
+    for (int i = 0; i < A; i++) {
+      if ((hidden_mask >> i) & 1) {
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, scalar_load_w(w_rs + 8 * jh));
+        jh++;
+      } else {
+        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(w_ms + 8 * jr));
+        jr++;
+      }
+    }
+  }
+  acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
+  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
+  // G1, one job list per lane.  even: V_phi = phi^c H1(svc)^{r_0}, V_E1 = E1^c g^{r_eps};  odd: V_E2 = E2^c y^{r_eps} h^{r_1}   (:91-108)
+  Jac<G1F> V0, V1;
+  g1_mul_glv_tab<C>(V0, tab0, c);
+  if (!odd || retr) {
+    const int b0 = odd ? g1_base_apk(key) : g1_base_hs(key);
+    acc_fixed_g1<C>(V0, key, b0, scalar_select<C>(odd, r_e, scalar_load_w(w_rs)));
+  }
+  if (odd && retr) acc_fixed_g1<C>(V0, key, g1_base_h(key), scalar_load_w(w_rs + 8));
+  if (retr) {
+    g1_mul_glv_tab<C>(V1, tab1, c);
+    if (!odd) acc_fixed_g1<C>(V1, key, g1_base_geg(key), r_e);
+  } else {
+    jac_set_inf(V1);
+  }
+  // canonical affine forms: one inversion per lane
+  Fp<C> z1[2], zi1[2];
+  Fp2<C> z2[2], zi2[2];
+  z1[0] = V0.Z;
+  z1[1] = V1.Z;
+  z2[0] = Vk.Z;
+  z2[1] = K.Z;
+  batch_zinv<C, 2, 2>(zi1, z1, zi2, z2);
+  Aff<G2F> aVk;
+  Aff<G1F> a0, a1;
+  jac_to_aff_with_zinv<G2F>(aVk, Vk, zi2[0]);
+  jac_to_aff_with_zinv<G2F>(aK, K, zi2[1]);
+  jac_to_aff_with_zinv<G1F>(a0, V0, zi1[0]);
+  jac_to_aff_with_zinv<G1F>(a1, V1, zi1[1]);
+  // this lane's two commitments as wire bytes, and the partner's
+  uint8_t mine[2][C::FBYTES], theirs[2][C::FBYTES];
+  g1_serialize<C>(mine[0], a0);
+  g1_serialize<C>(mine[1], a1);
+  for (int q = 0; q < 2; q++)
+    for (int i = 0; i < C::FBYTES; i += 4) {
+      const u32 wv = (u32)mine[q][i] | ((u32)mine[q][i + 1] << 8) | ((u32)mine[q][i + 2] << 16) | ((u32)mine[q][i + 3] << 24);
+      const u32 pv = (u32)pair_swap_i32((int32_t)wv);
+      theirs[q][i] = (uint8_t)pv;
+      theirs[q][i + 1] = (uint8_t)(pv >> 8);
+      theirs[q][i + 2] = (uint8_t)(pv >> 16);
+      theirs[q][i + 3] = (uint8_t)(pv >> 24);
+    }
+  // c' = Hr(SHA256(hex k | hex phi | [hex E1 | hex E2] | hex V_k | hex V_phi | [hex V_E1 | hex V_E2] | ad))          (:111-122)
+  uint8_t buf[2 * C::FBYTES];
+  Transcript t;
+  transcript_init(t);
+  g2_serialize_std<C>(buf, w_k);
+  sha256_update_hex(t.s, buf, 2 * C::FBYTES);
+  g1_serialize_std<C>(buf, w_phi);
+  sha256_update_hex(t.s, buf, C::FBYTES);
+  if (retr) {
+    g1_serialize_std<C>(buf, w_phi + G1W);
+    sha256_update_hex(t.s, buf, C::FBYTES);
+    g1_serialize_std<C>(buf, w_phi + 2 * G1W);
+    sha256_update_hex(t.s, buf, C::FBYTES);
+  }
+  transcript_g2<C>(t, aVk);
+  sha256_update_hex(t.s, odd ? theirs[0] : mine[0], C::FBYTES);          // V_phi (even lane's first job)
+  if (retr) {
+    sha256_update_hex(t.s, odd ? theirs[1] : mine[1], C::FBYTES);        // V_E1  (even lane's second job)
+    sha256_update_hex(t.s, odd ? mine[0] : theirs[0], C::FBYTES);        // V_E2  (odd lane's first job)
+  }
+  const Scalar c2 = transcript_challenge<C>(t, ad, ad_len);
+  return scalar_eq(c2, c);
+}
+
+template <class C>
+ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len) {
+  static_assert(is_paired<C>(), "paired layout only");
+  const bool odd = pair_odd();
+  const int G1W = 2 * C::N;
+  Aff<F1<C>> sig1, sig2, P0, P1;
+  Aff<F2<C>> kk, aK;
+  // both lanes need sig1 / sig2 (line evaluation); the NIZK points go to the lane that works on them: even phi, E1; odd E2
+  bool ok = g1_load<C>(sig1, rec);
+  ok &= g1_load<C>(sig2, rec + G1W);
+  aff_set_inf(P0);
+  aff_set_inf(P1);
+  if (!odd || retr) ok &= g1_load<C>(P0, rec + (odd ? 4 : 2) * G1W);
+  if (!odd && retr) ok &= g1_load<C>(P1, rec + 3 * G1W);
+  ok = pair_and(ok);
+  const bool okk = g2_load<C>(kk, rec + (retr ? 5 : 3) * G1W);
+  if (!ok || !okk) return false;
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
+  const Scalar c = scalar_load_w(rec + (retr ? 5 : 3) * G1W + 4 * C::N);
+  if (!verify_id_paired_nizk<C>(key, rec, hidden_mask, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
+  return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
 
 // ---- wire ingest (SURVEY.md section 8f rank 1 + 2): T-L-V parsing, point decompression (one Fp / Fp2 square root each) and
@@ -620,7 +822,7 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   if (aff_is_inf(sig1)) return false;                       // src/ps-verifier.cc:16-18
   const u32* ms = rec + 4 * C::N;
   Jac<G2F> K;
-  jac_from_aff(K, key.b2[G2_BASE_XX]);
+  jac_from_aff(K, aff_from_mem<G2F>(key.b2[G2_BASE_XX]));
   for (int i = 0; i < nattr; i++) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(ms + 8 * i));
   Aff<G2F> aK;
   jac_to_aff<G2F>(aK, K);
@@ -630,7 +832,7 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   Fp12<C> f_priv, g;
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& f = fh ? *fh : f_priv;
-  const LineCoef<C>* lines[1] = {key.gg_lines};
+  const LineMem<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
   final_exp<C>(g, f, key.hot);
   return fp12_is_one(g);
@@ -688,7 +890,7 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
   Jac<G1F> s1, s2;
   jac_set_inf(s1);
   acc_fixed_g1<C>(s1, key, G1_BASE_G, u);
-  jac_madd<G1F>(Ap, Ap, key.b1[g1_base_skx(key)]);
+  jac_madd<G1F>(Ap, Ap, aff_from_mem<G1F>(key.b1[g1_base_skx(key)]));
   Aff<G1F> aAp;
   jac_to_aff<G1F>(aAp, Ap);
   g1_mul_glv<C>(s2, aAp, u, key.hot);
@@ -831,8 +1033,8 @@ ELP_HEAVY bool prove_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_ma
   }
   // k = XX prod YY_j^{m_j} gg^t ; V_k = XX prod YY_j^{rho_j} gg^{rho_t}     :189-204, :227-246
   Jac<G2F> kk, Vk;
-  jac_from_aff(kk, key.b2[G2_BASE_XX]);
-  jac_from_aff(Vk, key.b2[G2_BASE_XX]);
+  jac_from_aff(kk, aff_from_mem<G2F>(key.b2[G2_BASE_XX]));
+  jac_from_aff(Vk, aff_from_mem<G2F>(key.b2[G2_BASE_XX]));
   {
     int j = 0;
     for (int i = 0; i < A; i++)

@@ -1,0 +1,7 @@
+// Paired-layout kernels for BN254 (two lanes per item, elp/common.h "Lane pairs"): a translation unit of their own so that they
+// compile in parallel with the plain-layout kernels.
+#define ELP_PAIR_TU 1
+#include "elpasso_impl.h"
+
+template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);

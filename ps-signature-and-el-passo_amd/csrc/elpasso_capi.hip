@@ -72,6 +72,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   elp_ctx* c = new elp_ctx();
   c->curve = curve;
   c->device = device;
+  if (const char* e = getenv("ELP_LAYOUT")) c->paired = strcmp(e, "plain") != 0;     // A/B runs: ELP_LAYOUT=plain
   if (hipStreamCreate(&c->stream) != hipSuccess) {
     delete c;
     return ELP_ERR_HIP;
@@ -95,6 +96,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
   if (!c) return ELP_ERR_ARG;
   switch (option) {
     case ELP_OPT_STRICT_SIGNATURE: c->strict_sig = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_PAIRED_LAYOUT: c->paired = value ? 1 : 0; return ELP_OK;
     default: return ELP_ERR_ARG;
   }
 }

@@ -6,6 +6,7 @@
 // One independent item (credential / proof / point) per lane; all arithmetic lives in elp/*.h.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/random.h>
 
@@ -88,6 +89,43 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_verify(KeyCtx<C> key, const u32* recs, in
     flags[i] = ok ? 1 : 0;
   }
   count_accept(ok, accepted);
+}
+
+// ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
+// waves per SIMD; the LDS hot slot is half as large per lane (8 workgroups x 13.5 KB per CU).
+#define ELP_PAIR_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK, 2)
+#define ELP_HOT_SETUP_PAIRED(key)                                                                    \
+  __shared__ __attribute__((aligned(16))) u32 elp_hot_lds[ELP_BLOCK * elp::ELP_HOT_WORDS_PAIRED];  \
+  (key).hot = elp_hot_lds + threadIdx.x * elp::ELP_HOT_WORDS_PAIRED
+__device__ __forceinline__ void count_accept_paired(bool ok, unsigned long long* counter) {
+  unsigned long long b = __ballot(ok && (threadIdx.x & 1) == 0);
+  if ((threadIdx.x & 63) == 0 && b != 0 && counter) atomicAdd(counter, (unsigned long long)__popcll(b));
+}
+template <class C>
+__global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_paired(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
+                                                          const u32* ad_off, u32 ad_len, uint8_t* flags, unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP_PAIRED(key);
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = verify_id_item_paired<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al);
+    if ((threadIdx.x & 1) == 0) flags[i] = ok ? 1 : 0;
+  }
+  count_accept_paired(ok, accepted);
+}
+template <class C>
+__global__ void ELP_PAIR_LAUNCH_BOUNDS k_ps_verify_paired(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* flags,
+                                                          unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP_PAIRED(key);
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  bool ok = false;
+  if (i < n) {
+    ok = ps_verify_item<C>(key, recs + i * (size_t)rec_words, nattr);
+    if ((threadIdx.x & 1) == 0) flags[i] = ok ? 1 : 0;
+  }
+  count_accept_paired(ok, accepted);
 }
 
 template <class C>
@@ -629,6 +667,7 @@ struct elp_ctx {
   bool retr_set = false;      // ... and all of g, authority_pk, h (needed by the id-retrieval variants)
   bool sk_set = false;        // elp_set_signer_secret installed X
   int strict_sig = 1;         // ELP_OPT_STRICT_SIGNATURE
+  int paired = 1;             // ELP_OPT_PAIRED_LAYOUT: verification kernels in the two-lanes-per-item layout where the build has them
   // workspace of the aggregated verification (grown on demand, reused across calls)
   void* agg_ws = nullptr;
   size_t agg_ws_bytes = 0;
@@ -647,17 +686,17 @@ struct elp_ctx {
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + ELP_BLOCK - 1) / ELP_BLOCK); }
 
 template <class C>
-static KeyCtx<C> make_key(const elp_ctx* c) {
+static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key material is the same plain-layout memory
   KeyCtx<C> k;
   k.A = c->A;
   k.W = c->W;
   k.nwin = c->nwin;
   k.per = c->per;
-  k.t1 = (const Aff<F1<C>>*)c->t1;
-  k.t2 = (const Aff<F2<C>>*)c->t2;
-  k.b1 = (const Aff<F1<C>>*)c->b1;
-  k.b2 = (const Aff<F2<C>>*)c->b2;
-  k.gg_lines = (const LineCoef<C>*)c->lines;
+  k.t1 = (const Aff<typename F1<C>::MemF>*)c->t1;
+  k.t2 = (const Aff<typename F2<C>::MemF>*)c->t2;
+  k.b1 = (const Aff<typename F1<C>::MemF>*)c->b1;
+  k.b2 = (const Aff<typename F2<C>::MemF>*)c->b2;
+  k.gg_lines = (const LineMem<C>*)c->lines;
   k.flags = c->strict_sig ? KEY_STRICT_SIG : 0;
   return k;
 }
@@ -1154,6 +1193,33 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   return ELP_OK;
 }
 
+// Which curves have the paired kernels in this build (their own translation unit, elpasso_<curve>_pair.hip).
+template <class B>
+struct PairedBuild {
+  static constexpr bool value = false;
+};
+template <>
+struct PairedBuild<BN254> {
+  static constexpr bool value = true;
+};
+static inline unsigned grid_for_paired(size_t n) { return (unsigned)((2 * n + ELP_BLOCK - 1) / ELP_BLOCK); }
+template <class B>
+void launch_verify_id_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr,
+                             const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  hipLaunchKernelGGL((k_verify_id_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
+                     (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
+                     (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+}
+template <class B>
+void launch_ps_verify_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
+  hipLaunchKernelGGL((k_ps_verify_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
+                     (const u32*)d_records, 4 * B::N + 8 * nattr, nattr, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+}
+#ifndef ELP_PAIR_TU
+extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+#endif
+
 template <class C>
 int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
                             const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
@@ -1163,6 +1229,13 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   const int H = popcount_mask(mask, c->A);
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
+  if constexpr (PairedBuild<C>::value) {
+    if (c->paired) {
+      launch_verify_id_paired<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+      HIPCHK(c, hipGetLastError());
+      return ELP_OK;
+    }
+  }
   hipLaunchKernelGGL((k_verify_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
                      (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
@@ -1188,6 +1261,13 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (rc) return rc;
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
+  if constexpr (PairedBuild<C>::value) {
+    if (c->paired) {
+      launch_ps_verify_paired<C>(c, (hipStream_t)stream, n, d_records, nattr, d_flags, d_accepted);
+      HIPCHK(c, hipGetLastError());
+      return ELP_OK;
+    }
+  }
   hipLaunchKernelGGL((k_ps_verify<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
                      (const u32*)d_records, 4 * C::N + 8 * nattr, nattr, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
   HIPCHK(c, hipGetLastError());

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("ELP_LIB") or os.path.join(HERE, "csrc", "libelpasso_h
 CURVE_BN254 = 0
 CURVE_BLS12_381 = 1
 OPT_STRICT_SIGNATURE = 1
+OPT_PAIRED_LAYOUT = 2
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -144,6 +145,10 @@ class Context:
     def set_strict_signature(self, on):
         """ELP_OPT_STRICT_SIGNATURE (default on): reject sig1 == infinity in verify_id; off = the reference's behaviour."""
         self._chk(self.lib.elp_set_option(self.h, OPT_STRICT_SIGNATURE, int(bool(on))))
+
+    def set_paired_layout(self, on):
+        """ELP_OPT_PAIRED_LAYOUT (default on): two-lanes-per-item verification kernels where the build has them; same results."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_PAIRED_LAYOUT, int(bool(on))))
 
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
         A = len(Yi) // self.G1

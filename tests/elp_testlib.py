@@ -131,7 +131,7 @@ def build_twin(so, flags):
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("host twin build failed")
-    subprocess.check_call(["g++", "-shared", "-o", so] + objs)
+    subprocess.check_call(["g++", "-shared", "-o", so] + objs + ["-lpthread"])
     for o in objs:
         os.remove(o)
 

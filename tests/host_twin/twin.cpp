@@ -1,8 +1,13 @@
 // TEST INFRASTRUCTURE ONLY: host (g++) build of the device arithmetic headers under
 // ps-signature-and-el-passo_amd/csrc/elp/, so the formulas can be unit-tested against the oracle in a container
 // that has no GPU.  This library is never linked into, or called from, the product (libelpasso_hip.so).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "elp/pipeline.h"
@@ -294,6 +299,138 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     return provide_id_item<C>(((TwinCtx<C>*)c)->key, rec, mask, ad, adlen, out) ? 1 : 0;                               \
   }                                                                                                                    \
   }
+
+// ---- lane pairs on the host: the two lanes of a pair are two threads; every exchange is a rendezvous (two barriers), so paired code
+// whose lanes take different paths around an exchange hangs here (reported after 60 s) instead of silently reading garbage.
+struct PairBus {
+  std::atomic<int> count{0};
+  std::atomic<int> sense{0};
+  void* slot[2] = {nullptr, nullptr};
+  size_t bytes[2] = {0, 0};
+};
+static thread_local PairBus* tl_bus = nullptr;
+static void pair_barrier(PairBus* b) {
+  const int s = b->sense.load(std::memory_order_acquire);
+  if (b->count.fetch_add(1, std::memory_order_acq_rel) == 1) {
+    b->count.store(0, std::memory_order_relaxed);
+    b->sense.store(1 - s, std::memory_order_release);
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (b->sense.load(std::memory_order_acquire) == s) {
+    if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+      fprintf(stderr, "host twin: the lanes of a pair diverged around an exchange (partner never arrived)\n");
+      abort();
+    }
+  }
+}
+static void pair_exchange(void* buf, size_t bytes) {
+  PairBus* b = tl_bus;
+  const int me = elp_pair_parity;
+  b->slot[me] = buf;
+  b->bytes[me] = bytes;
+  pair_barrier(b);
+  if (b->bytes[1 - me] != bytes) {
+    fprintf(stderr, "host twin: exchange size mismatch between the lanes of a pair\n");
+    abort();
+  }
+  unsigned char tmp[256];
+  memcpy(tmp, b->slot[1 - me], bytes);
+  pair_barrier(b);
+  memcpy(buf, tmp, bytes);
+}
+template <class Fn>
+static int run_pair(Fn fn) {   // fn(parity) -> int; both lanes must agree
+  PairBus bus;
+  int res[2] = {-1, -2};
+  auto lane = [&](int parity) {
+    elp_pair_parity = parity;
+    tl_bus = &bus;
+    elp_pair_exchange_hook = pair_exchange;
+    res[parity] = fn(parity);
+  };
+  std::thread t1(lane, 1);
+  lane(0);
+  t1.join();
+  elp_pair_parity = 0;
+  if (res[0] != res[1]) {
+    fprintf(stderr, "host twin: the lanes of a pair returned different verdicts (%d, %d)\n", res[0], res[1]);
+    return -100;
+  }
+  return res[0];
+}
+
+#if !defined(TWIN_PART) || TWIN_PART == 1
+typedef Paired<BN254> BN254P;
+template <class C>
+static KeyCtx<Paired<C>> paired_key(const TwinCtx<C>* c, u32* hot) {
+  KeyCtx<Paired<C>> k;
+  k.A = c->key.A;
+  k.W = c->key.W;
+  k.nwin = c->key.nwin;
+  k.per = c->key.per;
+  k.t1 = c->key.t1;
+  k.t2 = c->key.t2;
+  k.b1 = c->key.b1;
+  k.b2 = c->key.b2;
+  k.gg_lines = c->key.gg_lines;
+  k.hot = hot;
+  k.flags = c->key.flags;
+  return k;
+}
+extern "C" {
+// paired-layout verification on a context made by twin_bn254_ctx_new (tables are shared: plain layout in memory)
+int twin_bn254p_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
+  const TwinCtx<BN254>* c = (const TwinCtx<BN254>*)cv;
+  return run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<BN254P> k = paired_key<BN254>(c, getenv("ELP_TWIN_NO_HOT") ? nullptr : hot.data());
+    return verify_id_item_paired<BN254P>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
+  });
+}
+int twin_bn254p_ps_verify(void* cv, const u32* rec, int nattr) {
+  const TwinCtx<BN254>* c = (const TwinCtx<BN254>*)cv;
+  return run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<BN254P> k = paired_key<BN254>(c, hot.data());
+    return ps_verify_item<BN254P>(k, rec, nattr) ? 1 : 0;
+  });
+}
+// e(P, Q) computed by a lane pair; GT bytes as twin_bn254_pairing
+int twin_bn254p_pairing(const u32* P, const u32* Q, u32* o) {
+  return run_pair([&](int) {
+    Aff<F1<BN254P>> p;
+    Aff<F2<BN254P>> q;
+    if (!g1_load<BN254P>(p, P) || !g2_load<BN254P>(q, Q)) return 0;
+    Fp12<BN254P> f, g;
+    miller_loop<BN254P, 1, 0>(f, &p, &q, (const Aff<F1<BN254P>>*)0, (const LineMem<BN254P>* const*)0);
+    final_exp<BN254P>(g, f);
+    gt_store<BN254P>(o, g);
+    return 1;
+  });
+}
+int twin_bn254p_g2_mul_gls(const u32* P, const u32* k, u32* o) {
+  return run_pair([&](int) {
+    Aff<F2<BN254P>> p, r;
+    if (!g2_load<BN254P>(p, P)) return 0;
+    Jac<F2<BN254P>> j;
+    g2_mul_gls<BN254P>(j, p, scalar_load_w(k));
+    jac_to_aff<F2<BN254P>>(r, j);
+    g2_store<BN254P>(o, r);
+    return 1;
+  });
+}
+int twin_bn254p_g2_decompress(const uint8_t* in, u32* o) {
+  return run_pair([&](int) {
+    Aff<F2<BN254P>> p;
+    if (!g2_deserialize<BN254P>(p, in)) return 0;
+    g2_store<BN254P>(o, p);
+    return 1;
+  });
+}
+}
+#endif
 
 // TWIN_PART selects one curve so the two halves can be compiled in parallel (tests/elp_testlib.py); default: both
 #if !defined(TWIN_PART) || TWIN_PART == 1

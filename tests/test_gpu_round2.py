@@ -185,3 +185,43 @@ def test_strict_signature_default_and_state_checks(elp):
             ctx.verify_id_batch_aggregated(recs, mask, False, ads, seed=b"short")
     finally:
         ctx.close()
+
+
+def test_paired_and_plain_layouts_agree(gpu_ctx):
+    """ELP_OPT_PAIRED_LAYOUT: the two-lanes-per-item kernels (default) and the one-lane-per-item kernels give identical verdicts on
+    valid, NIZK-corrupted, signature-tampered, infinity and garbage records, for ragged batch sizes (pairs straddling nothing: 32 items
+    per wave), with and without id-retrieval, and for plain PS verification."""
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=77, window_bits=8)
+    for retr in (True, False):
+        n = 333
+        recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=retr, degenerate_items=(5, 64))
+        rsz = len(recs) // n
+        r = bytearray(recs)
+        r[7 * rsz + 64:7 * rsz + 128], r[8 * rsz + 64:8 * rsz + 128] = r[8 * rsz + 64:8 * rsz + 128], r[7 * rsz + 64:7 * rsz + 128]   # swap sig2
+        r[100 * rsz:100 * rsz + 64] = r[101 * rsz:101 * rsz + 64]                      # foreign sig1
+        r[200 * rsz:200 * rsz + 128] = bytes(128)                                      # (inf, inf)
+        r[201 * rsz + 128:201 * rsz + 192] = bytes(64)                                 # phi = inf
+        r[202 * rsz + 3] ^= 0x40                                                       # sig1.x off the curve
+        koff = (5 if retr else 3) * 64
+        r[203 * rsz + koff + 40] ^= 1                                                  # k off the curve
+        r[204 * rsz + koff:204 * rsz + koff + 128] = bytes(128)                        # k = inf
+        rnd = np.random.RandomState(3)
+        r[300 * rsz:301 * rsz] = rnd.randint(0, 256, size=rsz, dtype=np.uint8).tobytes()
+        bad = bytes(r)
+        for cut in (n, 1, 31, 32, 33, 65):
+            gpu_ctx.set_paired_layout(True)
+            fp, cp = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
+            gpu_ctx.set_paired_layout(False)
+            fq, cq = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
+            gpu_ctx.set_paired_layout(True)
+            assert (fp == fq).all() and cp == cq == int(fp.sum()), (retr, cut)
+        assert fp[5] == 1 and fp[64] == 1 and fp[7] == 0 and fp[8] == 0 and fp[100] == 0 and fp[13] == 0 and fp[202] == 0 and fp[203] == 0
+        assert fp[200] == 1 and fp[9] == 1       # the fixture context runs in reference-compatible mode: (inf, inf) is accepted
+    recs, expect = wl.ps_verify_batch(130)
+    gpu_ctx.set_paired_layout(True)
+    fp, cp = gpu_ctx.ps_verify_batch(recs, A)
+    gpu_ctx.set_paired_layout(False)
+    fq, cq = gpu_ctx.ps_verify_batch(recs, A)
+    gpu_ctx.set_paired_layout(True)
+    assert (fp == fq).all() and (fp == expect).all() and cp == cq

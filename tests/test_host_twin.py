@@ -279,3 +279,61 @@ def test_divstep_inversion_against_model_both_curves(L):
             inv(fb(a, nb), o)
             got = ib(o.raw)
             assert got == (pow(a, -1, p) if a else 0), (pfx, hex(a))
+
+
+# ---- paired layout (two lanes per item; the lanes are two threads here and every DPP exchange is a rendezvous)
+def test_paired_layout_primitives(L):
+    pk = CD.pk_decode(base64.b64decode(load_golden("bn254_oracle_flows.json")["scenarios"][0]["pk"]))
+    P, Q = G.g1_mul(pk.g, 12345), G.g2_mul(pk.gg, 6789)
+    og, og2 = ctypes.create_string_buffer(384), ctypes.create_string_buffer(384)
+    assert L.twin_bn254p_pairing(g1b(P), g2b(Q), og) == 1 and L.twin_bn254_pairing(g1b(P), g2b(Q), og2, 0) == 1
+    assert og.raw == og2.raw                      # GT bytes of the pair == GT bytes of the single lane (== the model's, tested above)
+    o2 = ctypes.create_string_buffer(128)
+    rnd = random.Random(5)
+    for k in [1, 2, M.r - 1, rnd.randrange(M.r), rnd.randrange(M.r)]:
+        assert L.twin_bn254p_g2_mul_gls(g2b(Q), fb(k), o2) and g2u(o2.raw) == G.g2_mul(Q, k)
+    for R in (Q, G.g2_neg(Q), pk.XX, None):
+        assert L.twin_bn254p_g2_decompress(M.g2_ser(R), o2) and g2u(o2.raw) == R
+
+
+def test_paired_layout_verify_id_golden(L):
+    """verify_id_item_paired (the body of k_verify_id_paired) on the golden verdicts, with and without id-retrieval, and PS verification."""
+    d = load_golden("bn254_oracle_flows.json")
+    n = 0
+    for s in d["scenarios"][:2]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        ctxs = {}
+        for p in s["proofs"][:2]:
+            for c in p["cases"]:
+                if c["svc"] not in ctxs:
+                    ctxs[c["svc"]] = _ctx(L, pk, svc=c["svc"].encode())
+                P = CD.proof_decode(base64.b64decode(c["proof"]))
+                ad = c["ad"].encode()
+                got = L.twin_bn254p_verify_id(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
+                assert bool(got) == c["expect"], (s["name"], c["label"])
+                n += 1
+    assert n >= 40
+    import copy
+    for r in load_golden("bn254_oracle_with_retrieval.json")["runs"][:2]:
+        pk = CD.pk_decode(base64.b64decode(r["pk"]))
+        g, apk, h = M.hash_to_g1(r["g_seed"]), M.hash_to_g1(r["authority_pk_seed"]), M.hash_to_g1(r["h_seed"])
+        P = CD.proof_decode(base64.b64decode(r["proof"]))
+        ctx = _ctx(L, pk, svc=r["svc"].encode(), g_eg=g, apk=apk, h=h)
+        mask = ctypes.c_uint64(hidden_mask(P.attributes))
+        assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, P), mask, 1, b"hello", 5) == 1
+        assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, P), mask, 1, b"hellO", 5) == 0
+        for fld in ("E1", "E2", "phi", "sig1", "sig2"):
+            Q = copy.copy(P)
+            setattr(Q, fld, G.g1_add(getattr(P, fld), pk.g))
+            assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, Q), mask, 1, b"hello", 5) == 0, fld
+        Q = copy.copy(P)
+        Q.rs = list(P.rs)
+        Q.rs[1] = (Q.rs[1] + 1) % M.r           # the response only the odd lane's job (V_E2) reads
+        assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, Q), mask, 1, b"hello", 5) == 0
+    s = d["scenarios"][0]
+    pk = CD.pk_decode(base64.b64decode(s["pk"]))
+    ctx = _ctx(L, pk)
+    ub = CD.cred_decode(base64.b64decode(s["requests"][0]["unblinded"]))
+    bl = CD.cred_decode(base64.b64decode(s["requests"][0]["credential"]))
+    assert L.twin_bn254p_ps_verify(ctx, pack_ps_verify(M, ub, s["attr_values"]), 3) == 1
+    assert L.twin_bn254p_ps_verify(ctx, pack_ps_verify(M, bl, s["attr_values"]), 3) == 0

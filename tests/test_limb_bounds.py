@@ -26,6 +26,8 @@ def test_flows_stay_within_limb_bounds(tmp_path):
         T.test_glv_gls_scalar_multiplication(L)
         T.test_ps_verify_and_provide_id(L)
         T.test_verify_id_with_retrieval_golden(L)
+        T.test_paired_layout_primitives(L)             # the two-lanes-per-item formulas under the same bound checks
+        T.test_paired_layout_verify_id_golden(L)
         TB.test_group_ops(L)
         TB.test_pairing_equals_model_and_is_bilinear(L)
         TB.test_protocol_flows(L)
