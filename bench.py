@@ -266,10 +266,18 @@ def main():
             out["valu_bound"] = {"error": str(e)}
 
     if rank == 0 and world == 1:
-        # PCIe-inclusive rate (host buffers in, flags out) -- reported, never the headline value
-        t1 = time.perf_counter()
-        fl2, cnt2 = ctx.verify_id_batch(recs, mask, True, wl.ad)
-        out["pcie_inclusive_value"] = B / (time.perf_counter() - t1)
+        # PCIe-inclusive rate (host buffers in, flags out: elp_verify_id_batch, the path PSVerifier::el_passo_verify_id_batch takes; pinned
+        # staging, chunks copied and verified on several streams) -- reported, never the headline value.  One warm-up call, median of 7.
+        ts = []
+        for it in range(8):
+            t1 = time.perf_counter()
+            fl2, cnt2 = ctx.verify_id_batch(recs, mask, True, wl.ad)
+            ts.append(time.perf_counter() - t1)
+        ts = sorted(ts[1:])
+        out["pcie_inclusive_value"] = B / ts[len(ts) // 2]
+        out["pcie_inclusive"] = {"value": B / ts[len(ts) // 2], "unit": "verifications/s", "median_ms": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3,
+                                 "max_ms": ts[-1] * 1e3, "calls": len(ts), "parity_ok": bool((fl2 == expect).all()) and cnt2 == int(expect.sum()),
+                                 "note": "host records in, verdicts out through elp_verify_id_batch (includes the Python wrapper's buffer handling)"}
         if args.cpu_sample != 0 and args.curve == "bn254":
             ncore = usable_cores()
             samp = args.cpu_sample if args.cpu_sample > 0 else max(1536, 48 * ncore)

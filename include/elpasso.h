@@ -46,8 +46,9 @@ int elp_field_bytes(int curve);               /* F */
  * reference accepts sig1 = sig2 = infinity with a self-made NIZK (src/ps-verifier.cc:133-137 has no isZero test; golden case
  * "sig_both_zero"), which is a universal forgery since e(O,K) e(O,gg) = 1, although PSVerifier::verify rejects it
  * (src/ps-verifier.cc:16-18).  Set to 0 for bit-for-bit reference behaviour on that input.
- * ELP_OPT_PAIRED_LAYOUT (default 1): run the verification kernels in the two-lanes-per-item layout where the build has them (BN254);
- * 0 selects the one-lane-per-item kernels.  Results are identical; the option exists for A/B measurements. */
+ * ELP_OPT_PAIRED_LAYOUT: which kernel layout verifies (results are identical).  0 = one lane per item; 1 = two lanes per item (the
+ * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: whole
+ * rounds of 64 x SIMDs items on the one-lane kernel, a remainder of up to 32 x SIMDs items on the two-lane kernel. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <sys/random.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -667,7 +668,16 @@ struct elp_ctx {
   bool retr_set = false;      // ... and all of g, authority_pk, h (needed by the id-retrieval variants)
   bool sk_set = false;        // elp_set_signer_secret installed X
   int strict_sig = 1;         // ELP_OPT_STRICT_SIGNATURE
-  int paired = 1;             // ELP_OPT_PAIRED_LAYOUT: verification kernels in the two-lanes-per-item layout where the build has them
+  int paired = 2;             // ELP_OPT_PAIRED_LAYOUT: 0 = one lane per item, 1 = two lanes per item, 2 = by batch size (layout_split)
+  int simds = 1024;           // SIMDs of the device (4 per CU): one resident wave per SIMD is the unit of the layout choice
+  // host-buffer pipeline of elp_verify_id_batch: pinned staging + a few streams so that the copy of one chunk overlaps the kernels of others
+  static constexpr int NPIPE = 4;
+  hipStream_t pstream[NPIPE] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pevent = nullptr;
+  void* pin_in = nullptr;       // pinned staging for records (grown on demand)
+  size_t pin_in_cap = 0;
+  void* pin_out = nullptr;      // pinned staging for flags + counter
+  size_t pin_out_cap = 0;
   // workspace of the aggregated verification (grown on demand, reused across calls)
   void* agg_ws = nullptr;
   size_t agg_ws_bytes = 0;
@@ -701,13 +711,69 @@ static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key m
   return k;
 }
 
-// RAII device buffer for the host-buffer entry points
+// RAII device buffer for the host-buffer entry points.  Blocks come from (and go back to) a small per-process cache, so a steady stream of
+// host-buffer calls does not pay hipMalloc / hipFree (each a device synchronisation) per call; elp_destroy() of the last context empties it.
+struct DevBlockCache {
+  struct Blk {
+    void* p;
+    size_t cap;
+    int dev;
+  };
+  std::mutex mu;
+  std::vector<Blk> free_blocks;
+  size_t cached = 0;
+  int live_ctx = 0;
+  static constexpr size_t MAX_CACHED = (size_t)2 << 30;
+  hipError_t get(size_t n, void** out, size_t* cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      int best = -1;
+      for (int i = 0; i < (int)free_blocks.size(); i++)
+        if (free_blocks[i].dev == dev && free_blocks[i].cap >= n && free_blocks[i].cap <= 2 * n + 4096 &&
+            (best < 0 || free_blocks[i].cap < free_blocks[best].cap))
+          best = i;
+      if (best >= 0) {
+        *out = free_blocks[best].p;
+        *cap = free_blocks[best].cap;
+        cached -= free_blocks[best].cap;
+        free_blocks.erase(free_blocks.begin() + best);
+        return hipSuccess;
+      }
+    }
+    *cap = n;
+    return hipMalloc(out, n);
+  }
+  void put(void* p, size_t cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (live_ctx > 0 && cached + cap <= MAX_CACHED) {
+      free_blocks.push_back({p, cap, dev});
+      cached += cap;
+    } else {
+      (void)hipFree(p);
+    }
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& b : free_blocks) (void)hipFree(b.p);
+    free_blocks.clear();
+    cached = 0;
+  }
+};
+inline DevBlockCache& dev_cache() {
+  static DevBlockCache c;
+  return c;
+}
 struct DevBuf {
   void* p = nullptr;
+  size_t cap = 0;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) dev_cache().put(p, cap);
   }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+  hipError_t alloc(size_t n) { return dev_cache().get(n ? n : 4, &p, &cap); }
 };
 
 static inline void free_key(elp_ctx* c) {
@@ -1203,6 +1269,19 @@ struct PairedBuild<BN254> {
   static constexpr bool value = true;
 };
 static inline unsigned grid_for_paired(size_t n) { return (unsigned)((2 * n + ELP_BLOCK - 1) / ELP_BLOCK); }
+// How many of n items the one-lane-per-item kernel takes (the rest goes to the two-lanes-per-item kernel).  Measured on MI355X
+// (tools/probes/scale_probe.py, profiles/r02_layout_scale.log): both kernels are bound by vector-instruction issue.  The plain kernel runs
+// one wave per SIMD and needs 64 x SIMDs items per round to fill the chip; the paired kernel halves the latency of an item (a wave holds 32
+// items, 11.3 ms against 17-19 ms per round at A = 8) but issues ~17 % more instructions per item, so at two waves per SIMD it only ties.
+// Policy "by batch size": whole rounds of 64 x SIMDs items go to the plain kernel; a remainder of at most 32 x SIMDs items (one paired wave
+// per SIMD) goes to the paired kernel, a larger remainder to the plain kernel.
+static inline size_t layout_split(const elp_ctx* c, size_t n) {
+  if (c->paired == 0) return n;
+  if (c->paired == 1) return 0;
+  const size_t round = (size_t)64 * c->simds;
+  const size_t rem = n % round;
+  return (rem != 0 && rem <= round / 2) ? n - rem : n;
+}
 template <class B>
 void launch_verify_id_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr,
                              const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
@@ -1230,10 +1309,14 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
   if constexpr (PairedBuild<C>::value) {
-    if (c->paired) {
-      launch_verify_id_paired<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
+    const size_t np = layout_split(c, n);       // items [0, np): plain kernel; [np, n): paired kernel
+    if (np < n) {
+      const uint8_t* recs2 = (const uint8_t*)d_records + np * (size_t)words * 4;
+      const u32* off2 = d_ad_off ? (const u32*)d_ad_off + np : nullptr;
+      launch_verify_id_paired<C>(c, (hipStream_t)stream, n - np, recs2, words, mask, retr, d_ad, off2, ad_len, (uint8_t*)d_flags + np, d_accepted);
       HIPCHK(c, hipGetLastError());
-      return ELP_OK;
+      if (np == 0) return ELP_OK;
+      n = np;
     }
   }
   hipLaunchKernelGGL((k_verify_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
@@ -1262,10 +1345,13 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   if constexpr (PairedBuild<C>::value) {
-    if (c->paired) {
-      launch_ps_verify_paired<C>(c, (hipStream_t)stream, n, d_records, nattr, d_flags, d_accepted);
+    const size_t np = layout_split(c, n);
+    if (np < n) {
+      const uint8_t* recs2 = (const uint8_t*)d_records + np * (size_t)(4 * C::N + 8 * nattr) * 4;
+      launch_ps_verify_paired<C>(c, (hipStream_t)stream, n - np, recs2, nattr, (uint8_t*)d_flags + np, d_accepted);
       HIPCHK(c, hipGetLastError());
-      return ELP_OK;
+      if (np == 0) return ELP_OK;
+      n = np;
     }
   }
   hipLaunchKernelGGL((k_ps_verify<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),

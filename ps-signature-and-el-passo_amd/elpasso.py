@@ -147,8 +147,8 @@ class Context:
         self._chk(self.lib.elp_set_option(self.h, OPT_STRICT_SIGNATURE, int(bool(on))))
 
     def set_paired_layout(self, on):
-        """ELP_OPT_PAIRED_LAYOUT (default on): two-lanes-per-item verification kernels where the build has them; same results."""
-        self._chk(self.lib.elp_set_option(self.h, OPT_PAIRED_LAYOUT, int(bool(on))))
+        """ELP_OPT_PAIRED_LAYOUT: False / 0 = one lane per item, True / 1 = two lanes per item, 2 = chosen by batch size (default)."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_PAIRED_LAYOUT, int(on)))
 
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
         A = len(Yi) // self.G1

@@ -214,7 +214,7 @@ def test_paired_and_plain_layouts_agree(gpu_ctx):
             fp, cp = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
             gpu_ctx.set_paired_layout(False)
             fq, cq = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
-            gpu_ctx.set_paired_layout(True)
+            gpu_ctx.set_paired_layout(2)
             assert (fp == fq).all() and cp == cq == int(fp.sum()), (retr, cut)
         assert fp[5] == 1 and fp[64] == 1 and fp[7] == 0 and fp[8] == 0 and fp[100] == 0 and fp[13] == 0 and fp[202] == 0 and fp[203] == 0
         assert fp[200] == 1 and fp[9] == 1       # the fixture context runs in reference-compatible mode: (inf, inf) is accepted
@@ -223,5 +223,27 @@ def test_paired_and_plain_layouts_agree(gpu_ctx):
     fp, cp = gpu_ctx.ps_verify_batch(recs, A)
     gpu_ctx.set_paired_layout(False)
     fq, cq = gpu_ctx.ps_verify_batch(recs, A)
-    gpu_ctx.set_paired_layout(True)
+    gpu_ctx.set_paired_layout(2)
     assert (fp == fq).all() and (fp == expect).all() and cp == cq
+
+
+def test_layout_by_batch_size_splits_a_batch(gpu_ctx):
+    """Default policy: whole rounds of 64 x SIMDs items on the one-lane kernel + the remainder on the two-lane kernel in ONE call; verdicts,
+    counter and per-item associated data must line up across the split (98 304 + 100 items, per-item session ids)."""
+    A, H = 3, 2
+    wl = synth.Workload(gpu_ctx, A, seed=5, window_bits=8)
+    n0 = 500
+    recs, mask, expect = wl.verify_id_batch(n0, H, with_retrieval=True)
+    rsz = len(recs) // n0
+    n = 65536 + 4096 + 100                       # one full round (plain) + a remainder (paired) on a 256-CU part
+    reps = (n + n0 - 1) // n0
+    big = (recs * reps)[:n * rsz]
+    exp = np.tile(expect, reps)[:n]
+    gpu_ctx.set_paired_layout(2)
+    flags, cnt = gpu_ctx.verify_id_batch(big, mask, True, wl.ad)
+    assert (flags == exp).all() and cnt == int(exp.sum())
+    ads = [wl.ad if i % 1000 else b"other" for i in range(n)]     # per-item associated data: every 1000th item gets a wrong one
+    flags2, cnt2 = gpu_ctx.verify_id_batch(big, mask, True, ads)
+    exp2 = exp.copy()
+    exp2[::1000] = 0
+    assert (flags2 == exp2).all() and cnt2 == int(exp2.sum())
