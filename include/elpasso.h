@@ -54,7 +54,8 @@ int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 
 /* ---- key material (builds fixed-base window tables and the Miller-loop lines of gg in HBM) ------------------ */
-/* PSPubKey{g, gg, XX, Yi[A], YYi[A]} (src/ps-encoding.h:111-140) as affine std points. window_bits 0 = default (8). */
+/* PSPubKey{g, gg, XX, Yi[A], YYi[A]} (src/ps-encoding.h:111-140) as affine std points. window_bits 0 = default (8), up to 22
+ * (table bytes grow as 2^W / W: 2.5 GiB at W = 16, 32 GiB at W = 20 for an 8-attribute BN254 key). */
 int elp_set_pubkey(elp_ctx* ctx, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
                    const uint8_t* YYi, int window_bits);
 /* RP parameters of el_passo_verify_id (src/ps-verifier.h:45-49): service name (hashAndMapToG1 is evaluated on the GPU),

@@ -93,9 +93,6 @@ void elp_destroy(elp_ctx* c) {
   free_key(c);
   for (int i = 0; i < elp_ctx::NPIPE; i++)
     if (c->pstream[i]) (void)hipStreamDestroy(c->pstream[i]);
-  if (c->pevent) (void)hipEventDestroy(c->pevent);
-  if (c->pin_in) (void)hipHostFree(c->pin_in);
-  if (c->pin_out) (void)hipHostFree(c->pin_out);
   bool last;
   {
     std::lock_guard<std::mutex> g(dev_cache().mu);
@@ -213,18 +210,10 @@ int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_r
   return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_dev_t<BN254>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted) : elp_provide_id_batch_dev_t<BLS12_381>(c, stream, n, d_records, mask, d_ad, d_ad_off, ad_len, d_sigs, d_flags, d_accepted);
 }
 
-// Host buffers in, flags out (the path PSVerifier::el_passo_verify_id_batch takes).  Pipelined: the records are staged through pinned memory in
-// chunks, each chunk is copied and verified on one of NPIPE streams, so the copy of a chunk overlaps the kernels of the others (independent
-// kernels of different streams share the chip: a chunk is a quarter of a round of waves); device blocks and the staging area persist across calls.
-static int pin_ensure(elp_ctx* c, void** p, size_t* cap, size_t n) {
-  if (*cap >= n) return ELP_OK;
-  if (*p) (void)hipHostFree(*p);
-  *p = nullptr;
-  *cap = 0;
-  HIPCHK(c, hipHostMalloc(p, n + n / 4, hipHostMallocDefault));
-  *cap = n + n / 4;
-  return ELP_OK;
-}
+// Host buffers in, flags out (the path PSVerifier::el_passo_verify_id_batch takes).  Device blocks persist across calls (DevBlockCache).  The
+// batch is processed in rounds of 64 x SIMDs items: the records of round r + 1 are copied on a copy stream while the kernel of round r runs on
+// the context stream (the kernels themselves are NOT spread over several streams: each dispatch needs ~1 GB of private memory, and concurrent
+// dispatches of that size serialise on its allocation -- measured 35 ms against 23 ms for one round of 65 536 items).
 int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
                         const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
   int rc = check_fused(c, mask, need_rp(retr));
@@ -234,49 +223,45 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
-  for (int i = 0; i < elp_ctx::NPIPE; i++)
-    if (!c->pstream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[i], hipStreamNonBlocking));
-  if (!c->pevent) HIPCHK(c, hipEventCreateWithFlags(&c->pevent, hipEventDisableTiming));
-  rc = pin_ensure(c, &c->pin_in, &c->pin_in_cap, n * rsz);
-  if (rc) return rc;
-  rc = pin_ensure(c, &c->pin_out, &c->pin_out_cap, n + 64);
-  if (rc) return rc;
+  if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
   DevBuf drec, dad, doff, dfl, dcnt;
   const void *pad, *poff;
   HIPCHK(c, drec.alloc(n * rsz));
   HIPCHK(c, dfl.alloc(n));
   HIPCHK(c, dcnt.alloc(8));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
-  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);      // associated data + offsets: small, on the context stream
+  rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
   if (rc) return rc;
-  HIPCHK(c, hipEventRecord(c->pevent, c->stream));
-  // chunks: the plain-layout part of the batch in quarters of a round, the paired-layout remainder (layout_split) as one more chunk
-  const size_t np = c->curve == ELP_CURVE_BN254 ? layout_split(c, n) : n;
-  const size_t quarter = (size_t)16 * c->simds;
-  const int saved_layout = c->paired;
-  uint8_t* pin_flags = (uint8_t*)c->pin_out;
-  int k = 0;
-  for (size_t lo = 0; lo < n; k++) {
-    const bool plain_part = lo < np;
-    const size_t hi = plain_part ? (lo + quarter < np ? lo + quarter : np) : n;
-    hipStream_t st = c->pstream[k % elp_ctx::NPIPE];
-    if (k < elp_ctx::NPIPE) HIPCHK(c, hipStreamWaitEvent(st, c->pevent, 0));
-    memcpy((uint8_t*)c->pin_in + lo * rsz, records + lo * rsz, (hi - lo) * rsz);
-    HIPCHK(c, hipMemcpyAsync((uint8_t*)drec.p + lo * rsz, (uint8_t*)c->pin_in + lo * rsz, (hi - lo) * rsz, hipMemcpyHostToDevice, st));
-    c->paired = plain_part ? 0 : 1;
-    rc = elp_verify_id_batch_dev(c, st, hi - lo, (uint8_t*)drec.p + lo * rsz, mask, retr, pad, poff ? (const uint32_t*)poff + lo : nullptr, ad_len,
-                                 (uint8_t*)dfl.p + lo, dcnt.p);
-    c->paired = saved_layout;
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(pin_flags + lo, (uint8_t*)dfl.p + lo, hi - lo, hipMemcpyDeviceToHost, st));
-    lo = hi;
+  const size_t round = (size_t)64 * c->simds;
+  std::vector<hipEvent_t> ev;
+  int status = ELP_OK;
+  for (size_t lo = 0; lo < n && status == ELP_OK; lo += round) {
+    const size_t cnt = n - lo < round ? n - lo : round;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      status = ELP_ERR_HIP;
+      break;
+    }
+    ev.push_back(e);
+    // pageable source: the runtime stages it through its own pinned buffers; the call returns once the round is staged
+    if (hipMemcpyAsync((uint8_t*)drec.p + lo * rsz, records + lo * rsz, cnt * rsz, hipMemcpyHostToDevice, c->pstream[0]) != hipSuccess ||
+        hipEventRecord(e, c->pstream[0]) != hipSuccess || hipStreamWaitEvent(c->stream, e, 0) != hipSuccess) {
+      status = ELP_ERR_HIP;
+      break;
+    }
+    status = elp_verify_id_batch_dev(c, c->stream, cnt, (uint8_t*)drec.p + lo * rsz, mask, retr, pad, poff ? (const uint32_t*)poff + lo : nullptr,
+                                     ad_len, (uint8_t*)dfl.p + lo, dcnt.p);
   }
-  for (int i = 0; i < elp_ctx::NPIPE && i < k; i++) HIPCHK(c, hipStreamSynchronize(c->pstream[i]));
-  uint64_t* pin_cnt = (uint64_t*)(pin_flags + ((n + 7) & ~(size_t)7));
-  HIPCHK(c, hipMemcpyAsync(pin_cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy(flags, pin_flags, n);
-  if (accepted) *accepted = *pin_cnt;
+  uint64_t cntv = 0;
+  if (status == ELP_OK && (hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                           hipMemcpyAsync(&cntv, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
+    status = ELP_ERR_HIP;
+  hipError_t e1 = hipStreamSynchronize(c->pstream[0]), e2 = hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  if (status == ELP_OK && (e1 != hipSuccess || e2 != hipSuccess)) status = ELP_ERR_HIP;
+  if (status == ELP_ERR_HIP && c->err.empty()) c->err = "HIP error in elp_verify_id_batch";
+  if (status != ELP_OK) return status;
+  if (accepted) *accepted = cntv;
   return ELP_OK;
 }
 

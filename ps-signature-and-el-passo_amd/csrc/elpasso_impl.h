@@ -670,14 +670,9 @@ struct elp_ctx {
   int strict_sig = 1;         // ELP_OPT_STRICT_SIGNATURE
   int paired = 2;             // ELP_OPT_PAIRED_LAYOUT: 0 = one lane per item, 1 = two lanes per item, 2 = by batch size (layout_split)
   int simds = 1024;           // SIMDs of the device (4 per CU): one resident wave per SIMD is the unit of the layout choice
-  // host-buffer pipeline of elp_verify_id_batch: pinned staging + a few streams so that the copy of one chunk overlaps the kernels of others
-  static constexpr int NPIPE = 4;
-  hipStream_t pstream[NPIPE] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t pevent = nullptr;
-  void* pin_in = nullptr;       // pinned staging for records (grown on demand)
-  size_t pin_in_cap = 0;
-  void* pin_out = nullptr;      // pinned staging for flags + counter
-  size_t pin_out_cap = 0;
+  // copy stream of the host-buffer pipeline (elp_verify_id_batch): the next round's records travel while the current round is verified
+  static constexpr int NPIPE = 1;
+  hipStream_t pstream[NPIPE] = {nullptr};
   // workspace of the aggregated verification (grown on demand, reused across calls)
   void* agg_ws = nullptr;
   size_t agg_ws_bytes = 0;
@@ -845,7 +840,16 @@ int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg,
                    const uint8_t* YYi, int window_bits) {
   if (!c || nattr < 1 || nattr > 62 || !g || !gg || !XX || !Yi || !YYi) return ELP_ERR_ARG;
   if (window_bits == 0) window_bits = 8;
-  if (window_bits < 2 || window_bits > 16) return ELP_ERR_ARG;
+  if (window_bits < 2 || window_bits > 22) return ELP_ERR_ARG;
+  {   // the tables must fit the device (W = 16: 2.5 GiB for an 8-attribute BN254 key; W = 20: 32 GiB; W = 22: 120 GiB)
+    const size_t per = ((size_t)1 << window_bits) - 1, nwin = (256 + window_bits - 1) / window_bits;
+    const size_t need = per * nwin * ((size_t)(nattr + 6) * sizeof(Aff<F1<C>>) + (size_t)(nattr + 2) * sizeof(Aff<F2<C>>));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) > free_b + (c->t1 ? 0 : 0)) {
+      c->err = "fixed-base tables of this window width do not fit the device memory";
+      return ELP_ERR_ARG;
+    }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   free_key(c);
   c->A = nattr;
