@@ -41,7 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--attrs", type=int, default=0)
     ap.add_argument("--hidden", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launch, shard, count-reduce and report path; no kernel, value = null")
-    ap.add_argument("--window", type=int, default=16, help="fixed-base window bits of the key tables (library default 8)")
+    ap.add_argument("--window", type=int, default=20, help="fixed-base window bits of the key tables (library default 8; 20 = 32 GiB of tables "
+                    "for the 8-attribute key, 13 table additions per scalar instead of 16 at W = 16: profiles/r02_window_sweep.json)")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
@@ -239,31 +240,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_verify_id", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
                          "note": "integer-VALU bound path: see valu_bound"},
         }
-        # secondary ceiling: modular multiplications/s of this kernel vs the fp_mul micro-benchmark (same limb code)
-        try:
-            fm = ctypes.c_float()
-            lanes, iters = 256 * 4 * 64 * 8, 1000
-            ctx._chk(ctx.lib.elp_bench_fp_mul(ctx.h, lanes, iters, ctypes.byref(fm)))
-            peak = lanes * iters * 2 / (fm.value * 1e-3)
-            vb = {"fp_mul_peak_per_s": peak, "unit": "modmul/s",
-                  "note": "peak = Montgomery products/s of the fp_mul micro-benchmark (same limb code, 8 waves/SIMD; 162 multiply-adds each); achieved = "
-                          "multiply-adds per verification / 162 (profiles/op_counts.json, counted on the host twin of the kernel code) x "
-                          "verifications/s of k_verify_id"}
-            oc = os.path.join(ROOT, "profiles", "op_counts.json")
-            if os.path.exists(oc) and args.curve == "bn254" and A == 8 and H == 4:
-                try:
-                    ops = json.load(open(oc))["verify_id"]
-                    w = args.window or 8
-                    key = "W%d" % w if ("W%d" % w) in ops else "W16"
-                    per_item = ops[key]["fp_mul_equivalents"]      # multiply-adds / 162
-                    ach = per_item * B / (kern_ms * 1e-3)
-                    vb.update({"fp_mul_equivalents_per_verification": per_item, "multiply_adds_per_verification": ops[key]["multiply_adds"],
-                               "achieved": ach, "frac": ach / peak})
-                except Exception:
-                    pass
-            out["valu_bound"] = vb
-        except Exception as e:  # pragma: no cover
-            out["valu_bound"] = {"error": str(e)}
+        out["valu_bound"] = valu_bound(ctx, "verify_id" if (args.curve == "bn254" and A == 8 and H == 4) else None, args.window, B, kern_ms, 162)
 
     if rank == 0 and world == 1:
         # PCIe-inclusive rate (host buffers in, flags out: elp_verify_id_batch, the path PSVerifier::el_passo_verify_id_batch takes; pinned
@@ -345,6 +322,44 @@ def main():
         sys.exit(3)
 
 
+def valu_bound(ctx, ops_key, window, B, kern_ms, macs_per_mul):
+    """Secondary ceiling (the binding one: the path is integer-VALU bound, not HBM bound): Montgomery products/s of the kernel against the
+    fp_mul micro-benchmark of the same limb code at full occupancy, + the instruction-issue reading of the round's PMC pass."""
+    try:
+        fm = ctypes.c_float()
+        lanes, iters = 256 * 4 * 64 * 8, 1000
+        ctx._chk(ctx.lib.elp_bench_fp_mul(ctx.h, lanes, iters, ctypes.byref(fm)))
+        peak = lanes * iters * 2 / (fm.value * 1e-3)
+        vb = {"fp_mul_peak_per_s": peak, "unit": "modmul/s",
+              "note": "peak = Montgomery products/s of the fp_mul micro-benchmark (same limb code, 8 waves/SIMD; %d multiply-adds each); achieved = "
+                      "multiply-adds per verification / %d (profiles/op_counts.json: COUNTED on the host twin of the kernel code, sparse tables at this "
+                      "window width) x verifications/s of the kernel" % (macs_per_mul, macs_per_mul)}
+        oc = os.path.join(ROOT, "profiles", "op_counts.json")
+        if ops_key and os.path.exists(oc):
+            ops = json.load(open(oc)).get(ops_key, {})
+            key = "W%d" % (window or 8)
+            if key in ops:
+                per_item = ops[key]["fp_mul_equivalents"]
+                ach = per_item * B / (kern_ms * 1e-3)
+                vb.update({"fp_mul_equivalents_per_verification": per_item, "multiply_adds_per_verification": ops[key]["multiply_adds"],
+                           "op_count_source": "profiles/op_counts.json[%s][%s]%s" % (ops_key, key, " (extrapolated)" if ops[key].get("extrapolated") else " (counted)"),
+                           "achieved": ach, "frac": ach / peak})
+        pj = os.path.join(ROOT, "profiles", "r02_summary.json")
+        if ops_key == "verify_id" and os.path.exists(pj):
+            try:
+                pm = json.load(open(pj))
+                iv, waves = pm["pmc_per_launch"]["SQ_INSTS_VALU"], pm["pmc_per_launch"]["SQ_WAVES"]
+                vb["issue_model"] = {"valu_wave_instructions_per_launch": iv, "waves": waves, "source": "profiles/r02_summary.json (round PMC pass, W = %s)" % pm.get("window"),
+                                     "ns_per_valu_instruction_per_wave": kern_ms * 1e6 / (iv / waves),
+                                     "note": "one resident wave per SIMD: the wave issues one vector instruction every ~5 cycles whatever its type "
+                                             "(profiles/r01_ubench_valu.log), so kernel time = instructions per wave x issue interval; see DESIGN.md section 5"}
+            except Exception:
+                pass
+        return vb
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)}
+
+
 def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
     """Same workload on the BLS12-381 instantiation (12-word field, M-type twist): a secondary, shorter measurement."""
     import numpy as np
@@ -365,9 +380,14 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
     torch.cuda.synchronize()
     flags = d_flags.cpu().numpy()
     rsz = len(recs) // B
+    ach = B * (rsz + 4) / (ms.value * 1e-3) / 1e9
     res = {"value": B / (ms.value * 1e-3), "unit": "verifications/s", "batch": B, "kernel_ms": float(ms.value),
            "parity_ok": bool((flags == expect).all()) and int(d_cnt.item()) == 3 * int(expect.sum()),
-           "algorithmic_bytes_per_item": rsz + 4, "note": "BLS12-381 instantiation: no reference oracle exists; checked against the big-int model in tests"}
+           "algorithmic_bytes_per_item": rsz + 4,
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_verify_id<BLS12_381>", "kernel_ms": float(ms.value)},
+           "valu_bound": valu_bound(ctx, "verify_id_bls12_381" if (A == 8 and H == 4) else None, window, B, float(ms.value), 392),
+           "note": "BLS12-381 instantiation (14 limbs of 28 bits): parity unpinned -- no reference oracle exists; checked against the big-int model in tests"}
     ctx.close()
     return res
 

@@ -1272,6 +1272,10 @@ template <>
 struct PairedBuild<BN254> {
   static constexpr bool value = true;
 };
+template <>
+struct PairedBuild<BLS12_381> {
+  static constexpr bool value = true;
+};
 static inline unsigned grid_for_paired(size_t n) { return (unsigned)((2 * n + ELP_BLOCK - 1) / ELP_BLOCK); }
 // How many of n items the one-lane-per-item kernel takes (the rest goes to the two-lanes-per-item kernel).  Measured on MI355X
 // (tools/probes/scale_probe.py, profiles/r02_layout_scale.log): both kernels are bound by vector-instruction issue.  The plain kernel runs
@@ -1301,6 +1305,8 @@ void launch_ps_verify_paired(elp_ctx* c, hipStream_t stream, size_t n, const voi
 #ifndef ELP_PAIR_TU
 extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template void launch_verify_id_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template void launch_ps_verify_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
 #endif
 
 template <class C>

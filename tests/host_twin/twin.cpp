@@ -361,8 +361,6 @@ static int run_pair(Fn fn) {   // fn(parity) -> int; both lanes must agree
   return res[0];
 }
 
-#if !defined(TWIN_PART) || TWIN_PART == 1
-typedef Paired<BN254> BN254P;
 template <class C>
 static KeyCtx<Paired<C>> paired_key(const TwinCtx<C>* c, u32* hot) {
   KeyCtx<Paired<C>> k;
@@ -379,6 +377,41 @@ static KeyCtx<Paired<C>> paired_key(const TwinCtx<C>* c, u32* hot) {
   k.flags = c->key.flags;
   return k;
 }
+#if !defined(TWIN_PART) || TWIN_PART == 2
+typedef Paired<BLS12_381> BLSP;
+extern "C" {
+int twin_blsp_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
+  const TwinCtx<BLS12_381>* c = (const TwinCtx<BLS12_381>*)cv;
+  return run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<BLSP> k = paired_key<BLS12_381>(c, hot.data());
+    return verify_id_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
+  });
+}
+int twin_blsp_ps_verify(void* cv, const u32* rec, int nattr) {
+  const TwinCtx<BLS12_381>* c = (const TwinCtx<BLS12_381>*)cv;
+  return run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<BLSP> k = paired_key<BLS12_381>(c, hot.data());
+    return ps_verify_item<BLSP>(k, rec, nattr) ? 1 : 0;
+  });
+}
+int twin_blsp_pairing(const u32* P, const u32* Q, u32* o) {
+  return run_pair([&](int) {
+    Aff<F1<BLSP>> p;
+    Aff<F2<BLSP>> q;
+    if (!g1_load<BLSP>(p, P) || !g2_load<BLSP>(q, Q)) return 0;
+    Fp12<BLSP> f, g;
+    miller_loop<BLSP, 1, 0>(f, &p, &q, (const Aff<F1<BLSP>>*)0, (const LineMem<BLSP>* const*)0);
+    final_exp<BLSP>(g, f);
+    gt_store<BLSP>(o, g);
+    return 1;
+  });
+}
+}
+#endif
+#if !defined(TWIN_PART) || TWIN_PART == 1
+typedef Paired<BN254> BN254P;
 extern "C" {
 // paired-layout verification on a context made by twin_bn254_ctx_new (tables are shared: plain layout in memory)
 int twin_bn254p_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {

@@ -34,15 +34,20 @@ def _oracle_key(L, wl, ctx, A):
     return ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
 
 
-def test_headline_window16_config4_vs_oracle(gpu_ctx):
-    """bench.py's configuration: 8 attributes, 4 hidden, id-retrieval, W = 16 tables (2.5 GiB, 16-bit digit extraction, its own
-    k_table_fill chunking).  2 048 proofs incl. every-97th corrupted and valid proofs that send the group law through P + P at this
-    window width, every verdict compared with the C oracle (reference structure, src/ps-verifier.cc:37-138)."""
+@pytest.mark.parametrize("W", [20, 16])
+def test_headline_window_config4_vs_oracle(gpu_ctx, W):
+    """bench.py's configuration: 8 attributes, 4 hidden, id-retrieval, W = 20 tables (32 GiB, 13 windows of 20-bit digits; W = 16 was round 1's:
+    2.5 GiB, its own k_table_fill chunking).  2 048 proofs incl. every-97th corrupted and valid proofs that send the group law through P + P at
+    this window width, every verdict compared with the C oracle (reference structure, src/ps-verifier.cc:37-138), in both kernel layouts."""
     L = oracle()
     A, H, n = 8, 4, 2048
-    wl = synth.Workload(gpu_ctx, A, seed=20211, window_bits=16)
+    wl = synth.Workload(gpu_ctx, A, seed=20211, window_bits=W)
     degenerate = (5, 77, 150, 1000, 2047)
-    recs, mask, expect = wl.verify_id_batch(n, H, degenerate_items=degenerate, window_bits=16)
+    recs, mask, expect = wl.verify_id_batch(n, H, degenerate_items=degenerate, window_bits=W)
+    gpu_ctx.set_paired_layout(0)
+    flags0, cnt0 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+    gpu_ctx.set_paired_layout(2)
+    assert (flags0 == expect).all() and cnt0 == int(expect.sum())
     flags, cnt = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
     assert (flags == expect).all() and cnt == int(expect.sum())
     assert all(flags[i] == 1 for i in degenerate) and flags[13] == 0 and flags[110] == 0

@@ -107,3 +107,13 @@ def test_protocol_flows(L):
     pr2 = PR.prove_id(pk, cred, attrs, b"sess", b"service", None, None, None, rnd[:2] + rnd[3:3 + H + 1], with_retrieval=False)
     assert PR.verify_id_noretr(pk, pr2, b"sess", b"service")
     assert L.twin_bls_verify_id(ctx, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
+    # the same verdicts from the two-lanes-per-item layout (two threads here, every exchange a rendezvous)
+    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, pr), mask, 1, b"sess", 4) == 1
+    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, pr), mask, 1, b"sesS", 4) == 0
+    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, bad), mask, 1, b"sess", 4) == 0
+    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
+    assert L.twin_blsp_ps_verify(ctx, pack_ps_verify(M, cred, vals), A) == 1
+    assert L.twin_blsp_ps_verify(ctx, pack_ps_verify(M, want, vals), A) == 0
+    P, Q = G.g1_mul(BLS_G1, 321), G.g2_mul(BLS_G2, 654)
+    og, og2 = ctypes.create_string_buffer(12 * N), ctypes.create_string_buffer(12 * N)
+    assert L.twin_blsp_pairing(g1b(P, N), g2b(Q, N), og) == 1 and L.twin_bls_pairing(g1b(P, N), g2b(Q, N), og2, 0) == 1 and og.raw == og2.raw

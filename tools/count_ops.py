@@ -40,6 +40,50 @@ def counts(L):
     return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
 
+def bls_counts(L):
+    """The same count for the BLS12-381 instantiation: one valid proof made with the big-int model (8 attributes, 4 hidden, id-retrieval),
+    sparse tables at W = 16 and W = 20."""
+    from elp_testlib import BLS12_381, BLS_G2, Mcl, Protocol, g1_bases, g2_bases, hidden_mask, pack_verify_id, scalar_stream
+    M = Mcl(BLS12_381)
+    PR = Protocol(M)
+    seed, A, H = 20211, 8, 4
+    g = M.hash_to_g1("abc")
+    pk, skX = PR.key_gen(g, BLS_G2, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    attrs = [(b"a%d-0" % i, i < H) for i in range(A)]
+    rq, t1 = PR.request_id(pk, attrs, b"hello", [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)])
+    cred = PR.unblind(PR.provide_id(pk, skX, rq, b"hello", scalar_stream(seed, 99, M.r)), t1)
+    pr = PR.prove_id(pk, cred, attrs, b"hello", b"service", apk, g, h, [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)])
+    rec = pack_verify_id(M, pr)
+    mask = hidden_mask(pr.attributes)
+    b1 = g1_bases(M, pk, svc="service", g_eg=g, apk=apk, h=h, skX=skX)
+    b2 = g2_bases(M, pk)
+    F = 48
+    base = 5 * 2 * F + 4 * F
+    sc = [int.from_bytes(rec[base + 32 * i:base + 32 * i + 32], "little") for i in range(1 + (H + 2) + (A - H))]
+    c, rs, ms = sc[0], sc[1:1 + H + 2], sc[1 + H + 2:]
+    g2_terms = [(2 + j, rs[j]) for j in range(H)] + [(2 + H + i, ms[i]) for i in range(A - H)] + [(0, rs[H]), (1, (1 - c) % M.r)]
+    g1_terms = [(A + 1, rs[0]), (A + 2, rs[H + 1]), (A + 3, rs[H + 1]), (A + 4, rs[1])]
+    L.twin_bls_ctx_new_sparse.restype = ctypes.c_void_p
+    out = {"config": "BLS12-381, 8 attributes, 4 hidden, id-retrieval"}
+    for W in (16, 20):
+        ctx = ctypes.c_void_p(L.twin_bls_ctx_new_sparse(A, W, b1, b2))
+        assert ctx.value
+        for bse, k in g2_terms:
+            L.twin_bls_table_touch(ctx, 2, bse, int(k).to_bytes(32, "little"))
+        for bse, k in g1_terms:
+            L.twin_bls_table_touch(ctx, 1, bse, int(k).to_bytes(32, "little"))
+        counts(L)
+        assert L.twin_bls_verify_id(ctx, rec, ctypes.c_uint64(mask), 1, b"hello", 5) == 1, "a table entry was missing at W=%d" % W
+        m, s, pr_, qd = counts(L)
+        out["W%d" % W] = {"fp_mul": m, "fp_sqr": s, "fp_mul_pair": pr_, "fp_mul_quad": qd,
+                          "multiply_adds": 392 * m + 301 * s + 588 * pr_ + 980 * qd,
+                          "fp_mul_equivalents": round(m + 301 / 392 * s + 1.5 * pr_ + 2.5 * qd),
+                          "counted": "sparse tables: only the entries this item reads are present"}
+        L.twin_bls_ctx_free(ctx)
+    return out
+
+
 def main():
     L = build()
     A, H = 8, 4
@@ -70,7 +114,7 @@ def main():
     g2_terms = [(2 + j, rs[j]) for j in range(H)] + [(2 + H + i, ms[i]) for i in range(A - H)] + [(0, rs[H]), (1, (1 - c) % r)]
     g1_terms = [(A + 1, rs[0]), (A + 2, rs[H + 1]), (A + 3, rs[H + 1]), (A + 4, rs[1])]
     L.twin_bn254_ctx_new_sparse.restype = ctypes.c_void_p
-    for W in (12, 16):
+    for W in (12, 16, 20):
         ctx = ctypes.c_void_p(L.twin_bn254_ctx_new_sparse(A, W, b1, b2))
         assert ctx.value
         for base, k in g2_terms:
@@ -101,12 +145,17 @@ def main():
                 e["extrapolated"] = True
             return e
         res[name] = {"config": "BN254, 8 attributes, 4 hidden, id-retrieval", "W8": entry(*per_w[8][i]), "W4": entry(*per_w[4][i])}
-        for W in (12, 16):
+        for W in (12, 16, 20):
             if per_w.get(W) and per_w[W][i] is not None:
                 res[name]["W%d" % W] = entry(*per_w[W][i])
                 res[name]["W%d" % W]["counted"] = "sparse tables: only the entries this item reads are present"
-            else:
+            elif W != 20:
                 res[name]["W%d" % W] = entry(*extrapolate(i, W), extrapolated=True)
+    # ---- BLS12-381 (14 limbs of 28 bits: product 196 + reduction 196 multiply-adds; square 105 + 196; pair 2 x 196 + 196; quad 4 x 196 + 196)
+    try:
+        res["verify_id_bls12_381"] = bls_counts(L)
+    except Exception as e:  # pragma: no cover
+        res["verify_id_bls12_381"] = {"error": str(e)}
     res["note"] = ("Calls per item of the three Montgomery routines, counted on the host twin (same template code as the kernels), and the "
                    "multiply-add instructions they stand for; fp_mul_equivalents = multiply_adds / 162.")
     path = os.path.join(ROOT, "profiles", "op_counts.json")

@@ -1,4 +1,4 @@
-"""Kernel time of the verify_id kernel vs batch size in both layouts (one GPU).  Usage: python tools/probes/scale_probe.py [window]"""
+"""Kernel time of the verify_id kernel vs batch size in both layouts (one GPU).  Usage: python tools/probes/scale_probe.py [window] [bls]"""
 import ctypes
 import importlib
 import os
@@ -12,8 +12,9 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("ps-signature-and-el-passo_amd")
 synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+CURVE = pkg.CURVE_BLS12_381 if (len(sys.argv) > 2 and sys.argv[2] == "bls") else pkg.CURVE_BN254
 dev = torch.device("cuda", 0)
-ctx = pkg.Context(pkg.CURVE_BN254, 0)
+ctx = pkg.Context(CURVE, 0)
 wl = synth.Workload(ctx, 8, seed=20211, window_bits=W)
 B = 131072
 recs, mask, expect = wl.verify_id_batch(B, 4, with_retrieval=True)

@@ -7,7 +7,7 @@ import os
 import sys
 
 d, tag = sys.argv[1], sys.argv[2]
-out = {"tag": tag}
+out = {"tag": tag, "window": int(sys.argv[3]) if len(sys.argv) > 3 else None}
 rows = list(csv.DictReader(open(os.path.join(d, "trace", tag + "_kernel_stats.csv"))))
 out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "pct": float(r["Percentage"])}
                        for r in rows[:12]]
