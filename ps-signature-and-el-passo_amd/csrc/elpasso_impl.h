@@ -1286,6 +1286,7 @@ static inline unsigned grid_for_paired(size_t n) { return (unsigned)((2 * n + EL
 static inline size_t layout_split(const elp_ctx* c, size_t n) {
   if (c->paired == 0) return n;
   if (c->paired == 1) return 0;
+  if (c->curve == ELP_CURVE_BLS12_381) return 0;     // 14-limb field: the paired kernel is faster at every batch size (profiles/r02_layout_scale.log)
   const size_t round = (size_t)64 * c->simds;
   const size_t rem = n % round;
   return (rem != 0 && rem <= round / 2) ? n - rem : n;
