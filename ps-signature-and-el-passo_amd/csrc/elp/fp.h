@@ -225,6 +225,34 @@ ELP_INL void fp_reduce_weak(Fp<C>& a) {
   a.v[NL - 1] = (i32)t;
 }
 
+// The multiply-add of the column sums.  Written in C the compiler software-pipelines the columns: it starts the next column in a fresh accumulator
+// while the current one waits for its Montgomery digit and merges the two with a 64-bit add per column -- 17 extra instructions per product, which a
+// kernel at two waves per SIMD (multiply-add pipe bound) pays in full.  -DELP_ASM_MAC=1 (device builds) issues the multiply-adds as
+// opaque v_mad_i64_i32 statements chained through ONE accumulator register pair, which pins the serial order the source states.  Measured (round 2,
+// 65 536 proofs, W = 20): 4-5 % fewer vector instructions per product, and the BN254 paired kernel at TWO waves per SIMD gains (19.9 -> 19.0 ms), but
+// every kernel that runs ONE wave per SIMD loses, because a lone wave cannot hide the latency of back-to-back dependent multiply-adds: plain kernel
+// 18.6 -> 22.6 ms, a lone paired wave 9.9 -> 11.6 ms (and the paired layout is only chosen for batches that give one wave per SIMD); BLS12-381 paired
+// 56.9 -> 58.5 ms.  The compiler's pipelining is what these kernels need, so the switch stays off; it is kept for the record and for experiments
+// (profiles/r02_asm_mac_experiment.log).
+#ifndef ELP_ASM_MAC
+#define ELP_ASM_MAC 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && ELP_ASM_MAC
+#define ELP_MAC(acc, x, y)                                                                                    \
+  do {                                                                                                        \
+    unsigned long long cy_;                                                                                   \
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy_) : "v"((i32)(x)), "v"((i32)(y)));            \
+  } while (0)
+#define ELP_MAC_S(acc, x, ys) /* second factor in a scalar register (modulus limbs) */                        \
+  do {                                                                                                        \
+    unsigned long long cy_;                                                                                   \
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy_) : "v"((i32)(x)), "s"((i32)(ys)));           \
+  } while (0)
+#else
+#define ELP_MAC(acc, x, y) ((acc) += (i64)(x) * (y))
+#define ELP_MAC_S(acc, x, ys) ((acc) += (i64)(x) * (ys))
+#endif
+
 // Montgomery product a*b*R^-1 (mod p), column-wise with a single signed 64-bit accumulator.
 // Requirements: |a limb| * |b limb| summed over a column stays below 2^62 (true for carried inputs; one of the two may
 // be a lazy sum of two carried values).  Output is carried and |value| < |a||b|/R + 0.51 p.
@@ -252,19 +280,19 @@ ELP_FPMUL Fp<C> fp_mul(Fp<C> a, Fp<C> b) {
   ELP_UNROLL
   for (int k = 0; k < NL; k++) {
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, a.v[i], b.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+    for (int i = 0; i < k; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
     m[k] = elp_balanced30((u32)acc * C::INVL);
-    acc += (i64)m[k] * pl[0];
+    ELP_MAC_S(acc, m[k], pl[0]);
     acc >>= ELP_LIMB_BITS;                                      // exact: the low 30 bits are zero now
   }
   ELP_UNROLL
   for (int k = NL; k < 2 * NL - 1; k++) {
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, a.v[i], b.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
     r.v[k - NL] = elp_balanced30((u32)acc);
     acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;               // = (acc - balanced low part) >> 30
   }
@@ -304,23 +332,23 @@ ELP_FPMUL Fp<C> fp_mul_pair(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) {
   ELP_UNROLL
   for (int k = 0; k < NL; k++) {
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, a.v[i], b.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)c.v[i] * d.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, c.v[i], d.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+    for (int i = 0; i < k; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
     m[k] = elp_balanced30((u32)acc * C::INVL);
-    acc += (i64)m[k] * pl[0];
+    ELP_MAC_S(acc, m[k], pl[0]);
     acc >>= ELP_LIMB_BITS;
   }
   ELP_UNROLL
   for (int k = NL; k < 2 * NL - 1; k++) {
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, a.v[i], b.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)c.v[i] * d.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, c.v[i], d.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
     r.v[k - NL] = elp_balanced30((u32)acc);
     acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
   }
@@ -358,31 +386,31 @@ ELP_FPMUL Fp<C> fp_mul_quad(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d, Fp<C> e, Fp<C> f
   ELP_UNROLL
   for (int k = 0; k < NL; k++) {
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)a.v[i] * b.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, a.v[i], b.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)c.v[i] * d.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, c.v[i], d.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)e.v[i] * f.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, e.v[i], f.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i <= k; i++) acc += (i64)g.v[i] * h.v[k - i];
+    for (int i = 0; i <= k; i++) ELP_MAC(acc, g.v[i], h.v[k - i]);
     ELP_UNROLL
-    for (int i = 0; i < k; i++) acc += (i64)m[i] * pl[k - i];
+    for (int i = 0; i < k; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
     m[k] = elp_balanced30((u32)acc * C::INVL);
-    acc += (i64)m[k] * pl[0];
+    ELP_MAC_S(acc, m[k], pl[0]);
     acc >>= ELP_LIMB_BITS;
   }
   ELP_UNROLL
   for (int k = NL; k < 2 * NL - 1; k++) {
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)a.v[i] * b.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, a.v[i], b.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)c.v[i] * d.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, c.v[i], d.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)e.v[i] * f.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, e.v[i], f.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)g.v[i] * h.v[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC(acc, g.v[i], h.v[k - i]);
     ELP_UNROLL
-    for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * pl[k - i];
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
     r.v[k - NL] = elp_balanced30((u32)acc);
     acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
   }
