@@ -294,9 +294,9 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
   }
 }
 
-// a^e (e > 0, 64-bit) for a in the cyclotomic subgroup
+// a^e (e > 0, 64-bit) for a in the cyclotomic subgroup: plain square-and-multiply with Granger-Scott squarings
 template <class C>
-ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = nullptr) {
+ELP_HEAVY void fp12_exp_u64_gs(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = nullptr) {
   Fp12<C> acc_priv;
   Fp12<C>* ah = hot_as<Fp12<C>, C>(hot);
   Fp12<C>& acc = ah ? *ah : acc_priv;
@@ -309,6 +309,71 @@ ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = null
     if ((e >> i) & 1) fp12_mul<C>(acc, acc, a);
   }
   r = acc;
+}
+// The same power with COMPRESSED squarings (tower.h, Karabina): a^e = prod over the set bits i of a^(2^i); the run a^(2^i) is carried in compressed form
+// (6 instead of 9 Fp2 squarings per step), snapshots are taken at the set bits, decompressed with ONE shared Fp2 inversion and multiplied together.  The
+// exponents of the final exponentiation have 3 (BN254: |z|) to 6 set bits.  If some snapshot has c = 0 (it cannot be decompressed this way; never seen on
+// pairing values) the plain loop above is used instead, so the result is always the same element.
+#ifndef ELP_COMPRESSED_SQR
+#define ELP_COMPRESSED_SQR 1
+#endif
+template <class C>
+ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = nullptr) {
+#if ELP_COMPRESSED_SQR
+  constexpr int MAXS = 8;
+  int top = 63;
+  while (!((e >> top) & 1)) top--;
+  int nset = 0;
+  for (int i = 1; i <= top; i++) nset += (int)((e >> i) & 1);
+  if (nset >= 1 && nset <= MAXS) {
+    CycComp<C> snap[MAXS];
+    Fp2<C> nrm[MAXS], pre[MAXS];
+    CycComp<C> cur;
+    fp12_to_comp<C>(cur, a);
+    int k = 0;
+    ELP_NOUNROLL
+    for (int i = 1; i <= top; i++) {
+      cyc_comp_sqr<C>(cur, cur);
+      if ((e >> i) & 1) snap[k++] = cur;
+    }
+    // shared inversion of the norms (Montgomery's trick over Fp2)
+    Fp2<C> acc = fp2_one<C>();
+    bool bad = false;
+    ELP_NOUNROLL
+    for (int j = 0; j < nset; j++) {
+      nrm[j] = cyc_comp_norm<C>(snap[j]);
+      bad |= fp2_is_zero<C>(nrm[j]);
+      pre[j] = acc;
+      fp2_mul<C>(acc, acc, nrm[j]);
+    }
+    if (!bad) {
+      Fp2<C> inv;
+      fp2_inv<C>(inv, acc);
+      Fp12<C> prod, t;
+      bool have = false;
+      if (e & 1) {
+        prod = a;
+        have = true;
+      }
+      ELP_NOUNROLL
+      for (int j = nset - 1; j >= 0; j--) {
+        Fp2<C> ninv;
+        fp2_mul<C>(ninv, inv, pre[j]);
+        fp2_mul<C>(inv, inv, nrm[j]);
+        cyc_decompress<C>(t, snap[j], ninv);
+        if (have) {
+          fp12_mul<C>(prod, prod, t);
+        } else {
+          prod = t;
+          have = true;
+        }
+      }
+      r = prod;
+      return;
+    }
+  }
+#endif
+  fp12_exp_u64_gs<C>(r, a, e, hot);
 }
 // a^|z| for a in the cyclotomic subgroup
 template <class C>
