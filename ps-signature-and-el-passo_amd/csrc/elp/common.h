@@ -1,7 +1,8 @@
 // Common macros for the host/device arithmetic headers of the EL PASSO HIP path.
 //
 // The headers under csrc/elp/ are written once and compiled twice:
-//   * by hipcc for gfx950 (the product: kernels in ../kernels.hip behind the C-ABI of include/elpasso.h)
+//   * by hipcc for gfx950 (the product: kernels in ../elpasso_impl.h, instantiated per curve and layout by ../elpasso_*.hip, behind the
+//     C-ABI of include/elpasso.h)
 //   * by g++ for the host, ONLY by tests/host_twin (unit-testing the same formulas in a container
 //     that has no GPU).  The host build is test infrastructure and is never linked into the product.
 #pragma once

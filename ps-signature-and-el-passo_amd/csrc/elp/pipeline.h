@@ -1,5 +1,6 @@
 // Per-item bodies of the batched hot path.  Each function processes ONE independent item (credential / proof);
-// ../kernels.hip wraps them in __global__ kernels (one item per lane), tests/host_twin wraps them in host loops.
+// ../elpasso_impl.h wraps them in __global__ kernels (one item per lane, or per lane pair in the paired layout), tests/host_twin wraps
+// them in host loops.
 //
 // Reference call stacks restated here (optimised structure: fixed-base tables, one shared final exponentiation):
 //   verify_id_item        <- PSVerifier::el_passo_verify_id                       src/ps-verifier.cc:37-138
