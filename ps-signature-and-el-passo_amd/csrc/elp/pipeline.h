@@ -520,8 +520,33 @@ ELP_INL Scalar scalar_select(bool c, const Scalar& a, const Scalar& b) {
   for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
   return r;
 }
+// the fixed-stride record as a source for the paired kernels (scalars and transcript bytes straight from the record words)
 template <class C>
-ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const Aff<F1<C>>& P0,
+struct PairedRecordSrc {
+  const u32 *w_phi_, *w_k_, *w_rs_, *w_ms_;
+  u64 mask_;
+  int nrs_, jr_;
+  ELP_HD void init(const u32* rec, u64 hidden_mask, int A, bool retr) {
+    int H = 0;
+    for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+    mask_ = hidden_mask;
+    nrs_ = H + (retr ? 2 : 1);
+    jr_ = 0;
+    const int G1W = 2 * C::N, G2W = 4 * C::N;
+    w_phi_ = rec + 2 * G1W;
+    w_k_ = rec + (retr ? 5 : 3) * G1W;
+    w_rs_ = w_k_ + G2W + 8;
+    w_ms_ = w_rs_ + 8 * nrs_;
+  }
+  ELP_HD int nrs() const { return nrs_; }
+  ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
+  ELP_HD Scalar rs(int j) const { return scalar_load_w(w_rs_ + 8 * j); }
+  ELP_HD Scalar next_revealed_hash(int) { return scalar_load_w(w_ms_ + 8 * jr_++); }
+  ELP_HD void ser_k(uint8_t* out) const { g2_serialize_std<C>(out, w_k_); }
+  ELP_HD void ser_g1(int which, uint8_t* out) const { g1_serialize_std<C>(out, w_phi_ + which * 2 * C::N); }
+};
+template <class C, class Src>
+ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& P0,
                                      const Aff<F1<C>>& P1, const Aff<F2<C>>& kk, const Scalar& c, const uint8_t* ad, size_t ad_len,
                                      Aff<F2<C>>& aK) {
   static_assert(is_paired<C>(), "paired layout only");
@@ -529,16 +554,9 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, const u32* rec, u64 h
   typedef F2<C> G2F;
   const bool odd = pair_odd();
   const int A = key.A;
-  int H = 0;
-  for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
-  const int nrs = H + (retr ? 2 : 1);
-  const int G1W = 2 * C::N, G2W = 4 * C::N;
-  const u32* w_phi = rec + 2 * G1W;
-  const u32* w_k = rec + (retr ? 5 : 3) * G1W;
-  const u32* w_rs = w_k + G2W + 8;
-  const u32* w_ms = w_rs + 8 * nrs;
-  const Scalar r_t = scalar_load_w(w_rs + 8 * (retr ? nrs - 2 : nrs - 1));
-  const Scalar r_e = scalar_load_w(w_rs + 8 * (nrs - 1));        // used only with retrieval
+  const int nrs = src.nrs();
+  const Scalar r_t = src.rs(retr ? nrs - 2 : nrs - 1);
+  const Scalar r_e = src.rs(nrs - 1);        // used only with retrieval
   Scalar one;
   for (int i = 0; i < 8; i++) one.v[i] = 0;
   one.v[0] = 1;
@@ -580,14 +598,13 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, const u32* rec, u64 h
   g2_mul_gls_tab<C>(Vk, tabk, c);
   jac_from_aff(K, kk);
   {
-    int jh = 0, jr = 0;
+    int jh = 0;
     for (int i = 0; i < A; i++) {
-      if ((hidden_mask >> i) & 1) {
-        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, scalar_load_w(w_rs + 8 * jh));
+      if (src.hidden(i)) {
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, src.rs(jh));
         jh++;
       } else {
-        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(w_ms + 8 * jr));
-        jr++;
+        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
       }
     }
   }
@@ -598,9 +615,9 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, const u32* rec, u64 h
   g1_mul_glv_tab<C>(V0, tab0, c);
   if (!odd || retr) {
     const int b0 = odd ? g1_base_apk(key) : g1_base_hs(key);
-    acc_fixed_g1<C>(V0, key, b0, scalar_select<C>(odd, r_e, scalar_load_w(w_rs)));
+    acc_fixed_g1<C>(V0, key, b0, scalar_select<C>(odd, r_e, src.rs(0)));
   }
-  if (odd && retr) acc_fixed_g1<C>(V0, key, g1_base_h(key), scalar_load_w(w_rs + 8));
+  if (odd && retr) acc_fixed_g1<C>(V0, key, g1_base_h(key), src.rs(1));
   if (retr) {
     g1_mul_glv_tab<C>(V1, tab1, c);
     if (!odd) acc_fixed_g1<C>(V1, key, g1_base_geg(key), r_e);
@@ -638,14 +655,14 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, const u32* rec, u64 h
   uint8_t buf[2 * C::FBYTES];
   Transcript t;
   transcript_init(t);
-  g2_serialize_std<C>(buf, w_k);
+  src.ser_k(buf);
   sha256_update_hex(t.s, buf, 2 * C::FBYTES);
-  g1_serialize_std<C>(buf, w_phi);
+  src.ser_g1(0, buf);
   sha256_update_hex(t.s, buf, C::FBYTES);
   if (retr) {
-    g1_serialize_std<C>(buf, w_phi + G1W);
+    src.ser_g1(1, buf);
     sha256_update_hex(t.s, buf, C::FBYTES);
-    g1_serialize_std<C>(buf, w_phi + 2 * G1W);
+    src.ser_g1(2, buf);
     sha256_update_hex(t.s, buf, C::FBYTES);
   }
   transcript_g2<C>(t, aVk);
@@ -677,7 +694,9 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
   if (!ok || !okk) return false;
   if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
   const Scalar c = scalar_load_w(rec + (retr ? 5 : 3) * G1W + 4 * C::N);
-  if (!verify_id_paired_nizk<C>(key, rec, hidden_mask, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
+  PairedRecordSrc<C> src;
+  src.init(rec, hidden_mask, key.A, retr);
+  if (!verify_id_paired_nizk<C, PairedRecordSrc<C>>(key, src, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
   return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
 
@@ -721,15 +740,17 @@ struct WireSrc {
     s = scalar_load_le(p);
     return !scalar_geq_r<C>(s);
   }
-  ELP_HD bool open(const uint8_t* msg, size_t len, int A, bool retr, Aff<F1<C>>& sig1, Aff<F1<C>>& sig2, Aff<F1<C>>& phi,
-                   Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
+  const uint8_t *p1_, *p2_, *pk_, *pphi_, *pe1_, *pe2_;   // bodies of the point elements (validated lengths)
+  // structure, lengths and scalar ranges of the message; no point is decoded here
+  ELP_HD bool parse(const uint8_t* msg, size_t len, int A, bool retr, Scalar& c) {
     constexpr size_t L = C::FBYTES;
     b_ = msg;
     len_ = len;
     size_t off = 0, n;
-    const uint8_t *p1, *p2, *pk, *pphi, *pc;
-    if (!elem(msg, len, off, 1, L, p1) || !elem(msg, len, off, 1, L, p2) || !elem(msg, len, off, 2, 2 * L, pk) ||
-        !elem(msg, len, off, 1, L, pphi) || !elem(msg, len, off, 3, 32, pc))
+    const uint8_t* pc;
+    pe1_ = pe2_ = nullptr;
+    if (!elem(msg, len, off, 1, L, p1_) || !elem(msg, len, off, 1, L, p2_) || !elem(msg, len, off, 2, 2 * L, pk_) ||
+        !elem(msg, len, off, 1, L, pphi_) || !elem(msg, len, off, 3, 32, pc))
       return false;
     // FrList
     if (off >= len || msg[off] != 6) return false;
@@ -764,12 +785,24 @@ struct WireSrc {
     }
     if (nrs_ != H + (retr ? 2 : 1) || H < (retr ? 2 : 1)) return false;
     if (retr) {
-      const uint8_t *pe1, *pe2;
-      if (!elem(msg, len, off, 1, L, pe1) || !elem(msg, len, off, 1, L, pe2)) return false;   // src/ps-verifier.cc:68-70
-      if (!g1_deserialize<C>(E1, pe1) || !g1_deserialize<C>(E2, pe2)) return false;
+      if (!elem(msg, len, off, 1, L, pe1_) || !elem(msg, len, off, 1, L, pe2_)) return false;   // src/ps-verifier.cc:68-70
     }
-    if (!scalar_ok(pc, c)) return false;
-    return g1_deserialize<C>(sig1, p1) && g1_deserialize<C>(sig2, p2) && g1_deserialize<C>(phi, pphi) && g2_deserialize<C>(kk, pk);
+    return scalar_ok(pc, c);
+  }
+  ELP_HD bool open(const uint8_t* msg, size_t len, int A, bool retr, Aff<F1<C>>& sig1, Aff<F1<C>>& sig2, Aff<F1<C>>& phi,
+                   Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
+    if (!parse(msg, len, A, retr, c)) return false;
+    if (retr && (!g1_deserialize<C>(E1, pe1_) || !g1_deserialize<C>(E2, pe2_))) return false;
+    return g1_deserialize<C>(sig1, p1_) && g1_deserialize<C>(sig2, p2_) && g1_deserialize<C>(phi, pphi_) && g2_deserialize<C>(kk, pk_);
+  }
+  // wire bytes of the transcript's input points: the message's own bytes (every encoding the decoder accepts is canonical: x < p, the
+  // flag bit is the parity the decoder enforces on y, infinity is all-zero)
+  ELP_HD void ser_k(uint8_t* out) const {
+    for (int i = 0; i < 2 * C::FBYTES; i++) out[i] = pk_[i];
+  }
+  ELP_HD void ser_g1(int which, uint8_t* out) const {   // 0 = phi, 1 = E1, 2 = E2
+    const uint8_t* p = which == 0 ? pphi_ : (which == 1 ? pe1_ : pe2_);
+    for (int i = 0; i < C::FBYTES; i++) out[i] = p[i];
   }
   ELP_HD int nrs() const { return nrs_; }
   ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
@@ -809,6 +842,37 @@ ELP_HEAVY bool verify_id_wire_item(const KeyCtx<C>& key, const uint8_t* msg, siz
   WireSrc<C> src;
   if (!src.open(msg, len, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   return verify_id_core<C, WireSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
+}
+
+// The same in the paired layout: both lanes parse the message; the five G1 decompressions (one Fp square root each) are split between the
+// lanes (even: sig1, phi, E1; odd: sig2, E2), sig1 / sig2 are then swapped so both lanes hold both, k is decompressed by the pair together.
+template <class C>
+ELP_HEAVY bool verify_id_wire_item_paired(const KeyCtx<C>& key, const uint8_t* msg, size_t len, bool retr, const uint8_t* ad, size_t ad_len) {
+  static_assert(is_paired<C>(), "paired layout only");
+  const bool odd = pair_odd();
+  WireSrc<C> src;
+  Scalar c;
+  if (!src.parse(msg, len, key.A, retr, c)) return false;
+  Aff<F1<C>> S, P0, P1;
+  Aff<F2<C>> kk, aK;
+  bool ok = g1_deserialize<C>(S, odd ? src.p2_ : src.p1_);
+  aff_set_inf(P0);
+  aff_set_inf(P1);
+  if (!odd || retr) ok &= g1_deserialize<C>(P0, odd ? src.pe2_ : src.pphi_);
+  if (!odd && retr) ok &= g1_deserialize<C>(P1, src.pe1_);
+  ok = pair_and(ok);
+  const bool okk = g2_deserialize<C>(kk, src.pk_);
+  if (!ok || !okk) return false;
+  Aff<F1<C>> T, sig1, sig2;
+  T.x = fp_pair_swap(S.x);
+  T.y = fp_pair_swap(S.y);
+  sig1.x = fp_select(odd, T.x, S.x);
+  sig1.y = fp_select(odd, T.y, S.y);
+  sig2.x = fp_select(odd, S.x, T.x);
+  sig2.y = fp_select(odd, S.y, T.y);
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
+  if (!verify_id_paired_nizk<C, WireSrc<C>>(key, src, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
+  return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -117,6 +117,20 @@ __global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_paired(KeyCtx<C> key, const u
   count_accept_paired(ok, accepted);
 }
 template <class C>
+__global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_wire_paired(KeyCtx<C> key, const uint8_t* msgs, const u32* msg_off, int retr, const uint8_t* ad,
+                                                               const u32* ad_off, u32 ad_len, uint8_t* flags, unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP_PAIRED(key);
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = verify_id_wire_item_paired<C>(key, msgs + msg_off[i], (size_t)(msg_off[i + 1] - msg_off[i]), retr != 0, a, al);
+    if ((threadIdx.x & 1) == 0) flags[i] = ok ? 1 : 0;
+  }
+  count_accept_paired(ok, accepted);
+}
+template <class C>
 __global__ void ELP_PAIR_LAUNCH_BOUNDS k_ps_verify_paired(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* flags,
                                                           unsigned long long* accepted, size_t n) {
   ELP_HOT_SETUP_PAIRED(key);
@@ -1299,6 +1313,13 @@ void launch_verify_id_paired(elp_ctx* c, hipStream_t stream, size_t n, const voi
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
 template <class B>
+void launch_verify_id_wire_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad,
+                                  const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
+  hipLaunchKernelGGL((k_verify_id_wire_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
+                     (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (uint8_t*)d_flags,
+                     (unsigned long long*)d_accepted, n);
+}
+template <class B>
 void launch_ps_verify_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted) {
   hipLaunchKernelGGL((k_ps_verify_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
                      (const u32*)d_records, 4 * B::N + 8 * nattr, nattr, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
@@ -1306,8 +1327,10 @@ void launch_ps_verify_paired(elp_ctx* c, hipStream_t stream, size_t n, const voi
 #ifndef ELP_PAIR_TU
 extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template void launch_verify_id_wire_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_verify_id_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
+extern template void launch_verify_id_wire_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 #endif
 
 template <class C>
@@ -1342,6 +1365,16 @@ int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const voi
   int rc = check_fused(c, 0, need_rp(retr));
   if (rc) return rc;
   if (n == 0) return ELP_OK;
+  if constexpr (PairedBuild<C>::value) {
+    const size_t np = layout_split(c, n);       // messages [0, np): plain kernel; [np, n): paired kernel
+    if (np < n) {
+      launch_verify_id_wire_paired<C>(c, (hipStream_t)stream, n - np, d_msgs, (const u32*)d_msg_off + np, retr, d_ad,
+                                      d_ad_off ? (const u32*)d_ad_off + np : nullptr, ad_len, (uint8_t*)d_flags + np, d_accepted);
+      HIPCHK(c, hipGetLastError());
+      if (np == 0) return ELP_OK;
+      n = np;
+    }
+  }
   hipLaunchKernelGGL((k_verify_id_wire<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
                      (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);

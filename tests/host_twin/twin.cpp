@@ -422,6 +422,14 @@ int twin_bn254p_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, con
     return verify_id_item_paired<BN254P>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
   });
 }
+int twin_bn254p_verify_id_wire(void* cv, const uint8_t* msg, size_t len, int retr, const uint8_t* ad, size_t adlen) {
+  const TwinCtx<BN254>* c = (const TwinCtx<BN254>*)cv;
+  return run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<BN254P> k = paired_key<BN254>(c, hot.data());
+    return verify_id_wire_item_paired<BN254P>(k, msg, len, retr != 0, ad, adlen) ? 1 : 0;
+  });
+}
 int twin_bn254p_ps_verify(void* cv, const u32* rec, int nattr) {
   const TwinCtx<BN254>* c = (const TwinCtx<BN254>*)cv;
   return run_pair([&](int) {

@@ -223,6 +223,17 @@ def test_paired_and_plain_layouts_agree(gpu_ctx):
             assert (fp == fq).all() and cp == cq == int(fp.sum()), (retr, cut)
         assert fp[5] == 1 and fp[64] == 1 and fp[7] == 0 and fp[8] == 0 and fp[100] == 0 and fp[13] == 0 and fp[202] == 0 and fp[203] == 0
         assert fp[200] == 1 and fp[9] == 1       # the fixture context runs in reference-compatible mode: (inf, inf) is accepted
+        # the same (valid and corrupted) proofs as wire messages through both layouts' wire-ingest kernels
+        msgs, moff = wl.wire_messages(recs, n, H, with_retrieval=retr)
+        m = [msgs[moff[i]:moff[i + 1]] for i in range(n)]
+        m[40] = m[40][:-5]                       # truncated
+        m[41] = m[41] + b"\x00"                  # trailing byte
+        gpu_ctx.set_paired_layout(True)
+        wp, wcp = gpu_ctx.verify_id_wire_batch(m, retr, wl.ad)
+        gpu_ctx.set_paired_layout(False)
+        wq, wcq = gpu_ctx.verify_id_wire_batch(m, retr, wl.ad)
+        gpu_ctx.set_paired_layout(2)
+        assert (wp == wq).all() and wcp == wcq and wp[40] == 0 and wp[13] == 0 and wp[9] == 1 and wp[5] == 1
     recs, expect = wl.ps_verify_batch(130)
     gpu_ctx.set_paired_layout(True)
     fp, cp = gpu_ctx.ps_verify_batch(recs, A)

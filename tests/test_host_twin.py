@@ -337,3 +337,26 @@ def test_paired_layout_verify_id_golden(L):
     bl = CD.cred_decode(base64.b64decode(s["requests"][0]["credential"]))
     assert L.twin_bn254p_ps_verify(ctx, pack_ps_verify(M, ub, s["attr_values"]), 3) == 1
     assert L.twin_bn254p_ps_verify(ctx, pack_ps_verify(M, bl, s["attr_values"]), 3) == 0
+
+
+def test_paired_layout_wire_ingest(L):
+    """verify_id_wire_item_paired: T-L-V parse on both lanes, the G1 decompressions split between the lanes, k decompressed by the pair."""
+    d = load_golden("bn254_oracle_flows.json")
+    for s in d["scenarios"][:2]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        ctxs = {}
+        for p in s["proofs"][:1]:
+            for c in p["cases"]:
+                if c["svc"] not in ctxs:
+                    ctxs[c["svc"]] = _ctx(L, pk, svc=c["svc"].encode())
+                raw, ad = base64.b64decode(c["proof"]), c["ad"].encode()
+                assert bool(L.twin_bn254p_verify_id_wire(ctxs[c["svc"]], raw, len(raw), 0, ad, len(ad))) == c["expect"], (s["name"], c["label"])
+    r = load_golden("bn254_oracle_with_retrieval.json")["runs"][0]
+    pk = CD.pk_decode(base64.b64decode(r["pk"]))
+    g, apk, h = M.hash_to_g1(r["g_seed"]), M.hash_to_g1(r["authority_pk_seed"]), M.hash_to_g1(r["h_seed"])
+    ctx = _ctx(L, pk, svc=r["svc"].encode(), g_eg=g, apk=apk, h=h)
+    raw = base64.b64decode(r["proof"])
+    assert L.twin_bn254p_verify_id_wire(ctx, raw, len(raw), 1, b"hello", 5) == 1
+    assert L.twin_bn254p_verify_id_wire(ctx, raw, len(raw), 1, b"hellO", 5) == 0
+    for cut in (1, 2, 35, 100, len(raw) - 1):
+        assert L.twin_bn254p_verify_id_wire(ctx, raw[:cut], cut, 1, b"hello", 5) == 0
