@@ -8,12 +8,13 @@ void elpSetStrictSignature(bool strict) { g_strict_signature = strict; }
 ElpKey::ElpKey(const PSPubKey& pk, int device, int window_bits) {
   if (pk.Yi.size() != pk.YYi.size() || pk.Yi.empty() || pk.Yi.size() > 62) throw std::runtime_error("ElpKey: bad public key shape");
   nattr_ = pk.Yi.size();
-  elpCheck(nullptr, elp_init(ELP_CURVE_BN254, device, &ctx_), "elp_init");
+  elpCheck(nullptr, elp_init(curveId(), device, &ctx_), "elp_init");      // the curve initPairing() selected for the process
   elp_set_option(ctx_, ELP_OPT_STRICT_SIGNATURE, g_strict_signature ? 1 : 0);
-  std::vector<uint8_t> yi(64 * nattr_), yyi(128 * nattr_);
+  const size_t S1 = G1::size(), S2 = G2::size();
+  std::vector<uint8_t> yi(S1 * nattr_), yyi(S2 * nattr_);
   for (size_t i = 0; i < nattr_; i++) {
-    memcpy(&yi[64 * i], pk.Yi[i].b, 64);
-    memcpy(&yyi[128 * i], pk.YYi[i].b, 128);
+    memcpy(&yi[S1 * i], pk.Yi[i].b, S1);
+    memcpy(&yyi[S2 * i], pk.YYi[i].b, S2);
   }
   int rc = elp_set_pubkey(ctx_, (int)nattr_, pk.g.b, pk.gg.b, pk.XX.b, yi.data(), yyi.data(), window_bits);
   if (rc != ELP_OK) {

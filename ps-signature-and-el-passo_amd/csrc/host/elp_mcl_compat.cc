@@ -10,9 +10,24 @@ namespace bls12 {
 typedef unsigned __int128 u128;
 static elp_ctx* g_ctx = nullptr;
 
-// BN254 (mcl default) group order r and base-field prime p, little-endian 64-bit limbs
-static const uint64_t R_[4] = {0xa10000000000000dull, 0xff9f800000000010ull, 0xba344d8000000007ull, 0x2523648240000001ull};
-static const uint64_t P_[4] = {0xa700000000000013ull, 0x6121000000000013ull, 0xba344d8000000008ull, 0x2523648240000001ull};
+// per-curve constants, little-endian 64-bit limbs: group order r (4 limbs) and base-field prime p (6 limbs, zero-extended)
+struct CurveConst {
+  int id;
+  size_t F;          // field bytes
+  int rbits;         // bit length of r
+  int pbits;         // bit length of p
+  uint64_t r[4];
+  uint64_t p[6];
+};
+static const CurveConst kBN254 = {ELP_CURVE_BN254, 32, 254, 254,
+                                  {0xa10000000000000dull, 0xff9f800000000010ull, 0xba344d8000000007ull, 0x2523648240000001ull},
+                                  {0xa700000000000013ull, 0x6121000000000013ull, 0xba344d8000000008ull, 0x2523648240000001ull, 0, 0}};
+static const CurveConst kBLS12_381 = {ELP_CURVE_BLS12_381, 48, 255, 381,
+                                      {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull},
+                                      {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull,
+                                       0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull}};
+static const CurveConst* g_cv = &kBN254;
+#define R_ (g_cv->r)
 
 void elpCheck(elp_ctx* ctx, int rc, const char* what) {
   if (rc != ELP_OK) throw std::runtime_error(std::string(what) + " failed: " + (ctx ? elp_last_error(ctx) : "no context") +
@@ -22,9 +37,16 @@ elp_ctx* defaultContext() {
   if (!g_ctx) throw std::runtime_error("initPairing() has not been called");
   return g_ctx;
 }
-void initPairing(int device) {
-  if (g_ctx) return;
-  int rc = elp_init(ELP_CURVE_BN254, device, &g_ctx);
+int curveId() { return g_cv->id; }
+size_t fieldBytes() { return g_cv->F; }
+void initPairing(CurveParam curve, int device) {
+  const CurveConst* want = curve == BLS12_381 ? &kBLS12_381 : &kBN254;
+  if (g_ctx) {
+    if (want != g_cv) throw std::runtime_error("initPairing: the process already runs on the other curve");
+    return;
+  }
+  g_cv = want;
+  int rc = elp_init(g_cv->id, device, &g_ctx);
   if (rc != ELP_OK) throw std::runtime_error("elp_init failed (" + std::to_string(rc) + "): a GPU is required, there is no CPU fallback");
 }
 std::string toHex(const uint8_t* p, size_t n) {
@@ -37,7 +59,7 @@ std::string toHex(const uint8_t* p, size_t n) {
   return s;
 }
 
-// ---- 256-bit helpers
+// ---- 256-bit helpers (scalars)
 static void ld(uint64_t v[4], const uint8_t* b) { memcpy(v, b, 32); }
 static void st(uint8_t* b, const uint64_t v[4]) { memcpy(b, v, 32); }
 static int cmp4(const uint64_t* a, const uint64_t* m) {
@@ -65,6 +87,11 @@ static uint64_t add4(uint64_t* r, const uint64_t* a, const uint64_t* b) {
   }
   return (uint64_t)c;
 }
+static void maskScalar(uint64_t v[4]) {   // mcl setArrayMask: keep bitlen(r) bits, drop one more if still >= r
+  const int top = g_cv->rbits - 192;      // bits kept in the top limb (62 or 63)
+  v[3] &= (1ull << top) - 1;
+  if (cmp4(v, R_) >= 0) v[3] &= (1ull << (top - 1)) - 1;
+}
 
 // ---- Fr
 void Fr::setInt(uint64_t v) {
@@ -81,7 +108,7 @@ void Fr::setByCSPRNG() {
   uint64_t v[4];
   do {
     for (int i = 0; i < 4; i++) v[i] = ((uint64_t)rd() << 32) | rd();
-    v[3] &= (1ull << 62) - 1;
+    v[3] &= (1ull << (g_cv->rbits - 192)) - 1;
   } while (cmp4(v, R_) >= 0);
   st(b, v);
 }
@@ -90,15 +117,14 @@ void Fr::setHashOf(const std::string& msg) {
   std::string d = h.digest(msg);
   uint64_t v[4];
   memcpy(v, d.data(), 32);
-  v[3] &= (1ull << 62) - 1;                 // 254 bits
-  if (cmp4(v, R_) >= 0) v[3] &= (1ull << 61) - 1;
+  maskScalar(v);
   st(b, v);
 }
 void Fr::add(Fr& z, const Fr& x, const Fr& y) {
   uint64_t a[4], c[4], r[4];
   ld(a, x.b);
   ld(c, y.b);
-  add4(r, a, c);  // < 2r < 2^255: no carry out
+  add4(r, a, c);  // < 2r < 2^256: no carry out
   if (cmp4(r, R_) >= 0) sub4(r, r, R_);
   st(z.b, r);
 }
@@ -153,24 +179,30 @@ size_t Fr::deserialize(const void* buf, size_t size) {
 }
 std::string Fr::serializeToHexStr() const { return toHex(b, 32); }
 
-// ---- G1 / G2 (all group arithmetic on the GPU)
+// ---- G1 / G2 (all group arithmetic on the GPU; coordinates are F = fieldBytes() bytes each)
 static bool allZero(const uint8_t* p, size_t n) {
   uint8_t t = 0;
   for (size_t i = 0; i < n; i++) t |= p[i];
   return t == 0;
 }
-static void negCoord(uint8_t* out, const uint8_t* in) {  // p - y (y != 0), or 0
-  uint64_t y[4], r[4];
-  ld(y, in);
-  if ((y[0] | y[1] | y[2] | y[3]) == 0) {
-    st(out, y);
+static void negCoord(uint8_t* out, const uint8_t* in) {  // p - y (y != 0), or 0; F-byte coordinates
+  const size_t F = g_cv->F, L = F / 8;
+  uint64_t y[6] = {0, 0, 0, 0, 0, 0}, r[6];
+  memcpy(y, in, F);
+  if (allZero(in, F)) {
+    memcpy(out, in, F);
     return;
   }
-  sub4(r, P_, y);
-  st(out, r);
+  u128 br = 0;
+  for (size_t i = 0; i < L; i++) {
+    u128 t = (u128)g_cv->p[i] - y[i] - br;
+    r[i] = (uint64_t)t;
+    br = (t >> 64) & 1;
+  }
+  memcpy(out, r, F);
 }
-bool G1::isZero() const { return allZero(b, 64); }
-bool G1::operator==(const G1& o) const { return memcmp(b, o.b, 64) == 0; }
+bool G1::isZero() const { return allZero(b, size()); }
+bool G1::operator==(const G1& o) const { return memcmp(b, o.b, size()) == 0; }
 void G1::mul(G1& z, const G1& x, const Fr& k) {
   G1 r;
   elpCheck(defaultContext(), elp_g1_mul(defaultContext(), 1, x.b, k.b, r.b), "elp_g1_mul");
@@ -183,7 +215,7 @@ void G1::add(G1& z, const G1& x, const G1& y) {
 }
 void G1::neg(G1& z, const G1& x) {
   G1 r = x;
-  negCoord(r.b + 32, x.b + 32);
+  negCoord(r.b + g_cv->F, x.b + g_cv->F);
   z = r;
 }
 void G1::sub(G1& z, const G1& x, const G1& y) {
@@ -192,51 +224,59 @@ void G1::sub(G1& z, const G1& x, const G1& y) {
   add(z, x, n);
 }
 size_t G1::serialize(void* buf, size_t maxSize) const {
-  if (maxSize < 32) return 0;
+  const size_t F = g_cv->F;
+  if (maxSize < F) return 0;
   uint8_t* o = (uint8_t*)buf;
-  memcpy(o, b, 32);
-  if (b[32] & 1) o[31] |= 0x80;
-  return 32;
+  memcpy(o, b, F);
+  if (b[F] & 1) o[F - 1] |= 0x80;
+  return F;
 }
 size_t G1::deserialize(const void* buf, size_t size) {
-  if (size != 32) return 0;
+  if (size != g_cv->F) return 0;
   uint8_t ok = 0;
   G1 r;
   elpCheck(defaultContext(), elp_g1_decompress(defaultContext(), 1, (const uint8_t*)buf, r.b, &ok), "elp_g1_decompress");
   if (!ok) return 0;
   *this = r;
-  return 32;
+  return size;
 }
 std::string G1::serializeToHexStr() const {
-  uint8_t w[32];
-  serialize(w, 32);
-  return toHex(w, 32);
+  uint8_t w[48];
+  size_t n = serialize(w, sizeof w);
+  return toHex(w, n);
 }
-static std::string toDecimal(const uint8_t* le32) {
-  uint64_t v[4];
-  ld(v, le32);
+static std::string toDecimal(const uint8_t* le, size_t nbytes) {
+  uint64_t v[6] = {0, 0, 0, 0, 0, 0};
+  memcpy(v, le, nbytes);
+  const int L = (int)(nbytes / 8);
+  auto nz = [&]() {
+    uint64_t t = 0;
+    for (int i = 0; i < L; i++) t |= v[i];
+    return t != 0;
+  };
   std::string out;
   const uint64_t base = 1000000000000000000ull;  // 10^18
-  while (v[0] | v[1] | v[2] | v[3]) {
+  while (nz()) {
     u128 rem = 0;
-    for (int i = 3; i >= 0; i--) {
+    for (int i = L - 1; i >= 0; i--) {
       u128 cur = (rem << 64) | v[i];
       v[i] = (uint64_t)(cur / base);
       rem = cur % base;
     }
     std::string chunk = std::to_string((uint64_t)rem);
-    if (v[0] | v[1] | v[2] | v[3]) chunk = std::string(18 - chunk.size(), '0') + chunk;
+    if (nz()) chunk = std::string(18 - chunk.size(), '0') + chunk;
     out = chunk + out;
   }
   return out.empty() ? "0" : out;
 }
 std::string G1::getStr() const {
   if (isZero()) return "0";
-  return "1 " + toDecimal(b) + " " + toDecimal(b + 32);
+  const size_t F = g_cv->F;
+  return "1 " + toDecimal(b, F) + " " + toDecimal(b + F, F);
 }
 
-bool G2::isZero() const { return allZero(b, 128); }
-bool G2::operator==(const G2& o) const { return memcmp(b, o.b, 128) == 0; }
+bool G2::isZero() const { return allZero(b, size()); }
+bool G2::operator==(const G2& o) const { return memcmp(b, o.b, size()) == 0; }
 void G2::mul(G2& z, const G2& x, const Fr& k) {
   G2 r;
   elpCheck(defaultContext(), elp_g2_mul(defaultContext(), 1, x.b, k.b, r.b), "elp_g2_mul");
@@ -248,9 +288,10 @@ void G2::add(G2& z, const G2& x, const G2& y) {
   z = r;
 }
 void G2::neg(G2& z, const G2& x) {
+  const size_t F = g_cv->F;
   G2 r = x;
-  negCoord(r.b + 64, x.b + 64);
-  negCoord(r.b + 96, x.b + 96);
+  negCoord(r.b + 2 * F, x.b + 2 * F);
+  negCoord(r.b + 3 * F, x.b + 3 * F);
   z = r;
 }
 void G2::sub(G2& z, const G2& x, const G2& y) {
@@ -259,27 +300,28 @@ void G2::sub(G2& z, const G2& x, const G2& y) {
   add(z, x, n);
 }
 size_t G2::serialize(void* buf, size_t maxSize) const {
-  if (maxSize < 64) return 0;
+  const size_t F = g_cv->F;
+  if (maxSize < 2 * F) return 0;
   uint8_t* o = (uint8_t*)buf;
-  memcpy(o, b, 64);
-  if (b[64] & 1) o[63] |= 0x80;
-  return 64;
+  memcpy(o, b, 2 * F);
+  if (b[2 * F] & 1) o[2 * F - 1] |= 0x80;
+  return 2 * F;
 }
 size_t G2::deserialize(const void* buf, size_t size) {
-  if (size != 64) return 0;
+  if (size != 2 * g_cv->F) return 0;
   uint8_t ok = 0;
   G2 r;
   elpCheck(defaultContext(), elp_g2_decompress(defaultContext(), 1, (const uint8_t*)buf, r.b, &ok), "elp_g2_decompress");
   if (!ok) return 0;
   *this = r;
-  return 64;
+  return size;
 }
 std::string G2::serializeToHexStr() const {
-  uint8_t w[64];
-  serialize(w, 64);
-  return toHex(w, 64);
+  uint8_t w[96];
+  size_t n = serialize(w, sizeof w);
+  return toHex(w, n);
 }
-bool GT::operator==(const GT& o) const { return memcmp(b, o.b, 384) == 0; }
+bool GT::operator==(const GT& o) const { return memcmp(b, o.b, 12 * g_cv->F) == 0; }
 
 void pairing(GT& e, const G1& P, const G2& Q) {
   elpCheck(defaultContext(), elp_pairing(defaultContext(), 1, P.b, Q.b, e.b), "elp_pairing");
@@ -289,7 +331,26 @@ void hashAndMapToG1(G1& P, const std::string& msg) {
   elpCheck(defaultContext(), elp_hash_to_g1(defaultContext(), 1, (const uint8_t*)msg.data(), off, P.b), "elp_hash_to_g1");
 }
 void hashAndMapToG2(G2& P, const std::string& msg) {
-  // x = (Fp::setHashOf(msg || ctr || 0), Fp::setHashOf(msg || ctr || 1)); first x on the twist wins; then clear the cofactor 2p - r
+  if (g_cv->id == ELP_CURVE_BLS12_381) {
+    // stand-in (only ever used to pick a generator, src/ps-signer.cc:17): [Fr::setHashOf(msg)] times the standard G2 generator
+    static const char* gen[4] = {
+        "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8",
+        "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e",
+        "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801",
+        "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be"};
+    G2 g;
+    for (int c = 0; c < 4; c++)
+      for (int i = 0; i < 48; i++) {   // big-endian hex -> little-endian bytes
+        auto hv = [](char ch) { return (uint8_t)(ch <= '9' ? ch - '0' : ch - 'a' + 10); };
+        g.b[48 * c + i] = (uint8_t)((hv(gen[c][2 * (47 - i)]) << 4) | hv(gen[c][2 * (47 - i) + 1]));
+      }
+    Fr k;
+    k.setHashOf(msg);
+    if (k.isZero()) k.setInt(1);
+    G2::mul(P, g, k);
+    return;
+  }
+  // BN254: x = (Fp::setHashOf(msg || ctr || 0), Fp::setHashOf(msg || ctr || 1)); first x on the twist wins; then clear the cofactor 2p - r
   for (uint32_t ctr = 0;; ctr++) {
     uint8_t wire[64];
     for (int half = 0; half < 2; half++) {
@@ -298,7 +359,7 @@ void hashAndMapToG2(G2& P, const std::string& msg) {
       uint64_t v[4];
       memcpy(v, d.data(), 32);
       v[3] &= (1ull << 62) - 1;
-      if (cmp4(v, P_) >= 0) v[3] &= (1ull << 61) - 1;
+      if (cmp4(v, g_cv->p) >= 0) v[3] &= (1ull << 61) - 1;
       memcpy(wire + 32 * half, v, 32);
     }
     uint8_t ok = 0;
@@ -306,7 +367,7 @@ void hashAndMapToG2(G2& P, const std::string& msg) {
     elpCheck(defaultContext(), elp_g2_decompress(defaultContext(), 1, wire, q.b, &ok), "elp_g2_decompress");
     if (!ok || q.isZero()) continue;
     uint64_t cof[4], two_p[4];
-    add4(two_p, P_, P_);
+    add4(two_p, g_cv->p, g_cv->p);
     sub4(cof, two_p, R_);
     uint8_t k[32];
     st(k, cof);

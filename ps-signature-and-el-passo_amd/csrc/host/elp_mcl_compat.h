@@ -23,8 +23,13 @@ namespace bls12 {
 
 // Process-wide default context (created by initPairing(), used by the free functions and the static G1/G2 operations).
 elp_ctx* defaultContext();
-// Replaces mcl's initPairing() (reference: test/ps-tests.cc:142).  The reference runs on mcl's default curve (BN254).
-void initPairing(int device = 0);
+// Replaces mcl's initPairing(const mcl::CurveParam& = mcl::BN254) (reference: test/ps-tests.cc:142, called without an argument: the reference
+// runs on mcl's default curve BN254 although it includes the bls12_381 header).  BLS12_381 selects the north-star curve for the whole
+// process: same classes, 48-byte coordinates; its conventions that only mcl could pin (hash-to-curve) are this project's own.
+enum CurveParam { BN254 = 0, BLS12_381 = 1 };
+void initPairing(CurveParam curve = BN254, int device = 0);
+int curveId();            // ELP_CURVE_* of the process (after initPairing)
+size_t fieldBytes();      // F: 32 (BN254) or 48 (BLS12-381)
 
 struct Fr {
   uint8_t b[32];  // canonical little-endian integer < r
@@ -48,11 +53,12 @@ struct Fr {
 };
 
 struct G1 {
-  uint8_t b[64];  // affine x | y, canonical little-endian; all-zero = infinity
+  uint8_t b[96];  // affine x | y (F bytes each, canonical little-endian), zero padded; all-zero = infinity
   G1() { clear(); }
   void clear() {
-    for (int i = 0; i < 64; i++) b[i] = 0;
+    for (int i = 0; i < 96; i++) b[i] = 0;
   }
+  static size_t size() { return 2 * fieldBytes(); }        // bytes of the affine form handed to the C-ABI
   bool isZero() const;
   bool operator==(const G1& o) const;
   bool operator!=(const G1& o) const { return !(*this == o); }
@@ -60,18 +66,19 @@ struct G1 {
   static void add(G1& z, const G1& x, const G1& y);
   static void sub(G1& z, const G1& x, const G1& y);
   static void neg(G1& z, const G1& x);
-  size_t serialize(void* buf, size_t maxSize) const;     // 32-byte mcl wire form
+  size_t serialize(void* buf, size_t maxSize) const;     // F-byte mcl wire form
   size_t deserialize(const void* buf, size_t size);       // point decompression on the GPU; 0 on failure
   std::string serializeToHexStr() const;
   std::string getStr() const;                             // "1 <x> <y>" decimal, "0" for infinity
 };
 
 struct G2 {
-  uint8_t b[128];
+  uint8_t b[192];  // x.a | x.b | y.a | y.b (F bytes each), zero padded
   G2() { clear(); }
   void clear() {
-    for (int i = 0; i < 128; i++) b[i] = 0;
+    for (int i = 0; i < 192; i++) b[i] = 0;
   }
+  static size_t size() { return 4 * fieldBytes(); }
   bool isZero() const;
   bool operator==(const G2& o) const;
   bool operator!=(const G2& o) const { return !(*this == o); }
@@ -79,13 +86,16 @@ struct G2 {
   static void add(G2& z, const G2& x, const G2& y);
   static void sub(G2& z, const G2& x, const G2& y);
   static void neg(G2& z, const G2& x);
-  size_t serialize(void* buf, size_t maxSize) const;     // 64-byte mcl wire form
+  size_t serialize(void* buf, size_t maxSize) const;     // 2F-byte mcl wire form
   size_t deserialize(const void* buf, size_t size);
   std::string serializeToHexStr() const;
 };
 
 struct GT {
-  uint8_t b[384];
+  uint8_t b[576];  // 12 F bytes used
+  GT() {
+    for (int i = 0; i < 576; i++) b[i] = 0;
+  }
   bool operator==(const GT& o) const;
   bool operator!=(const GT& o) const { return !(*this == o); }
 };

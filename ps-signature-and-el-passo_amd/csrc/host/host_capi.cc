@@ -43,7 +43,14 @@ const char* elph_last_error() { return g_err.c_str(); }
 
 int elph_init(int device) {
   return guarded([&] {
-    initPairing(device);
+    initPairing(BN254, device);
+    return 0;
+  });
+}
+// curve: 0 = BN254 (what the reference runs on), 1 = BLS12-381; one curve per process
+int elph_init_curve(int curve, int device) {
+  return guarded([&] {
+    initPairing(curve == 1 ? BLS12_381 : BN254, device);
     return 0;
   });
 }

@@ -77,8 +77,8 @@ PSCredential PSRequester::unblind_credential(const PSCredential& sig) const {
 bool PSRequester::verify(const PSCredential& sig, const std::vector<std::string>& all_attributes) const {
   if (all_attributes.size() > m_key->attrs()) return false;
   std::vector<uint8_t> rec;
-  rec.insert(rec.end(), sig.sig1.b, sig.sig1.b + 64);
-  rec.insert(rec.end(), sig.sig2.b, sig.sig2.b + 64);
+  rec.insert(rec.end(), sig.sig1.b, sig.sig1.b + G1::size());
+  rec.insert(rec.end(), sig.sig2.b, sig.sig2.b + G1::size());
   for (const std::string& a : all_attributes) {
     Fr m;
     m.setHashOf(a);
@@ -92,15 +92,16 @@ bool PSRequester::verify(const PSCredential& sig, const std::vector<std::string>
 
 PSCredential PSRequester::randomize_credential(const PSCredential& sig) const {
   Fr t = draw();
-  uint8_t pts[128], ks[64], out[128];
-  memcpy(pts, sig.sig1.b, 64);
-  memcpy(pts + 64, sig.sig2.b, 64);
+  const size_t S1 = G1::size();
+  uint8_t pts[192], ks[64], out[192];
+  memcpy(pts, sig.sig1.b, S1);
+  memcpy(pts + S1, sig.sig2.b, S1);
   memcpy(ks, t.b, 32);
   memcpy(ks + 32, t.b, 32);
   elpCheck(m_key->ctx(), elp_g1_mul(m_key->ctx(), 2, pts, ks, out), "elp_g1_mul");
   PSCredential r;
-  memcpy(r.sig1.b, out, 64);
-  memcpy(r.sig2.b, out + 64, 64);
+  memcpy(r.sig1.b, out, S1);
+  memcpy(r.sig2.b, out + S1, S1);
   return r;
 }
 
@@ -221,8 +222,8 @@ std::vector<IdProof> PSRequester::el_passo_prove_id_batch(const std::vector<PSCr
     if (attributes[u].size() != A) throw std::runtime_error("attribute size does not match");
     for (size_t i = 0; i < A; i++)
       if (std::get<1>(attributes[u][i]) != (((mask >> i) & 1) != 0)) throw std::runtime_error("hidden pattern differs inside the batch");
-    put(recs, sigs[u].sig1.b, 64);
-    put(recs, sigs[u].sig2.b, 64);
+    put(recs, sigs[u].sig1.b, G1::size());
+    put(recs, sigs[u].sig2.b, G1::size());
     for (size_t i = 0; i < A; i++) {
       Fr m;
       m.setHashOf(std::get<0>(attributes[u][i]));
@@ -249,17 +250,17 @@ std::vector<IdProof> PSRequester::el_passo_prove_id_batch(const std::vector<PSCr
     const uint8_t* p = proofs.data() + u * osz;
     IdProof& pr = out[u];
     auto take = [&p](uint8_t* dst, size_t len) { memcpy(dst, p, len); p += len; };
-    take(pr.sig1.b, 64);
-    take(pr.sig2.b, 64);
-    take(pr.phi.b, 64);
+    take(pr.sig1.b, G1::size());
+    take(pr.sig2.b, G1::size());
+    take(pr.phi.b, G1::size());
     if (retr) {
       G1 e1, e2;
-      take(e1.b, 64);
-      take(e2.b, 64);
+      take(e1.b, G1::size());
+      take(e2.b, G1::size());
       pr.E1 = e1;
       pr.E2 = e2;
     }
-    take(pr.k.b, 128);
+    take(pr.k.b, G2::size());
     take(pr.c.b, 32);
     pr.rs.resize(H + (retr ? 2 : 1));
     for (Fr& r : pr.rs) take(r.b, 32);

@@ -23,22 +23,23 @@ PSPubKey PSSigner::key_gen_from(const Fr& x, const std::vector<Fr>& ys) {
   if (ys.size() != m_attribute_num) throw std::runtime_error("attribute size does not match");
   // one batched variable-base launch per group: {x, y_1..y_A} times the generator
   const size_t n = 1 + m_attribute_num;
-  std::vector<uint8_t> p1(64 * n), p2(128 * n), ks(32 * n), o1(64 * n), o2(128 * n);
+  const size_t S1 = G1::size(), S2 = G2::size();
+  std::vector<uint8_t> p1(S1 * n), p2(S2 * n), ks(32 * n), o1(S1 * n), o2(S2 * n);
   for (size_t i = 0; i < n; i++) {
-    memcpy(&p1[64 * i], m_pk.g.b, 64);
-    memcpy(&p2[128 * i], m_pk.gg.b, 128);
+    memcpy(&p1[S1 * i], m_pk.g.b, S1);
+    memcpy(&p2[S2 * i], m_pk.gg.b, S2);
     memcpy(&ks[32 * i], i == 0 ? x.b : ys[i - 1].b, 32);
   }
   elp_ctx* ctx = defaultContext();
   elpCheck(ctx, elp_g1_mul(ctx, n, p1.data(), ks.data(), o1.data()), "elp_g1_mul");
   elpCheck(ctx, elp_g2_mul(ctx, n, p2.data(), ks.data(), o2.data()), "elp_g2_mul");
-  memcpy(m_sk_X.b, &o1[0], 64);
-  memcpy(m_pk.XX.b, &o2[0], 128);
+  memcpy(m_sk_X.b, &o1[0], S1);
+  memcpy(m_pk.XX.b, &o2[0], S2);
   m_pk.Yi.assign(m_attribute_num, G1());
   m_pk.YYi.assign(m_attribute_num, G2());
   for (size_t i = 0; i < m_attribute_num; i++) {
-    memcpy(m_pk.Yi[i].b, &o1[64 * (i + 1)], 64);
-    memcpy(m_pk.YYi[i].b, &o2[128 * (i + 1)], 128);
+    memcpy(m_pk.Yi[i].b, &o1[S1 * (i + 1)], S1);
+    memcpy(m_pk.YYi[i].b, &o2[S2 * (i + 1)], S2);
   }
   installKey();
   return m_pk;
@@ -79,7 +80,7 @@ std::vector<bool> PSSigner::el_passo_provide_id_batch(const std::vector<PSCredRe
     std::vector<uint32_t> adoff(1, 0);
     for (size_t i : idx) {
       const PSCredRequest& q = reqs[i];
-      recs.insert(recs.end(), q.A.b, q.A.b + 64);
+      recs.insert(recs.end(), q.A.b, q.A.b + G1::size());
       recs.insert(recs.end(), q.c.b, q.c.b + 32);
       for (const Fr& r : q.rs) recs.insert(recs.end(), r.b, r.b + 32);
       for (const std::string& a : q.attributes)
@@ -98,7 +99,8 @@ std::vector<bool> PSSigner::el_passo_provide_id_batch(const std::vector<PSCredRe
       adoff.push_back((uint32_t)adbuf.size());
     }
     if (adbuf.empty()) adbuf.push_back(0);
-    std::vector<uint8_t> flags(idx.size()), out_sigs(128 * idx.size());
+    const size_t S1 = G1::size();
+    std::vector<uint8_t> flags(idx.size()), out_sigs(2 * S1 * idx.size());
     uint64_t acc = 0;
     elpCheck(m_key->ctx(),
              elp_provide_id_batch(m_key->ctx(), idx.size(), recs.data(), mask, adbuf.data(), adoff.data(), 0, out_sigs.data(), flags.data(), &acc),
@@ -106,8 +108,8 @@ std::vector<bool> PSSigner::el_passo_provide_id_batch(const std::vector<PSCredRe
     for (size_t j = 0; j < idx.size(); j++) {
       if (!flags[j]) continue;
       out[idx[j]] = true;
-      memcpy(sigs[idx[j]].sig1.b, &out_sigs[128 * j], 64);
-      memcpy(sigs[idx[j]].sig2.b, &out_sigs[128 * j + 64], 64);
+      memcpy(sigs[idx[j]].sig1.b, &out_sigs[2 * S1 * j], S1);
+      memcpy(sigs[idx[j]].sig2.b, &out_sigs[2 * S1 * j + S1], S1);
     }
   }
   return out;

@@ -24,8 +24,8 @@ std::vector<bool> PSVerifier::verify_batch(const std::vector<PSCredential>& sigs
   for (auto& [na, idx] : groups) {
     std::vector<uint8_t> recs;
     for (size_t i : idx) {
-      put(recs, sigs[i].sig1.b, 64);
-      put(recs, sigs[i].sig2.b, 64);
+      put(recs, sigs[i].sig1.b, G1::size());
+      put(recs, sigs[i].sig2.b, G1::size());
       for (const std::string& a : attrs[i]) {
         Fr m;
         m.setHashOf(a);
@@ -62,14 +62,14 @@ std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, c
     std::vector<uint32_t> adoff(1, 0);
     for (size_t i : idx) {
       const IdProof& p = proofs[i];
-      put(recs, p.sig1.b, 64);
-      put(recs, p.sig2.b, 64);
-      put(recs, p.phi.b, 64);
+      put(recs, p.sig1.b, G1::size());
+      put(recs, p.sig2.b, G1::size());
+      put(recs, p.phi.b, G1::size());
       if (retr) {
-        put(recs, p.E1->b, 64);
-        put(recs, p.E2->b, 64);
+        put(recs, p.E1->b, G1::size());
+        put(recs, p.E2->b, G1::size());
       }
-      put(recs, p.k.b, 128);
+      put(recs, p.k.b, G2::size());
       put(recs, p.c.b, 32);
       for (const Fr& r : p.rs) put(recs, r.b, 32);
       for (const std::string& a : p.attributes)

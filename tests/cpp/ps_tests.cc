@@ -171,7 +171,7 @@ static void test_codec() {
   G1 g2;
   size_t off = c.parseFrElement(0, f2);
   CHECK(off == 34 && f2 == f);
-  CHECK(c.parseG1Element(off, g2) == 34 && g2 == g);
+  CHECK(c.parseG1Element(off, g2) == 2 + fieldBytes() && g2 == g);
   CHECK(c.parseG1Element(0, g2) == 0);                  // type mismatch -> 0
   for (size_t n : {0u, 1u, 2u, 3u, 4u, 5u, 100u}) {
     PSBuffer raw;
@@ -184,12 +184,30 @@ static void test_codec() {
   CHECK(z.getStr() == "0" && z.isZero());
 }
 
-int main() {
-  initPairing();
+int main(int argc, char** argv) {
+  // `ps_tests bls12_381` runs the same flows on the north-star curve (initPairing(BLS12_381)): same classes, 48-byte coordinates
+  const bool bls = argc > 1 && std::string(argv[1]) == "bls12_381";
+  initPairing(bls ? BLS12_381 : BN254);
   test_codec();
   test_ps_sign_verify();
   test_el_passo(3);
+  test_el_passo(4);      // test/encoding-test.cc:279-280 runs 3 and 4 attributes
   test_el_passo(8);
+  {
+    // test/encoding-test.cc:84-118: key sizes for 3 and 20 attributes (BN254: 464 / 2130 bytes)
+    G1 g;
+    G2 gg;
+    hashAndMapToG1(g, "abc");
+    hashAndMapToG2(gg, "edf");
+    for (size_t n : {3u, 20u}) {
+      PSSigner idp(n, g, gg);
+      PSPubKey pk = idp.key_gen();
+      const size_t F = fieldBytes(), want = (2 + F) + 2 * (2 + 2 * F) + 2 + n * (1 + F) + 2 + n * (1 + 2 * F);
+      CHECK(pk.toBufferString().size() == want);
+      if (!bls) CHECK(pk.toBufferString().size() == (n == 3 ? 464u : 2130u));
+      CHECK(roundTrip(pk).toBufferString() == pk.toBufferString());
+    }
+  }
   std::cout << (g_fail ? "FAILED" : "ALL OK") << std::endl;
   return g_fail ? 1 : 0;
 }
