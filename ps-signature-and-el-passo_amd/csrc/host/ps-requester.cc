@@ -238,7 +238,7 @@ std::vector<IdProof> PSRequester::el_passo_prove_id_batch(const std::vector<PSCr
     adoff.push_back((uint32_t)adbuf.size());
   }
   if (adbuf.empty()) adbuf.push_back(0);
-  const size_t osz = elp_verify_id_record_size(ELP_CURVE_BN254, (int)A, (int)H, retr ? 1 : 0);
+  const size_t osz = elp_verify_id_record_size(curveId(), (int)A, (int)H, retr ? 1 : 0);
   std::vector<uint8_t> proofs(n * osz), flags(n);
   uint64_t produced = 0;
   elpCheck(m_key->ctx(),
