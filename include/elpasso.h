@@ -47,8 +47,9 @@ int elp_field_bytes(int curve);               /* F */
  * "sig_both_zero"), which is a universal forgery since e(O,K) e(O,gg) = 1, although PSVerifier::verify rejects it
  * (src/ps-verifier.cc:16-18).  Set to 0 for bit-for-bit reference behaviour on that input.
  * ELP_OPT_PAIRED_LAYOUT: which kernel layout verifies (results are identical).  0 = one lane per item; 1 = two lanes per item (the
- * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: whole
- * rounds of 64 x SIMDs items on the one-lane kernel, a remainder of up to 32 x SIMDs items on the two-lane kernel. */
+ * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: the
+ * two-lane kernel when the last round of 64 x SIMDs items would be at most half full (small batches, odd remainders) and always on
+ * BLS12-381, the one-lane kernel otherwise. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);

@@ -1291,19 +1291,20 @@ struct PairedBuild<BLS12_381> {
   static constexpr bool value = true;
 };
 static inline unsigned grid_for_paired(size_t n) { return (unsigned)((2 * n + ELP_BLOCK - 1) / ELP_BLOCK); }
-// How many of n items the one-lane-per-item kernel takes (the rest goes to the two-lanes-per-item kernel).  Measured on MI355X
-// (tools/probes/scale_probe.py, profiles/r02_layout_scale.log): both kernels are bound by vector-instruction issue.  The plain kernel runs
-// one wave per SIMD and needs 64 x SIMDs items per round to fill the chip; the paired kernel halves the latency of an item (a wave holds 32
-// items, 11.3 ms against 17-19 ms per round at A = 8) but issues ~17 % more instructions per item, so at two waves per SIMD it only ties.
-// Policy "by batch size": whole rounds of 64 x SIMDs items go to the plain kernel; a remainder of at most 32 x SIMDs items (one paired wave
-// per SIMD) goes to the paired kernel, a larger remainder to the plain kernel.
+// How many of n items the one-lane-per-item kernel takes (the rest goes to the two-lanes-per-item kernel; today the answer is all or none).
+// Measured on MI355X (tools/probes/scale_probe.py, profiles/r02_layout_scale_*.log): both kernels are bound by vector-instruction issue.  The
+// plain kernel runs one wave per SIMD and needs 64 x SIMDs items per round to fill the chip (18.0 ms per round of 65 536 at A = 8, W = 20); the paired
+// kernel halves the latency of an item (a wave holds 32 items: 10.3 ms for 32 768 items) but issues ~17 % more instructions per item, so at two waves per
+// SIMD it only ties (18.1 ms per 65 536).  Policy "by batch size": when the last round of the batch is at most half full (n mod 64 x SIMDs in
+// (0, 32 x SIMDs]) the whole batch goes to the paired kernel in ONE launch (98 304 items: 26.8 ms against 34.1 ms plain and 28.3 ms for a plain
+// round followed by a paired remainder), otherwise to the plain kernel.  BLS12-381 always takes the paired kernel.
 static inline size_t layout_split(const elp_ctx* c, size_t n) {
   if (c->paired == 0) return n;
   if (c->paired == 1) return 0;
   if (c->curve == ELP_CURVE_BLS12_381) return 0;     // 14-limb field: the paired kernel is faster at every batch size (profiles/r02_layout_scale.log)
   const size_t round = (size_t)64 * c->simds;
   const size_t rem = n % round;
-  return (rem != 0 && rem <= round / 2) ? n - rem : n;
+  return (rem != 0 && rem <= round / 2) ? 0 : n;
 }
 template <class B>
 void launch_verify_id_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr,
