@@ -93,7 +93,8 @@ ELP_HD constexpr bool is_paired() { return PairInfo<C>::paired; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 ELP_INL bool pair_odd() { return (threadIdx.x & 1u) != 0; }             // workgroups are one-dimensional with an even size
-ELP_INL int32_t pair_swap_i32(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false); }
+// bound_ctrl = true: every source lane of quad_perm is inside the row, and no "old" value has to be preloaded (one instruction instead of two)
+ELP_INL int32_t pair_swap_i32(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true); }
 #else
 // Host twin (tests only): the two lanes of a pair are two threads; the twin installs the hook that swaps a buffer with the partner
 // thread's (a rendezvous, so a divergence between the lanes of a pair shows up as a hang / mismatch in the CPU tests).
