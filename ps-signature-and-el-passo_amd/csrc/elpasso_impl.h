@@ -94,7 +94,10 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_verify(KeyCtx<C> key, const u32* recs, in
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
 // waves per SIMD; the LDS hot slot is half as large per lane (8 workgroups x 13.5 KB per CU).
-#define ELP_PAIR_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK, 2)
+#ifndef ELP_PAIR_WAVES
+#define ELP_PAIR_WAVES 2
+#endif
+#define ELP_PAIR_LAUNCH_BOUNDS __launch_bounds__(ELP_BLOCK, ELP_PAIR_WAVES)
 #define ELP_HOT_SETUP_PAIRED(key)                                                                    \
   __shared__ __attribute__((aligned(16))) u32 elp_hot_lds[ELP_BLOCK * elp::ELP_HOT_WORDS_PAIRED];  \
   (key).hot = elp_hot_lds + threadIdx.x * elp::ELP_HOT_WORDS_PAIRED
