@@ -27,6 +27,16 @@ ELP_INL Fp2<C> fp2_from_mem(const Fp2<typename PairInfo<C>::Base>& m) {
   return r;
 }
 
+template <class C>
+ELP_INL void fp12_from_mem(Fp12<C>& r, const Fp12<typename PairInfo<C>::Base>& m) {
+  r.c0.c0 = fp2_from_mem<C>(m.c0.c0);
+  r.c0.c1 = fp2_from_mem<C>(m.c0.c1);
+  r.c0.c2 = fp2_from_mem<C>(m.c0.c2);
+  r.c1.c0 = fp2_from_mem<C>(m.c1.c0);
+  r.c1.c1 = fp2_from_mem<C>(m.c1.c1);
+  r.c1.c2 = fp2_from_mem<C>(m.c1.c2);
+}
+
 template <class F>
 struct Aff;
 // ---- field-operation adaptors so that the group law is written once for Fp and Fp2.

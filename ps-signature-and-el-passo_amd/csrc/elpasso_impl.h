@@ -146,6 +146,25 @@ __global__ void ELP_PAIR_LAUNCH_BOUNDS k_ps_verify_paired(KeyCtx<C> key, const u
   count_accept_paired(ok, accepted);
 }
 
+// Closing step of aggregated verification on ONE lane pair (the plain-layout k_agg_final runs it on one lane): F * f(-S2, gg), final exponentiation,
+// comparison with 1.  The pair halves the latency of this serial tail (7.4 -> ~4.5 ms on BN254), which every aggregated batch pays once.
+template <class C>
+__global__ void ELP_PAIR_LAUNCH_BOUNDS k_agg_final_paired(KeyCtx<C> key, const Fp12<typename PairInfo<C>::Base>* F, const u32* s2_std, int* agg_ok) {
+  if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+  Aff<F1<C>> s2, ns2;
+  bool ok = g1_load<C>(s2, s2_std);
+  aff_neg(ns2, s2);
+  if (aff_is_inf(s2)) aff_set_inf(ns2);
+  Fp12<C> f, g, Fm;
+  fp12_from_mem<C>(Fm, F[0]);
+  const LineMem<C>* lines[1] = {key.gg_lines};
+  miller_loop<C, 0, 1>(f, &ns2, (const Aff<F2<C>>*)0, &ns2, lines);
+  fp12_mul<C>(f, f, Fm);
+  final_exp<C>(g, f);
+  const bool one = fp12_is_one(g);
+  if (threadIdx.x == 0) *agg_ok = (ok && one) ? 1 : 0;
+}
+
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_provide_id(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, const uint8_t* ad,
                                                           const u32* ad_off, u32 ad_len, u32* sigs, uint8_t* flags,
@@ -330,7 +349,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_pairing_check(const u32* g1, const u32* g2, 
 //                   (byte w of each scalar), shfl-based exclusive scan, LDS counting sort of the slice's indices by digit, then
 //                   lane b sums the points of bucket b (no elliptic-curve atomics, no divergence inside the additions)
 //   k_msm_reduce  : per window: slices combined, then sum_b b*B_b as a suffix scan + tree reduction through LDS
-//   k_msm_final   : Horner over the 32 windows, normalisation, one std affine point out
+//   k_msm_final   : Horner over the non-empty windows (of 32), normalisation, one std affine point out
 #define ELP_MSM_SLICE 8192
 #define ELP_MSM_TPB 256
 
@@ -428,8 +447,10 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_final(const void* win_, u32* out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   if (G == 1) {
     const Jac<F1<C>>* win = (const Jac<F1<C>>*)win_;
-    Jac<F1<C>> r = win[31];
-    for (int w = 30; w >= 0; w--) {
+    int top = 31;                           // short scalars (the 128-bit multipliers of aggregated verification) leave the upper windows empty
+    while (top > 0 && jac_is_inf(win[top])) top--;
+    Jac<F1<C>> r = win[top];
+    for (int w = top - 1; w >= 0; w--) {
       for (int k = 0; k < 8; k++) jac_dbl<F1<C>>(r, r);
       jac_add<F1<C>>(r, r, win[w]);
     }
@@ -438,8 +459,10 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_final(const void* win_, u32* out) {
     g1_store<C>(out, a);
   } else {
     const Jac<F2<C>>* win = (const Jac<F2<C>>*)win_;
-    Jac<F2<C>> r = win[31];
-    for (int w = 30; w >= 0; w--) {
+    int top = 31;
+    while (top > 0 && jac_is_inf(win[top])) top--;
+    Jac<F2<C>> r = win[top];
+    for (int w = top - 1; w >= 0; w--) {
       for (int k = 0; k < 8; k++) jac_dbl<F2<C>>(r, r);
       jac_add<F2<C>>(r, r, win[w]);
     }
@@ -1216,6 +1239,22 @@ static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, cons
   hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
 }
 
+// Which curves have the paired kernels in this build (their own translation unit, elpasso_<curve>_pair.hip).
+template <class B>
+struct PairedBuild {
+  static constexpr bool value = false;
+};
+template <>
+struct PairedBuild<BN254> {
+  static constexpr bool value = true;
+};
+template <>
+struct PairedBuild<BLS12_381> {
+  static constexpr bool value = true;
+};
+template <class B>
+void launch_agg_final_paired(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);   // defined with the other paired launchers below
+
 template <class C>
 int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr,
                                          const void* d_ad, const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags,
@@ -1272,7 +1311,14 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   F = (const Fp12<C>*)cur;
   // S2 = sum d_i sig2_i
   msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm);
-  hipLaunchKernelGGL((k_agg_final<C>), dim3(1), dim3(ELP_BLOCK), 0, stream, key, F, (const u32*)(ws + o_s2), c->agg_ok);
+  bool tail_done = false;
+  if constexpr (PairedBuild<C>::value) {
+    if (c->paired != 0) {                                     // the serial tail on a lane pair: about 0.6x the latency of one lane
+      launch_agg_final_paired<C>(c, stream, F, ws + o_s2);
+      tail_done = true;
+    }
+  }
+  if (!tail_done) hipLaunchKernelGGL((k_agg_final<C>), dim3(1), dim3(ELP_BLOCK), 0, stream, key, F, (const u32*)(ws + o_s2), c->agg_ok);
   hipLaunchKernelGGL((k_agg_finish<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                      (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (const uint8_t*)(ws + o_flags), (const int*)c->agg_ok,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
@@ -1280,19 +1326,6 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   return ELP_OK;
 }
 
-// Which curves have the paired kernels in this build (their own translation unit, elpasso_<curve>_pair.hip).
-template <class B>
-struct PairedBuild {
-  static constexpr bool value = false;
-};
-template <>
-struct PairedBuild<BN254> {
-  static constexpr bool value = true;
-};
-template <>
-struct PairedBuild<BLS12_381> {
-  static constexpr bool value = true;
-};
 static inline unsigned grid_for_paired(size_t n) { return (unsigned)((2 * n + ELP_BLOCK - 1) / ELP_BLOCK); }
 // How many of n items the one-lane-per-item kernel takes (the rest goes to the two-lanes-per-item kernel; today the answer is all or none).
 // Measured on MI355X (tools/probes/scale_probe.py, profiles/r02_layout_scale_*.log): both kernels are bound by vector-instruction issue.  The
@@ -1328,6 +1361,11 @@ void launch_ps_verify_paired(elp_ctx* c, hipStream_t stream, size_t n, const voi
   hipLaunchKernelGGL((k_ps_verify_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
                      (const u32*)d_records, 4 * B::N + 8 * nattr, nattr, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
+template <class B>
+void launch_agg_final_paired(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std) {
+  hipLaunchKernelGGL((k_agg_final_paired<Paired<B>>), dim3(1), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c), (const Fp12<B>*)F, (const u32*)s2_std,
+                     c->agg_ok);
+}
 #ifndef ELP_PAIR_TU
 extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
@@ -1335,6 +1373,8 @@ extern template void launch_verify_id_wire_paired<BN254>(elp_ctx* c, hipStream_t
 extern template void launch_verify_id_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
 extern template void launch_verify_id_wire_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template void launch_agg_final_paired<BN254>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
+extern template void launch_agg_final_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
 #endif
 
 template <class C>

@@ -466,6 +466,15 @@ def test_aggregated_verification_keeps_exact_verdicts(gpu_ctx):
     for m in (1, 63, 65):
         flags, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs[:m * rsz], mask, True, b"hello", seed)
         assert held and (flags == expect[:m]).all()
+    # the closing step (last Miller loop + final exponentiation) runs on a lane pair by default; the one-lane kernel must agree
+    try:
+        gpu_ctx.set_paired_layout(0)
+        flags, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, b"hello", seed)
+        assert held and (flags == expect).all() and cnt == int(expect.sum())
+        flags, cnt, held = gpu_ctx.verify_id_batch_aggregated(bad, mask, True, b"hello", seed)
+        assert not held and (flags == ref_flags).all() and cnt == ref_cnt
+    finally:
+        gpu_ctx.set_paired_layout(2)
 
 
 def test_irregular_hidden_pattern_and_long_attributes(gpu_ctx):
