@@ -484,6 +484,62 @@ ELP_INL void limbs_add_eights(u32* m) {
   }
 }
 
+// ---- where the per-item tables of small multiples (1P .. 8P) live.
+// In private memory a read with a lane-dependent index touches one 256-byte row per DISTINCT index in the wave (private memory is interleaved by lane), eight
+// rows per loaded word: an 8x read amplification that is harmless while the rows sit in L2 and dominates once they do not (the variable-base multiplications
+// ran 1.6-2x slower on a full chip than on an idle one, and at full speed when every lane used the same scalar: DESIGN.md section 5).  The verification
+// kernels therefore give every lane a slice of a launch workspace in HBM (KeyCtx::vtab): entries are contiguous per lane, padded to 16 bytes and moved as
+// 128-bit words, so a lookup costs each lane its own one or two cache lines.  PrivTab is the fallback (host twin, kernels without a workspace).
+template <class F>
+ELP_HD constexpr int vtab_entry_words() { return (int)(((sizeof(Aff<F>) / 4 + 3) / 4) * 4); }
+template <class F>
+struct PrivTab {
+  const Aff<F>* p;
+  ELP_INL Aff<F> operator()(int i) const { return p[i]; }
+};
+template <class F>
+struct WsTab {
+  const u32* base;                                         // 16-byte aligned, 8 entries of vtab_entry_words<F>() words
+  ELP_INL Aff<F> operator()(int i) const {
+    constexpr int EW = vtab_entry_words<F>();
+    union {
+      u32 w[EW];
+      Aff<F> a;
+    } u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4* q = reinterpret_cast<const uint4*>(base + (size_t)i * EW);
+    ELP_UNROLL
+    for (int k = 0; k < EW / 4; k++) {
+      const uint4 v = q[k];
+      u.w[4 * k] = v.x;
+      u.w[4 * k + 1] = v.y;
+      u.w[4 * k + 2] = v.z;
+      u.w[4 * k + 3] = v.w;
+    }
+#else
+    for (int k = 0; k < EW; k++) u.w[k] = base[(size_t)i * EW + k];
+#endif
+    return u.a;
+  }
+};
+template <class F>
+ELP_INL void vtab_store(u32* base, int i, const Aff<F>& a) {
+  constexpr int EW = vtab_entry_words<F>();
+  union {
+    u32 w[EW];
+    Aff<F> a;
+  } u;
+  for (int k = 0; k < EW; k++) u.w[k] = 0;
+  u.a = a;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint4* q = reinterpret_cast<uint4*>(base + (size_t)i * EW);
+  ELP_UNROLL
+  for (int k = 0; k < EW / 4; k++) q[k] = make_uint4(u.w[4 * k], u.w[4 * k + 1], u.w[4 * k + 2], u.w[4 * k + 3]);
+#else
+  for (int k = 0; k < EW; k++) base[(size_t)i * EW + k] = u.w[k];
+#endif
+}
+
 // ---- GLV / GLS multiplication over AFFINE tables 1P .. 8P (mixed additions: 11 / 29 instead of 16 / 43 products).
 // [k]P for P in the order-r subgroup of G1: k = k1 + k2 lam with phi(x, y) = (beta x, y) = [lam](x, y); one shared chain of 132 doublings,
 // two table additions per 4-bit window (the second through phi).  [k]Q in G2: k = k0 + k1 lam + k2 lam^2 + k3 lam^3 with psi(Q) = [lam]Q,
@@ -500,8 +556,10 @@ ELP_HEAVY void jac_multiples8(Jac<F>* t, const Aff<F>& p) {   // t[i] = (i + 1) 
   jac_madd<F>(t[6], t[5], p);
   jac_dbl<F>(t[7], t[3]);
 }
-template <class C>
-ELP_HEAVY void g1_mul_glv_tab(Jac<F1<C>>& r, const Aff<F1<C>>* tab, const Scalar& k_in) {
+// The entry of the NEXT (window, sub-scalar) step is loaded before the current addition is computed (its index only depends on the scalar), so the
+// latency of the lookup -- an HBM round trip once the tables are out of L2 -- is covered by the ~3 000 instructions of a mixed addition.
+template <class C, class Tab>
+ELP_HEAVY void g1_mul_glv_with(Jac<F1<C>>& r, const Tab& tab, const Scalar& k_in) {
   typedef F1<C> F;
   u32 m[2][5];
   bool neg[2];
@@ -512,27 +570,38 @@ ELP_HEAVY void g1_mul_glv_tab(Jac<F1<C>>& r, const Aff<F1<C>>* tab, const Scalar
   ELP_LOAD_FP(beta, C::glv_beta(i_));
   Jac<F> acc;
   jac_set_inf(acc);
+  int dg = limbs_window<5>(m[0], 4 * 32, 4) - 8;
+  Aff<F> t = tab(dg == 0 ? 0 : (dg < 0 ? -dg : dg) - 1);
   ELP_NOUNROLL
-  for (int w = 32; w >= 0; w--) {
-    if (w != 32) {
+  for (int step = 0; step < 66; step++) {
+    const int w = 32 - (step >> 1), j = step & 1;
+    if (j == 0 && w != 32) {
       ELP_NOUNROLL
       for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
     }
-    ELP_NOUNROLL
-    for (int j = 0; j < 2; j++) {
-      const int dg = limbs_window<5>(m[j], 4 * w, 4) - 8;
-      if (dg == 0) continue;
-      Aff<F> t = tab[(dg < 0 ? -dg : dg) - 1];
-      if (aff_is_inf(t)) continue;
+    int dgn = 0;
+    Aff<F> tn = t;
+    if (step + 1 < 66) {
+      const int wn = 32 - ((step + 1) >> 1), jn = (step + 1) & 1;
+      dgn = limbs_window<5>(m[jn], 4 * wn, 4) - 8;
+      tn = tab(dgn == 0 ? 0 : (dgn < 0 ? -dgn : dgn) - 1);
+    }
+    if (dg != 0 && !aff_is_inf(t)) {
       if (j == 1) t.x = fp_mul<C>(t.x, beta);
       if (neg[j] != (dg < 0)) t.y = fp_neg(t.y);
       jac_madd_inl<F>(acc, acc, t);
     }
+    dg = dgn;
+    t = tn;
   }
   r = acc;
 }
 template <class C>
-ELP_HEAVY void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar& k_in) {
+ELP_INL void g1_mul_glv_tab(Jac<F1<C>>& r, const Aff<F1<C>>* tab, const Scalar& k_in) {
+  g1_mul_glv_with<C, PrivTab<F1<C>>>(r, PrivTab<F1<C>>{tab}, k_in);
+}
+template <class C, class Tab>
+ELP_HEAVY void g2_mul_gls_with(Jac<F2<C>>& r, const Tab& tab, const Scalar& k_in) {
   typedef F2<C> F;
   u32 m[4][3];
   bool neg[4];
@@ -540,18 +609,23 @@ ELP_HEAVY void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar
   for (int j = 0; j < 4; j++) limbs_add_eights<3, 17>(m[j]);
   Jac<F> acc;
   jac_set_inf(acc);
+  int dg = limbs_window<3>(m[0], 4 * 16, 4) - 8;
+  Aff<F> t = tab(dg == 0 ? 0 : (dg < 0 ? -dg : dg) - 1);
   ELP_NOUNROLL
-  for (int w = 16; w >= 0; w--) {
-    if (w != 16) {
+  for (int step = 0; step < 68; step++) {
+    const int w = 16 - (step >> 2), j = step & 3;
+    if (j == 0 && w != 16) {
       ELP_NOUNROLL
       for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
     }
-    ELP_NOUNROLL
-    for (int j = 0; j < 4; j++) {
-      const int dg = limbs_window<3>(m[j], 4 * w, 4) - 8;
-      if (dg == 0) continue;
-      Aff<F> t = tab[(dg < 0 ? -dg : dg) - 1];
-      if (aff_is_inf(t)) continue;
+    int dgn = 0;
+    Aff<F> tn = t;
+    if (step + 1 < 68) {
+      const int wn = 16 - ((step + 1) >> 2), jn = (step + 1) & 3;
+      dgn = limbs_window<3>(m[jn], 4 * wn, 4) - 8;
+      tn = tab(dgn == 0 ? 0 : (dgn < 0 ? -dgn : dgn) - 1);
+    }
+    if (dg != 0 && !aff_is_inf(t)) {
       if (j != 0) {                        // psi^j on an affine point: (conj^j x * gx_j, conj^j y * gy_j)
         Fp2<C> gx, gy;
         if (j == 1) {
@@ -574,8 +648,14 @@ ELP_HEAVY void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar
       if (neg[j] != (dg < 0)) t.y = fp2_neg(t.y);
       jac_madd_inl<F>(acc, acc, t);
     }
+    dg = dgn;
+    t = tn;
   }
   r = acc;
+}
+template <class C>
+ELP_INL void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar& k_in) {
+  g2_mul_gls_with<C, PrivTab<F2<C>>>(r, PrivTab<F2<C>>{tab}, k_in);
 }
 
 // Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,

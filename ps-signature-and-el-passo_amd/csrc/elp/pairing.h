@@ -332,9 +332,12 @@ ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = null
     fp12_to_comp<C>(cur, a);
     int k = 0;
     ELP_NOUNROLL
-    for (int i = 1; i <= top; i++) {
-      cyc_comp_sqr<C>(cur, cur);
-      if ((e >> i) & 1) snap[k++] = cur;
+    for (int i = 1; i <= top;) {                 // one run of squarings per set bit (bit `top` is set, so the last run ends there)
+      int j = i;
+      while (!((e >> j) & 1)) j++;
+      cyc_comp_sqr_n<C>(cur, j - i + 1);
+      snap[k++] = cur;
+      i = j + 1;
     }
     // shared inversion of the norms (Montgomery's trick over Fp2)
     Fp2<C> acc = fp2_one<C>();

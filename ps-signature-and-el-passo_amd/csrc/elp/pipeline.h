@@ -39,12 +39,17 @@ struct KeyCtx {
   const Aff<typename F2<C>::MemF>* b2;   // G2 bases (affine):  0 = gg, 1 = XX, 2+i = YY_i
   const LineMem<C>* gg_lines;            // precomputed Miller lines of gg
   u32* hot = nullptr;             // this lane's LDS hot slot (ELP_HOT_WORDS words) or null, see common.h
+  u32* vtab = nullptr;            // this lane's slice of the launch workspace for the tables of small multiples (vtab_words<C>() words, 16-byte aligned) or null:
+                                  // the host hands the base of the workspace in, the kernel advances it to its lane (curve.h, WsTab)
   int flags = 0;                  // KEY_STRICT_SIG: proofs with sig1 == infinity are rejected (PS / EL PASSO require sigma_1 != 1)
 };
 // The reference's el_passo_verify_id accepts sig1 = sig2 = infinity with a self-made NIZK (e(O,K) e(O,gg) = 1: a universal forgery;
 // golden case "sig_both_zero", src/ps-verifier.cc:133-137 has no isZero test although PSVerifier::verify :16-18 has one).  The library
 // rejects it by default (elp_set_option(ELP_OPT_STRICT_SIGNATURE)); reference-compatible behaviour is opt-in.
 enum { KEY_STRICT_SIG = 1 };
+// words of workspace per lane: 1P .. 8P of k and of up to three G1 points
+template <class C>
+ELP_HD constexpr int vtab_words() { return 8 * vtab_entry_words<F2<C>>() + 3 * 8 * vtab_entry_words<F1<C>>(); }
 enum { G1_BASE_G = 0, G1_BASE_Y0 = 1 };
 enum { G2_BASE_GG = 0, G2_BASE_XX = 1, G2_BASE_YY0 = 2 };
 template <class C>
@@ -360,7 +365,19 @@ ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const A
       for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab1[t][i], j1[t][i], zi1[7 * t + i - 1]);
     }
   }
-  g2_mul_gls_tab<C>(Vk, tabk, c);         // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
+  // with a launch workspace the tables are read from this lane's slice of it (contiguous per lane), not from private memory: curve.h, WsTab
+  u32* const wsk = key.vtab;
+  u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<G2F>() : nullptr;
+  if (wsk) {
+    for (int i = 0; i < 8; i++) vtab_store<G2F>(wsk, i, tabk[i]);
+    for (int t = 0; t < 3; t++) {
+      if (t != 0 && !retr) continue;
+      for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1 + t * 8 * vtab_entry_words<G1F>(), i, tab1[t][i]);
+    }
+    g2_mul_gls_with<C, WsTab<G2F>>(Vk, WsTab<G2F>{wsk}, c);
+  } else {
+    g2_mul_gls_tab<C>(Vk, tabk, c);       // [c]k by the 4-dimensional GLS decomposition (k is expected in the order-r subgroup)
+  }
   jac_from_aff(K, kk);
   {
     int jh = 0, jr = 0;
@@ -376,13 +393,22 @@ ELP_HEAVY bool verify_id_nizk(const KeyCtx<C>& key, Src& src, bool retr, const A
   }
   acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
   acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
-  g1_mul_glv_tab<C>(Vphi, tab1[0], c);
+  if (ws1)
+    g1_mul_glv_with<C, WsTab<G1F>>(Vphi, WsTab<G1F>{ws1 + 0 * 8 * vtab_entry_words<G1F>()}, c);
+  else
+    g1_mul_glv_tab<C>(Vphi, tab1[0], c);
   acc_fixed_g1<C>(Vphi, key, g1_base_hs(key), src.rs(0));
   if (retr) {
     const Scalar r_e = src.rs(nrs - 1);
-    g1_mul_glv_tab<C>(VE1, tab1[1], c);
+    if (ws1)
+      g1_mul_glv_with<C, WsTab<G1F>>(VE1, WsTab<G1F>{ws1 + 1 * 8 * vtab_entry_words<G1F>()}, c);
+    else
+      g1_mul_glv_tab<C>(VE1, tab1[1], c);
     acc_fixed_g1<C>(VE1, key, g1_base_geg(key), r_e);
-    g1_mul_glv_tab<C>(VE2, tab1[2], c);
+    if (ws1)
+      g1_mul_glv_with<C, WsTab<G1F>>(VE2, WsTab<G1F>{ws1 + 2 * 8 * vtab_entry_words<G1F>()}, c);
+    else
+      g1_mul_glv_tab<C>(VE2, tab1[2], c);
     acc_fixed_g1<C>(VE2, key, g1_base_apk(key), r_e);
     acc_fixed_g1<C>(VE2, key, g1_base_h(key), src.rs(1));
   }
@@ -595,7 +621,18 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, Src& src, bool retr, 
   }
   // G2, by the pair:  V_k = k^c prod_{hidden} YY_j^{r_j} gg^{r_t} XX^{1-c},  K = k prod_{revealed} YY_i^{m_i}     (src/ps-verifier.cc:72-88,214-229)
   Jac<G2F> Vk, K;
-  g2_mul_gls_tab<C>(Vk, tabk, c);
+  u32* const wsk = key.vtab;
+  u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<G2F>() : nullptr;
+  if (wsk) {
+    for (int i = 0; i < 8; i++) {
+      vtab_store<G2F>(wsk, i, tabk[i]);
+      vtab_store<G1F>(ws1, i, tab0[i]);
+      if (retr) vtab_store<G1F>(ws1 + 8 * vtab_entry_words<G1F>(), i, tab1[i]);
+    }
+    g2_mul_gls_with<C, WsTab<G2F>>(Vk, WsTab<G2F>{wsk}, c);
+  } else {
+    g2_mul_gls_tab<C>(Vk, tabk, c);
+  }
   jac_from_aff(K, kk);
   {
     int jh = 0;
@@ -612,14 +649,20 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, Src& src, bool retr, 
   acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
   // G1, one job list per lane.  even: V_phi = phi^c H1(svc)^{r_0}, V_E1 = E1^c g^{r_eps};  odd: V_E2 = E2^c y^{r_eps} h^{r_1}   (:91-108)
   Jac<G1F> V0, V1;
-  g1_mul_glv_tab<C>(V0, tab0, c);
+  if (ws1)
+    g1_mul_glv_with<C, WsTab<G1F>>(V0, WsTab<G1F>{ws1}, c);
+  else
+    g1_mul_glv_tab<C>(V0, tab0, c);
   if (!odd || retr) {
     const int b0 = odd ? g1_base_apk(key) : g1_base_hs(key);
     acc_fixed_g1<C>(V0, key, b0, scalar_select<C>(odd, r_e, src.rs(0)));
   }
   if (odd && retr) acc_fixed_g1<C>(V0, key, g1_base_h(key), src.rs(1));
   if (retr) {
-    g1_mul_glv_tab<C>(V1, tab1, c);
+    if (ws1)
+      g1_mul_glv_with<C, WsTab<G1F>>(V1, WsTab<G1F>{ws1 + 8 * vtab_entry_words<G1F>()}, c);
+    else
+      g1_mul_glv_tab<C>(V1, tab1, c);
     if (!odd) acc_fixed_g1<C>(V1, key, g1_base_geg(key), r_e);
   } else {
     jac_set_inf(V1);

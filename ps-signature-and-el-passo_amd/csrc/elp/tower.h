@@ -939,7 +939,7 @@ ELP_INL void fp4_sqr(Fp2<C>& r0, Fp2<C>& r1, const Fp2<C>& x0, const Fp2<C>& x1)
   }
 }
 template <class C>
-ELP_HEAVY void cyc_comp_sqr(CycComp<C>& r, const CycComp<C>& a) {
+ELP_INL void cyc_comp_sqr_inl(CycComp<C>& r, const CycComp<C>& a) {
   Fp2<C> B0, B1, C0, C1;
   fp4_sqr<C>(B0, B1, a.z2, a.z3);
   fp4_sqr<C>(C0, C1, a.z4, a.z5);
@@ -967,6 +967,18 @@ ELP_HEAVY void cyc_comp_sqr(CycComp<C>& r, const CycComp<C>& a) {
   r.z3 = o3;
   r.z4 = o4;
   r.z5 = o5;
+}
+template <class C>
+ELP_HEAVY void cyc_comp_sqr(CycComp<C>& r, const CycComp<C>& a) {
+  cyc_comp_sqr_inl<C>(r, a);
+}
+// n squarings in a row with the four coefficients held in registers (as single calls every step moves them through memory twice)
+template <class C>
+ELP_HEAVY void cyc_comp_sqr_n(CycComp<C>& a, int n) {
+  CycComp<C> c = a;
+  ELP_NOUNROLL
+  for (int i = 0; i < n; i++) cyc_comp_sqr_inl<C>(c, c);
+  a = c;
 }
 // N(c) = z4^2 - xi z5^2 (the Fp4/Fp2 norm of c): zero iff c = 0
 template <class C>

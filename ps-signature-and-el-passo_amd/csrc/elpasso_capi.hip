@@ -73,6 +73,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   c->curve = curve;
   c->device = device;
   if (const char* e = getenv("ELP_LAYOUT")) c->paired = !strcmp(e, "plain") ? 0 : !strcmp(e, "paired") ? 1 : 2;     // A/B runs
+  if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->simds = 4 * prop.multiProcessorCount;
   if (hipStreamCreate(&c->stream) != hipSuccess) {
@@ -100,6 +101,8 @@ void elp_destroy(elp_ctx* c) {
   }
   if (last) dev_cache().trim();
   if (c->agg_ws) (void)hipFree(c->agg_ws);
+  for (auto& w : c->vtab_ws)
+    if (w.p) (void)hipFree(w.p);
   if (c->agg_ok) (void)hipFree(c->agg_ok);
   (void)hipStreamDestroy(c->stream);
   delete c;

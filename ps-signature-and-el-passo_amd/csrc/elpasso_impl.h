@@ -52,6 +52,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_verify_id(KeyCtx<C> key, const u32* recs, in
                                                          const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
                                                          unsigned long long* accepted, size_t n) {
   ELP_HOT_SETUP(key);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -68,6 +69,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_verify_id_wire(KeyCtx<C> key, const uint8_t*
                                                               const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
                                                               unsigned long long* accepted, size_t n) {
   ELP_HOT_SETUP(key);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -109,6 +111,7 @@ template <class C>
 __global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_paired(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
                                                           const u32* ad_off, u32 ad_len, uint8_t* flags, unsigned long long* accepted, size_t n) {
   ELP_HOT_SETUP_PAIRED(key);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   bool ok = false;
   if (i < n) {
@@ -123,6 +126,7 @@ template <class C>
 __global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_wire_paired(KeyCtx<C> key, const uint8_t* msgs, const u32* msg_off, int retr, const uint8_t* ad,
                                                                const u32* ad_off, u32 ad_len, uint8_t* flags, unsigned long long* accepted, size_t n) {
   ELP_HOT_SETUP_PAIRED(key);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   bool ok = false;
   if (i < n) {
@@ -717,6 +721,14 @@ struct elp_ctx {
   void* agg_ws = nullptr;
   size_t agg_ws_bytes = 0;
   int* agg_ok = nullptr;      // device flag of the last aggregated batch
+  // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
+  struct VtabWs {
+    hipStream_t stream;
+    void* p;
+    size_t bytes;
+  };
+  std::vector<VtabWs> vtab_ws;
+  int use_vtab = 1;           // ELP_VTAB=0 in the environment keeps the tables in private memory (A/B measurements)
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -743,6 +755,35 @@ static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key m
   k.b2 = (const Aff<typename F2<C>::MemF>*)c->b2;
   k.gg_lines = (const LineMem<C>*)c->lines;
   k.flags = c->strict_sig ? KEY_STRICT_SIG : 0;
+  return k;
+}
+
+// make_key + this launch's table workspace: `lanes` slices of vtab_words<C>() words.  No workspace (allocation failure, ELP_VTAB=0) is not an error:
+// the kernels then keep the tables in private memory.
+template <class C>
+static KeyCtx<C> make_key_ws(elp_ctx* c, hipStream_t stream, size_t lanes) {
+  KeyCtx<C> k = make_key<C>(c);
+  if (!c->use_vtab) return k;
+  const size_t need = lanes * (size_t)vtab_words<C>() * 4;
+  elp_ctx::VtabWs* w = nullptr;
+  for (auto& e : c->vtab_ws)
+    if (e.stream == stream) w = &e;
+  if (!w) {
+    c->vtab_ws.push_back({stream, nullptr, 0});
+    w = &c->vtab_ws.back();
+  }
+  if (w->bytes < need) {
+    if (w->p) (void)hipFree(w->p);        // hipFree waits for the work that may still read it
+    w->p = nullptr;
+    w->bytes = 0;
+    if (hipMalloc(&w->p, need) != hipSuccess) {
+      (void)hipGetLastError();
+      w->p = nullptr;
+      return k;
+    }
+    w->bytes = need;
+  }
+  k.vtab = (u32*)w->p;
   return k;
 }
 
@@ -1345,14 +1386,14 @@ static inline size_t layout_split(const elp_ctx* c, size_t n) {
 template <class B>
 void launch_verify_id_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr,
                              const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  hipLaunchKernelGGL((k_verify_id_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
+  hipLaunchKernelGGL((k_verify_id_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key_ws<Paired<B>>(c, stream, (size_t)grid_for_paired(n) * ELP_BLOCK),
                      (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
 template <class B>
 void launch_verify_id_wire_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad,
                                   const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
-  hipLaunchKernelGGL((k_verify_id_wire_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c),
+  hipLaunchKernelGGL((k_verify_id_wire_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, make_key_ws<Paired<B>>(c, stream, (size_t)grid_for_paired(n) * ELP_BLOCK),
                      (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (uint8_t*)d_flags,
                      (unsigned long long*)d_accepted, n);
 }
@@ -1397,7 +1438,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       n = np;
     }
   }
-  hipLaunchKernelGGL((k_verify_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+  hipLaunchKernelGGL((k_verify_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key_ws<C>(c, (hipStream_t)stream, (size_t)grid_for(n) * ELP_BLOCK),
                      (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
   HIPCHK(c, hipGetLastError());
@@ -1419,7 +1460,7 @@ int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const voi
       n = np;
     }
   }
-  hipLaunchKernelGGL((k_verify_id_wire<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key<C>(c),
+  hipLaunchKernelGGL((k_verify_id_wire<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key_ws<C>(c, (hipStream_t)stream, (size_t)grid_for(n) * ELP_BLOCK),
                      (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
   HIPCHK(c, hipGetLastError());

@@ -23,6 +23,7 @@ struct TwinCtx {
   std::vector<Aff<F2<C>>> t2, b2;
   std::vector<LineCoef<C>> lines;
   std::vector<u32> hot;   // stands in for the lane's LDS hot slot so the aliasing rules of KeyCtx::hot are exercised on the host
+  std::vector<u32> vtab;  // stands in for the lane's slice of the launch workspace (KeyCtx::vtab); ELP_TWIN_NO_VTAB=1 exercises the private-memory fallback
   void *t1s = nullptr, *t2s = nullptr;   // sparse (calloc-backed, lazily committed) tables of ctx_new_sparse
   ~TwinCtx() {
     free(t1s);
@@ -240,6 +241,8 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     c->key.gg_lines = c->lines.data();                                                                                 \
     c->hot.assign(ELP_HOT_WORDS, 0xdeadbeefu);                                                                         \
     c->key.hot = getenv("ELP_TWIN_NO_HOT") ? nullptr : c->hot.data();                                                  \
+    c->vtab.assign(vtab_words<C>(), 0xdeadbeefu);                                                                      \
+    c->key.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : c->vtab.data();                                              \
     return c;                                                                                                          \
   }                                                                                                                    \
   /* Tables of ANY window width without building them: zero-filled virtual memory (an all-zero entry reads as infinity) into which   \
@@ -269,6 +272,8 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     c->key.gg_lines = c->lines.data();                                                                                 \
     c->hot.assign(ELP_HOT_WORDS, 0xdeadbeefu);                                                                         \
     c->key.hot = c->hot.data();                                                                                        \
+    c->vtab.assign(vtab_words<C>(), 0xdeadbeefu);                                                                      \
+    c->key.vtab = c->vtab.data();                                                                                      \
     return c;                                                                                                          \
   }                                                                                                                    \
   void pfx##_table_touch(void* cv, int group, int base, const u32* k) {                                                \
@@ -385,6 +390,8 @@ int twin_blsp_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const
   return run_pair([&](int) {
     std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
     KeyCtx<BLSP> k = paired_key<BLS12_381>(c, hot.data());
+    std::vector<u32> vt(vtab_words<BLSP>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return verify_id_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
   });
 }
@@ -393,6 +400,8 @@ int twin_blsp_ps_verify(void* cv, const u32* rec, int nattr) {
   return run_pair([&](int) {
     std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
     KeyCtx<BLSP> k = paired_key<BLS12_381>(c, hot.data());
+    std::vector<u32> vt(vtab_words<BLSP>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return ps_verify_item<BLSP>(k, rec, nattr) ? 1 : 0;
   });
 }
@@ -419,6 +428,8 @@ int twin_bn254p_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, con
   return run_pair([&](int) {
     std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
     KeyCtx<BN254P> k = paired_key<BN254>(c, getenv("ELP_TWIN_NO_HOT") ? nullptr : hot.data());
+    std::vector<u32> vt(vtab_words<BN254P>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return verify_id_item_paired<BN254P>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
   });
 }
@@ -427,6 +438,8 @@ int twin_bn254p_verify_id_wire(void* cv, const uint8_t* msg, size_t len, int ret
   return run_pair([&](int) {
     std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
     KeyCtx<BN254P> k = paired_key<BN254>(c, hot.data());
+    std::vector<u32> vt(vtab_words<BN254P>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return verify_id_wire_item_paired<BN254P>(k, msg, len, retr != 0, ad, adlen) ? 1 : 0;
   });
 }
@@ -435,6 +448,8 @@ int twin_bn254p_ps_verify(void* cv, const u32* rec, int nattr) {
   return run_pair([&](int) {
     std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
     KeyCtx<BN254P> k = paired_key<BN254>(c, hot.data());
+    std::vector<u32> vt(vtab_words<BN254P>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return ps_verify_item<BN254P>(k, rec, nattr) ? 1 : 0;
   });
 }
