@@ -664,22 +664,42 @@ template <class F>
 ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<typename F::MemF>* table, int W, const Scalar& k, u32* hot = nullptr) {
   const int nwin = (256 + W - 1) / W;
   const int per = (1 << W) - 1;
-  Jac<F>* ah = hot_as<Jac<F>, typename F::Curve>(hot);   // the running sum lives in the hot slot while the windows are added (table entries are read in place)
+  Jac<F>* ah = hot_as<Jac<F>, typename F::Curve>(hot);   // the running sum lives in the hot slot while the windows are added
   Jac<F>& a = ah ? *ah : acc;
   if (ah) a = acc;
-  ELP_NOUNROLL
-  for (int j = 0; j < nwin; j++) {
-    int bit = j * W;
-    int w = (bit + W <= 256) ? W : 256 - bit;
-    int d = scalar_window(k, bit, w);
-    if (d != 0) {
-      // the mixed addition is part of this loop for the Fp2 group (as a routine of its own it saves and restores ~170 registers per call)
-      if constexpr (is_paired<typename F::Curve>()) {
+  // The entries are random reads of a table far larger than any cache (one HBM round trip each, with nothing else in the wave to hide it): the entry of
+  // the NEXT window is requested before the current addition is computed.  Digit 0 reads entry 0 of the window and ignores it.
+  auto digit = [&](int j) {
+    const int bit = j * W;
+    return scalar_window(k, bit, (bit + W <= 256) ? W : 256 - bit);
+  };
+  if constexpr (is_paired<typename F::Curve>()) {
+    // paired kernels (256 registers per lane): the look-ahead costs more in spills than it hides (measured: +1.5 %); plain loop
+    ELP_NOUNROLL
+    for (int j = 0; j < nwin; j++) {
+      const int d = digit(j);
+      if (d != 0) {
         const Aff<F> e = aff_from_mem<F>(table[(size_t)j * per + (d - 1)]);
         if (F::IS_EXT) jac_madd_inl<F>(a, a, e); else jac_madd<F>(a, a, e);
-      } else {
-        if (F::IS_EXT) jac_madd_inl<F>(a, a, table[(size_t)j * per + (d - 1)]); else jac_madd<F>(a, a, table[(size_t)j * per + (d - 1)]);
       }
+    }
+  } else {
+    int d = digit(0);
+    Aff<F> e = aff_from_mem<F>(table[d ? d - 1 : 0]);
+    ELP_NOUNROLL
+    for (int j = 0; j < nwin; j++) {
+      int dn = 0;
+      Aff<F> en = e;
+      if (j + 1 < nwin) {
+        dn = digit(j + 1);
+        en = aff_from_mem<F>(table[(size_t)(j + 1) * per + (dn ? dn - 1 : 0)]);
+      }
+      if (d != 0) {
+        // the mixed addition is part of this loop for the Fp2 group (as a routine of its own it saves and restores ~170 registers per call)
+        if (F::IS_EXT) jac_madd_inl<F>(a, a, e); else jac_madd<F>(a, a, e);
+      }
+      d = dn;
+      e = en;
     }
   }
   if (ah) acc = a;
