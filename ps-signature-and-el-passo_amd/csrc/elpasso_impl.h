@@ -503,6 +503,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_verify_id_agg(KeyCtx<C> key, const u32* recs
   __shared__ __attribute__((aligned(16))) Fp12<C> sh[ELP_BLOCK];
   static_assert(sizeof(Fp12<C>) >= (size_t)elp::ELP_HOT_WORDS * 4, "hot slot must fit an Fp12 entry");
   key.hot = reinterpret_cast<u32*>(&sh[threadIdx.x]);   // the lane's entry of the product buffer doubles as its hot slot until the reduction
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   Fp12<C> f;
   fp12_set_one(f);
@@ -1332,10 +1333,11 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     c->err = "getrandom failed";
     return ELP_ERR_STATE;
   }
-  KeyCtx<C> key = make_key<C>(c);
+  KeyCtx<C> key = make_key_ws<C>(c, stream, (size_t)nw * ELP_BLOCK);
   hipLaunchKernelGGL((k_verify_id_agg<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                      (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
                      (Fp12<C>*)(ws + o_f1), n);
+  key.vtab = nullptr;   // the kernels below do not advance the pointer to their lane (the rare per-item fallback keeps its tables in private memory)
   // product of the per-wave Miller values: nw -> nw2 -> 1
   hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nw2), dim3(ELP_BLOCK), 0, stream, (const Fp12<C>*)(ws + o_f1), nw, (Fp12<C>*)(ws + o_f2));
   const Fp12<C>* F = (const Fp12<C>*)(ws + o_f2);
