@@ -153,7 +153,10 @@ int elp_prove_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t 
                        uint64_t* produced);
 
 /* Same fused batches over DEVICE buffers, asynchronous on `stream` (hipStream_t; NULL = default stream).  Nothing is
- * copied or synchronised; *d_accepted (uint64 in device memory) is atomically incremented. */
+ * copied or synchronised; *d_accepted (uint64 in device memory) is atomically incremented.
+ * The verify_id entry points keep a device workspace per stream they were called on (the per-item tables of the variable-base
+ * multiplications: 3 KB per item of the largest batch seen, e.g. 201 MB for 65 536 items), grown on demand -- growing it
+ * synchronises the device once -- and freed by elp_destroy. */
 int elp_verify_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
                             int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
                             void* d_accepted);
