@@ -49,8 +49,11 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_PAIRED_LAYOUT: which kernel layout verifies (results are identical).  0 = one lane per item; 1 = two lanes per item (the
  * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: the
  * two-lane kernel when the last round of 64 x SIMDs items would be at most half full (small batches, odd remainders) and always on
- * BLS12-381, the one-lane kernel otherwise. */
-enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2 };
+ * BLS12-381, the one-lane kernel otherwise.
+ * ELP_OPT_TABLE_WORKSPACE (default 1): the verify_id kernels keep the per-item tables of their variable-base multiplications in a
+ * launch workspace in device memory (3 KB per item, see the *_dev entry points) instead of the lanes' private memory; results are
+ * identical, 0 saves the memory at a few per cent of throughput. */
+enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

@@ -117,6 +117,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
       if (value < 0 || value > 2) return ELP_ERR_ARG;
       c->paired = value;
       return ELP_OK;
+    case ELP_OPT_TABLE_WORKSPACE: c->use_vtab = value ? 1 : 0; return ELP_OK;
     default: return ELP_ERR_ARG;
   }
 }

@@ -12,6 +12,7 @@ CURVE_BN254 = 0
 CURVE_BLS12_381 = 1
 OPT_STRICT_SIGNATURE = 1
 OPT_PAIRED_LAYOUT = 2
+OPT_TABLE_WORKSPACE = 3
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -149,6 +150,10 @@ class Context:
     def set_paired_layout(self, on):
         """ELP_OPT_PAIRED_LAYOUT: False / 0 = one lane per item, True / 1 = two lanes per item, 2 = chosen by batch size (default)."""
         self._chk(self.lib.elp_set_option(self.h, OPT_PAIRED_LAYOUT, int(on)))
+
+    def set_table_workspace(self, on):
+        """ELP_OPT_TABLE_WORKSPACE: per-item tables of the variable-base multiplications in a launch workspace (default) or in private memory."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_TABLE_WORKSPACE, int(bool(on))))
 
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
         A = len(Yi) // self.G1

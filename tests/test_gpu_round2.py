@@ -221,6 +221,17 @@ def test_paired_and_plain_layouts_agree(gpu_ctx):
             fq, cq = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
             gpu_ctx.set_paired_layout(2)
             assert (fp == fq).all() and cp == cq == int(fp.sum()), (retr, cut)
+            # ELP_OPT_TABLE_WORKSPACE off: the tables of 1P .. 8P in private memory instead of the launch workspace, both layouts
+            try:
+                gpu_ctx.set_table_workspace(False)
+                gpu_ctx.set_paired_layout(True)
+                fp2, cp2 = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
+                gpu_ctx.set_paired_layout(False)
+                fq2, cq2 = gpu_ctx.verify_id_batch(bad[:cut * rsz], mask, retr, wl.ad)
+            finally:
+                gpu_ctx.set_table_workspace(True)
+                gpu_ctx.set_paired_layout(2)
+            assert (fp2 == fp).all() and (fq2 == fp).all() and cp2 == cq2 == cp, (retr, cut)
         assert fp[5] == 1 and fp[64] == 1 and fp[7] == 0 and fp[8] == 0 and fp[100] == 0 and fp[13] == 0 and fp[202] == 0 and fp[203] == 0
         assert fp[200] == 1 and fp[9] == 1       # the fixture context runs in reference-compatible mode: (inf, inf) is accepted
         # the same (valid and corrupted) proofs as wire messages through both layouts' wire-ingest kernels
