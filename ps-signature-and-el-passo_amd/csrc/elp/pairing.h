@@ -238,7 +238,7 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
     ELP_NOUNROLL
     for (int half = 0; half < 2; half++) {          // 0: doubling step, 1: addition step (only for a non-zero digit)
       if (half == 1 && d == 0) break;
-      if constexpr (NV == 1 && NF == 1 && FUSE && C::TWIST_D) {
+      if constexpr (NV == 1 && NF == 1 && FUSE) {
         if (live_v[0] && live_f[0]) {        // both pairs live: multiply the two lines first, then f once
           if (half == 0) {
             ml_dbl_step_inl<C>(T[0], l);
@@ -247,8 +247,12 @@ ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* q
             ml_add_step_inl<C>(T[0], l, qv[0].x, yq);
           }
           const LineCoef<C>& lf = line_from_mem<C>(lines[0][n]);
-          fp12_mul_by_two_lines_inl<C>(fw, fp2_mul_fp(l.a, pv[0].y), fp2_mul_fp(l.b, pv[0].x), l.c, fp2_mul_fp(lf.a, pf[0].y),
-                                       fp2_mul_fp(lf.b, pf[0].x), lf.c);
+          if constexpr (C::TWIST_D)
+            fp12_mul_by_two_lines_inl<C>(fw, fp2_mul_fp(l.a, pv[0].y), fp2_mul_fp(l.b, pv[0].x), l.c, fp2_mul_fp(lf.a, pf[0].y),
+                                         fp2_mul_fp(lf.b, pf[0].x), lf.c);
+          else
+            fp12_mul_by_two_lines_m_inl<C>(fw, l.c, fp2_mul_fp(l.b, pv[0].x), fp2_mul_fp(l.a, pv[0].y), lf.c, fp2_mul_fp(lf.b, pf[0].x),
+                                           fp2_mul_fp(lf.a, pf[0].y));
           n++;
           continue;
         }
