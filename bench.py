@@ -34,8 +34,8 @@ CONFIGS = {4: {"batch": 65536, "attrs": 8, "hidden": 4}, 5: {"batch": 131072, "a
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS), help="BASELINE.json configuration (4 = the metric's, 5 = 16 attributes, 131 072 per rank)")
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (default: the configuration's)")
     ap.add_argument("--attrs", type=int, default=0)
