@@ -396,7 +396,11 @@ ELP_INL void fp12_exp_z(Fp12<C>& r, const Fp12<C>& a, u32* hot = nullptr) {
 
 // f^((p^12 - 1)/r): easy part (p^6 - 1)(p^2 + 1), then the hard part (p^4 - p^2 + 1)/r.
 // `hot` may hold f_in itself: it is consumed by the first two statements and reused as the accumulator of the exponentiations.
-template <class C>
+// EXACT = false (callers that only test the result against 1): on BLS12 curves the hard part is taken to the THIRD power,
+//     3 (p^4-p^2+1)/r = (z-1)^2 (z+p) (z^2+p^2-1) + 3,
+// which replaces the one dense exponent of the exact chain, (z-1)/3 (32 of 63 bits set), by a fifth sparse power of z.  GT has prime order r and 3 does not
+// divide r, so the cube is 1 exactly when the pairing product is.  Values that leave the library as GT bytes (elp_pairing) use EXACT = true.
+template <class C, bool EXACT = true>
 ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
   Fp12<C> f, t0, t1;
   fp12_inv<C>(t0, f_in);
@@ -444,8 +448,14 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
     // BLS12 (Hayashida-Hayasaka-Teruya): (p^4-p^2+1)/r = ((z-1)^2/3) (z+p) (z^2+p^2-1) + 1, evaluated exactly:
     // a = f^((z-1)/3), a = a^(z-1), b = a^(z+p), c = b^(z^2+p^2-1), result = c * f.
     Fp12<C> a, b, c, t;
-    fp12_exp_u64<C>(a, f, C::ZM1D3_ABS, hot);
-    if (C::Z_NEG) fp12_conj(a, a);          // z - 1 < 0 as well
+    if constexpr (EXACT) {
+      fp12_exp_u64<C>(a, f, C::ZM1D3_ABS, hot);
+      if (C::Z_NEG) fp12_conj(a, a);        // z - 1 < 0 as well
+    } else {
+      fp12_exp_z<C>(t, f, hot);
+      fp12_conj(b, f);
+      fp12_mul<C>(a, t, b);                 // f^(z-1)
+    }
     fp12_exp_z<C>(t, a, hot);
     fp12_conj(b, a);
     fp12_mul<C>(a, t, b);                   // a^(z-1)
@@ -458,8 +468,21 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
     fp12_mul<C>(c, c, t);
     fp12_conj(t, b);
     fp12_mul<C>(c, c, t);                   // b^(z^2+p^2-1)
-    fp12_mul<C>(r, c, f);
+    if constexpr (EXACT) {
+      fp12_mul<C>(r, c, f);
+    } else {
+      fp12_cyc_sqr<C>(t, f);
+      fp12_mul<C>(t, t, f);                 // f^3
+      fp12_mul<C>(r, c, t);
+    }
   }
+}
+// final_exp(f) == 1, by the cheaper chain where there is one
+template <class C>
+ELP_INL bool final_exp_is_one(const Fp12<C>& f_in, u32* hot = nullptr) {
+  Fp12<C> g;
+  final_exp<C, C::IS_BN>(g, f_in, hot);    // BN: the exact chain has no dense exponent, one instantiation serves both uses
+  return fp12_is_one(g);
 }
 
 }  // namespace elp

@@ -455,13 +455,12 @@ ELP_HEAVY bool ps_pairing_check(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, co
   Aff<F1<C>> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
-  Fp12<C> f_priv, g;
+  Fp12<C> f_priv;
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& f = fh ? *fh : f_priv;
   const LineMem<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
-  final_exp<C>(g, f, key.hot);
-  return fp12_is_one(g);
+  return final_exp_is_one<C>(f, key.hot);
 }
 
 template <class C, class Src>
@@ -937,13 +936,12 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   Aff<G1F> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
-  Fp12<C> f_priv, g;
+  Fp12<C> f_priv;
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& f = fh ? *fh : f_priv;
   const LineMem<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
-  final_exp<C>(g, f, key.hot);
-  return fp12_is_one(g);
+  return final_exp_is_one<C>(f, key.hot);
 }
 
 // ------------------------------------------------------------------------------------------------------------

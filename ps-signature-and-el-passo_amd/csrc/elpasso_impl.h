@@ -159,13 +159,12 @@ __global__ void ELP_PAIR_LAUNCH_BOUNDS k_agg_final_paired(KeyCtx<C> key, const F
   bool ok = g1_load<C>(s2, s2_std);
   aff_neg(ns2, s2);
   if (aff_is_inf(s2)) aff_set_inf(ns2);
-  Fp12<C> f, g, Fm;
+  Fp12<C> f, Fm;
   fp12_from_mem<C>(Fm, F[0]);
   const LineMem<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 0, 1>(f, &ns2, (const Aff<F2<C>>*)0, &ns2, lines);
   fp12_mul<C>(f, f, Fm);
-  final_exp<C>(g, f);
-  const bool one = fp12_is_one(g);
+  const bool one = final_exp_is_one<C>(f);
   if (threadIdx.x == 0) *agg_ok = (ok && one) ? 1 : 0;
 }
 
@@ -335,11 +334,10 @@ __global__ void ELP_LAUNCH_BOUNDS k_pairing_check(const u32* g1, const u32* g2, 
     ok &= g2_load<C>(q[j], g2 + (i * NP + j) * 4 * C::N);
   }
   if (ok) {
-    Fp12<C> f, g;
+    Fp12<C> f;
     const LineCoef<C>* no_lines[1] = {reinterpret_cast<const LineCoef<C>*>(g2)};   // never read, see miller_loop
     miller_loop<C, NP, 0>(f, p, q, p, no_lines);
-    final_exp<C>(g, f);
-    ok = fp12_is_one(g);
+    ok = final_exp_is_one<C>(f);
   }
   okf[i] = ok;
 }
@@ -539,12 +537,11 @@ __global__ void ELP_LAUNCH_BOUNDS k_agg_final(KeyCtx<C> key, const Fp12<C>* F, c
   bool ok = g1_load<C>(s2, s2_std);
   aff_neg(ns2, s2);
   if (aff_is_inf(s2)) aff_set_inf(ns2);
-  Fp12<C> f, g;
+  Fp12<C> f;
   const LineCoef<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 0, 1>(f, (const Aff<F1<C>>*)0, (const Aff<F2<C>>*)0, &ns2, lines);
   fp12_mul<C>(f, f, F[0]);
-  final_exp<C>(g, f);
-  *agg_ok = (ok && fp12_is_one(g)) ? 1 : 0;
+  *agg_ok = (ok && final_exp_is_one<C>(f)) ? 1 : 0;
 }
 
 // verdicts: the NIZK flags when the batch equation held, otherwise the exact per-item verification (rare, slow path)
