@@ -396,7 +396,8 @@ ELP_INL void fp12_exp_z(Fp12<C>& r, const Fp12<C>& a, u32* hot = nullptr) {
 
 // f^((p^12 - 1)/r): easy part (p^6 - 1)(p^2 + 1), then the hard part (p^4 - p^2 + 1)/r.
 // `hot` may hold f_in itself: it is consumed by the first two statements and reused as the accumulator of the exponentiations.
-// EXACT = false (callers that only test the result against 1): on BLS12 curves the hard part is taken to the THIRD power,
+// EXACT = false (callers that only test the result against 1) computes a small multiple of the exponent: on BN curves the multiple below (FKR), on BLS12
+// curves the hard part is taken to the THIRD power,
 //     3 (p^4-p^2+1)/r = (z-1)^2 (z+p) (z^2+p^2-1) + 3,
 // which replaces the one dense exponent of the exact chain, (z-1)/3 (32 of 63 bits set), by a fifth sparse power of z.  GT has prime order r and 3 does not
 // divide r, so the cube is 1 exactly when the pairing product is.  Values that leave the library as GT bytes (elp_pairing) use EXACT = true.
@@ -408,7 +409,33 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
   fp12_mul<C>(f, t1, t0);      // f^(p^6 - 1)
   fp12_frob<C>(t0, f, 2);
   fp12_mul<C>(f, t0, f);       // ^(p^2 + 1)
-  if constexpr (C::IS_BN) {
+  if constexpr (C::IS_BN && !EXACT) {
+    // Fuentes-Castaneda, Knapp, Rodriguez-Henriquez: the multiple 2z(6z^2+3z+1) of the hard part (a non-zero integer below r, hence prime to it),
+    //     l0 + l1 p + l2 p^2 + l3 p^3,   l2 = 6z + 6z^2 + 12z^3,  l1 = l2 - 2z,  l0 = l2 + 6z^2 + 1,  l3 = l1 - 1:
+    // three powers of z, three squarings, ten products, three Frobenius maps (the exact chain below: thirteen products, four squarings, seven maps).
+    Fp12<C> fz, f2z, f6z, f6z2, f12z3, a, b, t;
+    fp12_exp_z<C>(fz, f, hot);
+    fp12_cyc_sqr<C>(f2z, fz);
+    fp12_cyc_sqr<C>(t, f2z);                // f^4z
+    fp12_mul<C>(f6z, t, f2z);
+    fp12_exp_z<C>(f6z2, f6z, hot);
+    fp12_cyc_sqr<C>(t, f6z2);               // f^12z^2
+    fp12_exp_z<C>(f12z3, t, hot);
+    fp12_mul<C>(a, f12z3, f6z2);
+    fp12_mul<C>(a, a, f6z);                 // f^l2
+    fp12_conj(t, f2z);
+    fp12_mul<C>(b, a, t);                   // f^l1
+    fp12_mul<C>(r, a, f6z2);
+    fp12_mul<C>(r, r, f);                   // f^l0
+    fp12_frob<C>(t, b, 1);
+    fp12_mul<C>(r, r, t);                   // (f^l1)^p
+    fp12_frob<C>(t, a, 2);
+    fp12_mul<C>(r, r, t);                   // (f^l2)^p^2
+    fp12_conj(t, f);
+    fp12_mul<C>(b, b, t);                   // f^l3
+    fp12_frob<C>(t, b, 3);
+    fp12_mul<C>(r, r, t);                   // (f^l3)^p^3
+  } else if constexpr (C::IS_BN) {
     // Devegili-Scott-Dahab: (p^4-p^2+1)/r = p^3 + (6z^2+1) p^2 + (-36z^3-18z^2-12z+1) p + (-36z^3-30z^2-18z-2)
     // evaluated with the vectorial addition chain  y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36.
     Fp12<C> fz, fz2, fz3, y0, y1, y2, y3, y4, y5, y6, T0, T1, t;
@@ -481,7 +508,7 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
 template <class C>
 ELP_INL bool final_exp_is_one(const Fp12<C>& f_in, u32* hot = nullptr) {
   Fp12<C> g;
-  final_exp<C, C::IS_BN>(g, f_in, hot);    // BN: the exact chain has no dense exponent, one instantiation serves both uses
+  final_exp<C, false>(g, f_in, hot);
   return fp12_is_one(g);
 }
 
