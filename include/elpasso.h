@@ -52,8 +52,10 @@ int elp_field_bytes(int curve);               /* F */
  * BLS12-381, the one-lane kernel otherwise.
  * ELP_OPT_TABLE_WORKSPACE (default 1): the verify_id kernels keep the per-item tables of their variable-base multiplications in a
  * launch workspace in device memory (3 KB per item, see the *_dev entry points) instead of the lanes' private memory; results are
- * identical, 0 saves the memory at a few per cent of throughput. */
-enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3 };
+ * identical, 0 saves the memory at a few per cent of throughput.
+ * ELP_OPT_SPLIT_PHASES (default 1): the one-lane-per-item el_passo_verify_id runs as two kernels -- the NIZK half with two job lanes per
+ * item (two waves per SIMD), then the pairing check -- instead of one fused kernel; results are identical (BN254 builds). */
+enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

@@ -106,8 +106,16 @@ inline int32_t pair_swap_i32(int32_t v) {
   return v;
 }
 #endif
-ELP_INL bool pair_and(bool b) { return b && pair_swap_i32(b ? 1 : 0) != 0; }   // true iff true on both lanes of the pair
-ELP_INL bool pair_or(bool b) { return b || pair_swap_i32(b ? 1 : 0) != 0; }
+// both lanes always execute the exchange (a lane that skipped it would leave its partner reading an inactive lane on the device and
+// desynchronise the rendezvous of the host twin)
+ELP_INL bool pair_and(bool b) {   // true iff true on both lanes of the pair
+  const int o = pair_swap_i32(b ? 1 : 0);
+  return b & (o != 0);
+}
+ELP_INL bool pair_or(bool b) {
+  const int o = pair_swap_i32(b ? 1 : 0);
+  return b | (o != 0);
+}
 // Per-lane "hot slot": ELP_HOT_WORDS 32-bit words of LDS that a kernel hands to the device routines (KeyCtx::hot) for the one
 // accumulator that is read and written by every step of a long loop (Miller value, exponentiation accumulator, point accumulator).
 // Routines take it through generic references, so the same code runs on private memory when the slot is absent (host twin, hot == 0)

@@ -152,8 +152,12 @@ ELP_HEAVY bool g1_deserialize(Aff<F1<C>>& p, const uint8_t* in) {
   p.y = y;
   return true;
 }
+// `canon_flag` (optional) receives the flag bit of the point's CANONICAL encoding: mcl's decoder (and this one) accepts a set flag on a
+// point whose y.a is 0 (negation leaves y.a = 0), while re-serialising such a point gives flag 0 -- the reference hashes the re-serialised
+// bytes into the transcript (src/ps-verifier.cc:113), so a caller that hashes the message's own bytes must canonicalise the flag.
 template <class C>
-ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in) {
+ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in, bool* canon_flag = nullptr) {
+  if (canon_flag) *canon_flag = false;
   uint8_t tmp[2 * C::FBYTES];
   u32 any = 0;
   for (int i = 0; i < 2 * C::FBYTES; i++) {
@@ -174,6 +178,7 @@ ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in) {
   if (!fp2_sqrt<C>(y, rhs)) return false;
   StdFp<C> ya = fp_to_std<C>(fp2_gather<C>(y).c0);
   if (((ya.w[0] & 1) != 0) != odd) y = fp2_neg(y);
+  if (canon_flag) *canon_flag = odd && !std_is_zero<C>(ya);     // y.a == 0: both roots have an even (zero) y.a
   p.x = x;
   p.y = y;
   return true;

@@ -280,7 +280,7 @@ ELP_HD constexpr int verify_id_record_words(int A, int H, bool retr) {
 // with point decompression and attribute hashing done here on the device.
 template <class C>
 struct RecordSrc {
-  const u32 *rs_, *ms_;
+  const u32 *rs_, *ms_, *w_phi_, *w_k_;
   u64 mask_;
   int nrs_, jr_;
   ELP_HD bool open(const u32* rec, u64 hidden_mask, int A, bool retr, Aff<F1<C>>& sig1, Aff<F1<C>>& sig2, Aff<F1<C>>& phi,
@@ -294,11 +294,13 @@ struct RecordSrc {
     const u32* p = rec;
     ok &= g1_load<C>(sig1, p); p += 2 * C::N;
     ok &= g1_load<C>(sig2, p); p += 2 * C::N;
+    w_phi_ = p;
     ok &= g1_load<C>(phi, p);  p += 2 * C::N;
     if (retr) {
       ok &= g1_load<C>(E1, p); p += 2 * C::N;
       ok &= g1_load<C>(E2, p); p += 2 * C::N;
     }
+    w_k_ = p;
     ok &= g2_load<C>(kk, p); p += 4 * C::N;
     c = scalar_load_w(p); p += 8;
     rs_ = p; p += 8 * nrs_;
@@ -309,6 +311,9 @@ struct RecordSrc {
   ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
   ELP_HD Scalar rs(int j) const { return scalar_load_w(rs_ + 8 * j); }
   ELP_HD Scalar next_revealed_hash(int) { return scalar_load_w(ms_ + 8 * jr_++); }   // revealed attributes in order
+  // wire bytes of the transcript's input points straight from their canonical coordinates (a validated record has one encoding per point)
+  ELP_HD void ser_k(uint8_t* out) const { g2_serialize_std<C>(out, w_k_); }
+  ELP_HD void ser_g1(int which, uint8_t* out) const { g1_serialize_std<C>(out, w_phi_ + which * 2 * C::N); }   // 0 = phi, 1 = E1, 2 = E2
 };
 
 // NIZK half of VerifyID: recomputes V_k, V_phi, (V_E1, V_E2), the challenge, and K (returned in affine form for the pairing).
@@ -529,6 +534,233 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   RecordSrc<C> src;
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   return verify_id_core<C, RecordSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// EL PASSO VerifyID as TWO PHASES (round 3; kernels k_vid_nizk / k_vid_pair in ../elpasso_impl.h).
+//
+// One item per lane at the headline batch gives the chip exactly one wave per SIMD, and a lone wave issues one vector instruction
+// per ~5 cycles whatever it is; two resident waves share the SIMD at ~3.4 cycles per instruction of this mix and hide each other's
+// memory latency.  The NIZK half of a verification consists of independent jobs over different groups, so phase 1
+// gives every item TWO lanes in two different waves of one workgroup, each lane a whole job in the plain layout (no lane exchanges,
+// no duplicated work):
+//   G2 job : V_k = k^c prod_{hidden} YY_j^{r_j} gg^{r_t} XX^{1-c}                                      src/ps-verifier.cc:72-88
+//   G1 job : V_phi, V_E1, V_E2 (three GLV multiplications + four fixed-base terms)  and  K = k prod_{revealed} YY_i^{m_i}
+//                                                                                            src/ps-verifier.cc:91-108, 214-229
+// The jobs meet in LDS (VidShared: the serialised commitments), the G2 lane hashes the transcript and publishes the verdict of the
+// NIZK half; K goes to a per-item slot of the launch workspace.  Phase 2 (one lane per item, the whole register file) is the pairing
+// check on (sig1, sig2, K).  Both phases fit 256 / 512 registers without the other's temporaries in their frames.
+template <class C>
+struct VidShared {
+  u32 vk[2 * C::FBYTES / 4];       // serialised V_k                  (G2 job)
+  u32 v1[3][C::FBYTES / 4];        // serialised V_phi, V_E1, V_E2    (G1 job)
+  u32 ok_g1;                       // the G1 job's inputs were valid
+};
+ELP_INL void bytes_to_words(u32* w, const uint8_t* b, int nbytes) {
+  for (int i = 0; i < nbytes / 4; i++) w[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
+}
+ELP_INL void words_to_bytes(uint8_t* b, const u32* w, int nbytes) {
+  for (int i = 0; i < nbytes / 4; i++) {
+    const u32 x = w[i];
+    b[4 * i] = (uint8_t)x;
+    b[4 * i + 1] = (uint8_t)(x >> 8);
+    b[4 * i + 2] = (uint8_t)(x >> 16);
+    b[4 * i + 3] = (uint8_t)(x >> 24);
+  }
+}
+template <class C>
+ELP_INL Scalar scalar_one_minus(const Scalar& c) {   // 1 - c mod r (c >= r cannot match the recomputed challenge; reduced defensively)
+  Scalar one;
+  for (int i = 0; i < 8; i++) one.v[i] = 0;
+  one.v[0] = 1;
+  Scalar cred = c;
+  if (scalar_geq_r<C>(cred)) {
+    Scalar rr;
+    for (int i = 0; i < 8; i++) rr.v[i] = C::rmod(i);
+    cred = scalar_sub_mod_r<C>(cred, rr);
+  }
+  return scalar_sub_mod_r<C>(one, cred);
+}
+// G2 job.  `vk` receives the wire bytes of V_k (as words).
+template <class C, class Src>
+ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F2<C>>& kk, const Scalar& c, u32* vk) {
+  typedef F2<C> G2F;
+  const int A = key.A;
+  const int nrs = src.nrs();
+  const Scalar r_t = src.rs(retr ? nrs - 2 : nrs - 1);
+  Jac<G2F> Vk;
+  {
+    // 1k .. 8k: Jacobian multiples, one inversion (of the product of the norms) for the seven that need it
+    Aff<G2F> tabk[8];
+    {
+      Jac<G2F> jk[8];
+      jac_multiples8<G2F>(jk, kk);
+      Fp2<C> z2[7], zi2[7];
+      for (int i = 1; i < 8; i++) z2[i - 1] = jk[i].Z;
+      batch_zinv<C, 0, 7>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
+      tabk[0] = kk;
+      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G2F>(tabk[i], jk[i], zi2[i - 1]);
+    }
+    u32* const wsk = key.vtab;
+    if (wsk) {
+      for (int i = 0; i < 8; i++) vtab_store<G2F>(wsk, i, tabk[i]);
+      g2_mul_gls_with<C, WsTab<G2F>>(Vk, WsTab<G2F>{wsk}, c);
+    } else {
+      g2_mul_gls_tab<C>(Vk, tabk, c);
+    }
+  }
+  {
+    int jh = 0;
+    for (int i = 0; i < A; i++)
+      if (src.hidden(i)) {
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, src.rs(jh));
+        jh++;
+      }
+  }
+  acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
+  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, scalar_one_minus<C>(c));
+  Aff<G2F> aVk;
+  jac_to_aff<G2F>(aVk, Vk);
+  uint8_t b[2 * C::FBYTES];
+  g2_serialize<C>(b, aVk);
+  bytes_to_words(vk, b, 2 * C::FBYTES);
+}
+// G1 job.  `v1` receives the wire bytes of V_phi, V_E1, V_E2 (as words), aK the affine K for the pairing.
+template <class C, class Src>
+ELP_HEAVY void vid_job_g1(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2,
+                          const Aff<F2<C>>& kk, const Scalar& c, u32 (*v1)[C::FBYTES / 4], Aff<F2<C>>& aK) {
+  typedef F1<C> G1F;
+  typedef F2<C> G2F;
+  const int A = key.A;
+  const int nrs = src.nrs();
+  Jac<G1F> V[3];
+  u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<G2F>() : nullptr;
+  const int nmul = retr ? 3 : 1;
+  {
+    Aff<G1F> tab1[3][8];
+    {
+      Jac<G1F> j1[3][8];
+      jac_multiples8<G1F>(j1[0], phi);
+      if (retr) {
+        jac_multiples8<G1F>(j1[1], E1);
+        jac_multiples8<G1F>(j1[2], E2);
+      }
+      Fp<C> z1[21], zi1[21];
+      for (int t = 0; t < 3; t++)
+        for (int i = 1; i < 8; i++) z1[7 * t + i - 1] = (t < nmul) ? j1[t][i].Z : fp_one<C>();
+      batch_zinv<C, 21, 0>(zi1, z1, (Fp2<C>*)0, (const Fp2<C>*)0);
+      for (int t = 0; t < nmul; t++) {
+        tab1[t][0] = t == 0 ? phi : (t == 1 ? E1 : E2);
+        for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab1[t][i], j1[t][i], zi1[7 * t + i - 1]);
+      }
+    }
+    for (int t = 0; t < nmul; t++) {
+      if (ws1) {
+        u32* const w = ws1 + t * 8 * vtab_entry_words<G1F>();
+        for (int i = 0; i < 8; i++) vtab_store<G1F>(w, i, tab1[t][i]);
+        g1_mul_glv_with<C, WsTab<G1F>>(V[t], WsTab<G1F>{w}, c);
+      } else {
+        g1_mul_glv_tab<C>(V[t], tab1[t], c);
+      }
+    }
+  }
+  acc_fixed_g1<C>(V[0], key, g1_base_hs(key), src.rs(0));
+  if (retr) {
+    const Scalar r_e = src.rs(nrs - 1);
+    acc_fixed_g1<C>(V[1], key, g1_base_geg(key), r_e);
+    acc_fixed_g1<C>(V[2], key, g1_base_apk(key), r_e);
+    acc_fixed_g1<C>(V[2], key, g1_base_h(key), src.rs(1));
+  }
+  Jac<G2F> K;
+  jac_from_aff(K, kk);
+  for (int i = 0; i < A; i++)
+    if (!src.hidden(i)) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
+  Fp<C> z1[3], zi1[3];
+  Fp2<C> z2[1], zi2[1];
+  for (int t = 0; t < 3; t++) z1[t] = (t < nmul) ? V[t].Z : fp_one<C>();
+  z2[0] = K.Z;
+  batch_zinv<C, 3, 1>(zi1, z1, zi2, z2);
+  jac_to_aff_with_zinv<G2F>(aK, K, zi2[0]);
+  for (int t = 0; t < nmul; t++) {
+    Aff<G1F> a;
+    jac_to_aff_with_zinv<G1F>(a, V[t], zi1[t]);
+    uint8_t b[C::FBYTES];
+    g1_serialize<C>(b, a);
+    bytes_to_words(v1[t], b, C::FBYTES);
+  }
+}
+// closing step of phase 1: c == Hr(SHA256(hex k | hex phi | [hex E1 | hex E2] | hex V_k | hex V_phi | [hex V_E1 | hex V_E2] | ad))
+// (src/ps-verifier.cc:111-130); the input points come from the source's own serialisations (ser_k / ser_g1)
+template <class C, class Src>
+ELP_HEAVY bool vid_challenge_ok(const Src& src, bool retr, const u32* vk, const u32 (*v1)[C::FBYTES / 4], const Scalar& c, const uint8_t* ad,
+                                size_t ad_len) {
+  Transcript t;
+  transcript_init(t);
+  uint8_t b[2 * C::FBYTES];
+  src.ser_k(b);
+  sha256_update_hex(t.s, b, 2 * C::FBYTES);
+  for (int q = 0; q < (retr ? 3 : 1); q++) {
+    src.ser_g1(q, b);
+    sha256_update_hex(t.s, b, C::FBYTES);
+  }
+  words_to_bytes(b, vk, 2 * C::FBYTES);
+  sha256_update_hex(t.s, b, 2 * C::FBYTES);
+  for (int q = 0; q < (retr ? 3 : 1); q++) {
+    words_to_bytes(b, v1[q], C::FBYTES);
+    sha256_update_hex(t.s, b, C::FBYTES);
+  }
+  const Scalar c2 = transcript_challenge<C>(t, ad, ad_len);
+  return scalar_eq(c2, c);
+}
+// K of one item in the launch workspace: word w of item i at ws[w * stride + i] (coalesced across the lanes of a wave)
+template <class C>
+ELP_HD constexpr int vid_k_words() { return (int)(sizeof(Aff<F2<C>>) / 4); }
+template <class C>
+ELP_INL void vid_store_k(u32* ws, size_t stride, size_t i, const Aff<F2<C>>& aK) {
+  const u32* w = reinterpret_cast<const u32*>(&aK);
+  ELP_UNROLL
+  for (int q = 0; q < vid_k_words<C>(); q++) ws[(size_t)q * stride + i] = w[q];
+}
+template <class C>
+ELP_INL void vid_load_k(Aff<F2<C>>& aK, const u32* ws, size_t stride, size_t i) {
+  u32* w = reinterpret_cast<u32*>(&aK);
+  ELP_UNROLL
+  for (int q = 0; q < vid_k_words<C>(); q++) w[q] = ws[(size_t)q * stride + i];
+}
+// Phase 1 of one item from the fixed-stride record, role by role (role 0: G2 job + closing step, role 1: G1 job).  On the device the two
+// roles are two waves and `sh` is in LDS with a workgroup barrier between vid_nizk_jobs and vid_nizk_finish; the host twin calls them in turn.
+template <class C>
+struct VidNizkState {      // what a lane keeps across the barrier
+  RecordSrc<C> src;
+  Scalar c;
+  bool ok;
+};
+template <class C>
+ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64 hidden_mask, bool retr, VidShared<C>& sh, VidNizkState<C>& st,
+                             Aff<F2<C>>& aK) {
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk;
+  st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
+  if (role == 0) {
+    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk);
+  } else {
+    sh.ok_g1 = st.ok ? 1u : 0u;
+    aff_set_inf(aK);
+    if (st.ok) vid_job_g1<C, RecordSrc<C>>(key, st.src, retr, phi, E1, E2, kk, st.c, sh.v1, aK);
+  }
+}
+template <class C>
+ELP_HEAVY bool vid_nizk_finish(const VidShared<C>& sh, const VidNizkState<C>& st, bool retr, const uint8_t* ad, size_t ad_len) {
+  if (!st.ok || !sh.ok_g1) return false;
+  return vid_challenge_ok<C, RecordSrc<C>>(st.src, retr, sh.vk, sh.v1, st.c, ad, ad_len);
+}
+// Phase 2 of one item: the pairing check on the record's signature and the K of phase 1 (src/ps-verifier.cc:133-137).
+template <class C>
+ELP_HEAVY bool vid_pair_item(const KeyCtx<C>& key, const u32* rec, const Aff<F2<C>>& aK) {
+  Aff<F1<C>> sig1, sig2;
+  if (!g1_load<C>(sig1, rec) || !g1_load<C>(sig2, rec + 2 * C::N)) return false;
+  return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -783,6 +1015,7 @@ struct WireSrc {
     return !scalar_geq_r<C>(s);
   }
   const uint8_t *p1_, *p2_, *pk_, *pphi_, *pe1_, *pe2_;   // bodies of the point elements (validated lengths)
+  bool kflag_ = false;                                    // flag bit of k's canonical encoding (set by whoever decodes k)
   // structure, lengths and scalar ranges of the message; no point is decoded here
   ELP_HD bool parse(const uint8_t* msg, size_t len, int A, bool retr, Scalar& c) {
     constexpr size_t L = C::FBYTES;
@@ -835,12 +1068,14 @@ struct WireSrc {
                    Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
     if (!parse(msg, len, A, retr, c)) return false;
     if (retr && (!g1_deserialize<C>(E1, pe1_) || !g1_deserialize<C>(E2, pe2_))) return false;
-    return g1_deserialize<C>(sig1, p1_) && g1_deserialize<C>(sig2, p2_) && g1_deserialize<C>(phi, pphi_) && g2_deserialize<C>(kk, pk_);
+    return g1_deserialize<C>(sig1, p1_) && g1_deserialize<C>(sig2, p2_) && g1_deserialize<C>(phi, pphi_) && g2_deserialize<C>(kk, pk_, &kflag_);
   }
-  // wire bytes of the transcript's input points: the message's own bytes (every encoding the decoder accepts is canonical: x < p, the
-  // flag bit is the parity the decoder enforces on y, infinity is all-zero)
+  // wire bytes of the transcript's input points: the message's own bytes.  Every G1 encoding the decoder accepts is canonical (x < p, the
+  // flag is the parity the decoder enforces on y != 0, infinity is all-zero); for k the flag is replaced by the canonical one (a set flag on
+  // a point with y.a = 0 is accepted by the reference's decoder and re-serialised with the flag clear: g2_deserialize, encode.h)
   ELP_HD void ser_k(uint8_t* out) const {
     for (int i = 0; i < 2 * C::FBYTES; i++) out[i] = pk_[i];
+    out[2 * C::FBYTES - 1] = (uint8_t)((out[2 * C::FBYTES - 1] & 0x7f) | (kflag_ ? 0x80 : 0));
   }
   ELP_HD void ser_g1(int which, uint8_t* out) const {   // 0 = phi, 1 = E1, 2 = E2
     const uint8_t* p = which == 0 ? pphi_ : (which == 1 ? pe1_ : pe2_);
@@ -903,7 +1138,7 @@ ELP_HEAVY bool verify_id_wire_item_paired(const KeyCtx<C>& key, const uint8_t* m
   if (!odd || retr) ok &= g1_deserialize<C>(P0, odd ? src.pe2_ : src.pphi_);
   if (!odd && retr) ok &= g1_deserialize<C>(P1, src.pe1_);
   ok = pair_and(ok);
-  const bool okk = g2_deserialize<C>(kk, src.pk_);
+  const bool okk = g2_deserialize<C>(kk, src.pk_, &src.kflag_);
   if (!ok || !okk) return false;
   Aff<F1<C>> T, sig1, sig2;
   T.x = fp_pair_swap(S.x);

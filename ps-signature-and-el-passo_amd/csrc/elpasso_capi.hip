@@ -73,6 +73,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   c->curve = curve;
   c->device = device;
   if (const char* e = getenv("ELP_LAYOUT")) c->paired = !strcmp(e, "plain") ? 0 : !strcmp(e, "paired") ? 1 : 2;     // A/B runs
+  if (const char* e = getenv("ELP_SPLIT")) c->split = strcmp(e, "0") != 0;                                            // A/B runs: one fused kernel per verification
   if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->simds = 4 * prop.multiProcessorCount;
@@ -118,6 +119,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
       c->paired = value;
       return ELP_OK;
     case ELP_OPT_TABLE_WORKSPACE: c->use_vtab = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_SPLIT_PHASES: c->split = value ? 1 : 0; return ELP_OK;
     default: return ELP_ERR_ARG;
   }
 }

@@ -94,6 +94,53 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_verify(KeyCtx<C> key, const u32* recs, in
   count_accept(ok, accepted);
 }
 
+// ---- two-phase verification (elp/pipeline.h "EL PASSO VerifyID as TWO PHASES").
+// Phase 1: 128-thread workgroups = two waves over the same 64 items: wave 0 runs the G2 job and the closing hash, wave 1 the G1 job (+ K).  256
+// registers per lane, so every SIMD holds two such waves (of different workgroups, usually of different roles) and issues from both; the
+// LDS carries a Jacobian-sized hot slot per lane and the 164-byte exchange record per item: 38 KB per workgroup, four workgroups per CU.
+#define ELP_NIZK_BLOCK 128
+template <class C>
+__global__ void __launch_bounds__(ELP_NIZK_BLOCK, 2) k_vid_nizk(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
+                                                                const u32* ad_off, u32 ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n) {
+  constexpr int HOTW = (int)(sizeof(Jac<F2<C>>) / 4);      // the only users of the slot in this kernel are the running sums of jac_acc_fixed
+  __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_NIZK_BLOCK * HOTW];
+  __shared__ VidShared<C> sh[64];
+  const int role = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  key.hot = hot_lds + threadIdx.x * HOTW;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  if (key.vtab) key.vtab += i * (size_t)vtab_words<C>();     // one slice per item: the G2 job uses its first part, the G1 job the rest
+  VidNizkState<C> st;
+  st.ok = false;
+  if (i < n) {
+    Aff<F2<C>> aK;
+    vid_nizk_jobs<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK);
+    if (role == 1) vid_store_k<C>(kws, kstride, i, aK);
+  }
+  __syncthreads();
+  if (role == 0 && i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    const size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    nizk_ok[i] = vid_nizk_finish<C>(sh[lane], st, retr != 0, a, al) ? 1 : 0;
+  }
+}
+// Phase 2: one lane per item with the whole register file: Miller loop on (sig1, K), (-sig2, gg) and the final exponentiation.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_vid_pair(KeyCtx<C> key, const u32* recs, int rec_words, const uint8_t* nizk_ok, const u32* kws, size_t kstride,
+                                             uint8_t* flags, unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    if (nizk_ok[i]) {
+      Aff<F2<C>> aK;
+      vid_load_k<C>(aK, kws, kstride, i);
+      ok = vid_pair_item<C>(key, recs + i * (size_t)rec_words, aK);
+    }
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
 // waves per SIMD; the LDS hot slot is half as large per lane (8 workgroups x 13.5 KB per CU).
 #ifndef ELP_PAIR_WAVES
@@ -727,6 +774,7 @@ struct elp_ctx {
   };
   std::vector<VtabWs> vtab_ws;
   int use_vtab = 1;           // ELP_VTAB=0 in the environment keeps the tables in private memory (A/B measurements)
+  int split = 1;              // ELP_OPT_SPLIT_PHASES: el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -734,6 +782,7 @@ struct elp_ctx {
     hipError_t e_ = (expr);                                                                     \
     if (e_ != hipSuccess) {                                                                     \
       (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+      (void)hipDeviceSynchronize(); /* queued work may still use DevBufs that go back to the block cache on this exit */ \
       return ELP_ERR_HIP;                                                                       \
     }                                                                                           \
   } while (0)
@@ -759,10 +808,12 @@ static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key m
 // make_key + this launch's table workspace: `lanes` slices of vtab_words<C>() words.  No workspace (allocation failure, ELP_VTAB=0) is not an error:
 // the kernels then keep the tables in private memory.
 template <class C>
-static KeyCtx<C> make_key_ws(elp_ctx* c, hipStream_t stream, size_t lanes) {
+static KeyCtx<C> make_key_ws(elp_ctx* c, hipStream_t stream, size_t lanes, size_t extra_bytes = 0, void** extra = nullptr) {
   KeyCtx<C> k = make_key<C>(c);
-  if (!c->use_vtab) return k;
-  const size_t need = lanes * (size_t)vtab_words<C>() * 4;
+  if (extra) *extra = nullptr;
+  if (!c->use_vtab && !extra_bytes) return k;
+  const size_t tab_bytes = c->use_vtab ? ((lanes * (size_t)vtab_words<C>() * 4 + 255) & ~(size_t)255) : 0;
+  const size_t need = tab_bytes + extra_bytes;   // `extra`: per-launch state behind the tables (the K's and verdicts of the two-phase kernels)
   elp_ctx::VtabWs* w = nullptr;
   for (auto& e : c->vtab_ws)
     if (e.stream == stream) w = &e;
@@ -781,7 +832,8 @@ static KeyCtx<C> make_key_ws(elp_ctx* c, hipStream_t stream, size_t lanes) {
     }
     w->bytes = need;
   }
-  k.vtab = (u32*)w->p;
+  if (c->use_vtab) k.vtab = (u32*)w->p;
+  if (extra) *extra = (uint8_t*)w->p + tab_bytes;
   return k;
 }
 
@@ -923,8 +975,12 @@ int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg,
   {   // the tables must fit the device (W = 16: 2.5 GiB for an 8-attribute BN254 key; W = 20: 32 GiB; W = 22: 120 GiB)
     const size_t per = ((size_t)1 << window_bits) - 1, nwin = (256 + window_bits - 1) / window_bits;
     const size_t need = per * nwin * ((size_t)(nattr + 6) * sizeof(Aff<F1<C>>) + (size_t)(nattr + 2) * sizeof(Aff<F2<C>>));
+    HIPCHK(c, hipSetDevice(c->device));      // the guard must look at THIS context's device, and count the tables about to be released
+    size_t held = 0;
+    if (c->t1) held += (size_t)c->per * c->nwin * (size_t)(c->A + 6) * sizeof(Aff<F1<C>>);
+    if (c->t2) held += (size_t)c->per * c->nwin * (size_t)(c->A + 2) * sizeof(Aff<F2<C>>);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) > free_b + (c->t1 ? 0 : 0)) {
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) > free_b + held) {
       c->err = "fixed-base tables of this window width do not fit the device memory";
       return ELP_ERR_ARG;
     }
@@ -1406,6 +1462,25 @@ void launch_agg_final_paired(elp_ctx* c, hipStream_t stream, const void* F, cons
   hipLaunchKernelGGL((k_agg_final_paired<Paired<B>>), dim3(1), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c), (const Fp12<B>*)F, (const u32*)s2_std,
                      c->agg_ok);
 }
+// phase 1 of the two-phase verification lives in a translation unit of its own (elpasso_<curve>_nizk.hip): its device functions are compiled
+// for 256 registers (two waves per SIMD) without constraining the kernels of the plain-layout unit, which own the whole register file
+template <class B>
+struct SplitBuild {
+  static constexpr bool value = false;
+};
+template <>
+struct SplitBuild<BN254> {
+  static constexpr bool value = true;
+};
+template <class B>
+void launch_vid_nizk(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                     const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<B>& key) {
+  hipLaunchKernelGGL((k_vid_nizk<B>), dim3(grid_for(n)), dim3(ELP_NIZK_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n);
+}
+#ifndef ELP_NIZK_TU
+extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key);
+#endif
 #ifndef ELP_PAIR_TU
 extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
@@ -1435,6 +1510,27 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       HIPCHK(c, hipGetLastError());
       if (np == 0) return ELP_OK;
       n = np;
+    }
+  }
+  if constexpr (SplitBuild<C>::value) {
+    if (c->split) {
+      // two phases: k_vid_nizk (two job waves per 64 items, two waves per SIMD) -> per-item verdict + K in the workspace -> k_vid_pair
+      const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
+      const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
+      void* extra = nullptr;
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + lanes, &extra);
+      if (!extra) {
+        c->err = "no device memory for the verification workspace";
+        return ELP_ERR_HIP;
+      }
+      u32* kws = (u32*)extra;
+      uint8_t* nizk_ok = (uint8_t*)extra + k_bytes;
+      launch_vid_nizk<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key);
+      key.vtab = nullptr;
+      hipLaunchKernelGGL((k_vid_pair<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, key, (const u32*)d_records, words,
+                         (const uint8_t*)nizk_ok, (const u32*)kws, lanes, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+      HIPCHK(c, hipGetLastError());
+      return ELP_OK;
     }
   }
   hipLaunchKernelGGL((k_verify_id<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, make_key_ws<C>(c, (hipStream_t)stream, (size_t)grid_for(n) * ELP_BLOCK),

@@ -13,6 +13,7 @@ CURVE_BLS12_381 = 1
 OPT_STRICT_SIGNATURE = 1
 OPT_PAIRED_LAYOUT = 2
 OPT_TABLE_WORKSPACE = 3
+OPT_SPLIT_PHASES = 4
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -154,6 +155,10 @@ class Context:
     def set_table_workspace(self, on):
         """ELP_OPT_TABLE_WORKSPACE: per-item tables of the variable-base multiplications in a launch workspace (default) or in private memory."""
         self._chk(self.lib.elp_set_option(self.h, OPT_TABLE_WORKSPACE, int(bool(on))))
+
+    def set_split_phases(self, on):
+        """ELP_OPT_SPLIT_PHASES (default on): one-lane-per-item verify_id as two kernels (NIZK half with two job lanes per item, then the pairing)."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_SPLIT_PHASES, int(bool(on))))
 
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
         A = len(Yi) // self.G1

@@ -288,6 +288,22 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
   int pfx##_verify_id(void* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {             \
     return verify_id_item<C>(((TwinCtx<C>*)c)->key, rec, mask, retr != 0, ad, adlen) ? 1 : 0;                          \
   }                                                                                                                    \
+  /* the two-phase form (k_vid_nizk / k_vid_pair): the two job roles in turn, K through the workspace layout */          \
+  int pfx##_verify_id_split(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {        \
+    TwinCtx<C>* c = (TwinCtx<C>*)cv;                                                                                   \
+    VidShared<C> sh;                                                                                                   \
+    memset(&sh, 0xa5, sizeof sh);                                                                                      \
+    VidNizkState<C> st0, st1;                                                                                          \
+    Aff<F2<C>> aK, unused;                                                                                             \
+    vid_nizk_jobs<C>(c->key, 0, rec, mask, retr != 0, sh, st0, unused);                                                \
+    vid_nizk_jobs<C>(c->key, 1, rec, mask, retr != 0, sh, st1, aK);                                                    \
+    if (!vid_nizk_finish<C>(sh, st0, retr != 0, ad, adlen)) return 0;                                                  \
+    std::vector<u32> ws((size_t)vid_k_words<C>() * 3, 0xdeadbeefu);                                                    \
+    vid_store_k<C>(ws.data(), 3, 1, aK);                                                                               \
+    Aff<F2<C>> k2;                                                                                                     \
+    vid_load_k<C>(k2, ws.data(), 3, 1);                                                                                \
+    return vid_pair_item<C>(c->key, rec, k2) ? 1 : 0;                                                                  \
+  }                                                                                                                    \
   int pfx##_verify_id_wire(void* c, const uint8_t* msg, size_t len, int retr, const uint8_t* ad, size_t adlen) {          \
     return verify_id_wire_item<C>(((TwinCtx<C>*)c)->key, msg, len, retr != 0, ad, adlen) ? 1 : 0;                      \
   }                                                                                                                    \

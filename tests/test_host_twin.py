@@ -111,6 +111,9 @@ def test_verify_id_golden(L):
                 ad = c["ad"].encode()
                 got = L.twin_bn254_verify_id(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
                 assert bool(got) == c["expect"], (s["name"], c["label"])
+                # the two-phase form (two job roles + pairing phase) gives the same verdict
+                got = L.twin_bn254_verify_id_split(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
+                assert bool(got) == c["expect"], ("split", s["name"], c["label"])
                 n += 1
     assert n > 80
 
@@ -125,6 +128,7 @@ def test_verify_id_with_retrieval_golden(L):
         rec = pack_verify_id(M, P)
         for ad, exp in ((b"hello", 1), (b"hellO", 0)):
             assert L.twin_bn254_verify_id(ctx, rec, ctypes.c_uint64(hidden_mask(P.attributes)), 1, ad, len(ad)) == exp
+            assert L.twin_bn254_verify_id_split(ctx, rec, ctypes.c_uint64(hidden_mask(P.attributes)), 1, ad, len(ad)) == exp
 
 
 def test_ps_verify_and_provide_id(L):
