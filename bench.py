@@ -253,7 +253,7 @@ def main():
         }
         out["valu_bound"] = valu_bound(ctx, "verify_id" if (args.curve == "bn254" and A == 8 and H == 4) else None, args.window, B, kern_ms, 162)
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:     # profiling runs: every verification dispatch of the process is a timed-region dispatch
         # PCIe-inclusive rate (host buffers in, flags out: elp_verify_id_batch, the path PSVerifier::el_passo_verify_id_batch takes; pinned
         # staging, chunks copied and verified on several streams) -- reported, never the headline value.  One warm-up call, median of 7.
         ts = []

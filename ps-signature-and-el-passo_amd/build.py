@@ -9,6 +9,40 @@ LIB = os.path.join(CSRC, "libelpasso_hip.so")
 HOST_LIB = os.path.join(CSRC, "libelpasso_host.so")
 
 
+def _digest(paths, extra=()):
+    """sha256 over the names and contents of every source file under `paths` (+ the flag strings in `extra`): the rebuild key.  Modification
+    times are not trusted: a tree copied to another machine can carry a stale .so that is newer than its sources."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for p in paths:
+        if os.path.isdir(p):
+            for dp, _, fs in os.walk(p):
+                files += [os.path.join(dp, f) for f in fs if f.endswith((".h", ".hip", ".cc", ".cpp"))]
+        elif os.path.exists(p):
+            files.append(p)
+    for f in sorted(os.path.abspath(x) for x in files):
+        h.update(os.path.relpath(f, HERE).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _stamp_ok(target, digest):
+    try:
+        return os.path.exists(target) and open(target + ".srchash").read().strip() == digest
+    except OSError:
+        return False
+
+
+def _stamp(target, digest):
+    with open(target + ".srchash", "w") as f:
+        f.write(digest + "\n")
+
+
 def _newest(paths):
     t = 0.0
     for p in paths:
@@ -26,14 +60,19 @@ def _newest(paths):
 # instantiations of every kernel); per-unit flags: BN254 additionally inlines the Fp6-level routines into Fp12-level leaf
 # functions (+13 % on the verify kernel; on the 14-limb BLS12-381 field it only doubles the compile time).
 HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_pair.hip", ["-DELP_FP6_INLINE=1"]),
-             ("elpasso_bn254_nizk.hip", ["-DELP_FP6_INLINE=1"]),
+             ("elpasso_bn254_nizk.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_g2job.hip", ["-DELP_FP6_INLINE=1"]),
+             ("elpasso_bn254_g1job.hip", ["-DELP_FP6_INLINE=1"]),
              ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", [])]
 
 
 def build_hip(force=False, verbose=False):
     deps = [os.path.join(CSRC, u) for u, _ in HIP_UNITS] + [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elp"),
                                                            os.path.join(HERE, "..", "include")]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+    # rebuild key = hash of the sources and flags (per unit: the shared headers + that unit's own file), not modification times
+    shared = [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elp"), os.path.join(HERE, "..", "include")]
+    unit_extra = {u: os.environ.get("ELP_EXTRA_FLAGS_" + u.split(".")[0].upper(), "").split() for u, _ in HIP_UNITS}     # experiments only
+    lib_digest = _digest(deps, [(u, f, unit_extra[u]) for u, f in HIP_UNITS])
+    if not force and _stamp_ok(LIB, lib_digest):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -44,18 +83,23 @@ def build_hip(force=False, verbose=False):
     for unit, flags in HIP_UNITS:
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
         objs.append(obj)
-        extra = os.environ.get("ELP_EXTRA_FLAGS_" + unit.split(".")[0].upper(), "").split()     # experiments only
+        extra = unit_extra[unit]
+        udig = _digest(shared + [os.path.join(CSRC, unit)], [flags, extra])
+        if not force and _stamp_ok(obj, udig):
+            continue                                   # this unit's sources and flags are unchanged: keep its object
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags + extra + ["-c", "-o", obj, os.path.join(CSRC, unit)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((cmd, subprocess.Popen(cmd), obj, udig))
+    for cmd, p, obj, udig in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        _stamp(obj, udig)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    _stamp(LIB, lib_digest)
     return LIB
 
 
@@ -66,13 +110,15 @@ def build_host(force=False, verbose=False):
     """Host C++ protocol layer (PSSigner / PSRequester / PSVerifier over the C-ABI) -> libelpasso_host.so."""
     build_hip(force=False, verbose=verbose)
     hd = os.path.join(CSRC, "host")
-    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= max(_newest([hd, os.path.join(HERE, "..", "include")]), os.path.getmtime(LIB)):
+    host_digest = _digest([hd, os.path.join(HERE, "..", "include")], [open(LIB + ".srchash").read() if os.path.exists(LIB + ".srchash") else ""])
+    if not force and _stamp_ok(HOST_LIB, host_digest):
         return HOST_LIB
     cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", hd, "-o", HOST_LIB] + [os.path.join(hd, f) for f in HOST_SOURCES] + \
           ["-L", CSRC, "-lelpasso_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    _stamp(HOST_LIB, host_digest)
     return HOST_LIB
 
 

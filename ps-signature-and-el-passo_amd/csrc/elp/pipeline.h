@@ -307,6 +307,19 @@ struct RecordSrc {
     ms_ = p;
     return ok;
   }
+  // the same view of a record whose points somebody else has validated: scalars and the transcript's input bytes only
+  ELP_HD void open_lite(const u32* rec, u64 hidden_mask, int A, bool retr, Scalar& c) {
+    int H = 0;
+    for (int i = 0; i < A; i++) H += (int)((hidden_mask >> i) & 1);
+    mask_ = hidden_mask;
+    nrs_ = H + (retr ? 2 : 1);
+    jr_ = 0;
+    w_phi_ = rec + 4 * C::N;
+    w_k_ = rec + (retr ? 5 : 3) * 2 * C::N;
+    c = scalar_load_w(w_k_ + 4 * C::N);
+    rs_ = w_k_ + 4 * C::N + 8;
+    ms_ = rs_ + 8 * nrs_;
+  }
   ELP_HD int nrs() const { return nrs_; }
   ELP_HD bool hidden(int i) const { return (mask_ >> i) & 1; }
   ELP_HD Scalar rs(int j) const { return scalar_load_w(rs_ + 8 * j); }
@@ -625,13 +638,22 @@ ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F
   g2_serialize<C>(b, aVk);
   bytes_to_words(vk, b, 2 * C::FBYTES);
 }
-// G1 job.  `v1` receives the wire bytes of V_phi, V_E1, V_E2 (as words), aK the affine K for the pairing.
+// K = k prod_{revealed} YY_i^{m_i}, affine (src/ps-verifier.cc:214-229): four fixed-base terms at A = 8, H = 4; whichever job has the time takes it
+template <class C, class Src>
+ELP_HEAVY void vid_job_k(const KeyCtx<C>& key, Src& src, const Aff<F2<C>>& kk, Aff<F2<C>>& aK) {
+  typedef F2<C> G2F;
+  Jac<G2F> K;
+  jac_from_aff(K, kk);
+  for (int i = 0; i < key.A; i++)
+    if (!src.hidden(i)) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
+  jac_to_aff<G2F>(aK, K);
+}
+// G1 job.  `v1` receives the wire bytes of V_phi, V_E1, V_E2 (as words).
 template <class C, class Src>
 ELP_HEAVY void vid_job_g1(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2,
-                          const Aff<F2<C>>& kk, const Scalar& c, u32 (*v1)[C::FBYTES / 4], Aff<F2<C>>& aK) {
+                          const Scalar& c, u32 (*v1)[C::FBYTES / 4]) {
   typedef F1<C> G1F;
   typedef F2<C> G2F;
-  const int A = key.A;
   const int nrs = src.nrs();
   Jac<G1F> V[3];
   u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<G2F>() : nullptr;
@@ -671,16 +693,9 @@ ELP_HEAVY void vid_job_g1(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F
     acc_fixed_g1<C>(V[2], key, g1_base_apk(key), r_e);
     acc_fixed_g1<C>(V[2], key, g1_base_h(key), src.rs(1));
   }
-  Jac<G2F> K;
-  jac_from_aff(K, kk);
-  for (int i = 0; i < A; i++)
-    if (!src.hidden(i)) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
   Fp<C> z1[3], zi1[3];
-  Fp2<C> z2[1], zi2[1];
   for (int t = 0; t < 3; t++) z1[t] = (t < nmul) ? V[t].Z : fp_one<C>();
-  z2[0] = K.Z;
-  batch_zinv<C, 3, 1>(zi1, z1, zi2, z2);
-  jac_to_aff_with_zinv<G2F>(aK, K, zi2[0]);
+  batch_zinv<C, 3, 0>(zi1, z1, (Fp2<C>*)0, (const Fp2<C>*)0);
   for (int t = 0; t < nmul; t++) {
     Aff<G1F> a;
     jac_to_aff_with_zinv<G1F>(a, V[t], zi1[t]);
@@ -747,7 +762,10 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
   } else {
     sh.ok_g1 = st.ok ? 1u : 0u;
     aff_set_inf(aK);
-    if (st.ok) vid_job_g1<C, RecordSrc<C>>(key, st.src, retr, phi, E1, E2, kk, st.c, sh.v1, aK);
+    if (st.ok) {
+      vid_job_g1<C, RecordSrc<C>>(key, st.src, retr, phi, E1, E2, st.c, sh.v1);
+      vid_job_k<C, RecordSrc<C>>(key, st.src, kk, aK);
+    }
   }
 }
 template <class C>

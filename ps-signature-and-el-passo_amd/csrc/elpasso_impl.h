@@ -123,6 +123,87 @@ __global__ void __launch_bounds__(ELP_NIZK_BLOCK, 2) k_vid_nizk(KeyCtx<C> key, c
     nizk_ok[i] = vid_nizk_finish<C>(sh[lane], st, retr != 0, a, al) ? 1 : 0;
   }
 }
+// ---- the same phase 1 as two CONCURRENT kernels with asymmetric register budgets (ELP_OPT_SPLIT_PHASES = 2): the G2 job (+ K) on the caller's stream
+// with 384 registers per lane (256 + 128 accumulation registers as spill space: its Fp2 mixed additions do not fit 256), the G1 job on a second stream
+// with 128 -- one wave of each per SIMD.  The jobs hand their results (serialised commitments, K) to phase 2 through the launch workspace, word w of
+// item i at ws[w * stride + i]; phase 2 opens with the transcript hash.
+template <class C>
+ELP_HD constexpr int vid_ws_words() { return 2 * C::FBYTES / 4 + 3 * C::FBYTES / 4 + vid_k_words<C>(); }   // vk | v1[3] | K
+#ifndef ELP_G2JOB_VGPRS
+#define ELP_G2JOB_VGPRS 384
+#endif
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK) __attribute__((amdgpu_num_vgpr(ELP_G2JOB_VGPRS)))
+k_vid_g2(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, uint8_t* ok_g2, u32* ws, size_t stride, size_t n) {
+  constexpr int HOTW = (int)(sizeof(Jac<F2<C>>) / 4);
+  __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_BLOCK * HOTW];
+  key.hot = hot_lds + threadIdx.x * HOTW;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (key.vtab) key.vtab += i * (size_t)vtab_words<C>();
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk, aK;
+  Scalar c;
+  RecordSrc<C> src;
+  bool ok = src.open(recs + i * (size_t)rec_words, mask, key.A, retr != 0, sig1, sig2, phi, E1, E2, kk, c);
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) ok = false;
+  ok_g2[i] = ok ? 1 : 0;
+  if (!ok) return;
+  u32 vk[2 * C::FBYTES / 4];
+  vid_job_g2<C, RecordSrc<C>>(key, src, retr != 0, kk, c, vk);
+  for (int q = 0; q < 2 * C::FBYTES / 4; q++) ws[(size_t)q * stride + i] = vk[q];
+  vid_job_k<C, RecordSrc<C>>(key, src, kk, aK);
+  vid_store_k<C>(ws + (size_t)(5 * C::FBYTES / 4) * stride, stride, i, aK);
+}
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK, 4) k_vid_g1(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, u32* ws, size_t stride, size_t n) {
+  constexpr int HOTW = (int)(sizeof(Jac<F1<C>>) / 4);
+  __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_BLOCK * HOTW];
+  key.hot = hot_lds + threadIdx.x * HOTW;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (key.vtab) key.vtab += i * (size_t)vtab_words<C>();
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk;
+  Scalar c;
+  RecordSrc<C> src;
+  if (!src.open(recs + i * (size_t)rec_words, mask, key.A, retr != 0, sig1, sig2, phi, E1, E2, kk, c)) return;   // k_vid_g2 publishes the verdict on the inputs
+  u32 v1[3][C::FBYTES / 4];
+  vid_job_g1<C, RecordSrc<C>>(key, src, retr != 0, phi, E1, E2, c, v1);
+  for (int t = 0; t < (retr ? 3 : 1); t++)
+    for (int q = 0; q < C::FBYTES / 4; q++) ws[(size_t)(2 * C::FBYTES / 4 + t * (C::FBYTES / 4) + q) * stride + i] = v1[t][q];
+}
+// Phase 2 behind the concurrent jobs: transcript hash (src/ps-verifier.cc:111-130), then the pairing check.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_vid_pair2(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
+                                              const uint8_t* ok_g2, const u32* ws, size_t stride, uint8_t* flags, unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    if (ok_g2[i]) {
+      const u32* rec = recs + i * (size_t)rec_words;
+      Aff<F1<C>> sig1, sig2, phi, E1, E2;
+      Aff<F2<C>> kk, aK;
+      Scalar c;
+      RecordSrc<C> src;
+      src.open_lite(rec, mask, key.A, retr != 0, c);
+      u32 vk[2 * C::FBYTES / 4], v1[3][C::FBYTES / 4];
+      for (int q = 0; q < 2 * C::FBYTES / 4; q++) vk[q] = ws[(size_t)q * stride + i];
+      for (int t = 0; t < (retr ? 3 : 1); t++)
+        for (int q = 0; q < C::FBYTES / 4; q++) v1[t][q] = ws[(size_t)(2 * C::FBYTES / 4 + t * (C::FBYTES / 4) + q) * stride + i];
+      const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+      const size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+      if (vid_challenge_ok<C, RecordSrc<C>>(src, retr != 0, vk, v1, c, a, al)) {
+        vid_load_k<C>(aK, ws + (size_t)(5 * C::FBYTES / 4) * stride, stride, i);
+        ok = vid_pair_item<C>(key, rec, aK);
+      }
+    }
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
 // Phase 2: one lane per item with the whole register file: Miller loop on (sig1, K), (-sig2, gg) and the final exponentiation.
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_vid_pair(KeyCtx<C> key, const u32* recs, int rec_words, const uint8_t* nizk_ok, const u32* kws, size_t kstride,
@@ -774,7 +855,10 @@ struct elp_ctx {
   };
   std::vector<VtabWs> vtab_ws;
   int use_vtab = 1;           // ELP_VTAB=0 in the environment keeps the tables in private memory (A/B measurements)
-  int split = 1;              // ELP_OPT_SPLIT_PHASES: el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them
+  int split = 0;              // ELP_OPT_SPLIT_PHASES: 1 = el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them; 2 = the two jobs
+                              // of the first phase as concurrent kernels on two streams (k_vid_g2 || k_vid_g1, then k_vid_pair2)
+  hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
+  hipEvent_t jev[2] = {nullptr, nullptr};
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -1478,6 +1562,21 @@ void launch_vid_nizk(elp_ctx* c, hipStream_t stream, size_t n, const void* d_rec
   hipLaunchKernelGGL((k_vid_nizk<B>), dim3(grid_for(n)), dim3(ELP_NIZK_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                      (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n);
 }
+template <class B>
+void launch_vid_g2(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, uint8_t* ok_g2, u32* ws, size_t stride,
+                   const KeyCtx<B>& key) {
+  hipLaunchKernelGGL((k_vid_g2<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, ok_g2, ws, stride, n);
+}
+template <class B>
+void launch_vid_g1(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<B>& key) {
+  hipLaunchKernelGGL((k_vid_g1<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, ws, stride, n);
+}
+#ifndef ELP_G2JOB_TU
+extern template void launch_vid_g2<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, uint8_t* ok_g2, u32* ws, size_t stride, const KeyCtx<BN254>& key);
+#endif
+#ifndef ELP_G1JOB_TU
+extern template void launch_vid_g1<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<BN254>& key);
+#endif
 #ifndef ELP_NIZK_TU
 extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key);
 #endif
@@ -1513,6 +1612,37 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
     }
   }
   if constexpr (SplitBuild<C>::value) {
+    if (c->split == 2) {
+      // k_vid_g2 (this stream) || k_vid_g1 (second stream), then k_vid_pair2
+      hipStream_t st = (hipStream_t)stream;
+      if (!c->jstream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->jstream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->jev[0], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->jev[1], hipEventDisableTiming));
+      }
+      const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
+      const size_t ws_bytes = (lanes * (size_t)vid_ws_words<C>() * 4 + 255) & ~(size_t)255;
+      void* extra = nullptr;
+      KeyCtx<C> key = make_key_ws<C>(c, st, lanes, ws_bytes + lanes, &extra);
+      if (!extra) {
+        c->err = "no device memory for the verification workspace";
+        return ELP_ERR_HIP;
+      }
+      u32* ws = (u32*)extra;
+      uint8_t* ok_g2 = (uint8_t*)extra + ws_bytes;
+      HIPCHK(c, hipEventRecord(c->jev[0], st));                 // everything queued before this call (the records) precedes the G1 job too
+      HIPCHK(c, hipStreamWaitEvent(c->jstream, c->jev[0], 0));
+      launch_vid_g2<C>(st, n, d_records, words, mask, retr, ok_g2, ws, lanes, key);
+      launch_vid_g1<C>(c->jstream, n, d_records, words, mask, retr, ws, lanes, key);
+      HIPCHK(c, hipEventRecord(c->jev[1], c->jstream));
+      HIPCHK(c, hipStreamWaitEvent(st, c->jev[1], 0));
+      key.vtab = nullptr;
+      hipLaunchKernelGGL((k_vid_pair2<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, st, key, (const u32*)d_records, words, (u64)mask, retr,
+                         (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (const uint8_t*)ok_g2, (const u32*)ws, lanes, (uint8_t*)d_flags,
+                         (unsigned long long*)d_accepted, n);
+      HIPCHK(c, hipGetLastError());
+      return ELP_OK;
+    }
     if (c->split) {
       // two phases: k_vid_nizk (two job waves per 64 items, two waves per SIMD) -> per-item verdict + K in the workspace -> k_vid_pair
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;

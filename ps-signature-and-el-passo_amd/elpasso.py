@@ -158,7 +158,7 @@ class Context:
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default on): one-lane-per-item verify_id as two kernels (NIZK half with two job lanes per item, then the pairing)."""
-        self._chk(self.lib.elp_set_option(self.h, OPT_SPLIT_PHASES, int(bool(on))))
+        self._chk(self.lib.elp_set_option(self.h, OPT_SPLIT_PHASES, int(on)))
 
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):
         A = len(Yi) // self.G1

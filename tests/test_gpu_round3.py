@@ -40,7 +40,10 @@ def test_two_phase_equals_fused_and_oracle(gpu_ctx, retr):
                                                    degenerate_items=(5,) if n > 5 else (), window_bits=8)
             gpu_ctx.set_split_phases(False)
             f0, c0 = gpu_ctx.verify_id_batch(recs, mask, retr, wl.ad)
-            gpu_ctx.set_split_phases(True)
+            gpu_ctx.set_split_phases(2)         # the two jobs as concurrent kernels on two streams
+            f2_, c2_ = gpu_ctx.verify_id_batch(recs, mask, retr, wl.ad)
+            assert (f2_ == expect).all() and c2_ == int(expect.sum())
+            gpu_ctx.set_split_phases(1)         # the two jobs as two waves of one workgroup
             f1, c1 = gpu_ctx.verify_id_batch(recs, mask, retr, wl.ad)
             assert (f0 == expect).all() and (f1 == expect).all() and c0 == c1 == int(expect.sum())
             rsz = len(recs) // n

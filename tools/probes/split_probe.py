@@ -26,7 +26,7 @@ d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 ms = ctypes.c_float()
 ctx.set_paired_layout(0)
-for split in (0, 1, 0, 1):
+for split in (0, 1, 2, 0, 1, 2):
     ctx.set_split_phases(split)
     for n in sizes:
         d_flags.zero_()
