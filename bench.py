@@ -324,6 +324,11 @@ def main():
             out["secondary"] = secondary_workloads(pkg, synth, local_rank, dev, args.window)
         except Exception as e:  # pragma: no cover
             out["secondary"] = {"error": str(e)}
+    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only:
+        try:   # the reference-API path: std::vector<IdProof> / wire messages through the C++ PSVerifier (key set-up excluded and reported)
+            out["host_api"] = host_api(pkg, wl, recs, B, A, H, first, expect, args.window, local_rank)
+        except Exception as e:  # pragma: no cover
+            out["host_api"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
@@ -505,6 +510,38 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
                                     "parity_ok": produced == n and int(d_cnt.item()) == n,
                                     "note": "every proof of the batch prover is accepted by the batch verifier"}
     ctx.close()
+    return res
+
+
+def host_api(pkg, wl, recs, B, A, H, first, expect, window, device):
+    """B el_passo_verify_id proofs through the C++ protocol classes of csrc/host (the reference's API surface, src/ps-verifier.h:18-49):
+    IdProof objects -> PSVerifier::el_passo_verify_id_batch (records packed by host threads, attributes hashed on the host, one
+    elp_verify_id_batch per context) and wire messages -> el_passo_verify_id_wire_batch / _wire_packed (T-L-V parse, decompression and
+    attribute hashing on the GPU).  Times are host wall-clock per call (PCIe included), key set-up reported separately; a second run
+    shards the batch over two contexts on the same GPU (the multi-device dispatcher: one host thread + one stream per context)."""
+    import numpy as np
+    b = importlib.import_module(PKG + ".build")
+    L = ctypes.CDLL(b.HOST_LIB)
+    L.elph_last_error.restype = ctypes.c_char_p
+    msgs, moff = wl.wire_messages(recs, B, H, first_item=first, with_retrieval=True)
+    moff = np.ascontiguousarray(moff, dtype=np.uint32)
+    res = {"note": "C++ PSVerifier over the C-ABI (csrc/host): objects = std::vector<IdProof> -> el_passo_verify_id_batch; wire = std::vector<PSBuffer> "
+                   "-> el_passo_verify_id_wire_batch; wire_packed = one contiguous buffer + offsets; host wall-clock per call, PCIe included, best / median of 5"}
+    for tag, W, nctx in (("one_context", window, 1), ("two_contexts_one_gpu_w16", 16, 2)):
+        outv = (ctypes.c_double * 8)()
+        acc = (ctypes.c_uint64 * 3)()
+        flags = np.zeros(B, dtype=np.uint8)
+        rc = L.elph_bench_verify_id(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad,
+                                    recs, ctypes.c_size_t(B), ctypes.c_uint64(first), msgs, moff.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(W),
+                                    ctypes.c_int(nctx), ctypes.c_int(device), ctypes.c_int(5), outv, acc, flags.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            res[tag] = {"error": (L.elph_last_error() or b"").decode()}
+            continue
+        ok = bool((flags == expect).all()) and int(acc[0]) == int(acc[1]) == int(acc[2]) == int(expect.sum())
+        res[tag] = {"window_bits": W, "contexts": nctx, "setup_s": outv[0], "build_objects_s": outv[1], "parity_ok": ok,
+                    "objects": {"value": B / (outv[2] * 1e-3), "unit": "verifications/s", "best_ms": outv[2], "median_ms": outv[3]},
+                    "wire": {"value": B / (outv[4] * 1e-3), "unit": "verifications/s", "best_ms": outv[4], "median_ms": outv[5], "bytes_per_message": len(msgs) / B},
+                    "wire_packed": {"value": B / (outv[6] * 1e-3), "unit": "verifications/s", "best_ms": outv[6], "median_ms": outv[7]}}
     return res
 
 

@@ -403,6 +403,18 @@ int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t 
   return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_t<BN254>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted) : elp_provide_id_batch_t<BLS12_381>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted);
 }
 
+int elp_host_alloc(elp_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return ELP_ERR_ARG;
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return ELP_OK;
+}
+void elp_host_free(elp_ctx* c, void* p) {
+  if (!c || !p) return;
+  (void)hipSetDevice(c->device);
+  (void)hipHostFree(p);
+}
 int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const void* d_records, uint64_t mask, int retr,
                            const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted, float* avg_ms) {
   if (!c || reps < 1 || !avg_ms) return ELP_ERR_ARG;

@@ -5,9 +5,83 @@
 static bool g_strict_signature = true;
 void elpSetStrictSignature(bool strict) { g_strict_signature = strict; }
 
+static int g_default_device = -1;      // -1: the device initPairing() selected
+static int g_default_window = 0;
+void elpSetDefaults(int device, int window_bits) {
+  g_default_device = device;
+  g_default_window = window_bits < 0 ? 0 : window_bits;
+}
+int elpDefaultDevice() { return g_default_device; }
+int elpDefaultWindowBits() { return g_default_window; }
+
+ElpPinned::~ElpPinned() {
+  if (p_) elp_host_free(ctx_, p_);
+}
+uint8_t* ElpPinned::get(elp_ctx* ctx, size_t bytes) {
+  if (bytes <= cap_ && ctx == ctx_) return p_;
+  if (p_) elp_host_free(ctx_, p_);
+  p_ = nullptr;
+  cap_ = 0;
+  ctx_ = ctx;
+  void* q = nullptr;
+  const size_t want = bytes + bytes / 4 + 4096;
+  elpCheck(ctx, elp_host_alloc(ctx, want, &q), "elp_host_alloc");
+  p_ = (uint8_t*)q;
+  cap_ = want;
+  return p_;
+}
+
+void elpParallelFor(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn, unsigned threads) {
+  if (n == 0) return;
+  unsigned hw = threads ? threads : std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  if (hw > 32) hw = 32;
+  size_t parts = (n + grain - 1) / (grain ? grain : 1);
+  if (parts > hw) parts = hw;
+  if (parts <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::exception_ptr> errs(parts);
+  std::vector<std::thread> th;
+  auto run = [&](size_t t) {
+    try {
+      fn(n * t / parts, n * (t + 1) / parts);
+    } catch (...) {
+      errs[t] = std::current_exception();
+    }
+  };
+  for (size_t t = 1; t < parts; t++) th.emplace_back(run, t);
+  run(0);
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+ElpShardSet::ElpShardSet(const PSPubKey& pk, const std::vector<int>& devices, int window_bits) {
+  if (devices.empty()) throw std::runtime_error("ElpShardSet: no devices");
+  keys_.resize(devices.size());
+  std::vector<std::exception_ptr> errs(devices.size());
+  std::vector<std::thread> th;
+  auto make = [&](size_t r) {
+    try {
+      keys_[r] = std::make_shared<ElpKey>(pk, devices[r], window_bits);
+    } catch (...) {
+      errs[r] = std::current_exception();
+    }
+  };
+  for (size_t r = 1; r < devices.size(); r++) th.emplace_back(make, r);     // the table builds of the devices overlap
+  make(0);
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
 ElpKey::ElpKey(const PSPubKey& pk, int device, int window_bits) {
   if (pk.Yi.size() != pk.YYi.size() || pk.Yi.empty() || pk.Yi.size() > 62) throw std::runtime_error("ElpKey: bad public key shape");
   nattr_ = pk.Yi.size();
+  if (device < 0) device = g_default_device >= 0 ? g_default_device : mcl::bls12::defaultDevice();
+  if (window_bits < 0) window_bits = g_default_window;
   elpCheck(nullptr, elp_init(curveId(), device, &ctx_), "elp_init");      // the curve initPairing() selected for the process
   elp_set_option(ctx_, ELP_OPT_STRICT_SIGNATURE, g_strict_signature ? 1 : 0);
   const size_t S1 = G1::size(), S2 = G2::size();

@@ -9,6 +9,7 @@ namespace bls12 {
 
 typedef unsigned __int128 u128;
 static elp_ctx* g_ctx = nullptr;
+static int g_device = 0;
 
 // per-curve constants, little-endian 64-bit limbs: group order r (4 limbs) and base-field prime p (6 limbs, zero-extended)
 struct CurveConst {
@@ -38,6 +39,7 @@ elp_ctx* defaultContext() {
   return g_ctx;
 }
 int curveId() { return g_cv->id; }
+int defaultDevice() { return g_device; }
 size_t fieldBytes() { return g_cv->F; }
 void initPairing(CurveParam curve, int device) {
   const CurveConst* want = curve == BLS12_381 ? &kBLS12_381 : &kBN254;
@@ -46,6 +48,7 @@ void initPairing(CurveParam curve, int device) {
     return;
   }
   g_cv = want;
+  g_device = device;
   int rc = elp_init(g_cv->id, device, &g_ctx);
   if (rc != ELP_OK) throw std::runtime_error("elp_init failed (" + std::to_string(rc) + "): a GPU is required, there is no CPU fallback");
 }

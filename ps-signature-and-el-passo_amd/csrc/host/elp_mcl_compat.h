@@ -29,6 +29,7 @@ elp_ctx* defaultContext();
 enum CurveParam { BN254 = 0, BLS12_381 = 1 };
 void initPairing(CurveParam curve = BN254, int device = 0);
 int curveId();            // ELP_CURVE_* of the process (after initPairing)
+int defaultDevice();      // the GPU ordinal initPairing() was given
 size_t fieldBytes();      // F: 32 (BN254) or 48 (BLS12-381)
 
 struct Fr {

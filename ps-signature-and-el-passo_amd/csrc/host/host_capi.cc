@@ -2,6 +2,8 @@
 // base64 wire messages in, verdicts / base64 messages out.
 #include <string.h>
 
+#include <algorithm>
+#include <chrono>
 #include <sstream>
 
 #include "ps-requester.h"
@@ -158,5 +160,107 @@ int elph_unblind_randomize_b64(const char* pk_b64, const char* attrs_spec, const
     return 0;
   });
 }
+
+// ---- benchmark of the reference-API path (bench.py "host_api"): n el_passo_verify_id proofs as IdProof OBJECTS through
+// PSVerifier::el_passo_verify_id_batch, and the same proofs as wire messages through el_passo_verify_id_wire_batch / _wire_packed.
+// The proofs arrive as the fixed-stride records the synthetic generator made (sig1 | sig2 | phi | E1 | E2 | k | c | rs[H+2] | m[A-H]); the objects are
+// rebuilt from them with the generator's attribute strings "a<i>-<item>" (attributes 0 .. H-1 hidden), so the path under test starts where a caller
+// of the reference's API starts: from std::vector<IdProof>.  out[0] = verifier set-up s (tables), out[1] = building the objects s,
+// out[2] / out[3] = object path best / median ms, out[4] / out[5] = wire-message path, out[6] / out[7] = packed wire path.
+// accepted[0..2] = accepted counts of the three paths; flags = verdicts of the object path.  `ncontexts` contexts on `device` (sharding test) .
+int elph_bench_verify_id(int A, int H, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi,
+                         const uint8_t* apk, const uint8_t* g_eg, const uint8_t* h, const char* service, const char* ad, const uint8_t* recs,
+                         size_t n, uint64_t first_item, const uint8_t* msgs, const uint32_t* moff, int window_bits, int ncontexts, int device,
+                         int reps, double* out, uint64_t* accepted, uint8_t* flags) {
+  return guarded([&] {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    initPairing(BN254, device);
+    const size_t S1 = G1::size(), S2 = G2::size();
+    PSPubKey pk;
+    memcpy(pk.g.b, g, S1);
+    memcpy(pk.gg.b, gg, S2);
+    memcpy(pk.XX.b, XX, S2);
+    pk.Yi.resize(A);
+    pk.YYi.resize(A);
+    for (int i = 0; i < A; i++) {
+      memcpy(pk.Yi[i].b, Yi + S1 * i, S1);
+      memcpy(pk.YYi[i].b, YYi + S2 * i, S2);
+    }
+    G1 Gapk, Gg, Gh;
+    memcpy(Gapk.b, apk, S1);
+    memcpy(Gg.b, g_eg, S1);
+    memcpy(Gh.b, h, S1);
+    auto t0 = clk::now();
+    PSVerifier rp(pk, std::vector<int>((size_t)(ncontexts > 0 ? ncontexts : 1), device), window_bits);
+    // the first call installs the RP parameters (H1(service), authority_pk, g, h and their tables): part of the set-up
+    (void)rp.el_passo_verify_id_batch({}, {}, service, Gapk, Gg, Gh);
+    out[0] = secs(t0, clk::now());
+    t0 = clk::now();
+    const size_t rsz = 5 * S1 + S2 + 32 * (size_t)(1 + H + 2 + (A - H));
+    std::vector<IdProof> proofs(n);
+    elpParallelFor(n, 256, [&](size_t lo, size_t hi) {
+      for (size_t j = lo; j < hi; j++) {
+        const uint8_t* r = recs + j * rsz;
+        IdProof& p = proofs[j];
+        memcpy(p.sig1.b, r, S1); r += S1;
+        memcpy(p.sig2.b, r, S1); r += S1;
+        memcpy(p.phi.b, r, S1); r += S1;
+        p.E1.emplace();
+        p.E2.emplace();
+        memcpy(p.E1->b, r, S1); r += S1;
+        memcpy(p.E2->b, r, S1); r += S1;
+        memcpy(p.k.b, r, S2); r += S2;
+        memcpy(p.c.b, r, 32); r += 32;
+        p.rs.resize(H + 2);
+        for (int q = 0; q < H + 2; q++) {
+          memcpy(p.rs[q].b, r, 32);
+          r += 32;
+        }
+        p.attributes.resize(A);
+        for (int i = H; i < A; i++) p.attributes[i] = "a" + std::to_string(i) + "-" + std::to_string(first_item + j);
+      }
+    });
+    std::vector<std::string> ads(n, ad);
+    out[1] = secs(t0, clk::now());
+    auto timeit = [&](auto&& fn, double& best, double& med) {
+      std::vector<double> ts;
+      for (int it = 0; it < reps + 1; it++) {
+        auto a = clk::now();
+        fn();
+        if (it) ts.push_back(secs(a, clk::now()) * 1e3);     // the first call is the warm-up
+      }
+      std::sort(ts.begin(), ts.end());
+      best = ts.front();
+      med = ts[ts.size() / 2];
+    };
+    std::vector<bool> verdicts;
+    timeit([&] { verdicts = rp.el_passo_verify_id_batch(proofs, ads, service, Gapk, Gg, Gh); }, out[2], out[3]);
+    accepted[0] = 0;
+    for (size_t j = 0; j < n; j++) {
+      flags[j] = verdicts[j] ? 1 : 0;
+      accepted[0] += flags[j];
+    }
+    accepted[1] = accepted[2] = 0;
+    out[4] = out[5] = out[6] = out[7] = 0;
+    if (msgs && moff) {
+      std::vector<PSBuffer> wire(n);
+      for (size_t j = 0; j < n; j++) wire[j].assign(msgs + moff[j], msgs + moff[j + 1]);
+      std::vector<bool> v2;
+      timeit([&] { v2 = rp.el_passo_verify_id_wire_batch(wire, ads, service, &Gapk, &Gg, &Gh); }, out[4], out[5]);
+      for (size_t j = 0; j < n; j++) accepted[1] += v2[j] ? 1 : 0;
+      std::vector<uint8_t> f3(n);
+      uint64_t a3 = 0;
+      timeit([&] { a3 = rp.el_passo_verify_id_wire_packed(msgs, moff, n, ad, service, f3.data(), &Gapk, &Gg, &Gh); }, out[6], out[7]);
+      accepted[2] = a3;
+      for (size_t j = 0; j < n; j++)
+        if (f3[j] != flags[j] || v2[j] != verdicts[j]) throw std::runtime_error("wire path and object path disagree on item " + std::to_string(j));
+    }
+    return 0;
+  });
+}
+
+// process defaults of the contexts the protocol classes create (elpSetDefaults)
+void elph_set_defaults(int device, int window_bits) { elpSetDefaults(device, window_bits); }
 
 }  // extern "C"

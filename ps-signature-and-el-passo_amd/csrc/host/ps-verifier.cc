@@ -12,7 +12,14 @@ namespace {
 void put(std::vector<uint8_t>& v, const uint8_t* p, size_t n) { v.insert(v.end(), p, p + n); }
 }  // namespace
 
-PSVerifier::PSVerifier(const PSPubKey& pk) : m_pk(pk), m_key(std::make_shared<ElpKey>(pk)) {}
+PSVerifier::PSVerifier(const PSPubKey& pk) : PSVerifier(pk, std::vector<int>(1, -1), -1) {}
+PSVerifier::PSVerifier(const PSPubKey& pk, const std::vector<int>& devices, int window_bits)
+    : m_pk(pk), m_set(std::make_shared<ElpShardSet>(pk, devices, window_bits)), m_stage(std::make_shared<Stage>()) {
+  m_key = std::shared_ptr<ElpKey>(m_set, &m_set->key(0));
+}
+void PSVerifier::useRpAll(const std::string& service, const G1* apk, const G1* g, const G1* h) const {
+  m_set->forEachShard(m_set->size(), [&](size_t r, size_t, size_t) { m_set->key(r).useRp(service, apk, g, h); });
+}
 
 std::vector<bool> PSVerifier::verify_batch(const std::vector<PSCredential>& sigs,
                                            const std::vector<std::vector<std::string>>& attrs) const {
@@ -57,37 +64,59 @@ std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, c
     if (p.rs.size() != H + (retr ? 2 : 1) || H < (retr ? 2u : 1u)) continue;
     groups[mask].push_back(i);
   }
+  const size_t S1 = G1::size(), S2 = G2::size();
+  std::lock_guard<std::mutex> lock(m_stage->mu);
   for (auto& [mask, idx] : groups) {
-    std::vector<uint8_t> recs, adbuf;
-    std::vector<uint32_t> adoff(1, 0);
-    for (size_t i : idx) {
-      const IdProof& p = proofs[i];
-      put(recs, p.sig1.b, G1::size());
-      put(recs, p.sig2.b, G1::size());
-      put(recs, p.phi.b, G1::size());
-      if (retr) {
-        put(recs, p.E1->b, G1::size());
-        put(recs, p.E2->b, G1::size());
-      }
-      put(recs, p.k.b, G2::size());
-      put(recs, p.c.b, 32);
-      for (const Fr& r : p.rs) put(recs, r.b, 32);
-      for (const std::string& a : p.attributes)
-        if (!a.empty()) {
-          Fr m;
-          m.setHashOf(a);                                                 // src/ps-verifier.cc:224
-          put(recs, m.b, 32);
+    // fixed-stride records of the group, packed by several host threads (the record of item j starts at j * rsz; the revealed attributes
+    // are hashed here, src/ps-verifier.cc:224); the per-item associated data goes into one blob with offsets
+    const size_t n = idx.size();
+    const size_t H = (size_t)__builtin_popcountll(mask);
+    const size_t rsz = elp_verify_id_record_size(curveId(), (int)A, (int)H, retr ? 1 : 0);
+    std::vector<uint32_t> adoff(n + 1, 0);
+    for (size_t j = 0; j < n; j++) adoff[j + 1] = adoff[j] + (uint32_t)ads[idx[j]].size();
+    uint8_t* const recs = m_stage->recs.get(m_key->ctx(), n * rsz);
+    uint8_t* const adbuf = m_stage->ads.get(m_key->ctx(), adoff[n] ? adoff[n] : 1);
+    uint8_t* const flags = m_stage->flags.get(m_key->ctx(), n);
+    elpParallelFor(n, 512, [&](size_t lo, size_t hi) {
+      for (size_t j = lo; j < hi; j++) {
+        const IdProof& p = proofs[idx[j]];
+        uint8_t* w = recs + j * rsz;
+        auto put = [&](const uint8_t* src, size_t len) {
+          memcpy(w, src, len);
+          w += len;
+        };
+        put(p.sig1.b, S1);
+        put(p.sig2.b, S1);
+        put(p.phi.b, S1);
+        if (retr) {
+          put(p.E1->b, S1);
+          put(p.E2->b, S1);
         }
-      put(adbuf, (const uint8_t*)ads[i].data(), ads[i].size());
-      adoff.push_back((uint32_t)adbuf.size());
-    }
-    if (adbuf.empty()) adbuf.push_back(0);
-    std::vector<uint8_t> flags(idx.size());
-    uint64_t acc = 0;
-    elpCheck(m_key->ctx(),
-             elp_verify_id_batch(m_key->ctx(), idx.size(), recs.data(), mask, retr ? 1 : 0, adbuf.data(), adoff.data(), 0, flags.data(), &acc),
-             "elp_verify_id_batch");
-    for (size_t j = 0; j < idx.size(); j++) out[idx[j]] = flags[j] != 0;
+        put(p.k.b, S2);
+        put(p.c.b, 32);
+        for (const Fr& r : p.rs) put(r.b, 32);
+        for (const std::string& a : p.attributes)
+          if (!a.empty()) {
+            Fr m;
+            m.setHashOf(a);
+            put(m.b, 32);
+          }
+        const std::string& ad = ads[idx[j]];
+        if (!ad.empty()) memcpy(adbuf + adoff[j], ad.data(), ad.size());
+      }
+    });
+    // contiguous shards, one context (host thread + HIP stream, possibly another GPU) each; per-shard offsets are rebased to the shard
+    m_set->forEachShard(n, [&](size_t r, size_t first, size_t count) {
+      if (count == 0) return;
+      std::vector<uint32_t> off(count + 1);
+      for (size_t j = 0; j <= count; j++) off[j] = adoff[first + j] - adoff[first];
+      uint64_t acc = 0;
+      elp_ctx* ctx = m_set->key(r).ctx();
+      elpCheck(ctx, elp_verify_id_batch(ctx, count, recs + first * rsz, mask, retr ? 1 : 0, adbuf + adoff[first], off.data(), 0,
+                                        flags + first, &acc),
+               "elp_verify_id_batch");
+    });
+    for (size_t j = 0; j < n; j++) out[idx[j]] = flags[j] != 0;
   }
   return out;
 }
@@ -96,14 +125,14 @@ std::vector<bool> PSVerifier::el_passo_verify_id_batch(const std::vector<IdProof
                                                        const std::string& service_name, const G1& authority_pk, const G1& g,
                                                        const G1& h) const {
   if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
-  m_key->useRp(service_name, &authority_pk, &g, &h);
+  useRpAll(service_name, &authority_pk, &g, &h);
   return verifyIdImpl(proofs, ads, true);
 }
 std::vector<bool> PSVerifier::el_passo_verify_id_without_id_retrieval_batch(const std::vector<IdProof>& proofs,
                                                                             const std::vector<std::string>& ads,
                                                                             const std::string& service_name) const {
   if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
-  m_key->useRp(service_name, nullptr, nullptr, nullptr);
+  useRpAll(service_name, nullptr, nullptr, nullptr);
   return verifyIdImpl(proofs, ads, false);
 }
 std::vector<bool> PSVerifier::el_passo_verify_id_wire_batch(const std::vector<PSBuffer>& messages, const std::vector<std::string>& ads,
@@ -111,26 +140,59 @@ std::vector<bool> PSVerifier::el_passo_verify_id_wire_batch(const std::vector<PS
                                                             const G1* h) const {
   if (ads.size() != messages.size()) throw std::runtime_error("associated data count does not match");
   const bool retr = authority_pk != nullptr;
-  m_key->useRp(service_name, authority_pk, g, h);
-  std::vector<uint8_t> buf, adbuf;
-  std::vector<uint32_t> moff(1, 0), adoff(1, 0);
-  for (size_t i = 0; i < messages.size(); i++) {
-    put(buf, messages[i].data(), messages[i].size());
-    moff.push_back((uint32_t)buf.size());
-    put(adbuf, (const uint8_t*)ads[i].data(), ads[i].size());
-    adoff.push_back((uint32_t)adbuf.size());
+  useRpAll(service_name, authority_pk, g, h);
+  const size_t n = messages.size();
+  std::vector<uint32_t> moff(n + 1, 0), adoff(n + 1, 0);
+  for (size_t i = 0; i < n; i++) {
+    moff[i + 1] = moff[i] + (uint32_t)messages[i].size();
+    adoff[i + 1] = adoff[i] + (uint32_t)ads[i].size();
   }
-  if (buf.empty()) buf.push_back(0);
-  if (adbuf.empty()) adbuf.push_back(0);
-  std::vector<uint8_t> flags(messages.size());
-  uint64_t acc = 0;
-  elpCheck(m_key->ctx(),
-           elp_verify_id_wire_batch(m_key->ctx(), messages.size(), buf.data(), moff.data(), retr ? 1 : 0, adbuf.data(), adoff.data(), 0,
-                                    flags.data(), &acc),
-           "elp_verify_id_wire_batch");
-  std::vector<bool> out(messages.size());
-  for (size_t i = 0; i < messages.size(); i++) out[i] = flags[i] != 0;
+  std::lock_guard<std::mutex> lock(m_stage->mu);
+  uint8_t* const buf = m_stage->recs.get(m_key->ctx(), moff[n] ? moff[n] : 1);
+  uint8_t* const adbuf = m_stage->ads.get(m_key->ctx(), adoff[n] ? adoff[n] : 1);
+  uint8_t* const flags = m_stage->flags.get(m_key->ctx(), n ? n : 1);
+  elpParallelFor(n, 1024, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      if (!messages[i].empty()) memcpy(buf + moff[i], messages[i].data(), messages[i].size());
+      if (!ads[i].empty()) memcpy(adbuf + adoff[i], ads[i].data(), ads[i].size());
+    }
+  });
+  m_set->forEachShard(n, [&](size_t r, size_t first, size_t count) {
+    if (count == 0) return;
+    std::vector<uint32_t> mo(count + 1), ao(count + 1);
+    for (size_t j = 0; j <= count; j++) {
+      mo[j] = moff[first + j] - moff[first];
+      ao[j] = adoff[first + j] - adoff[first];
+    }
+    uint64_t acc = 0;
+    elp_ctx* ctx = m_set->key(r).ctx();
+    elpCheck(ctx, elp_verify_id_wire_batch(ctx, count, buf + moff[first], mo.data(), retr ? 1 : 0, adbuf + adoff[first], ao.data(), 0,
+                                           flags + first, &acc),
+             "elp_verify_id_wire_batch");
+  });
+  std::vector<bool> out(n);
+  for (size_t i = 0; i < n; i++) out[i] = flags[i] != 0;
   return out;
+}
+uint64_t PSVerifier::el_passo_verify_id_wire_packed(const uint8_t* messages, const uint32_t* offsets, size_t n, const std::string& ad,
+                                                    const std::string& service_name, uint8_t* flags, const G1* authority_pk, const G1* g,
+                                                    const G1* h) const {
+  const bool retr = authority_pk != nullptr;
+  useRpAll(service_name, authority_pk, g, h);
+  std::vector<uint64_t> acc(m_set->size(), 0);
+  const uint8_t zero = 0;
+  m_set->forEachShard(n, [&](size_t r, size_t first, size_t count) {
+    if (count == 0) return;
+    std::vector<uint32_t> mo(count + 1);
+    for (size_t j = 0; j <= count; j++) mo[j] = offsets[first + j] - offsets[first];
+    elp_ctx* ctx = m_set->key(r).ctx();
+    elpCheck(ctx, elp_verify_id_wire_batch(ctx, count, messages + offsets[first], mo.data(), retr ? 1 : 0, ad.empty() ? &zero : (const uint8_t*)ad.data(),
+                                           nullptr, ad.size(), flags + first, &acc[r]),
+             "elp_verify_id_wire_batch");
+  });
+  uint64_t total = 0;
+  for (uint64_t a : acc) total += a;         // the only reduction across shards: the accepted counts
+  return total;
 }
 
 bool PSVerifier::el_passo_verify_id(const IdProof& proof, const std::string& associated_data, const std::string& service_name,

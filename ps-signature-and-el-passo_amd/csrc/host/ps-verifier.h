@@ -4,13 +4,18 @@
 #define ELP_HOST_PS_VERIFIER_H_
 
 #include <memory>
+#include <mutex>
 
 #include "elp_key.h"
 #include "ps-encoding.h"
 
 class PSVerifier {
  public:
-  PSVerifier(const PSPubKey& pk);
+  PSVerifier(const PSPubKey& pk);                       // the reference's constructor (src/ps-verifier.h:18): device and table width from elpSetDefaults
+  // one context per entry of `devices` (ordinals may repeat); batches are cut into contiguous shards, one host thread + one HIP stream per context
+  // (SURVEY.md section 8e); window_bits < 0 = the process default
+  PSVerifier(const PSPubKey& pk, const std::vector<int>& devices, int window_bits = -1);
+  size_t contexts() const { return m_set->size(); }
 
   bool verify(const PSCredential& sig, const std::vector<std::string>& all_attributes) const;
 
@@ -34,12 +39,25 @@ class PSVerifier {
   std::vector<bool> el_passo_verify_id_wire_batch(const std::vector<PSBuffer>& messages, const std::vector<std::string>& associated_data,
                                                   const std::string& service_name, const G1* authority_pk = nullptr,
                                                   const G1* g = nullptr, const G1* h = nullptr) const;
+  // the same on messages that are already contiguous (message i = bytes [offsets[i], offsets[i+1]) of `messages`): no per-message copy on the host.
+  // `flags` receives one byte per message; returns the number of accepted messages.  One associated-data string for the whole batch.
+  uint64_t el_passo_verify_id_wire_packed(const uint8_t* messages, const uint32_t* offsets, size_t n, const std::string& associated_data,
+                                          const std::string& service_name, uint8_t* flags, const G1* authority_pk = nullptr, const G1* g = nullptr,
+                                          const G1* h = nullptr) const;
   std::vector<bool> verify_batch(const std::vector<PSCredential>& sigs, const std::vector<std::vector<std::string>>& all_attributes) const;
 
  private:
   std::vector<bool> verifyIdImpl(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retrieval) const;
+  void useRpAll(const std::string& service, const G1* authority_pk, const G1* g, const G1* h) const;
   PSPubKey m_pk;
-  std::shared_ptr<ElpKey> m_key;
+  std::shared_ptr<ElpShardSet> m_set;    // the contexts of this verifier (one unless constructed with a device list)
+  std::shared_ptr<ElpKey> m_key;         // = context 0
+  // page-locked staging of the batch entry points (records / messages, associated data, verdicts); one batch call at a time per verifier
+  struct Stage {
+    std::mutex mu;
+    ElpPinned recs, ads, flags;
+  };
+  std::shared_ptr<Stage> m_stage;
 };
 
 #endif  // ELP_HOST_PS_VERIFIER_H_

@@ -82,3 +82,85 @@ def test_two_phase_golden_verdicts(gpu_ctx):
     finally:
         gpu_ctx.set_paired_layout(2)
     assert total > 100
+
+
+def test_cpp_verifier_shards_over_several_contexts(gpu_ctx):
+    """The C++ PSVerifier with a device list (three contexts on GPU 0: one host thread + one stream each, contiguous shards, counts summed):
+    IdProof objects, wire messages and the packed wire buffer give the generator's verdicts, ragged shard sizes included."""
+    import os
+    b = importlib.import_module("ps-signature-and-el-passo_amd.build")
+    L = ctypes.CDLL(b.HOST_LIB)
+    L.elph_last_error.restype = ctypes.c_char_p
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=11, window_bits=8)
+    for n, nctx in ((301, 3), (64, 1), (5, 4)):
+        recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=2)
+        msgs, moff = wl.wire_messages(recs, n, H, with_retrieval=True)
+        moff = np.ascontiguousarray(moff, dtype=np.uint32)
+        outv = (ctypes.c_double * 8)()
+        acc = (ctypes.c_uint64 * 3)()
+        flags = np.zeros(n, dtype=np.uint8)
+        rc = L.elph_bench_verify_id(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad,
+                                    recs, ctypes.c_size_t(n), ctypes.c_uint64(0), msgs, moff.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(8),
+                                    ctypes.c_int(nctx), ctypes.c_int(0), ctypes.c_int(1), outv, acc, flags.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, L.elph_last_error()
+        assert (flags == expect).all() and int(acc[0]) == int(acc[1]) == int(acc[2]) == int(expect.sum())
+
+
+def test_headline_batch_full_size_w20_with_4096_oracle_samples(gpu_ctx):
+    """The batch bench.py sells: 65 536 el_passo_verify_id proofs, 8 attributes with 4 hidden, id-retrieval, W = 20 tables (32 GiB), one-lane-per-item
+    kernel -- every verdict against the generator's expectation, and 4 096+ of them (a stride over the batch + EVERY corrupted item) against the C oracle
+    (reference structure, src/ps-verifier.cc:37-138).  Also the two-phase kernels on the same batch."""
+    L = oracle()
+    A, H, n = 8, 4, 65536
+    wl = synth.Workload(gpu_ctx, A, seed=20211, window_bits=20)
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True)
+    gpu_ctx.set_paired_layout(0)
+    try:
+        flags, cnt = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+        bad = [i for i in range(n) if i % 97 == 13]
+        assert (flags == expect).all() and cnt == int(expect.sum()) == n - len(bad)
+        for mode in (1, 2):
+            gpu_ctx.set_split_phases(mode)
+            f2, c2 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            assert (f2 == flags).all() and c2 == cnt
+    finally:
+        gpu_ctx.set_split_phases(0)
+        gpu_ctx.set_paired_layout(2)
+    key = _oracle_key(L, wl, gpu_ctx, A)
+    rsz = len(recs) // n
+    idx = sorted(set(list(range(0, n, 19)) + bad))
+    assert len(idx) >= 4096
+    samp = b"".join(recs[i * rsz:(i + 1) * rsz] for i in idx)
+    ofl = np.zeros(len(idx), dtype=np.uint8)
+    L.elpo_verify_id_batch(key, len(idx), samp, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+    assert (ofl == flags[idx]).all() and int((ofl == 0).sum()) == len(bad)
+
+
+def test_config5_end_to_end_eight_virtual_ranks(gpu_ctx):
+    """BASELINE.json configuration 5 end to end on ONE GPU: 2^20 el_passo_verify_id proofs (16 attributes, 4 hidden, id-retrieval) cut by shard_range into the
+    eight contiguous shards eight ranks would take, each shard verified in turn, per-shard accepted counts summed exactly as the count all-reduce would:
+    total == 2^20 - #corrupted; per shard every verdict == the generator's, plus oracle samples in every shard."""
+    shard = importlib.import_module("ps-signature-and-el-passo_amd.shard")
+    L = oracle()
+    A, H, N, R = 16, 4, 1 << 20, 8
+    wl = synth.Workload(gpu_ctx, A, seed=20211, window_bits=16)
+    key = _oracle_key(L, wl, gpu_ctx, A)
+    total, covered = 0, 0
+    for r in range(R):
+        first, count = shard.shard_range(N, r, R)
+        assert first == covered and count == N // R
+        covered += count
+        recs, mask, expect = wl.verify_id_batch(count, H, first_item=first)
+        flags, cnt = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+        assert (flags == expect).all() and cnt == int(expect.sum())
+        assert cnt == count - len([i for i in range(first, first + count) if i % 97 == 13])
+        total += cnt
+        rsz = len(recs) // count
+        idx = list(range(0, count, 2048)) + [i for i in range(count) if (first + i) % 97 == 13][:8]
+        samp = b"".join(recs[i * rsz:(i + 1) * rsz] for i in idx)
+        ofl = np.zeros(len(idx), dtype=np.uint8)
+        L.elpo_verify_id_batch(key, len(idx), samp, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+        assert (ofl == flags[idx]).all()
+    assert covered == N
+    assert total == N - len([i for i in range(N) if i % 97 == 13])
