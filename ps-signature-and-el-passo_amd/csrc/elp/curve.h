@@ -658,43 +658,53 @@ ELP_INL void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar& 
   g2_mul_gls_with<C, PrivTab<F2<C>>>(r, PrivTab<F2<C>>{tab}, k_in);
 }
 
-// Fixed-base tables: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^W - 1,
-// j = 0 .. ceil(256/W)-1.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
+// Fixed-base tables with SIGNED digits: for base B and window width W, entry [j][d-1] = d * 2^(W j) * B (affine), d = 1 .. 2^(W-1),
+// j = 0 .. ceil(256/W)-1 -- half the entries of an unsigned table.  A scalar (reduced mod r first, so that the top window cannot overflow)
+// is recoded on the fly into digits in (-2^(W-1), 2^(W-1)]:  d_j = window_j + carry;  d_j > 2^(W-1)  =>  d_j -= 2^W, carry into window j+1;
+// a negative digit adds the NEGATED entry |d_j|.  Accumulating a scalar costs ceil(256/W) mixed additions and no doublings.
+ELP_HD constexpr int fixed_base_entries(int W) { return 1 << (W - 1); }
+ELP_INL int fixed_base_digit(const Scalar& k, int j, int W, int& carry) {   // call with j = 0, 1, 2, ... in order, carry starting at 0
+  const int bit = j * W;
+  int d = scalar_window(k, bit, (bit + W <= 256) ? W : 256 - bit) + carry;
+  carry = d > (1 << (W - 1)) ? 1 : 0;
+  if (carry) d -= 1 << W;
+  return d;
+}
 template <class F>
-ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<typename F::MemF>* table, int W, const Scalar& k, u32* hot = nullptr) {
+ELP_HEAVY void jac_acc_fixed(Jac<F>& acc, const Aff<typename F::MemF>* table, int W, const Scalar& k_in, u32* hot = nullptr) {
   const int nwin = (256 + W - 1) / W;
-  const int per = (1 << W) - 1;
+  const int per = fixed_base_entries(W);
+  const Scalar k = scalar_mod_r<typename F::Curve>(k_in);
   Jac<F>* ah = hot_as<Jac<F>, typename F::Curve>(hot);   // the running sum lives in the hot slot while the windows are added
   Jac<F>& a = ah ? *ah : acc;
   if (ah) a = acc;
+  int carry = 0;
   // The entries are random reads of a table far larger than any cache (one HBM round trip each, with nothing else in the wave to hide it): the entry of
   // the NEXT window is requested before the current addition is computed.  Digit 0 reads entry 0 of the window and ignores it.
-  auto digit = [&](int j) {
-    const int bit = j * W;
-    return scalar_window(k, bit, (bit + W <= 256) ? W : 256 - bit);
-  };
   if constexpr (is_paired<typename F::Curve>()) {
     // paired kernels (256 registers per lane): the look-ahead costs more in spills than it hides (measured: +1.5 %); plain loop
     ELP_NOUNROLL
     for (int j = 0; j < nwin; j++) {
-      const int d = digit(j);
+      const int d = fixed_base_digit(k, j, W, carry);
       if (d != 0) {
-        const Aff<F> e = aff_from_mem<F>(table[(size_t)j * per + (d - 1)]);
+        Aff<F> e = aff_from_mem<F>(table[(size_t)j * per + ((d < 0 ? -d : d) - 1)]);
+        if (d < 0) e.y = F::neg(e.y);
         if (F::IS_EXT) jac_madd_inl<F>(a, a, e); else jac_madd<F>(a, a, e);
       }
     }
   } else {
-    int d = digit(0);
-    Aff<F> e = aff_from_mem<F>(table[d ? d - 1 : 0]);
+    int d = fixed_base_digit(k, 0, W, carry);
+    Aff<F> e = aff_from_mem<F>(table[d ? (d < 0 ? -d : d) - 1 : 0]);
     ELP_NOUNROLL
     for (int j = 0; j < nwin; j++) {
       int dn = 0;
       Aff<F> en = e;
       if (j + 1 < nwin) {
-        dn = digit(j + 1);
-        en = aff_from_mem<F>(table[(size_t)(j + 1) * per + (dn ? dn - 1 : 0)]);
+        dn = fixed_base_digit(k, j + 1, W, carry);
+        en = aff_from_mem<F>(table[(size_t)(j + 1) * per + (dn ? (dn < 0 ? -dn : dn) - 1 : 0)]);
       }
       if (d != 0) {
+        if (d < 0) e.y = F::neg(e.y);
         // the mixed addition is part of this loop for the Fp2 group (as a routine of its own it saves and restores ~170 registers per call)
         if (F::IS_EXT) jac_madd_inl<F>(a, a, e); else jac_madd<F>(a, a, e);
       }

@@ -31,7 +31,7 @@ template <class C>
 struct KeyCtx {
   int A;                          // attributes in the key
   int W;                          // fixed-base window width
-  int nwin, per;                  // windows per scalar, entries per window
+  int nwin, per;                  // windows per scalar, entries per window (signed digits: 2^(W-1), curve.h fixed_base_entries)
   // key material lives in HBM in the PLAIN layout (built by the unpaired set-up kernels) whatever layout C computes in
   const Aff<typename F1<C>::MemF>* t1;   // G1 tables: base b at t1 + b * nwin * per
   const Aff<typename F2<C>::MemF>* t2;   // G2 tables
@@ -1481,7 +1481,7 @@ ELP_HEAVY bool prove_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_ma
 // ------------------------------------------------------------------------------------------------------------
 // Setup helpers
 
-// entry (j, d) of the fixed-base table of `base`:  d * 2^(W j) * base, d = 1..2^W-1; one call fills entries
+// entry (j, d) of the fixed-base table of `base`:  d * 2^(W j) * base, d = 1..2^(W-1) (signed digits); one call fills entries
 // [d0, d0+cnt) of window j.  bj = 2^(W j) * base (affine).
 template <class F>
 ELP_HEAVY void table_fill_chunk(Aff<F>* win, const Aff<F>& bj, int d0, int cnt) {

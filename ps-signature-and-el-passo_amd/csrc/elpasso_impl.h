@@ -1056,8 +1056,8 @@ int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg,
   if (!c || nattr < 1 || nattr > 62 || !g || !gg || !XX || !Yi || !YYi) return ELP_ERR_ARG;
   if (window_bits == 0) window_bits = 8;
   if (window_bits < 2 || window_bits > 22) return ELP_ERR_ARG;
-  {   // the tables must fit the device (W = 16: 2.5 GiB for an 8-attribute BN254 key; W = 20: 32 GiB; W = 22: 120 GiB)
-    const size_t per = ((size_t)1 << window_bits) - 1, nwin = (256 + window_bits - 1) / window_bits;
+  {   // the tables must fit the device (signed digits: W = 16: 1.25 GiB for an 8-attribute BN254 key; W = 20: 16 GiB; W = 22: 60 GiB)
+    const size_t per = (size_t)fixed_base_entries(window_bits), nwin = (256 + window_bits - 1) / window_bits;
     const size_t need = per * nwin * ((size_t)(nattr + 6) * sizeof(Aff<F1<C>>) + (size_t)(nattr + 2) * sizeof(Aff<F2<C>>));
     HIPCHK(c, hipSetDevice(c->device));      // the guard must look at THIS context's device, and count the tables about to be released
     size_t held = 0;
@@ -1074,7 +1074,7 @@ int elp_set_pubkey_t(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg,
   c->A = nattr;
   c->W = window_bits;
   c->nwin = (256 + window_bits - 1) / window_bits;
-  c->per = (1 << window_bits) - 1;
+  c->per = fixed_base_entries(window_bits);
   const size_t G1 = Sizes<C>::G1, G2 = Sizes<C>::G2;
   c->h_b1.assign((size_t)(nattr + 6) * G1, 0);
   memcpy(c->h_b1.data(), g, G1);

@@ -118,7 +118,9 @@ class Workload:
             nrnd = 4 + H + 2
             u, t, rr, eps, *rest = self._fresh(nrnd)
             if n in degenerate_items and H < A:
-                d0 = m[H] & ((1 << window_bits) - 1)
+                d0 = (m[H] % r) & ((1 << window_bits) - 1)
+                if d0 > (1 << (window_bits - 1)):
+                    d0 -= 1 << window_bits             # signed digits (csrc/elp/curve.h fixed_base_digit): the entry added first is the NEGATED |d0| YY_H
                 if d0:
                     t = (d0 * ys[H] - x - sum(ys[j] * m[j] for j in range(H))) % r
             rho = rest[:H]

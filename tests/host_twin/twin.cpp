@@ -37,10 +37,12 @@ static void touch_entries(Aff<F>* base_tbl, const Aff<F>& base, int W, int nwin,
   if (aff_is_inf(base)) return;
   std::vector<Aff<F>> bj(nwin);
   table_window_bases<F>(bj.data(), base, W, nwin);
+  const Scalar kr = scalar_mod_r<typename F::Curve>(k);       // the same signed recoding as jac_acc_fixed
+  int carry = 0;
   for (int j = 0; j < nwin; j++) {
-    int bit = j * W, w = (bit + W <= 256) ? W : 256 - bit;
-    int d = scalar_window(k, bit, w);
+    int d = fixed_base_digit(kr, j, W, carry);
     if (d == 0) continue;
+    if (d < 0) d = -d;
     Scalar s;
     for (int i = 0; i < 8; i++) s.v[i] = 0;
     s.v[0] = (u32)d;
@@ -225,7 +227,7 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
       if (!g1_load<C>(c->b1[i], g1b + i * 2 * C::N)) return 0;                                                         \
     for (int i = 0; i < A + 2; i++)                                                                                    \
       if (!g2_load<C>(c->b2[i], g2b + i * 4 * C::N)) return 0;                                                         \
-    int nwin = (256 + W - 1) / W, per = (1 << W) - 1;                                                                  \
+    int nwin = (256 + W - 1) / W, per = fixed_base_entries(W);                                                                  \
     build_tables<F1<C>>(c->t1, c->b1, W, nwin, per);                                                                   \
     build_tables<F2<C>>(c->t2, c->b2, W, nwin, per);                                                                   \
     c->lines.resize(ml_num_lines<C>());                                                                                \
@@ -255,7 +257,7 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
       if (!g1_load<C>(c->b1[i], g1b + i * 2 * C::N)) return 0;                                                         \
     for (int i = 0; i < A + 2; i++)                                                                                    \
       if (!g2_load<C>(c->b2[i], g2b + i * 4 * C::N)) return 0;                                                         \
-    int nwin = (256 + W - 1) / W, per = (1 << W) - 1;                                                                  \
+    int nwin = (256 + W - 1) / W, per = fixed_base_entries(W);                                                                  \
     c->t1s = calloc((size_t)(A + 6) * nwin * per, sizeof(Aff<F1<C>>));                                                 \
     c->t2s = calloc((size_t)(A + 2) * nwin * per, sizeof(Aff<F2<C>>));                                                 \
     if (!c->t1s || !c->t2s) return 0;                                                                                  \

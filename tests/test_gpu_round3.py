@@ -129,7 +129,7 @@ def test_headline_batch_full_size_w20_with_4096_oracle_samples(gpu_ctx):
         gpu_ctx.set_paired_layout(2)
     key = _oracle_key(L, wl, gpu_ctx, A)
     rsz = len(recs) // n
-    idx = sorted(set(list(range(0, n, 19)) + bad))
+    idx = sorted(set(list(range(0, n, 17)) + bad))
     assert len(idx) >= 4096
     samp = b"".join(recs[i * rsz:(i + 1) * rsz] for i in idx)
     ofl = np.zeros(len(idx), dtype=np.uint8)
