@@ -41,8 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--attrs", type=int, default=0)
     ap.add_argument("--hidden", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launch, shard, count-reduce and report path; no kernel, value = null")
-    ap.add_argument("--window", type=int, default=20, help="fixed-base window bits of the key tables (library default 8; 20 = 32 GiB of tables "
-                    "for the 8-attribute key, 13 table additions per scalar instead of 16 at W = 16: profiles/r02_window_sweep.json)")
+    ap.add_argument("--window", type=int, default=20, help="fixed-base window bits of the key tables (library default 8; 20 = 16 GiB of signed-digit tables "
+                    "for the 8-attribute key, 13 table additions per scalar instead of 16 at W = 16: profiles/r02_window_sweep.json); reported in `config` and `key_tables`")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
@@ -247,6 +247,9 @@ def main():
             "config": workload_config(args, world), "ranks_seen": ranks_seen,
             "parity_ok": parity_ok, "accepted": total_accepted, "expected_accepted": int(exp_total.item()),
             "setup_s": t_setup,
+            "key_tables": {"window_bits": args.window or 8, "table_bytes": ctx.key_table_bytes(), "table_GiB": ctx.key_table_bytes() / 2.0**30,
+                           "set_pubkey_ms": wl.t_set_pubkey_ms, "set_rp_and_secret_ms": wl.t_set_params_ms,
+                           "note": "signed-digit fixed-base window tables of the key's 14 G1 and 10 G2 bases, per key and per GPU; built on the GPU (k_window_bases, k_table_fill)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_verify_id", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
                          "note": "integer-VALU bound path: see valu_bound"},
@@ -275,6 +278,11 @@ def main():
             out["bls12_381"] = second_curve(pkg, synth, local_rank, dev, A, H, B, args.window)
         except Exception as e:  # pragma: no cover
             out["bls12_381"] = {"error": str(e)}
+    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and (args.window or 8) != 16:
+        try:   # the same workload on the 16-bit tables (1/16 of the memory): what the wide tables buy
+            out["w16"] = other_config(pkg, synth, local_rank, dev, 4, 16)
+        except Exception as e:  # pragma: no cover
+            out["w16"] = {"error": str(e)}
     if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only:
         try:   # BASELINE.json config 5 at N = 1: one rank's share (131 072 proofs, 16 attributes) on this GPU
             out["config5_rank_share"] = other_config(pkg, synth, local_rank, dev, 5, args.window)
@@ -403,7 +411,23 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "k_verify_id<BLS12_381>", "kernel_ms": float(ms.value)},
            "valu_bound": valu_bound(ctx, "verify_id_bls12_381" if (A == 8 and H == 4) else None, window, B, float(ms.value), 392),
-           "note": "BLS12-381 instantiation (14 limbs of 28 bits): parity unpinned -- no reference oracle exists; checked against the big-int model in tests"}
+           "note": "BLS12-381 instantiation (14 limbs of 28 bits): parity unpinned -- no reference oracle exists; checked against the big-int model and the "
+                   "C oracle's BLS12-381 build in tests"}
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic_bls12_381.json")      # per-launch HBM bytes of the round's separate --pmc passes over this kernel
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            res["roofline"]["traffic"] = tj.get("bytes_per_launch")
+            res["roofline"]["traffic_source"] = "profiles/hbm_traffic_bls12_381.json (%s): FETCH_SIZE x2 + WRITE_SIZE of separate rocprofv3 --pmc passes; not re-measured in this run" % tj.get("tag")
+        except Exception:
+            pass
+    try:     # CPU baseline of this curve: the C oracle's BLS12-381 build on a bounded sample, verdicts compared with the GPU's
+        ncore = usable_cores()
+        res["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(B, max(768, 24 * ncore)), bls=True)
+        res["cpu_baseline"]["kind"] = "port"
+        res["cpu_baseline"]["note"] = "parity unpinned: the oracle for this curve is this project's own second implementation, not a reference artefact"
+    except Exception as e:  # pragma: no cover
+        res["cpu_baseline"] = {"error": str(e)}
     ctx.close()
     return res
 
@@ -432,7 +456,8 @@ def other_config(pkg, synth, local_rank, dev, config, window):
     rsz = len(recs) // B
     ach = B * (rsz + 4) / (ms.value * 1e-3) / 1e9
     res = {"workload": "BASELINE.json config %d, one rank's share: %d el_passo_verify_id, %d attributes with %d hidden, id-retrieval, BN254" % (config, B, A, H),
-           "value": B / (ms.value * 1e-3), "unit": "verifications/s", "batch": B, "kernel_ms": float(ms.value),
+           "value": B / (ms.value * 1e-3), "unit": "verifications/s", "batch": B, "kernel_ms": float(ms.value), "window_bits": window,
+           "table_bytes": ctx.key_table_bytes(), "set_pubkey_ms": wl.t_set_pubkey_ms,
            "parity_ok": bool((flags == expect).all()) and int(d_cnt.item()) == 3 * int(expect.sum()),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_item": rsz + 4}}
@@ -568,13 +593,13 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(wl, ctx, recs, rsz, mask, gpu_flags, sample):
-    """The C oracle (reference-structure restatement, oracle/elp_oracle.c) timed on the host cores over the first `sample`
-    items of the same workload; its verdicts are also compared with the GPU's."""
+def cpu_baseline(wl, ctx, recs, rsz, mask, gpu_flags, sample, bls=False):
+    """The C oracle (reference-structure restatement, oracle/elp_oracle.c; bls: its BLS12-381 build) timed on the host cores over the
+    first `sample` items of the same workload; its verdicts are also compared with the GPU's."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from elp_testlib import oracle
-    L = oracle()
+    from elp_testlib import oracle, oracle_bls
+    L = oracle_bls() if bls else oracle()
     A = wl.A
     g1 = wl.g + wl.Yi + ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
     g2 = wl.gg + wl.XX + wl.YYi

@@ -54,8 +54,12 @@ int elp_field_bytes(int curve);               /* F */
  * launch workspace in device memory (3 KB per item, see the *_dev entry points) instead of the lanes' private memory; results are
  * identical, 0 saves the memory at a few per cent of throughput.
  * ELP_OPT_SPLIT_PHASES (default 1): the one-lane-per-item el_passo_verify_id runs as two kernels -- the NIZK half with two job lanes per
- * item (two waves per SIMD), then the pairing check -- instead of one fused kernel; results are identical (BN254 builds). */
-enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4 };
+ * item (two waves per SIMD), then the pairing check -- instead of one fused kernel; results are identical (BN254 builds).
+ * ELP_OPT_SUBGROUP_CHECK (default 1; BLS12-381 only, BN254 has G1 cofactor 1): the prover-supplied G1 points of a proof or request (phi, E1, E2;
+ * the commitment A of el_passo_provide_id) must lie in the order-r subgroup, otherwise the item is rejected (one [z^2]P per point, ~9 % of a
+ * verification).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
+ * pseudonyms or an undecryptable token.  The reference never meets the case (it runs on BN254); mcl's default does not check.  0 = no check. */
+enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 
@@ -181,6 +185,9 @@ int elp_request_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d
 int elp_prove_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
                            int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_proofs,
                            void* d_flags, void* d_accepted);
+
+/* bytes of device memory held by the installed key's fixed-base tables (0 without a key) */
+size_t elp_key_table_bytes(const elp_ctx* ctx);
 
 /* ---- host staging memory ------------------------------------------------------------------------------------------- */
 /* Page-locked host memory for the buffers handed to the host-buffer entry points (records, messages, verdicts): copies from / to it are

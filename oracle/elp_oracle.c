@@ -21,8 +21,15 @@
  * Pinning: tests/test_oracle_golden.py checks this library against every golden vector captured from the reference's
  * own prebuilt wasm (tests/golden/bn254_*.json) and against the independent big-int model oracle/pymodel.py.
  *
- * Representation: 4 x 64-bit limbs, unsigned __int128 products (deliberately different from the HIP path's 8 x 32-bit
+ * Representation: 4 x 64-bit limbs, unsigned __int128 products (deliberately different from the HIP path's 9 x 29-bit signed
  * limbs; the Miller loop uses Jacobian line formulas, the HIP path homogeneous ones).
+ *
+ * Second build, -DELPO_BLS12_381 (libelp_oracle_bls.so): the same restatement over BLS12-381 (6 x 64-bit limbs, y^2 = x^3 + 4, M-type twist
+ * y^2 = x^3 + 4 xi, Miller loop over |z| = 0xd201000000010000, final exponentiation by the Hayashida-Hayasaka-Teruya chain AND, as a
+ * self-check, by plain square-and-multiply with the integer (p^4-p^2+1)/r).  PARITY UNPINNED: the reference never runs on this curve
+ * and mcl is absent, so nothing reference-made pins it; its role is to be a second, independently written implementation beside
+ * oracle/pymodel.py for the HIP path's BLS12-381 instantiation (equal GT values, signatures, verdicts) and the CPU baseline of that
+ * curve.  hashAndMapToG1 follows this project's own convention for the curve (csrc/elp/encode.h), not mcl's.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -32,17 +39,40 @@ typedef uint64_t u64;
 typedef unsigned __int128 u128;
 
 /* ------------------------------------------------------------------------------------------------ Fp */
-typedef struct { u64 v[4]; } fp;
-
-static const u64 P[4] = {0xa700000000000013ull, 0x6121000000000013ull, 0xba344d8000000008ull, 0x2523648240000001ull};
+#ifdef ELPO_BLS12_381
+#define NL 6            /* 64-bit limbs of a field element */
+#define FB 48           /* bytes of a field element on the wire / in records */
+#define PBITS 381
+#define RBITS 255
+#define CURVE_B_INT 4
+typedef struct { u64 v[NL]; } fp;
+static const u64 P[NL] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+static const u64 RORD[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+static const u64 ZABS = 0xd201000000010000ull; /* |z|, z < 0 */
+static const u64 ZM1D3_ABS = 0x460055555555aaabull;      /* |z - 1| / 3 */
+static const u64 G1_COFACTOR[4] = {0x8c00aaab0000aaabull, 0x396c8c005555e156ull, 0, 0};   /* (z - 1)^2 / 3 */
+/* (p^4 - p^2 + 1) / r, 1268 bits: the hard part of the final exponentiation as one integer (self-check of the chain) */
+static const u64 HARD_EXP[20] = {0xe516c3f438e3ba79ull, 0xfa9912aae208ccf1ull, 0x905ce937335d5b68ull, 0xc71a2629b0dea236ull, 0x83774940996754c8ull,
+                                 0x21d160aeb6a1e799ull, 0x2ed0b283ed237db4ull, 0x915c97f36c6f1821ull, 0x67f17fcbde783765ull, 0x2378b9039096d1b7ull,
+                                 0x7988f8761bdc51dcull, 0x2076995003fc77a1ull, 0x827eca0ba621315bull, 0xe5a72bce8d63cb9full, 0xf68f7764c28b6f8aull,
+                                 0x2f230063cf081517ull, 0x94506632528d6a9aull, 0xd3cde88eeb996ca3ull, 0xc0bd38c3195c899eull, 0x000f686b3d807d01ull};
+#else
+#define NL 4
+#define FB 32
+#define PBITS 254
+#define RBITS 254
+#define CURVE_B_INT 2
+typedef struct { u64 v[NL]; } fp;
+static const u64 P[NL] = {0xa700000000000013ull, 0x6121000000000013ull, 0xba344d8000000008ull, 0x2523648240000001ull};
 static const u64 RORD[4] = {0xa10000000000000dull, 0xff9f800000000010ull, 0xba344d8000000007ull, 0x2523648240000001ull};
 static const u64 ZABS = 0x4080000000000001ull; /* |z|, z < 0 */
+#endif
 static u64 PINV;                                /* -p^-1 mod 2^64 */
 static fp FP_ONE, FP_R2, FP_ZERO;
 static int g_init = 0;
 
 static int geq_p(const u64* a) {
-  for (int i = 3; i >= 0; i--) {
+  for (int i = NL - 1; i >= 0; i--) {
     if (a[i] > P[i]) return 1;
     if (a[i] < P[i]) return 0;
   }
@@ -50,7 +80,7 @@ static int geq_p(const u64* a) {
 }
 static void sub_p(u64* a) {
   u128 br = 0;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NL; i++) {
     u128 t = (u128)a[i] - P[i] - br;
     a[i] = (u64)t;
     br = (t >> 64) & 1;
@@ -58,33 +88,37 @@ static void sub_p(u64* a) {
 }
 static void fp_add(fp* r, const fp* a, const fp* b) {
   u128 c = 0;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NL; i++) {
     c += (u128)a->v[i] + b->v[i];
     r->v[i] = (u64)c;
     c >>= 64;
   }
-  if (geq_p(r->v)) sub_p(r->v);
+  if (geq_p(r->v)) sub_p(r->v);      /* p < 2^(64 NL - 1) on both curves: the sum of two reduced values has no carry out */
 }
 static void fp_sub(fp* r, const fp* a, const fp* b) {
   u128 br = 0;
-  u64 t[4];
-  for (int i = 0; i < 4; i++) {
+  u64 t[NL];
+  for (int i = 0; i < NL; i++) {
     u128 d = (u128)a->v[i] - b->v[i] - br;
     t[i] = (u64)d;
     br = (d >> 64) & 1;
   }
   if (br) {
     u128 c = 0;
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NL; i++) {
       c += (u128)t[i] + P[i];
       t[i] = (u64)c;
       c >>= 64;
     }
   }
-  memcpy(r->v, t, 32);
+  memcpy(r->v, t, 8 * NL);
 }
-static int fp_is_zero(const fp* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
-static int fp_eq(const fp* a, const fp* b) { return memcmp(a->v, b->v, 32) == 0; }
+static int fp_is_zero(const fp* a) {
+  u64 t = 0;
+  for (int i = 0; i < NL; i++) t |= a->v[i];
+  return t == 0;
+}
+static int fp_eq(const fp* a, const fp* b) { return memcmp(a->v, b->v, 8 * NL) == 0; }
 static void fp_neg(fp* r, const fp* a) {
   if (fp_is_zero(a)) { *r = *a; return; }
   fp_sub(r, &FP_ZERO, a);
@@ -92,33 +126,34 @@ static void fp_neg(fp* r, const fp* a) {
 static void fp_dbl(fp* r, const fp* a) { fp_add(r, a, a); }
 /* Montgomery multiplication, operand scanning (separate product and reduction passes) */
 static void fp_mul(fp* r, const fp* a, const fp* b) {
-  u64 t[9] = {0};
-  for (int i = 0; i < 4; i++) {
+  u64 t[2 * NL + 1] = {0};
+  for (int i = 0; i < NL; i++) {
     u128 c = 0;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NL; j++) {
       c += (u128)a->v[j] * b->v[i] + t[i + j];
       t[i + j] = (u64)c;
       c >>= 64;
     }
-    t[i + 4] = (u64)c;
+    t[i + NL] = (u64)c;
   }
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NL; i++) {
     u64 m = t[i] * PINV;
     u128 c = 0;
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NL; j++) {
       c += (u128)m * P[j] + t[i + j];
       t[i + j] = (u64)c;
       c >>= 64;
     }
-    for (int k = i + 4; c && k < 9; k++) {
+    for (int k = i + NL; c && k < 2 * NL + 1; k++) {
       c += t[k];
       t[k] = (u64)c;
       c >>= 64;
     }
   }
-  u64 o[4] = {t[4], t[5], t[6], t[7]};
-  if (t[8] || geq_p(o)) sub_p(o);
-  memcpy(r->v, o, 32);
+  u64 o[NL];
+  for (int i = 0; i < NL; i++) o[i] = t[NL + i];
+  if (t[2 * NL] || geq_p(o)) sub_p(o);
+  memcpy(r->v, o, 8 * NL);
 }
 static void fp_sqr(fp* r, const fp* a) { fp_mul(r, a, a); }
 static void fp_pow(fp* r, const fp* a, const u64* e, int nl) {
@@ -131,31 +166,31 @@ static void fp_pow(fp* r, const fp* a, const u64* e, int nl) {
 }
 static void sub_small(u64* o, const u64* a, u64 k) { /* o = a - k */
   u128 br = k;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NL; i++) {
     u128 t = (u128)a[i] - br;
     o[i] = (u64)t;
     br = (t >> 64) & 1;
   }
 }
 static void shr(u64* a, int s) {
-  for (int i = 0; i < 4; i++) a[i] = (a[i] >> s) | (i < 3 ? a[i + 1] << (64 - s) : 0);
+  for (int i = 0; i < NL; i++) a[i] = (a[i] >> s) | (i < NL - 1 ? a[i + 1] << (64 - s) : 0);
 }
 static void fp_inv(fp* r, const fp* a) { /* a^(p-2) */
-  u64 e[4];
+  u64 e[NL];
   sub_small(e, P, 2);
-  fp_pow(r, a, e, 4);
+  fp_pow(r, a, e, NL);
 }
 static int fp_sqrt(fp* r, const fp* a) { /* p = 3 mod 4: a^((p+1)/4) */
-  u64 e[4];
+  u64 e[NL];
   u128 c = 1;
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NL; i++) {
     c += P[i];
     e[i] = (u64)c;
     c >>= 64;
   }
   shr(e, 2);
   fp t, s;
-  fp_pow(&t, a, e, 4);
+  fp_pow(&t, a, e, NL);
   fp_sqr(&s, &t);
   int ok = fp_eq(&s, a);   /* r may alias a */
   *r = t;
@@ -163,30 +198,34 @@ static int fp_sqrt(fp* r, const fp* a) { /* p = 3 mod 4: a^((p+1)/4) */
 }
 static int fp_legendre(const fp* a) {
   if (fp_is_zero(a)) return 0;
-  u64 e[4];
+  u64 e[NL];
   sub_small(e, P, 1);
   shr(e, 1);
   fp t;
-  fp_pow(&t, a, e, 4);
+  fp_pow(&t, a, e, NL);
   return fp_eq(&t, &FP_ONE) ? 1 : -1;
 }
 static void fp_from_u64(fp* r, u64 x) {
-  fp t = {{x, 0, 0, 0}};
+  fp t;
+  memset(&t, 0, sizeof t);
+  t.v[0] = x;
   fp_mul(r, &t, &FP_R2);
 }
 static void fp_from_le(fp* r, const uint8_t* b) { /* canonical LE bytes -> Montgomery (no range check) */
   fp t;
-  memcpy(t.v, b, 32);
+  memcpy(t.v, b, FB);
   fp_mul(r, &t, &FP_R2);
 }
 static void fp_to_le(uint8_t* b, const fp* a) {
-  fp one = {{1, 0, 0, 0}}, t;
+  fp one, t;
+  memset(&one, 0, sizeof one);
+  one.v[0] = 1;
   fp_mul(&t, a, &one);
-  memcpy(b, t.v, 32);
+  memcpy(b, t.v, FB);
 }
 static int le_lt_p(const uint8_t* b) {
-  u64 t[4];
-  memcpy(t, b, 32);
+  u64 t[NL];
+  memcpy(t, b, FB);
   return !geq_p(t);
 }
 
@@ -281,7 +320,7 @@ static int fp2_sqrt(fp2* r, const fp2* x) {
 typedef struct { fp2 c0, c1, c2; } fp6;      /* Fp2[v]/(v^3 - xi) */
 typedef struct { fp6 c0, c1; } fp12;         /* Fp6[w]/(w^2 - v)  */
 static fp2 FROB[4][6];                        /* FROB[n][k] = xi^(k (p^n - 1)/6), n = 1..3 */
-static fp2 TWIST_B;                           /* b/xi */
+static fp2 TWIST_B;                           /* b/xi (BN254, D-type twist) or b xi (BLS12-381, M-type twist) */
 
 static void fp6_add(fp6* r, const fp6* x, const fp6* y) { fp2_add(&r->c0, &x->c0, &y->c0); fp2_add(&r->c1, &x->c1, &y->c1); fp2_add(&r->c2, &x->c2, &y->c2); }
 static void fp6_sub(fp6* r, const fp6* x, const fp6* y) { fp2_sub(&r->c0, &x->c0, &y->c0); fp2_sub(&r->c1, &x->c1, &y->c1); fp2_sub(&r->c2, &x->c2, &y->c2); }
@@ -370,15 +409,36 @@ static void fp12_frob(fp12* r, const fp12* x, int n) { /* coefficient of w^k, k 
     *o[k] = t;
   }
 }
-/* f * (a + b w + c w^3): the D-twist line shape */
+/* f * line.  A line through points of the twist, evaluated at P = (x_P, y_P), is  a y_P  -  (...) x_P  +  c  with a, b, c in Fp2 (ml_dbl / ml_add pass
+   a y_P, b x_P and c).  D-type twist (BN254; untwist (x, y) -> (x w^2, y w^3)):  a + b w + c w^3.  M-type twist (BLS12-381; untwist (x, y) ->
+   (x / w^2, y / w^3)): the same line times w^3 -- an element of Fp4 = Fp2(w^3), which the final exponentiation maps to 1 --  c + b w^2 + a w^3. */
 static void fp12_mul_line(fp12* f, const fp2* a, const fp2* b, const fp2* c) {
   fp12 l;
   memset(&l, 0, sizeof l);
+#ifdef ELPO_BLS12_381
+  l.c0.c0 = *c;
+  l.c0.c1 = *b;   /* w^2 = v */
+  l.c1.c1 = *a;   /* w^3 = v w */
+#else
   l.c0.c0 = *a;
   l.c1.c0 = *b;
   l.c1.c1 = *c;
+#endif
   fp12_mul(f, f, &l);
 }
+#ifdef ELPO_BLS12_381
+static void fp12_pow_limbs(fp12* r, const fp12* x, const u64* e, int nl) {   /* plain square-and-multiply, e != 0 */
+  fp12 acc;
+  int started = 0;
+  for (int i = nl * 64 - 1; i >= 0; i--) {
+    if (started) fp12_sqr(&acc, &acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) {
+      if (started) fp12_mul(&acc, &acc, x); else { acc = *x; started = 1; }
+    }
+  }
+  *r = acc;
+}
+#endif
 static void fp12_pow_u64(fp12* r, const fp12* x, u64 e) {
   fp12 acc = *x;
   int top = 63;
@@ -534,6 +594,52 @@ static void ml_add(fp12* f, g2j* T, const g2a* q, const g1a* p) {
   g2_from_aff(&Q, q);
   g2_add(T, T, &Q);
 }
+#ifdef ELPO_BLS12_381
+static void miller_loop(fp12* f, const g1a* p, const g2a* q) {
+  fp12_one(f);
+  if (p->inf || q->inf) return;
+  /* optimal ate on BLS12: f_{|z|,Q}(P), conjugated because z < 0; no Frobenius steps */
+  int top = 63;
+  while (!((ZABS >> top) & 1)) top--;
+  g2j T;
+  g2_from_aff(&T, q);
+  for (int i = top - 1; i >= 0; i--) {
+    fp12_sqr(f, f);
+    ml_dbl(f, &T, p);
+    if ((ZABS >> i) & 1) ml_add(f, &T, q, p);
+  }
+  fp12_conj(f, f);
+}
+static void fp12_pow_z(fp12* r, const fp12* x) { /* x^z, z = -|z|, x unitary after the easy part */
+  fp12_pow_u64(r, x, ZABS);
+  fp12_conj(r, r);
+}
+/* hard part by the chain of Hayashida, Hayasaka and Teruya: (p^4-p^2+1)/r = ((z-1)^2/3) (z+p) (z^2+p^2-1) + 1 */
+static void final_exp_hard_chain(fp12* r, const fp12* f) {
+  fp12 a, b, c, t;
+  fp12_pow_u64(&a, f, ZM1D3_ABS); fp12_conj(&a, &a);                      /* f^((z-1)/3), (z-1)/3 < 0 */
+  fp12_pow_z(&t, &a); fp12_conj(&b, &a); fp12_mul(&a, &t, &b);            /* ^(z-1) */
+  fp12_pow_z(&t, &a); fp12_frob(&b, &a, 1); fp12_mul(&b, &b, &t);         /* ^(z+p) */
+  fp12_pow_z(&t, &b); fp12_pow_z(&t, &t); fp12_frob(&c, &b, 2); fp12_mul(&c, &c, &t);
+  fp12_conj(&t, &b); fp12_mul(&c, &c, &t);                                /* ^(z^2+p^2-1) */
+  fp12_mul(r, &c, f);
+}
+static void final_exp_easy(fp12* f, const fp12* fin) {
+  fp12 t0, t1;
+  fp12_inv(&t0, fin);
+  fp12_conj(&t1, fin);
+  fp12_mul(f, &t1, &t0);
+  fp12_frob(&t0, f, 2);
+  fp12_mul(f, &t0, f);
+}
+static void final_exp(fp12* r, const fp12* fin) {
+  fp12 f;
+  final_exp_easy(&f, fin);
+  final_exp_hard_chain(r, &f);
+}
+/* self-check: the chain equals the plain power by the integer (p^4-p^2+1)/r */
+int elpo_selftest_final_exp(const uint8_t* P_, const uint8_t* Q_);
+#else
 static void miller_loop(fp12* f, const g1a* p, const g2a* q) {
   fp12_one(f);
   if (p->inf || q->inf) return;
@@ -586,6 +692,7 @@ static void final_exp(fp12* r, const fp12* fin) {
   fp12_mul(&T0, &T1, &y1); fp12_mul(&T1, &T1, &y0);
   fp12_sqr(&T0, &T0); fp12_mul(r, &T0, &T1);
 }
+#endif
 static void pairing(fp12* r, const g1a* p, const g2a* q) {
   fp12 f;
   miller_loop(&f, p, q);
@@ -654,65 +761,101 @@ static int u256_geq(const u64* a, const u64* m) {
   }
   return 1;
 }
-/* Fr::setHashOf / Fp::setHashOf: LE(SHA-256(m)) masked to 254 bits; if still >= modulus, to 253 bits */
+/* Fr::setHashOf (and, on BN254, Fp::setHashOf): LE(SHA-256(m)) masked to the bit length of the modulus; if still >= modulus, to one bit less */
 static void set_hash_of(u64 out[4], const uint8_t* msg, size_t len, const u64* mod) {
   sha256_t s;
   uint8_t d[32];
   sha_init(&s); sha_update(&s, msg, len); sha_final(&s, d);
   memcpy(out, d, 32);
-  out[3] &= (1ull << 62) - 1;
-  if (u256_geq(out, mod)) out[3] &= (1ull << 61) - 1;
+  const int bits = RBITS;               /* on BN254 p and r have the same bit length */
+  out[3] &= (1ull << (bits - 192)) - 1;
+  if (u256_geq(out, mod)) out[3] &= (1ull << (bits - 193)) - 1;
 }
-static void g1_ser(uint8_t out[32], const g1a* p) {
-  if (p->inf) { memset(out, 0, 32); return; }
-  uint8_t y[32];
+static void g1_ser(uint8_t out[FB], const g1a* p) {
+  if (p->inf) { memset(out, 0, FB); return; }
+  uint8_t y[FB];
   fp_to_le(out, &p->x); fp_to_le(y, &p->y);
-  if (y[0] & 1) out[31] |= 0x80;
+  if (y[0] & 1) out[FB - 1] |= 0x80;
 }
-static void g2_ser(uint8_t out[64], const g2a* p) {
-  if (p->inf) { memset(out, 0, 64); return; }
-  uint8_t y[32];
-  fp_to_le(out, &p->x.a); fp_to_le(out + 32, &p->x.b); fp_to_le(y, &p->y.a);
-  if (y[0] & 1) out[63] |= 0x80;
+static void g2_ser(uint8_t out[2 * FB], const g2a* p) {
+  if (p->inf) { memset(out, 0, 2 * FB); return; }
+  uint8_t y[FB];
+  fp_to_le(out, &p->x.a); fp_to_le(out + FB, &p->x.b); fp_to_le(y, &p->y.a);
+  if (y[0] & 1) out[2 * FB - 1] |= 0x80;
 }
-static int g1_de(g1a* p, const uint8_t in[32]) {
-  uint8_t t[32];
-  memcpy(t, in, 32);
+static int g1_de(g1a* p, const uint8_t in[FB]) {
+  uint8_t t[FB];
+  memcpy(t, in, FB);
   int any = 0;
-  for (int i = 0; i < 32; i++) any |= t[i];
+  for (int i = 0; i < FB; i++) any |= t[i];
   memset(p, 0, sizeof *p);
   if (!any) { p->inf = 1; return 1; }
-  int odd = t[31] >> 7;
-  t[31] &= 0x7f;
+  int odd = t[FB - 1] >> 7;
+  t[FB - 1] &= 0x7f;
   if (!le_lt_p(t)) return 0;
   fp_from_le(&p->x, t);
   fp rhs;
   fp_sqr(&rhs, &p->x); fp_mul(&rhs, &rhs, &p->x); fp_add(&rhs, &rhs, &CURVE_B);
   if (!fp_sqrt(&p->y, &rhs)) return 0;
-  uint8_t y[32];
+  uint8_t y[FB];
   fp_to_le(y, &p->y);
   if ((y[0] & 1) != odd) fp_neg(&p->y, &p->y);
   return 1;
 }
-static int g2_de(g2a* p, const uint8_t in[64]) {
-  uint8_t t[64];
-  memcpy(t, in, 64);
+static int g2_de(g2a* p, const uint8_t in[2 * FB]) {
+  uint8_t t[2 * FB];
+  memcpy(t, in, 2 * FB);
   int any = 0;
-  for (int i = 0; i < 64; i++) any |= t[i];
+  for (int i = 0; i < 2 * FB; i++) any |= t[i];
   memset(p, 0, sizeof *p);
   if (!any) { p->inf = 1; return 1; }
-  int odd = t[63] >> 7;
-  t[63] &= 0x7f;
-  if (!le_lt_p(t) || !le_lt_p(t + 32)) return 0;
-  fp_from_le(&p->x.a, t); fp_from_le(&p->x.b, t + 32);
+  int odd = t[2 * FB - 1] >> 7;
+  t[2 * FB - 1] &= 0x7f;
+  if (!le_lt_p(t) || !le_lt_p(t + FB)) return 0;
+  fp_from_le(&p->x.a, t); fp_from_le(&p->x.b, t + FB);
   fp2 rhs;
   fp2_sqr(&rhs, &p->x); fp2_mul(&rhs, &rhs, &p->x); fp2_add(&rhs, &rhs, &TWIST_B);
   if (!fp2_sqrt(&p->y, &rhs)) return 0;
-  uint8_t y[32];
+  uint8_t y[FB];
   fp_to_le(y, &p->y.a);
   if ((y[0] & 1) != odd) fp2_neg(&p->y, &p->y);
   return 1;
 }
+#ifdef ELPO_BLS12_381
+/* hashAndMapToG1 on BLS12-381 -- this PROJECT's convention (csrc/elp/encode.h hash_and_map_to_g1; mcl's is pinned by nothing):
+   x_ctr = the first 48 bytes of SHA256(msg | ctr | 0) | SHA256(msg | ctr | 1) as a little-endian integer, masked to 381 bits and to 380 if still >= p;
+   the first ctr with x^3 + 4 a square wins, y = the root with even canonical value; the point is multiplied by the cofactor (z-1)^2/3. */
+static void g1_mul(g1j* r, const g1a* p, const u64* k);
+static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
+  for (unsigned ctr = 0;; ctr++) {
+    uint8_t d[64];
+    for (int half = 0; half < 2; half++) {
+      sha256_t s;
+      uint8_t c[2] = {(uint8_t)ctr, (uint8_t)half};
+      sha_init(&s); sha_update(&s, msg, len); sha_update(&s, c, 2); sha_final(&s, d + 32 * half);
+    }
+    u64 t[NL];
+    memcpy(t, d, FB);
+    t[NL - 1] &= (1ull << (PBITS - 64 * (NL - 1))) - 1;
+    if (geq_p(t)) t[NL - 1] &= (1ull << (PBITS - 1 - 64 * (NL - 1))) - 1;
+    fp x, y, rhs;
+    fp_from_le(&x, (const uint8_t*)t);
+    fp_sqr(&rhs, &x); fp_mul(&rhs, &rhs, &x); fp_add(&rhs, &rhs, &CURVE_B);
+    if (!fp_sqrt(&y, &rhs)) continue;
+    uint8_t yb[FB];
+    fp_to_le(yb, &y);
+    if (yb[0] & 1) fp_neg(&y, &y);
+    g1a pt;
+    memset(&pt, 0, sizeof pt);
+    pt.x = x; pt.y = y;
+    g1j j;
+    g1_mul(&j, &pt, G1_COFACTOR);
+    if (g1_is_inf(&j)) continue;
+    g1_to_aff(out, &j);
+    return;
+  }
+}
+#else
 /* hashAndMapToG1 on BN curves: t = Fp::setHashOf(msg), then the Shallue-van de Woestijne map */
 static fp SVDW_C1, SVDW_C2;
 static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
@@ -734,6 +877,8 @@ static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
   out->x = x; out->y = y; out->inf = 0;
 }
 
+#endif
+
 /* ------------------------------------------------------------------------------------------------ init */
 void elpo_init(void) {
   if (g_init) return;
@@ -742,32 +887,39 @@ void elpo_init(void) {
   for (int i = 0; i < 6; i++) inv *= 2 - P[0] * inv;
   PINV = (u64)0 - inv;
   memset(&FP_ZERO, 0, sizeof FP_ZERO);
-  /* R mod p and R^2 mod p by repeated doubling of 1 */
-  fp t = {{1, 0, 0, 0}};
-  for (int i = 0; i < 256; i++) fp_add(&t, &t, &t);
+  /* R mod p and R^2 mod p by repeated doubling of 1 (R = 2^(64 NL)) */
+  fp t;
+  memset(&t, 0, sizeof t);
+  t.v[0] = 1;
+  for (int i = 0; i < 64 * NL; i++) fp_add(&t, &t, &t);
   FP_ONE = t;
-  for (int i = 0; i < 256; i++) fp_add(&t, &t, &t);
+  for (int i = 0; i < 64 * NL; i++) fp_add(&t, &t, &t);
   FP_R2 = t;
   F2_ZERO.a = FP_ZERO; F2_ZERO.b = FP_ZERO;
   F2_ONE.a = FP_ONE; F2_ONE.b = FP_ZERO;
-  fp_from_u64(&CURVE_B, 2);
+  fp_from_u64(&CURVE_B, CURVE_B_INT);
   fp2 xi = {FP_ONE, FP_ONE}, xinv, b2 = {CURVE_B, FP_ZERO};
+#ifdef ELPO_BLS12_381
+  (void)xinv;
+  fp2_mul(&TWIST_B, &b2, &xi);          /* M-type twist: b' = b xi */
+#else
   fp2_inv(&xinv, &xi);
-  fp2_mul(&TWIST_B, &b2, &xinv);
+  fp2_mul(&TWIST_B, &b2, &xinv);        /* D-type twist: b' = b / xi */
+#endif
   /* gamma_{1,k} = xi^(k (p-1)/6); gamma_{2,k} = gamma_{1,k} conj(gamma_{1,k}); gamma_{3,k} = gamma_{1,k} * gamma_{2,k}^p...
      computed directly: gamma_{n,k} = gamma_{1,k}^(1 + p + ... + p^(n-1)), with x^p = conj(x) in Fp2 */
-  u64 e[4];
+  u64 e[NL];
   sub_small(e, P, 1);
   { /* e = (p-1)/6 */
     u128 rem = 0;
-    for (int i = 3; i >= 0; i--) {
+    for (int i = NL - 1; i >= 0; i--) {
       u128 cur = (rem << 64) | e[i];
       e[i] = (u64)(cur / 6);
       rem = cur % 6;
     }
   }
   fp2 g1;
-  fp2_pow(&g1, &xi, e, 4);
+  fp2_pow(&g1, &xi, e, NL);
   for (int k = 0; k < 6; k++) {
     fp2 a = F2_ONE;
     for (int j = 0; j < k; j++) fp2_mul(&a, &a, &g1);
@@ -778,6 +930,7 @@ void elpo_init(void) {
     fp2_mul(&a3, &a3, &a);        /* a^(1+p+p^2) */
     FROB[1][k] = a; FROB[2][k] = a2; FROB[3][k] = a3;
   }
+#ifndef ELPO_BLS12_381
   /* SvdW constants: c1 = sqrt(-3) (the root mcl uses has even canonical value ...04), c2 = (c1 - 1)/2 */
   fp m3, two, half;
   fp_from_u64(&m3, 3); fp_neg(&m3, &m3);
@@ -787,36 +940,39 @@ void elpo_init(void) {
   if (c1b[0] != 0x04) fp_neg(&SVDW_C1, &SVDW_C1);
   fp_from_u64(&two, 2); fp_inv(&half, &two);
   fp_sub(&SVDW_C2, &SVDW_C1, &FP_ONE); fp_mul(&SVDW_C2, &SVDW_C2, &half);
+#endif
   g_init = 1;
 }
 
 /* ------------------------------------------------------------------------------------------------ byte-level API */
-/* Formats are those of include/elpasso.h: G1 = x|y (32+32 LE, zeros = infinity), G2 = x.a|x.b|y.a|y.b, Fr = 32 LE. */
+#define G1B (2 * FB)
+#define G2B (4 * FB)
+/* Formats are those of include/elpasso.h: G1 = x|y (FB + FB bytes LE, zeros = infinity; FB = 32 / 48), G2 = x.a|x.b|y.a|y.b, Fr = 32 LE. */
 static int g1_load(g1a* p, const uint8_t* b) {
   int any = 0;
-  for (int i = 0; i < 64; i++) any |= b[i];
+  for (int i = 0; i < 2 * FB; i++) any |= b[i];
   memset(p, 0, sizeof *p);
   if (!any) { p->inf = 1; return 1; }
-  if (!le_lt_p(b) || !le_lt_p(b + 32)) return 0;
-  fp_from_le(&p->x, b); fp_from_le(&p->y, b + 32);
+  if (!le_lt_p(b) || !le_lt_p(b + FB)) return 0;
+  fp_from_le(&p->x, b); fp_from_le(&p->y, b + FB);
   return g1_on_curve(p);
 }
 static int g2_load(g2a* p, const uint8_t* b) {
   int any = 0;
-  for (int i = 0; i < 128; i++) any |= b[i];
+  for (int i = 0; i < 4 * FB; i++) any |= b[i];
   memset(p, 0, sizeof *p);
   if (!any) { p->inf = 1; return 1; }
-  for (int i = 0; i < 4; i++) if (!le_lt_p(b + 32 * i)) return 0;
-  fp_from_le(&p->x.a, b); fp_from_le(&p->x.b, b + 32); fp_from_le(&p->y.a, b + 64); fp_from_le(&p->y.b, b + 96);
+  for (int i = 0; i < 4; i++) if (!le_lt_p(b + FB * i)) return 0;
+  fp_from_le(&p->x.a, b); fp_from_le(&p->x.b, b + FB); fp_from_le(&p->y.a, b + 2 * FB); fp_from_le(&p->y.b, b + 3 * FB);
   return g2_on_curve(p);
 }
 static void g1_store(uint8_t* b, const g1a* p) {
-  if (p->inf) { memset(b, 0, 64); return; }
-  fp_to_le(b, &p->x); fp_to_le(b + 32, &p->y);
+  if (p->inf) { memset(b, 0, 2 * FB); return; }
+  fp_to_le(b, &p->x); fp_to_le(b + FB, &p->y);
 }
 static void g2_store(uint8_t* b, const g2a* p) {
-  if (p->inf) { memset(b, 0, 128); return; }
-  fp_to_le(b, &p->x.a); fp_to_le(b + 32, &p->x.b); fp_to_le(b + 64, &p->y.a); fp_to_le(b + 96, &p->y.b);
+  if (p->inf) { memset(b, 0, 4 * FB); return; }
+  fp_to_le(b, &p->x.a); fp_to_le(b + FB, &p->x.b); fp_to_le(b + 2 * FB, &p->y.a); fp_to_le(b + 3 * FB, &p->y.b);
 }
 static void k_load(u64 k[4], const uint8_t* b) { memcpy(k, b, 32); }
 
@@ -852,7 +1008,7 @@ void elpo_hash_to_g1(const uint8_t* msg, size_t len, uint8_t* out) { g1a p; hash
 void elpo_fr_set_hash_of(const uint8_t* msg, size_t len, uint8_t* out) { u64 k[4]; set_hash_of(k, msg, len, RORD); memcpy(out, k, 32); }
 static void gt_store(uint8_t* out, const fp12* f) {
   const fp2* e[6] = {&f->c0.c0, &f->c0.c1, &f->c0.c2, &f->c1.c0, &f->c1.c1, &f->c1.c2};
-  for (int i = 0; i < 6; i++) { fp_to_le(out + 64 * i, &e[i]->a); fp_to_le(out + 64 * i + 32, &e[i]->b); }
+  for (int i = 0; i < 6; i++) { fp_to_le(out + 2 * FB * i, &e[i]->a); fp_to_le(out + 2 * FB * i + FB, &e[i]->b); }
 }
 int elpo_pairing(const uint8_t* P_, const uint8_t* Q_, uint8_t* gt) {
   g1a p; g2a q; fp12 e;
@@ -860,6 +1016,27 @@ int elpo_pairing(const uint8_t* P_, const uint8_t* Q_, uint8_t* gt) {
   pairing(&e, &p, &q); gt_store(gt, &e);
   return 1;
 }
+
+int elpo_curve(void) {
+#ifdef ELPO_BLS12_381
+  return 1;
+#else
+  return 0;
+#endif
+}
+#ifdef ELPO_BLS12_381
+/* 1 iff, for e = f_{z,Q}(P), the hard part computed by the chain equals e_easy^((p^4-p^2+1)/r) computed by plain square-and-multiply */
+int elpo_selftest_final_exp(const uint8_t* P_, const uint8_t* Q_) {
+  elpo_init();
+  g1a p; g2a q; fp12 f, e, a, b;
+  if (!g1_load(&p, P_) || !g2_load(&q, Q_)) return -1;
+  miller_loop(&f, &p, &q);
+  final_exp_easy(&e, &f);
+  final_exp_hard_chain(&a, &e);
+  fp12_pow_limbs(&b, &e, HARD_EXP, 20);
+  return fp12_eq(&a, &b);
+}
+#endif
 
 /* ---- key container: plain copies of the points, no precomputation (reference structure) */
 typedef struct {
@@ -877,15 +1054,15 @@ elpo_key* elpo_key_new(int A, const uint8_t* g1_bases, const uint8_t* g2_bases) 
   k->Yi = (g1a*)calloc(A, sizeof(g1a));
   k->YYi = (g2a*)calloc(A, sizeof(g2a));
   int ok = g1_load(&k->g, g1_bases);
-  for (int i = 0; i < A; i++) ok &= g1_load(&k->Yi[i], g1_bases + 64 * (1 + i));
-  ok &= g1_load(&k->hs, g1_bases + 64 * (A + 1));
-  ok &= g1_load(&k->g_eg, g1_bases + 64 * (A + 2));
-  ok &= g1_load(&k->apk, g1_bases + 64 * (A + 3));
-  ok &= g1_load(&k->h, g1_bases + 64 * (A + 4));
-  ok &= g1_load(&k->skX, g1_bases + 64 * (A + 5));
+  for (int i = 0; i < A; i++) ok &= g1_load(&k->Yi[i], g1_bases + G1B * (1 + i));
+  ok &= g1_load(&k->hs, g1_bases + G1B * (A + 1));
+  ok &= g1_load(&k->g_eg, g1_bases + G1B * (A + 2));
+  ok &= g1_load(&k->apk, g1_bases + G1B * (A + 3));
+  ok &= g1_load(&k->h, g1_bases + G1B * (A + 4));
+  ok &= g1_load(&k->skX, g1_bases + G1B * (A + 5));
   ok &= g2_load(&k->gg, g2_bases);
-  ok &= g2_load(&k->XX, g2_bases + 128);
-  for (int i = 0; i < A; i++) ok &= g2_load(&k->YYi[i], g2_bases + 128 * (2 + i));
+  ok &= g2_load(&k->XX, g2_bases + G2B);
+  for (int i = 0; i < A; i++) ok &= g2_load(&k->YYi[i], g2_bases + G2B * (2 + i));
   if (!ok) { free(k->Yi); free(k->YYi); free(k); return 0; }
   return k;
 }
@@ -906,6 +1083,24 @@ static void challenge(u64 out[4], sha256_t* s, const uint8_t* ad, size_t adl) {
   set_hash_of(out, d, 32, RORD);           /* _local_c.setHashOf(_c_str) */
 }
 
+#ifdef ELPO_BLS12_381
+/* Project policy on this curve (G1 cofactor (z-1)^2/3 != 1; include/elpasso.h ELP_OPT_SUBGROUP_CHECK): prover-supplied G1 points must lie in the
+   order-r subgroup.  Checked here by the definition, [r]P == O, with plain double-and-add (the HIP path uses the endomorphism test). */
+static int g1_in_subgroup(const g1a* p) {
+  if (p->inf) return 1;
+  g1j acc, base;
+  g1_set_inf(&acc);
+  g1_from_aff(&base, p);
+  for (int i = 255; i >= 0; i--) {
+    g1_dbl(&acc, &acc);
+    if ((RORD[i >> 6] >> (i & 63)) & 1) g1_add(&acc, &acc, &base);
+  }
+  return g1_is_inf(&acc);
+}
+#else
+static int g1_in_subgroup(const g1a* p) { (void)p; return 1; }     /* BN254: E(Fp) has prime order r */
+#endif
+
 /* record: sig1 | sig2 | phi | [E1 | E2] | k | c | rs[..] | m[..]   (same as elp_verify_id_batch) */
 int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask, int retr, const uint8_t* ad, size_t adl) {
   const int A = key->A;
@@ -915,12 +1110,13 @@ int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask
   g1a sig1, sig2, phi, E1, E2;
   g2a kk;
   const uint8_t* p = rec;
-  int ok = g1_load(&sig1, p); p += 64;
-  ok &= g1_load(&sig2, p); p += 64;
-  ok &= g1_load(&phi, p); p += 64;
-  if (retr) { ok &= g1_load(&E1, p); p += 64; ok &= g1_load(&E2, p); p += 64; }
-  ok &= g2_load(&kk, p); p += 128;
+  int ok = g1_load(&sig1, p); p += G1B;
+  ok &= g1_load(&sig2, p); p += G1B;
+  ok &= g1_load(&phi, p); p += G1B;
+  if (retr) { ok &= g1_load(&E1, p); p += G1B; ok &= g1_load(&E2, p); p += G1B; }
+  ok &= g2_load(&kk, p); p += G2B;
   if (!ok) return 0;
+  if (!g1_in_subgroup(&phi) || (retr && (!g1_in_subgroup(&E1) || !g1_in_subgroup(&E2)))) return 0;
   u64 c[4], s[4];
   k_load(c, p); p += 32;
   const uint8_t* rs = p; p += 32 * nrs;
@@ -950,17 +1146,17 @@ int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask
   }
   /* c' = Hr(SHA256(hex(k) hex(phi) [hex(E1) hex(E2)] hex(V_k) hex(V_phi) [hex(V_E1) hex(V_E2)] ad))   :111-122 */
   sha256_t sh;
-  uint8_t b1[32], b2[64];
+  uint8_t b1[FB], b2[2 * FB];
   g2a aVk; g1a a1;
   sha_init(&sh);
-  g2_ser(b2, &kk); sha_update_hex(&sh, b2, 64);
-  g1_ser(b1, &phi); sha_update_hex(&sh, b1, 32);
-  if (retr) { g1_ser(b1, &E1); sha_update_hex(&sh, b1, 32); g1_ser(b1, &E2); sha_update_hex(&sh, b1, 32); }
-  g2_to_aff(&aVk, &Vk); g2_ser(b2, &aVk); sha_update_hex(&sh, b2, 64);
-  g1_to_aff(&a1, &Vphi); g1_ser(b1, &a1); sha_update_hex(&sh, b1, 32);
+  g2_ser(b2, &kk); sha_update_hex(&sh, b2, 2 * FB);
+  g1_ser(b1, &phi); sha_update_hex(&sh, b1, FB);
+  if (retr) { g1_ser(b1, &E1); sha_update_hex(&sh, b1, FB); g1_ser(b1, &E2); sha_update_hex(&sh, b1, FB); }
+  g2_to_aff(&aVk, &Vk); g2_ser(b2, &aVk); sha_update_hex(&sh, b2, 2 * FB);
+  g1_to_aff(&a1, &Vphi); g1_ser(b1, &a1); sha_update_hex(&sh, b1, FB);
   if (retr) {
-    g1_to_aff(&a1, &VE1); g1_ser(b1, &a1); sha_update_hex(&sh, b1, 32);
-    g1_to_aff(&a1, &VE2); g1_ser(b1, &a1); sha_update_hex(&sh, b1, 32);
+    g1_to_aff(&a1, &VE1); g1_ser(b1, &a1); sha_update_hex(&sh, b1, FB);
+    g1_to_aff(&a1, &VE2); g1_ser(b1, &a1); sha_update_hex(&sh, b1, FB);
   }
   u64 c2[4];
   challenge(c2, &sh, ad, adl);
@@ -982,12 +1178,12 @@ int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask
 /* record: sig1 | sig2 | m[nattr]        ps-verifier.cc:13-35 */
 int elpo_ps_verify(const elpo_key* key, const uint8_t* rec, int nattr) {
   g1a sig1, sig2;
-  if (!g1_load(&sig1, rec) || !g1_load(&sig2, rec + 64)) return 0;
+  if (!g1_load(&sig1, rec) || !g1_load(&sig2, rec + G1B)) return 0;
   if (sig1.inf) return 0;
   g2j K;
   g2_from_aff(&K, &key->XX);
   u64 s[4];
-  for (int i = 0; i < nattr; i++) { k_load(s, rec + 128 + 32 * i); g2_mul_add(&K, &key->YYi[i], s); }
+  for (int i = 0; i < nattr; i++) { k_load(s, rec + 2 * G1B + 32 * i); g2_mul_add(&K, &key->YYi[i], s); }
   g2a aK;
   g2_to_aff(&aK, &K);
   fp12 lhs, rhs;
@@ -1001,10 +1197,11 @@ int elpo_provide_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mas
   const int A = key->A;
   int H = 0;
   for (int i = 0; i < A; i++) H += (hidden_mask >> i) & 1;
-  memset(out, 0, 128);
+  memset(out, 0, 2 * G1B);
   g1a Ac;
   if (!g1_load(&Ac, rec)) return 0;
-  const uint8_t* p = rec + 64;
+  if (!g1_in_subgroup(&Ac)) return 0;
+  const uint8_t* p = rec + G1B;
   u64 c[4], s[4], u[4];
   k_load(c, p); p += 32;
   const uint8_t* rs = p; p += 32 * (H + 1);
@@ -1017,11 +1214,11 @@ int elpo_provide_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mas
   for (int i = 0; i < A; i++)
     if ((hidden_mask >> i) & 1) { k_load(s, rs + 32 * j); j++; g1_mul_add(&V, &key->Yi[i], s); }   /* :88-94 */
   sha256_t sh;
-  uint8_t b1[32];
+  uint8_t b1[FB];
   g1a aV;
   sha_init(&sh);
-  g1_ser(b1, &Ac); sha_update_hex(&sh, b1, 32);
-  g1_to_aff(&aV, &V); g1_ser(b1, &aV); sha_update_hex(&sh, b1, 32);
+  g1_ser(b1, &Ac); sha_update_hex(&sh, b1, FB);
+  g1_to_aff(&aV, &V); g1_ser(b1, &aV); sha_update_hex(&sh, b1, FB);
   u64 c2[4];
   challenge(c2, &sh, ad, adl);
   if (memcmp(c2, c, 32) != 0) return 0;                                   /* :106-108 */
@@ -1040,7 +1237,7 @@ int elpo_provide_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mas
   g1_to_aff(&aAp, &Ap);
   g1_mul(&s2, &aAp, u);                                                   /* :141 */
   g1_to_aff(&r1, &s1); g1_to_aff(&r2, &s2);
-  g1_store(out, &r1); g1_store(out + 64, &r2);
+  g1_store(out, &r1); g1_store(out + G1B, &r2);
   return 1;
 }
 

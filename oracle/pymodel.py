@@ -278,6 +278,14 @@ class Groups:
                 R = self.g1_add(R, P)
         return R
 
+    def g1_mul_plain(self, P, k):          # [k]P for any integer k >= 0, no reduction modulo r (points outside the order-r subgroup)
+        R = None
+        for bit in bin(k)[2:] if k else "":
+            R = self.g1_add(R, R)
+            if bit == "1":
+                R = self.g1_add(R, P)
+        return R
+
     # ---- G2 (on the twist E'(Fp2))
     def g2_on_curve(self, P):
         if P is None:
@@ -825,10 +833,18 @@ class Protocol:
         V = G.g2_add(V, G.g2_mul(pk.XX, (1 - pr.c) % self.m.r))
         return V
 
+    # Project policy on curves whose G1 cofactor is not 1 (BLS12-381; a no-op on BN254 where E(Fp) = G1, hence invisible to the golden vectors):
+    # prover-supplied G1 points must lie in the order-r subgroup (csrc/elp/pipeline.h g1_in_subgroup, include/elpasso.h ELP_OPT_SUBGROUP_CHECK).
+    # Here by the definition, [r]P == O.
+    def in_g1(self, P) -> bool:
+        return P is None or self.G.g1_mul_plain(P, self.m.r) is None
+
     # -- el_passo_verify_id (src/ps-verifier.cc:37-138)
     def verify_id(self, pk, pr: IdProof, ad, svc, authority_pk, g, h, pairing=True) -> bool:
         m, G = self.m, self.G
         if not pr.has_E:
+            return False
+        if not (self.in_g1(pr.phi) and self.in_g1(pr.E1) and self.in_g1(pr.E2)):
             return False
         Vk = self._vk(pk, pr, pr.rs[len(pr.rs) - 2])
         Hs = m.hash_to_g1(_b(svc))
@@ -848,6 +864,8 @@ class Protocol:
     # -- el_passo_verify_id_without_id_retrieval (src/ps-verifier.cc:140-212)
     def verify_id_noretr(self, pk, pr: IdProof, ad, svc, pairing=True) -> bool:
         m, G = self.m, self.G
+        if not self.in_g1(pr.phi):
+            return False
         Vk = self._vk(pk, pr, pr.rs[len(pr.rs) - 1])
         Hs = m.hash_to_g1(_b(svc))
         Vphi = G.g1_add(G.g1_mul(pr.phi, pr.c), G.g1_mul(Hs, pr.rs[0]))
@@ -862,6 +880,8 @@ class Protocol:
     # -- PSSigner::el_passo_nizk_verify_request (src/ps-signer.cc:74-110)
     def nizk_verify_request(self, pk, rq: CredRequest, ad) -> bool:
         m, G = self.m, self.G
+        if not self.in_g1(rq.A):
+            return False
         V = G.g1_mul(rq.A, rq.c)
         V = G.g1_add(V, G.g1_mul(pk.g, rq.rs[0]))
         j = 1

@@ -46,7 +46,7 @@ struct KeyCtx {
 // The reference's el_passo_verify_id accepts sig1 = sig2 = infinity with a self-made NIZK (e(O,K) e(O,gg) = 1: a universal forgery;
 // golden case "sig_both_zero", src/ps-verifier.cc:133-137 has no isZero test although PSVerifier::verify :16-18 has one).  The library
 // rejects it by default (elp_set_option(ELP_OPT_STRICT_SIGNATURE)); reference-compatible behaviour is opt-in.
-enum { KEY_STRICT_SIG = 1 };
+enum { KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2 };   // KEY_NO_SUBGROUP_CHECK: skip g1_in_subgroup on prover-supplied points (ELP_OPT_SUBGROUP_CHECK = 0)
 // words of workspace per lane: 1P .. 8P of k and of up to three G1 points
 template <class C>
 ELP_HD constexpr int vtab_words() { return 8 * vtab_entry_words<F2<C>>() + 3 * 8 * vtab_entry_words<F1<C>>(); }
@@ -97,6 +97,49 @@ ELP_HEAVY bool g1_load(Aff<F1<C>>& p, const u32* w) {
   p.x = fp_from_std<C>(x);
   p.y = fp_from_std<C>(y);
   return aff_on_curve<F1<C>>(p);
+}
+// Membership of an E(Fp) point in the order-r subgroup G1 on curves whose G1 cofactor is not 1 (BLS12-381; on BN curves E(Fp) = G1).
+// The reference never meets the question (it runs on BN254) and mcl's default does not check; this library REJECTS prover-supplied G1 points
+// outside the subgroup: phi is the user's pseudonym at the relying party and (E1, E2) the identity-retrieval token, and a small-order
+// component would give one user several pseudonyms / an undecryptable token, while the GLV multiplication used on them is only a scalar
+// multiplication inside G1.  sig1 / sig2 are exempt: a cofactor component vanishes in the pairing.
+// Test (Scott, "A note on group membership tests for G1, G2 and GT on BLS pairing-friendly curves"): P in G1  <=>  [z^2] P == -psi(P) for the
+// endomorphism psi(x, y) = (w x, y), w the primitive cube root of unity whose eigenvalue on G1 is -z^2.  Both endomorphisms z^2 + psi and
+// z^2 + psi^2 have degree z^4 - z^2 + 1 = r, so their kernels are cyclic of order r and contain no rational point outside G1: comparing with
+// BOTH roots is equally sound and needs no convention about which root the parameter file calls beta.  ~126 doublings + 10 additions.
+template <class C>
+ELP_HEAVY bool g1_in_subgroup(const Aff<F1<C>>& p) {
+  if constexpr (C::IS_BN) {
+    (void)p;
+    return true;
+  } else {
+    typedef F1<C> F;
+    if (aff_is_inf(p)) return true;
+    Jac<F> q, r;
+    jac_from_aff(q, p);
+    int top = 63;
+    while (!((C::ZABS >> top) & 1)) top--;
+    ELP_NOUNROLL
+    for (int i = top - 1; i >= 0; i--) {          // q = [|z|] P
+      jac_dbl<F>(q, q);
+      if ((C::ZABS >> i) & 1) jac_madd<F>(q, q, p);
+    }
+    r = q;
+    ELP_NOUNROLL
+    for (int i = top - 1; i >= 0; i--) {          // r = [|z|] q = [z^2] P
+      jac_dbl<F>(r, r);
+      if ((C::ZABS >> i) & 1) jac_add<F>(r, r, q);
+    }
+    if (jac_is_inf(r)) return false;              // a non-zero point killed by z^2 has an order prime to r
+    // r == -psi(P) = (w x, -y) in Jacobian form:  X == w x Z^2  and  Y == -y Z^3
+    const Fp<C> z2 = fp_sqr<C>(r.Z), z3 = fp_mul<C>(z2, r.Z);
+    if (!fp_is_zero<C>(fp_add_lazy(r.Y, fp_mul<C>(p.y, z3)))) return false;
+    Fp<C> beta;
+    ELP_LOAD_FP(beta, C::glv_beta(i_));
+    const Fp<C> xz = fp_mul<C>(p.x, z2);
+    const Fp<C> t1 = fp_mul<C>(xz, beta), t2 = fp_mul<C>(t1, beta);
+    return fp_is_zero<C>(fp_sub_lazy(r.X, t1)) || fp_is_zero<C>(fp_sub_lazy(r.X, t2));
+  }
 }
 template <class C>
 ELP_HEAVY bool g2_load(Aff<F2<C>>& p, const u32* w) {
@@ -283,6 +326,7 @@ struct RecordSrc {
   const u32 *rs_, *ms_, *w_phi_, *w_k_;
   u64 mask_;
   int nrs_, jr_;
+  bool sub_ = true;               // phi, E1, E2 must lie in the order-r subgroup (a no-op on BN curves); callers clear it from the key's flags
   ELP_HD bool open(const u32* rec, u64 hidden_mask, int A, bool retr, Aff<F1<C>>& sig1, Aff<F1<C>>& sig2, Aff<F1<C>>& phi,
                    Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
     int H = 0;
@@ -299,6 +343,9 @@ struct RecordSrc {
     if (retr) {
       ok &= g1_load<C>(E1, p); p += 2 * C::N;
       ok &= g1_load<C>(E2, p); p += 2 * C::N;
+    }
+    if constexpr (!C::IS_BN) {
+      if (ok && sub_) ok = g1_in_subgroup<C>(phi) && (!retr || (g1_in_subgroup<C>(E1) && g1_in_subgroup<C>(E2)));
     }
     w_k_ = p;
     ok &= g2_load<C>(kk, p); p += 4 * C::N;
@@ -517,6 +564,7 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   Aff<F2<C>> kk, aK;
   Scalar c;
   RecordSrc<C> src;
+  src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   fp12_set_one(f);
   for (int i = 0; i < 8; i++) delta_out[i] = 0;
   for (int i = 0; i < 2 * C::N; i++) sig2_out[i] = 0;
@@ -545,6 +593,7 @@ ELP_HEAVY bool verify_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_m
   Aff<F2<C>> kk;
   Scalar c;
   RecordSrc<C> src;
+  src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   return verify_id_core<C, RecordSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
 }
@@ -755,6 +804,7 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
                              Aff<F2<C>>& aK) {
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
   Aff<F2<C>> kk;
+  st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
   if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
   if (role == 0) {
@@ -981,6 +1031,9 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
   aff_set_inf(P1);
   if (!odd || retr) ok &= g1_load<C>(P0, rec + (odd ? 4 : 2) * G1W);
   if (!odd && retr) ok &= g1_load<C>(P1, rec + 3 * G1W);
+  if constexpr (!C::IS_BN) {     // order-r subgroup membership of phi, E1 (even lane) and E2 (odd lane), see g1_in_subgroup
+    if (ok && !(key.flags & KEY_NO_SUBGROUP_CHECK)) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(P1);
+  }
   ok = pair_and(ok);
   const bool okk = g2_load<C>(kk, rec + (retr ? 5 : 3) * G1W);
   if (!ok || !okk) return false;
@@ -1032,6 +1085,7 @@ struct WireSrc {
     s = scalar_load_le(p);
     return !scalar_geq_r<C>(s);
   }
+  bool sub_ = true;                                       // as RecordSrc::sub_
   const uint8_t *p1_, *p2_, *pk_, *pphi_, *pe1_, *pe2_;   // bodies of the point elements (validated lengths)
   bool kflag_ = false;                                    // flag bit of k's canonical encoding (set by whoever decodes k)
   // structure, lengths and scalar ranges of the message; no point is decoded here
@@ -1086,7 +1140,11 @@ struct WireSrc {
                    Aff<F1<C>>& E1, Aff<F1<C>>& E2, Aff<F2<C>>& kk, Scalar& c) {
     if (!parse(msg, len, A, retr, c)) return false;
     if (retr && (!g1_deserialize<C>(E1, pe1_) || !g1_deserialize<C>(E2, pe2_))) return false;
-    return g1_deserialize<C>(sig1, p1_) && g1_deserialize<C>(sig2, p2_) && g1_deserialize<C>(phi, pphi_) && g2_deserialize<C>(kk, pk_, &kflag_);
+    if (!(g1_deserialize<C>(sig1, p1_) && g1_deserialize<C>(sig2, p2_) && g1_deserialize<C>(phi, pphi_) && g2_deserialize<C>(kk, pk_, &kflag_))) return false;
+    if constexpr (!C::IS_BN) {
+      if (sub_ && !(g1_in_subgroup<C>(phi) && (!retr || (g1_in_subgroup<C>(E1) && g1_in_subgroup<C>(E2))))) return false;
+    }
+    return true;
   }
   // wire bytes of the transcript's input points: the message's own bytes.  Every G1 encoding the decoder accepts is canonical (x < p, the
   // flag is the parity the decoder enforces on y != 0, infinity is all-zero); for k the flag is replaced by the canonical one (a set flag on
@@ -1135,6 +1193,7 @@ ELP_HEAVY bool verify_id_wire_item(const KeyCtx<C>& key, const uint8_t* msg, siz
   Aff<F2<C>> kk;
   Scalar c;
   WireSrc<C> src;
+  src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   if (!src.open(msg, len, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   return verify_id_core<C, WireSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
 }
@@ -1155,6 +1214,9 @@ ELP_HEAVY bool verify_id_wire_item_paired(const KeyCtx<C>& key, const uint8_t* m
   aff_set_inf(P1);
   if (!odd || retr) ok &= g1_deserialize<C>(P0, odd ? src.pe2_ : src.pphi_);
   if (!odd && retr) ok &= g1_deserialize<C>(P1, src.pe1_);
+  if constexpr (!C::IS_BN) {
+    if (ok && !(key.flags & KEY_NO_SUBGROUP_CHECK)) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(P1);
+  }
   ok = pair_and(ok);
   const bool okk = g2_deserialize<C>(kk, src.pk_, &src.kflag_);
   if (!ok || !okk) return false;
@@ -1214,6 +1276,9 @@ ELP_HEAVY bool provide_id_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_
   Aff<G1F> Ac;
   for (int i = 0; i < 4 * C::N; i++) out[i] = 0;
   if (!g1_load<C>(Ac, rec)) return false;
+  if constexpr (!C::IS_BN) {
+    if (!(key.flags & KEY_NO_SUBGROUP_CHECK) && !g1_in_subgroup<C>(Ac)) return false;      // the commitment to sign must lie in G1
+  }
   const u32* p = rec + 2 * C::N;
   const Scalar c = scalar_load_w(p); p += 8;
   const u32* rs = p; p += 8 * (H + 1);

@@ -122,6 +122,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
       c->paired = value;
       return ELP_OK;
     case ELP_OPT_TABLE_WORKSPACE: c->use_vtab = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_SUBGROUP_CHECK: c->subgroup_check = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
       if (value < 0 || value > 2) return ELP_ERR_ARG;
       c->split = value;
@@ -403,6 +404,12 @@ int elp_provide_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t 
   return c->curve == ELP_CURVE_BN254 ? elp_provide_id_batch_t<BN254>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted) : elp_provide_id_batch_t<BLS12_381>(c, n, records, mask, ad, ad_off, ad_len, sigs, flags, accepted);
 }
 
+size_t elp_key_table_bytes(const elp_ctx* c) {
+  if (!c || !c->have_pk) return 0;
+  const size_t f = c->curve == ELP_CURVE_BN254 ? sizeof(Fp<BN254>) : sizeof(Fp<BLS12_381>);      // one Montgomery-form field element (9 x 29-bit / 14 x 28-bit limbs)
+  const size_t entries = (size_t)c->per * c->nwin;
+  return entries * ((size_t)(c->A + 6) * 2 * f + (size_t)(c->A + 2) * 4 * f);
+}
 int elp_host_alloc(elp_ctx* c, size_t bytes, void** out) {
   if (!c || !out) return ELP_ERR_ARG;
   *out = nullptr;

@@ -145,6 +145,7 @@ k_vid_g2(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, uint
   Aff<F2<C>> kk, aK;
   Scalar c;
   RecordSrc<C> src;
+  src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   bool ok = src.open(recs + i * (size_t)rec_words, mask, key.A, retr != 0, sig1, sig2, phi, E1, E2, kk, c);
   if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) ok = false;
   ok_g2[i] = ok ? 1 : 0;
@@ -167,6 +168,7 @@ __global__ void __launch_bounds__(ELP_BLOCK, 4) k_vid_g1(KeyCtx<C> key, const u3
   Aff<F2<C>> kk;
   Scalar c;
   RecordSrc<C> src;
+  src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   if (!src.open(recs + i * (size_t)rec_words, mask, key.A, retr != 0, sig1, sig2, phi, E1, E2, kk, c)) return;   // k_vid_g2 publishes the verdict on the inputs
   u32 v1[3][C::FBYTES / 4];
   vid_job_g1<C, RecordSrc<C>>(key, src, retr != 0, phi, E1, E2, c, v1);
@@ -838,6 +840,7 @@ struct elp_ctx {
   bool retr_set = false;      // ... and all of g, authority_pk, h (needed by the id-retrieval variants)
   bool sk_set = false;        // elp_set_signer_secret installed X
   int strict_sig = 1;         // ELP_OPT_STRICT_SIGNATURE
+  int subgroup_check = 1;     // ELP_OPT_SUBGROUP_CHECK (curves with a G1 cofactor: prover-supplied G1 points must lie in the order-r subgroup)
   int paired = 2;             // ELP_OPT_PAIRED_LAYOUT: 0 = one lane per item, 1 = two lanes per item, 2 = by batch size (layout_split)
   int simds = 1024;           // SIMDs of the device (4 per CU): one resident wave per SIMD is the unit of the layout choice
   // copy stream of the host-buffer pipeline (elp_verify_id_batch): the next round's records travel while the current round is verified
@@ -885,7 +888,7 @@ static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key m
   k.b1 = (const Aff<typename F1<C>::MemF>*)c->b1;
   k.b2 = (const Aff<typename F2<C>::MemF>*)c->b2;
   k.gg_lines = (const LineMem<C>*)c->lines;
-  k.flags = c->strict_sig ? KEY_STRICT_SIG : 0;
+  k.flags = (c->strict_sig ? KEY_STRICT_SIG : 0) | (c->subgroup_check ? 0 : KEY_NO_SUBGROUP_CHECK);
   return k;
 }
 

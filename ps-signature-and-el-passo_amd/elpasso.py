@@ -14,6 +14,7 @@ OPT_STRICT_SIGNATURE = 1
 OPT_PAIRED_LAYOUT = 2
 OPT_TABLE_WORKSPACE = 3
 OPT_SPLIT_PHASES = 4
+OPT_SUBGROUP_CHECK = 5
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -23,6 +24,7 @@ _SIGS = {
     "elp_last_error": (_c.c_char_p, [_c.c_void_p]),
     "elp_field_bytes": (_c.c_int, [_c.c_int]),
     "elp_set_option": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
+    "elp_key_table_bytes": (_c.c_size_t, [_c.c_void_p]),
     "elp_version": (_c.c_char_p, []),
     "elp_set_pubkey": (_c.c_int, [_c.c_void_p, _c.c_int, _u8p, _u8p, _u8p, _u8p, _u8p, _c.c_int]),
     "elp_set_rp": (_c.c_int, [_c.c_void_p, _u8p, _c.c_size_t, _u8p, _u8p, _u8p]),
@@ -155,6 +157,14 @@ class Context:
     def set_table_workspace(self, on):
         """ELP_OPT_TABLE_WORKSPACE: per-item tables of the variable-base multiplications in a launch workspace (default) or in private memory."""
         self._chk(self.lib.elp_set_option(self.h, OPT_TABLE_WORKSPACE, int(bool(on))))
+
+    def key_table_bytes(self):
+        """Device bytes of the installed key's fixed-base tables."""
+        return int(self.lib.elp_key_table_bytes(self.h))
+
+    def set_subgroup_check(self, on):
+        """ELP_OPT_SUBGROUP_CHECK (default on; BLS12-381): prover-supplied G1 points outside the order-r subgroup reject the item."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_SUBGROUP_CHECK, int(bool(on))))
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default on): one-lane-per-item verify_id as two kernels (NIZK half with two job lanes per item, then the pairing)."""

@@ -182,6 +182,37 @@ def oracle():
     return _oracle
 
 
+_oracle_bls = None
+
+
+def oracle_bls():
+    """The C oracle built for BLS12-381 (oracle/elp_oracle.c -DELPO_BLS12_381 -> libelp_oracle_bls.so): same entry points, 48-byte coordinates.
+    Parity unpinned (no reference artefact exists for this curve): a second implementation beside oracle/pymodel.py."""
+    global _oracle_bls
+    if _oracle_bls is None:
+        import subprocess
+        od = os.path.join(ROOT, "oracle")
+        so = os.path.join(od, "libelp_oracle_bls.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(od, "elp_oracle.c")):
+            subprocess.check_call(["make", "-C", od, "-s"])
+        L = ctypes.CDLL(so)
+        L.elpo_key_new.restype = ctypes.c_void_p
+        L.elpo_key_new.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+        L.elpo_key_free.argtypes = [ctypes.c_void_p]
+        L.elpo_verify_id.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        L.elpo_ps_verify.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        L.elpo_provide_id.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.elpo_verify_id_batch.restype = ctypes.c_long
+        L.elpo_verify_id_batch.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64,
+                                           ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        L.elpo_hash_to_g1.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.elpo_fr_set_hash_of.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.elpo_init()
+        assert L.elpo_curve() == 1
+        _oracle_bls = L
+    return _oracle_bls
+
+
 def oracle_key(m, pk, **kw):
     L = oracle()
     h = L.elpo_key_new(len(pk.Yi), g1_bases(m, pk, **kw), g2_bases(m, pk))

@@ -147,6 +147,12 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     g2_store<C>(o, r);                                                                                                 \
     return 1;                                                                                                          \
   }                                                                                                                    \
+  /* order-r subgroup membership of a point of E(Fp) (csrc/elp/pipeline.h g1_in_subgroup); -1 = not on the curve */    \
+  int pfx##_g1_in_subgroup(const u32* P) {                                                                             \
+    Aff<F1<C>> p;                                                                                                      \
+    if (!g1_load<C>(p, P)) return -1;                                                                                  \
+    return g1_in_subgroup<C>(p) ? 1 : 0;                                                                               \
+  }                                                                                                                    \
   int pfx##_g1_decompress(const uint8_t* in, u32* o) {                                                                 \
     Aff<F1<C>> p;                                                                                                      \
     if (!g1_deserialize<C>(p, in)) return 0;                                                                           \

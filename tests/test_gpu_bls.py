@@ -8,8 +8,8 @@ import random
 import numpy as np
 import pytest
 
-from elp_testlib import (BLS12_381, BLS_G1, BLS_G2, Mcl, Protocol, fb, g1b, g1u, g2b, g2u, hidden_mask, pack_provide_id, pack_prove_id, pack_ps_verify, pack_request_id,
-                         pack_verify_id, scalar_stream)
+from elp_testlib import (BLS12_381, BLS_G1, BLS_G2, Mcl, Protocol, fb, g1b, g1u, g2b, g2u, hidden_mask, oracle_bls, pack_provide_id, pack_prove_id, pack_ps_verify,
+                         pack_request_id, pack_verify_id, scalar_stream)
 
 pytestmark = pytest.mark.gpu
 M = Mcl(BLS12_381)
@@ -169,3 +169,79 @@ def test_msm_wire_and_aggregated_paths_on_bls(bls_ctx):
     wire = Codec(M).proof_encode(pr)
     fl4, _ = bls_ctx.verify_id_wire_batch([wire, wire[:-1]], True, b"hello")
     assert list(fl4) == [1, 0]
+
+
+def test_batch_against_the_c_oracle_bls_build(bls_ctx):
+    """The second independent implementation for this curve (oracle/elp_oracle.c -DELPO_BLS12_381; parity unpinned, tests/test_oracle_bls.py pins it to the
+    model): synthetic el_passo_verify_id and PS / issuance batches, every GPU verdict and every issued signature equal to the C oracle's, GT bytes equal."""
+    import ctypes
+    import importlib
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    L = oracle_bls()
+    A, H, n = 8, 4, 192
+    wl = synth.Workload(bls_ctx, A, seed=31, window_bits=8)
+    g1 = wl.g + wl.Yi + bls_ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+    key = ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
+    assert key.value
+    for retr in (True, False):
+        recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=retr, corrupt_every=5, corrupt_at=2)
+        flags, cnt = bls_ctx.verify_id_batch(recs, mask, retr, wl.ad)
+        rsz = len(recs) // n
+        ofl = np.zeros(n, dtype=np.uint8)
+        L.elpo_verify_id_batch(key, n, recs, rsz, mask, 1 if retr else 0, wl.ad, len(wl.ad), ofl.ctypes.data, 8)
+        assert (flags == expect).all() and (ofl == flags).all() and cnt == int(ofl.sum())
+    precs, pmask, pexpect = wl.provide_id_batch(64, H)
+    sigs, pflags, _ = bls_ctx.provide_id_batch(precs, pmask, wl.ad)
+    prsz = len(precs) // 64
+    out = ctypes.create_string_buffer(4 * N)
+    for i in range(0, 64, 7):
+        assert L.elpo_provide_id(key, precs[i * prsz:(i + 1) * prsz], pmask, wl.ad, len(wl.ad), out) == int(pflags[i])
+        assert out.raw == sigs[4 * N * i:4 * N * (i + 1)]
+    P, Q = G.g1_mul(BLS_G1, 424242), G.g2_mul(BLS_G2, 171717)
+    gt = ctypes.create_string_buffer(12 * N)
+    assert L.elpo_pairing(g1b(P, N), g2b(Q, N), gt) == 1 and gt.raw == bls_ctx.pairing(g1b(P, N), g2b(Q, N))
+
+
+def test_off_subgroup_g1_inputs_rejected_on_gpu(bls_ctx):
+    """ELP_OPT_SUBGROUP_CHECK (default on): a valid proof whose phi / E1 / E2 got a component of order 3 or 11 of the G1 cofactor added is rejected, through the
+    record path and the wire path (two lanes per item: the layout this curve always uses); the same for the commitment of a credential request.  The model and the
+    C oracle reject the same inputs (tests/test_oracle_bls.py).  With the option off nothing crashes and the verdict still comes back per item."""
+    from test_oracle_bls import _small_order_point
+    seed, A, H = 4242, 4, 2
+    g, gg = M.hash_to_g1("abc"), BLS_G2
+    pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    bls_ctx.set_pubkey(g1b(pk.g, N), g2b(pk.gg, N), g2b(pk.XX, N), b"".join(g1b(P, N) for P in pk.Yi), b"".join(g2b(P, N) for P in pk.YYi), 6)
+    bls_ctx.set_rp(b"service", g1b(apk, N), g1b(g, N), g1b(h, N))
+    bls_ctx.set_signer_secret(g1b(skX, N))
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    rq, t1 = PR.request_id(pk, attrs, b"ad", [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)])
+    u = scalar_stream(seed, 99, M.r)
+    cred = PR.unblind(PR.provide_id(pk, skX, rq, b"ad", u), t1)
+    rnd = [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)]
+    pr = PR.prove_id(pk, cred, attrs, b"sess", b"service", apk, g, h, rnd)
+    t3, t11 = _small_order_point(3), _small_order_point(11, seed=7)
+    items = [pr]
+    for field, t in (("phi", t3), ("phi", t11), ("E1", t3), ("E2", t11), ("E2", t3)):
+        bad = copy.copy(pr)
+        setattr(bad, field, G.g1_add(getattr(pr, field), t))
+        items.append(bad)
+    items.append(pr)
+    recs = b"".join(pack_verify_id(M, x) for x in items)
+    mask = hidden_mask(pr.attributes)
+    flags, cnt = bls_ctx.verify_id_batch(recs, mask, True, b"sess")
+    assert list(flags) == [1, 0, 0, 0, 0, 0, 1] and cnt == 2
+    assert [PR.verify_id(pk, x, b"sess", b"service", apk, g, h) for x in items] == [True] + [False] * 5 + [True]
+    cd = importlib.import_module("elp_testlib").Codec(M)
+    wflags, wcnt = bls_ctx.verify_id_wire_batch([cd.proof_encode(x) for x in items], True, b"sess")
+    assert list(wflags) == list(flags)
+    badrq = copy.copy(rq)
+    badrq.A = G.g1_add(rq.A, t3)
+    sigs, pflags, _ = bls_ctx.provide_id_batch(pack_provide_id(M, rq, u) + pack_provide_id(M, badrq, u), 3, b"ad")
+    assert list(pflags) == [1, 0] and sigs[192:] == bytes(192)
+    bls_ctx.set_subgroup_check(False)
+    try:
+        f2, _ = bls_ctx.verify_id_batch(recs, mask, True, b"sess")
+        assert f2[0] == 1 and f2[6] == 1 and len(f2) == 7
+    finally:
+        bls_ctx.set_subgroup_check(True)

@@ -1,0 +1,173 @@
+"""The C oracle's BLS12-381 build (oracle/elp_oracle.c -DELPO_BLS12_381) against the independent big-int model (oracle/pymodel.py).
+PARITY UNPINNED: the reference never runs on BLS12-381 and mcl is absent, so no reference-made vector exists for this curve; these
+tests establish that TWO independently written implementations (C: 6 x 64-bit Montgomery limbs, Jacobian lines, HHT chain; Python:
+big integers, affine formulas, plain exponentiation) agree bit for bit on primitives, GT values, issued signatures and verdicts --
+the pair then serves as the checker of the HIP path's BLS12-381 instantiation (tests/test_gpu_bls.py) and as its CPU baseline."""
+import copy
+import ctypes
+import random
+
+from elp_testlib import (BLS12_381, BLS_G1, BLS_G2, Mcl, Protocol, fb, g1_bases, g1b, g1u, g2_bases, g2b, g2u, hidden_mask, oracle_bls,
+                         pack_provide_id, pack_ps_verify, pack_verify_id, scalar_stream)
+
+M = Mcl(BLS12_381)
+PR = Protocol(M)
+G = M.G
+N = 48
+
+
+def test_primitives_equal_the_model():
+    L = oracle_bls()
+    rnd = random.Random(5)
+    o, o2 = ctypes.create_string_buffer(2 * N), ctypes.create_string_buffer(4 * N)
+    for k in [0, 1, 2, 31, 32, M.r - 1, M.r, rnd.randrange(M.r), rnd.randrange(2**256)]:
+        assert L.elpo_g1_mul(g1b(BLS_G1, N), fb(k), o) and g1u(o.raw, N) == G.g1_mul(BLS_G1, k)
+    for k in [0, 1, 7, M.r - 1, rnd.randrange(M.r)]:
+        assert L.elpo_g2_mul(g2b(BLS_G2, N), fb(k), o2) and g2u(o2.raw, N) == G.g2_mul(BLS_G2, k)
+    P, Q = G.g1_mul(BLS_G1, 5), G.g2_mul(BLS_G2, 7)
+    for a, b in [(P, BLS_G1), (P, P), (P, G.g1_neg(P)), (P, None), (None, None)]:
+        assert L.elpo_g1_add(g1b(a, N), g1b(b, N), o) and g1u(o.raw, N) == G.g1_add(a, b)
+    for a, b in [(Q, BLS_G2), (Q, Q), (Q, G.g2_neg(Q))]:
+        assert L.elpo_g2_add(g2b(a, N), g2b(b, N), o2) and g2u(o2.raw, N) == G.g2_add(a, b)
+    # wire encodings both ways
+    w1, w2 = ctypes.create_string_buffer(N), ctypes.create_string_buffer(2 * N)
+    for X in (P, G.g1_neg(P)):
+        assert L.elpo_g1_compress(g1b(X, N), w1) and w1.raw == M.g1_ser(X)
+        assert L.elpo_g1_decompress(M.g1_ser(X), o) and g1u(o.raw, N) == X
+    for X in (Q, G.g2_neg(Q)):
+        assert L.elpo_g2_compress(g2b(X, N), w2) and w2.raw == M.g2_ser(X)
+        assert L.elpo_g2_decompress(M.g2_ser(X), o2) and g2u(o2.raw, N) == X
+    assert not L.elpo_g1_mul(g1b((1, 1), N), fb(3), o)               # not on the curve
+    # hashes: Fr::setHashOf masking to 255 / 254 bits, and this project's hash-to-curve convention for the curve
+    h = ctypes.create_string_buffer(32)
+    for s in (b"", b"abc", b"attribute-7", b"x" * 100):
+        L.elpo_fr_set_hash_of(s, len(s), h)
+        assert int.from_bytes(h.raw, "little") == M.fr_hash(s)
+    for s in ("abc", "ghi", "jkl", "service", ""):
+        L.elpo_hash_to_g1(s.encode(), len(s), o)
+        assert g1u(o.raw, N) == M.hash_to_g1(s)
+
+
+def test_pairing_value_bilinearity_and_final_exponentiation_self_check():
+    L = oracle_bls()
+    P, Q = G.g1_mul(BLS_G1, 12345), G.g2_mul(BLS_G2, 6789)
+    og, og2 = ctypes.create_string_buffer(12 * N), ctypes.create_string_buffer(12 * N)
+    e = G.pairing(P, Q)
+    want = b"".join(fb(e[k][0], N) + fb(e[k][1], N) for k in [0, 2, 4, 1, 3, 5])
+    assert L.elpo_pairing(g1b(P, N), g2b(Q, N), og) == 1 and og.raw == want       # GT bytes equal the model's (model: plain exponentiation)
+    a = 998877665544332211
+    L.elpo_pairing(g1b(G.g1_mul(P, a), N), g2b(Q, N), og)
+    L.elpo_pairing(g1b(P, N), g2b(G.g2_mul(Q, a), N), og2)
+    assert og.raw == og2.raw
+    # the HHT chain of the hard part == plain square-and-multiply by the 1268-bit integer (p^4 - p^2 + 1) / r
+    assert L.elpo_selftest_final_exp(g1b(P, N), g2b(Q, N)) == 1
+    # e(P, O) = e(O, Q) = 1
+    one = fb(1, N) + bytes(11 * N)
+    assert L.elpo_pairing(g1b(None, N), g2b(Q, N), og) == 1 and og.raw == one
+
+
+def test_protocol_flows_equal_the_model():
+    L = oracle_bls()
+    seed, A, H = 777, 4, 2
+    g, gg = M.hash_to_g1("abc"), BLS_G2
+    pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    key = ctypes.c_void_p(L.elpo_key_new(A, g1_bases(M, pk, svc="service", g_eg=g, apk=apk, h=h, skX=skX), g2_bases(M, pk)))
+    assert key.value
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    rq, t1 = PR.request_id(pk, attrs, b"ad", [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)])
+    u = scalar_stream(seed, 99, M.r)
+    want = PR.provide_id(pk, skX, rq, b"ad", u)
+    out = ctypes.create_string_buffer(4 * N)
+    assert L.elpo_provide_id(key, pack_provide_id(M, rq, u), 3, b"ad", 2, out) == 1
+    assert out.raw == g1b(want.sig1, N) + g1b(want.sig2, N)                       # issued signature, bit for bit
+    assert L.elpo_provide_id(key, pack_provide_id(M, rq, u), 3, b"ae", 2, out) == 0
+    cred = PR.unblind(want, t1)
+    vals = [a for a, _ in attrs]
+    assert L.elpo_ps_verify(key, pack_ps_verify(M, cred, vals), A) == 1
+    assert L.elpo_ps_verify(key, pack_ps_verify(M, want, vals), A) == 0
+    rnd = [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)]
+    pr = PR.prove_id(pk, cred, attrs, b"sess", b"service", apk, g, h, rnd)
+    mask = hidden_mask(pr.attributes)
+    assert PR.verify_id(pk, pr, b"sess", b"service", apk, g, h)
+    assert L.elpo_verify_id(key, pack_verify_id(M, pr), mask, 1, b"sess", 4) == 1
+    assert L.elpo_verify_id(key, pack_verify_id(M, pr), mask, 1, b"sesS", 4) == 0
+    for tamper in ("sig2", "phi", "c", "rs"):
+        bad = copy.copy(pr)
+        if tamper == "sig2":
+            bad.sig2 = G.g1_add(pr.sig2, g)
+        elif tamper == "phi":
+            bad.phi = G.g1_add(pr.phi, g)
+        elif tamper == "c":
+            bad.c = pr.c ^ 1
+        else:
+            bad.rs = [pr.rs[0] ^ 1] + list(pr.rs[1:])
+        assert L.elpo_verify_id(key, pack_verify_id(M, bad), mask, 1, b"sess", 4) == int(PR.verify_id(pk, bad, b"sess", b"service", apk, g, h)) == 0
+    pr2 = PR.prove_id(pk, cred, attrs, b"sess", b"service", None, None, None, rnd[:2] + rnd[3:3 + H + 1], with_retrieval=False)
+    assert L.elpo_verify_id(key, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
+    L.elpo_key_free(key)
+
+
+def _small_order_point(order, seed=1):
+    """A point of E(Fp) of the given prime order dividing the G1 cofactor (z-1)^2/3 = 3 * 11^2 * 10177^2 * 859267^2 * 52437899^2."""
+    # E(Fp) = Z/((z-1)/3) x Z/((z-1) r): the exponent of the group is |z-1| r, so [|z-1| r / order] R has order `order` or is O
+    h1 = (BLS12_381.z - 1) ** 2 // 3
+    assert h1 % order == 0
+    n = abs(BLS12_381.z - 1) * M.r
+    x = seed
+    while True:
+        rhs = (x * x * x + 4) % M.p
+        y = pow(rhs, (M.p + 1) // 4, M.p)
+        if y * y % M.p == rhs:
+            T = G.g1_mul_plain((x, y), n // order)
+            if T is not None:
+                assert G.g1_mul_plain(T, order) is None and G.g1_on_curve(T)
+                return T
+        x += 1
+
+
+def test_off_subgroup_g1_inputs_are_rejected():
+    """Project policy on BLS12-381 (G1 cofactor != 1): phi, E1, E2 (and the commitment of a request) outside the order-r subgroup reject the item -- in the
+    model ([r]P == O), in the C oracle ([r]P by double-and-add) and in the HIP path's endomorphism test (host twin), on crafted inputs: a valid proof whose
+    phi / E1 / E2 got a component of order 3 or 11 added."""
+    from elp_testlib import twin
+    L, T = oracle_bls(), twin()
+    seed, A, H = 991, 4, 2
+    g, gg = M.hash_to_g1("abc"), BLS_G2
+    pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    bases = (g1_bases(M, pk, svc="service", g_eg=g, apk=apk, h=h, skX=skX), g2_bases(M, pk))
+    key = ctypes.c_void_p(L.elpo_key_new(A, *bases))
+    tctx = ctypes.c_void_p(T.twin_bls_ctx_new(A, 4, *bases))
+    assert key.value and tctx.value
+    t3, t11 = _small_order_point(3), _small_order_point(11, seed=7)
+    # the membership test itself: G1 points pass, cofactor-order points and mixtures fail
+    for P, want in [(BLS_G1, 1), (G.g1_mul(BLS_G1, 123456789), 1), (g, 1), (None, 1), (t3, 0), (t11, 0), (G.g1_add(BLS_G1, t3), 0), (G.g1_add(g, t11), 0)]:
+        assert T.twin_bls_g1_in_subgroup(g1b(P, N)) == want
+        assert PR.in_g1(P) == bool(want)
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    rq, t1 = PR.request_id(pk, attrs, b"ad", [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)])
+    u = scalar_stream(seed, 99, M.r)
+    cred = PR.unblind(PR.provide_id(pk, skX, rq, b"ad", u), t1)
+    rnd = [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)]
+    pr = PR.prove_id(pk, cred, attrs, b"sess", b"service", apk, g, h, rnd)
+    mask = hidden_mask(pr.attributes)
+    rec = pack_verify_id(M, pr)
+    assert L.elpo_verify_id(key, rec, mask, 1, b"sess", 4) == 1 and T.twin_bls_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == 1
+    for field, t in (("phi", t3), ("phi", t11), ("E1", t3), ("E2", t11)):
+        bad = copy.copy(pr)
+        setattr(bad, field, G.g1_add(getattr(pr, field), t))
+        assert G.g1_on_curve(getattr(bad, field))
+        rb = pack_verify_id(M, bad)
+        assert not PR.verify_id(pk, bad, b"sess", b"service", apk, g, h)
+        assert L.elpo_verify_id(key, rb, mask, 1, b"sess", 4) == 0
+        assert T.twin_bls_verify_id(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0
+        assert T.twin_blsp_verify_id(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0          # the two-lanes-per-item layout
+    # a request whose commitment left the subgroup is not signed
+    badrq = copy.copy(rq)
+    badrq.A = G.g1_add(rq.A, t3)
+    out = ctypes.create_string_buffer(4 * N)
+    assert PR.provide_id(pk, skX, badrq, b"ad", u) is None
+    assert L.elpo_provide_id(key, pack_provide_id(M, badrq, u), 3, b"ad", 2, out) == 0
+    assert T.twin_bls_provide_id(tctx, pack_provide_id(M, badrq, u), ctypes.c_uint64(3), b"ad", 2, out) == 0
+    L.elpo_key_free(key)
