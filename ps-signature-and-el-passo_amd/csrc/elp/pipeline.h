@@ -1031,8 +1031,15 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
   aff_set_inf(P1);
   if (!odd || retr) ok &= g1_load<C>(P0, rec + (odd ? 4 : 2) * G1W);
   if (!odd && retr) ok &= g1_load<C>(P1, rec + 3 * G1W);
-  if constexpr (!C::IS_BN) {     // order-r subgroup membership of phi, E1 (even lane) and E2 (odd lane), see g1_in_subgroup
-    if (ok && !(key.flags & KEY_NO_SUBGROUP_CHECK)) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(P1);
+  if constexpr (!C::IS_BN) {
+    // order-r subgroup membership (g1_in_subgroup): the even lane, which has two of the three multiplications to do, checks phi; the odd lane checks
+    // E2 and E1 (handed over by lane exchange)
+    if (!(key.flags & KEY_NO_SUBGROUP_CHECK)) {
+      Aff<F1<C>> Q1;
+      Q1.x = fp_pair_swap(P1.x);
+      Q1.y = fp_pair_swap(P1.y);
+      if (ok) ok = g1_in_subgroup<C>(P0) && (!odd || g1_in_subgroup<C>(Q1));
+    }
   }
   ok = pair_and(ok);
   const bool okk = g2_load<C>(kk, rec + (retr ? 5 : 3) * G1W);
@@ -1215,7 +1222,12 @@ ELP_HEAVY bool verify_id_wire_item_paired(const KeyCtx<C>& key, const uint8_t* m
   if (!odd || retr) ok &= g1_deserialize<C>(P0, odd ? src.pe2_ : src.pphi_);
   if (!odd && retr) ok &= g1_deserialize<C>(P1, src.pe1_);
   if constexpr (!C::IS_BN) {
-    if (ok && !(key.flags & KEY_NO_SUBGROUP_CHECK)) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(P1);
+    if (!(key.flags & KEY_NO_SUBGROUP_CHECK)) {      // as in verify_id_item_paired: even lane phi, odd lane E2 and E1
+      Aff<F1<C>> Q1;
+      Q1.x = fp_pair_swap(P1.x);
+      Q1.y = fp_pair_swap(P1.y);
+      if (ok) ok = g1_in_subgroup<C>(P0) && (!odd || g1_in_subgroup<C>(Q1));
+    }
   }
   ok = pair_and(ok);
   const bool okk = g2_deserialize<C>(kk, src.pk_, &src.kflag_);
