@@ -73,7 +73,8 @@ int elp_init(int curve, int device, elp_ctx** out) {
   c->curve = curve;
   c->device = device;
   if (const char* e = getenv("ELP_LAYOUT")) c->paired = !strcmp(e, "plain") ? 0 : !strcmp(e, "paired") ? 1 : 2;     // A/B runs
-  if (const char* e = getenv("ELP_SPLIT")) c->split = atoi(e);                                            // A/B runs: one fused kernel per verification
+  if (const char* e = getenv("ELP_SPLIT")) c->split = atoi(e);
+  if (const char* e = getenv("ELP_COOP")) c->coop = atoi(e) != 0;                                                      // A/B runs: cooperative pairing for small batches                                            // A/B runs: one fused kernel per verification
   if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->simds = 4 * prop.multiProcessorCount;
@@ -105,6 +106,7 @@ void elp_destroy(elp_ctx* c) {
   for (auto& w : c->vtab_ws)
     if (w.p) (void)hipFree(w.p);
   if (c->agg_ok) (void)hipFree(c->agg_ok);
+  if (c->coop_consts) (void)hipFree(c->coop_consts);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
   for (int i = 0; i < 2; i++)
     if (c->jev[i]) (void)hipEventDestroy(c->jev[i]);
@@ -122,6 +124,11 @@ int elp_set_option(elp_ctx* c, int option, int value) {
       c->paired = value;
       return ELP_OK;
     case ELP_OPT_TABLE_WORKSPACE: c->use_vtab = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_COOP_PAIRING:
+      if (value < 0) return ELP_ERR_ARG;
+      c->coop = value ? 1 : 0;
+      if (value > 1) c->coop_max = (size_t)value;
+      return ELP_OK;
     case ELP_OPT_SUBGROUP_CHECK: c->subgroup_check = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
       if (value < 0 || value > 2) return ELP_ERR_ARG;

@@ -42,6 +42,8 @@ using namespace elp;
   (key).hot = elp_hot_lds + threadIdx.x * elp::ELP_HOT_WORDS
 #endif
 
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + ELP_BLOCK - 1) / ELP_BLOCK); }
+
 __device__ __forceinline__ void count_accept(bool ok, unsigned long long* counter) {
   unsigned long long b = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && b != 0 && counter) atomicAdd(counter, (unsigned long long)__popcll(b));
@@ -223,6 +225,226 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_pair(KeyCtx<C> key, const u32* recs, int
   }
   count_accept(ok, accepted);
 }
+
+// ---- cooperative pairing check (elp/coop.h): 32 lanes per item, Fp2 register file in LDS, level-scheduled program from tools/gen_coop.py.
+// Only the translation unit elpasso_<curve>_coop.hip sees the program tables (ELP_COOP_TU); the other units call the launchers below.
+#ifdef ELP_COOP_TU
+template <class C>
+struct CoopTables;
+template <>
+struct CoopTables<BN254> {
+  static __device__ __forceinline__ CoopProg check() {
+    using namespace elp::coop_bn254;
+    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}};
+  }
+  static __device__ __forceinline__ CoopProg tail() {
+    using namespace elp::coop_bn254;
+    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}};
+  }
+  static constexpr int NREG = elp::coop_bn254::COOP_NREG, NP = elp::coop_bn254::COOP_NP, NCONST = elp::coop_bn254::COOP_NCONST;
+  static constexpr int IN_P1 = elp::coop_bn254::IN_P1, IN_P2 = elp::coop_bn254::IN_P2, IN_QX = elp::coop_bn254::IN_QX, IN_QY = elp::coop_bn254::IN_QY,
+                       IN_ONE = elp::coop_bn254::IN_ONE, IN_F0 = elp::coop_bn254::IN_F0;
+  static __device__ __forceinline__ const uint8_t (*kinds())[3] { return elp::coop_bn254::CONST_KIND; }
+};
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_coop_consts(Fp2<C>* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CoopTables<C>::NCONST) return;
+  out[i].c0 = coop_const<C>(CoopTables<C>::kinds(), i, 0);
+  out[i].c1 = coop_const<C>(CoopTables<C>::kinds(), i, 1);
+}
+// runs program P over the register files of the workgroup's two items; every lane walks all steps (empty slots and inactive items idle)
+template <class C>
+__device__ __forceinline__ void coop_run_device(const CoopProg& P, i32* R, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines) {
+  ELP_NOUNROLL
+  for (int s = 0; s < P.nsteps; s++) {
+    if (active) {
+      Fp<C> out;
+      const int dst = coop_exec_slot<C>(P, s, pair, comp, R, consts, lines, out);
+      if (dst >= 0) coop_st<C>(R, dst, comp, out);     // the register allocation never lets a step write a register that the same step reads
+    }
+    __syncthreads();
+  }
+}
+// is the Fp12 value in registers P.out[0..5] equal to 1?  (lane pair j < 6 tests coefficient j; result through LDS word `flagw`)
+template <class C>
+__device__ __forceinline__ bool coop_is_one(const CoopProg& P, i32* R, bool active, int pair, int comp, i32* flagw) {
+  if (pair == 0 && comp == 0) *flagw = 1;
+  __syncthreads();
+  if (active && pair < 6) {
+    Fp<C> v = coop_ld<C>(R, P.out[pair], comp);
+    if (pair == 0 && comp == 0) v = fp_sub_lazy(v, fp_one<C>());
+    if (!fp_is_zero<C>(v)) *flagw = 0;
+  }
+  __syncthreads();
+  return *flagw != 0;
+}
+// items [0, n): sig1 | sig2 at the head of the record, K in the workspace (vid_store_k layout); todo[i] != 0 selects the items to check.  An item whose sig1,
+// sig2 or K is the point at infinity (or fails validation) is left to the per-lane kernel: done[i] stays 0.  Otherwise flags[i] = verdict, done[i] = 1.
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK, 2) k_pair_coop(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
+                                                            size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n) {
+  typedef CoopTables<C> T;
+  constexpr int RW = T::NREG * 2 * C::NL;
+  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + 8];
+  const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
+  i32* R = Rall + slot * RW;
+  i32* flagw = Rall + 2 * RW + slot;            // [0..1]: is-one flags, [2..3]: "inputs usable"
+  const size_t i = (size_t)blockIdx.x * 2 + slot;
+  if (pair == 0 && comp == 0) {
+    int usable = 0;
+    if (i < n && todo[i]) {
+      const u32* rec = recs + i * (size_t)rec_words;
+      Aff<F1<C>> s1, s2;
+      Aff<F2<C>> K;
+      if (g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N)) {
+        vid_load_k<C>(K, kws, kstride, i);
+        if (!aff_is_inf(s1) && !aff_is_inf(s2) && !aff_is_inf(K)) {
+          usable = 1;
+          coop_st<C>(R, T::IN_P1, 0, s1.x);
+          coop_st<C>(R, T::IN_P1, 1, s1.y);
+          coop_st<C>(R, T::IN_P2, 0, s2.x);
+          coop_st<C>(R, T::IN_P2, 1, fp_neg(s2.y));
+          coop_st<C>(R, T::IN_QX, 0, K.x.c0);
+          coop_st<C>(R, T::IN_QX, 1, K.x.c1);
+          coop_st<C>(R, T::IN_QY, 0, K.y.c0);
+          coop_st<C>(R, T::IN_QY, 1, K.y.c1);
+          coop_st<C>(R, T::IN_ONE, 0, fp_one<C>());
+          coop_st<C>(R, T::IN_ONE, 1, fp_zero<C>());
+        }
+      }
+    }
+    flagw[2] = usable;
+  }
+  __syncthreads();
+  const bool active = flagw[2] != 0;
+  const CoopProg P = T::check();
+  coop_run_device<C>(P, R, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
+  const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
+  if (pair == 0 && comp == 0 && active) {
+    flags[i] = one ? 1 : 0;
+    done[i] = 1;
+    if (one && accepted) atomicAdd(accepted, 1ull);
+  }
+}
+// the items k_pair_coop left alone (points at infinity): the ordinary per-lane check
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_pair_rest(KeyCtx<C> key, const u32* recs, int rec_words, const uint8_t* todo, const uint8_t* done, const u32* kws, size_t kstride,
+                                              uint8_t* flags, unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n && !done[i]) {
+    if (todo[i]) {
+      Aff<F2<C>> aK;
+      vid_load_k<C>(aK, kws, kstride, i);
+      ok = vid_pair_item<C>(key, recs + i * (size_t)rec_words, aK);
+    }
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+// K of a plain PS verification (src/ps-verifier.cc:20-29: XX prod YY_i^{m_i}), affine, into the workspace; todo[i] = the record decodes and sig1 != infinity (:16-18)
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_ps_k(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+  constexpr int HOTW = (int)(sizeof(Jac<F2<C>>) / 4);
+  __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_BLOCK * HOTW];
+  key.hot = hot_lds + threadIdx.x * HOTW;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32* rec = recs + i * (size_t)rec_words;
+  Aff<F1<C>> s1, s2;
+  const bool ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && !aff_is_inf(s1);
+  todo[i] = ok ? 1 : 0;
+  if (!ok) return;
+  Jac<F2<C>> K;
+  jac_from_aff(K, aff_from_mem<F2<C>>(key.b2[G2_BASE_XX]));
+  for (int a = 0; a < nattr; a++) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + a, scalar_load_w(rec + 4 * C::N + 8 * a));
+  Aff<F2<C>> aK;
+  jac_to_aff<F2<C>>(aK, K);
+  vid_store_k<C>(kws, kstride, i, aK);
+}
+// closing step of aggregated verification on 32 lanes: [F f_gg(-S2)]^e == 1
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK, 2) k_agg_final_coop(KeyCtx<C> key, const Fp2<C>* consts, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
+  typedef CoopTables<C> T;
+  constexpr int RW = T::NREG * 2 * C::NL;
+  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + 8];
+  const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
+  i32* R = Rall + slot * RW;
+  i32* flagw = Rall + 2 * RW + slot;
+  if (pair == 0 && comp == 0) {
+    int state = 0;                                  // 0: run the program, 1: verdict is "false" (bad point)
+    if (slot == 0) {
+      Aff<F1<C>> s2;
+      if (!g1_load<C>(s2, s2_std)) state = 1;
+      // S2 = infinity: f_gg(O) = 1 -- the line evaluations degenerate; let a y-coordinate of 0 stand in (lines evaluated at (0, 0) leave only their
+      // constant coefficient, an element of a proper subfield): handled by the ordinary kernel instead, see launch code
+      coop_st<C>(R, T::IN_P2, 0, s2.x);
+      coop_st<C>(R, T::IN_P2, 1, fp_neg(s2.y));
+      coop_st<C>(R, T::IN_ONE, 0, fp_one<C>());
+      coop_st<C>(R, T::IN_ONE, 1, fp_zero<C>());
+      const Fp2<C>* e[6] = {&F->c0.c0, &F->c0.c1, &F->c0.c2, &F->c1.c0, &F->c1.c1, &F->c1.c2};
+      for (int j = 0; j < 6; j++) {
+        coop_st<C>(R, T::IN_F0 + j, 0, e[j]->c0);
+        coop_st<C>(R, T::IN_F0 + j, 1, e[j]->c1);
+      }
+    }
+    flagw[2] = (slot == 0 && state == 0) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool active = flagw[2] != 0;
+  const CoopProg P = T::tail();
+  coop_run_device<C>(P, R, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
+  const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
+  if (threadIdx.x == 0) *agg_ok = (active && one) ? 1 : 0;
+}
+template <class B>
+void launch_coop_consts(hipStream_t stream, void* d_consts) {
+  hipLaunchKernelGGL((k_coop_consts<B>), dim3(1), dim3(ELP_BLOCK), 0, stream, (Fp2<B>*)d_consts);
+}
+template <class B>
+void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
+                      uint8_t* d_flags, uint8_t* done, void* d_accepted) {
+  hipLaunchKernelGGL((k_pair_coop<B>), dim3((unsigned)((n + 1) / 2)), dim3(ELP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
+                     d_flags, done, (unsigned long long*)d_accepted, n);
+  hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, todo, (const uint8_t*)done, kws, kstride, d_flags,
+                     (unsigned long long*)d_accepted, n);
+}
+template <class B>
+void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride) {
+  hipLaunchKernelGGL((k_ps_k<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, nattr, todo, kws, kstride, n);
+}
+template <class B>
+void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok) {
+  hipLaunchKernelGGL((k_agg_final_coop<B>), dim3(1), dim3(ELP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const Fp12<B>*)F, (const u32*)s2_std, agg_ok);
+}
+#else
+template <class B>
+void launch_coop_consts(hipStream_t stream, void* d_consts);
+template <class B>
+void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
+                      uint8_t* d_flags, uint8_t* done, void* d_accepted);
+template <class B>
+void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
+template <class B>
+void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
+#endif
+// which curves have the cooperative kernels (their own translation unit, elpasso_<curve>_coop.hip)
+template <class B>
+struct CoopBuild {
+  static constexpr bool value = false;
+};
+template <>
+struct CoopBuild<BN254> {
+  static constexpr bool value = true;
+};
+#ifndef ELP_COOP_TU
+extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_consts);
+extern template void launch_pair_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
+extern template void launch_ps_k<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
+extern template void launch_agg_final_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
+#endif
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
 // waves per SIMD; the LDS hot slot is half as large per lane (8 workgroups x 13.5 KB per CU).
@@ -860,6 +1082,9 @@ struct elp_ctx {
   int use_vtab = 1;           // ELP_VTAB=0 in the environment keeps the tables in private memory (A/B measurements)
   int split = 0;              // ELP_OPT_SPLIT_PHASES: 1 = el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them; 2 = the two jobs
                               // of the first phase as concurrent kernels on two streams (k_vid_g2 || k_vid_g1, then k_vid_pair2)
+  int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
+  size_t coop_max = 8192;
+  void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
   hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
   hipEvent_t jev[2] = {nullptr, nullptr};
 };
@@ -874,7 +1099,6 @@ struct elp_ctx {
     }                                                                                           \
   } while (0)
 
-static inline unsigned grid_for(size_t n) { return (unsigned)((n + ELP_BLOCK - 1) / ELP_BLOCK); }
 
 template <class C>
 static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key material is the same plain-layout memory
@@ -922,6 +1146,20 @@ static KeyCtx<C> make_key_ws(elp_ctx* c, hipStream_t stream, size_t lanes, size_
   if (c->use_vtab) k.vtab = (u32*)w->p;
   if (extra) *extra = (uint8_t*)w->p + tab_bytes;
   return k;
+}
+
+template <class C>
+static const void* coop_consts_for(elp_ctx* c, hipStream_t stream) {
+  if (!c->coop_consts) {
+    if (hipMalloc(&c->coop_consts, 64 * sizeof(Fp2<C>)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->coop_consts = nullptr;
+      return nullptr;
+    }
+    launch_coop_consts<C>(stream, c->coop_consts);      // later launches on other streams: the table is complete long before (same device, in-order first use)
+    (void)hipStreamSynchronize(stream);
+  }
+  return c->coop_consts;
 }
 
 // RAII device buffer for the host-buffer entry points.  Blocks come from (and go back to) a small per-process cache, so a steady stream of
@@ -1495,7 +1733,18 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   // S2 = sum d_i sig2_i
   msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm);
   bool tail_done = false;
+  if constexpr (CoopBuild<C>::value) {
+    if (c->coop) {                                            // the serial tail on 32 lanes (level-scheduled program): ~4x faster than a lane pair
+      const void* consts = coop_consts_for<C>(c, stream);
+      if (consts) {
+        launch_agg_final_coop<C>(stream, key, consts, F, ws + o_s2, c->agg_ok);
+        tail_done = true;
+      }
+    }
+  }
   if constexpr (PairedBuild<C>::value) {
+    if (tail_done) {
+    } else
     if (c->paired != 0) {                                     // the serial tail on a lane pair: about 0.6x the latency of one lane
       launch_agg_final_paired<C>(c, stream, F, ws + o_s2);
       tail_done = true;
@@ -1603,6 +1852,27 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   const int H = popcount_mask(mask, c->A);
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
+  if constexpr (CoopBuild<C>::value && SplitBuild<C>::value) {
+    if (c->coop && n <= c->coop_max) {
+      // small batch: NIZK half with two job lanes per item (k_vid_nizk), pairing check on 32 lanes per item (k_pair_coop)
+      const void* consts = coop_consts_for<C>(c, (hipStream_t)stream);
+      const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
+      const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
+      void* extra = nullptr;
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + 2 * lanes, &extra);
+      if (consts && extra) {
+        u32* kws = (u32*)extra;
+        uint8_t* nizk_ok = (uint8_t*)extra + k_bytes;
+        uint8_t* done = nizk_ok + lanes;
+        HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
+        launch_vid_nizk<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key);
+        key.vtab = nullptr;
+        launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, nizk_ok, kws, lanes, (uint8_t*)d_flags, done, d_accepted);
+        HIPCHK(c, hipGetLastError());
+        return ELP_OK;
+      }
+    }
+  }
   if constexpr (PairedBuild<C>::value) {
     const size_t np = layout_split(c, n);       // items [0, np): plain kernel; [np, n): paired kernel
     if (np < n) {
@@ -1701,6 +1971,30 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (rc) return rc;
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
+  if constexpr (CoopBuild<C>::value) {
+    if (c->coop && n <= c->coop_max) {
+      // small batch: K per item on one lane each (three table sums), then the pairing check on 32 lanes per item
+      const void* consts = coop_consts_for<C>(c, (hipStream_t)stream);
+      const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
+      const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
+      void* extra = nullptr;
+      const int use_vtab = c->use_vtab;
+      c->use_vtab = 0;                                   // no tables of multiples on this path: only the state region of the workspace
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + 2 * lanes, &extra);
+      c->use_vtab = use_vtab;
+      if (consts && extra) {
+        u32* kws = (u32*)extra;
+        uint8_t* todo = (uint8_t*)extra + k_bytes;
+        uint8_t* done = todo + lanes;
+        HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
+        const int words = 4 * C::N + 8 * nattr;
+        launch_ps_k<C>((hipStream_t)stream, key, n, d_records, words, nattr, todo, kws, lanes);
+        launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, done, d_accepted);
+        HIPCHK(c, hipGetLastError());
+        return ELP_OK;
+      }
+    }
+  }
   if constexpr (PairedBuild<C>::value) {
     const size_t np = layout_split(c, n);
     if (np < n) {

@@ -15,6 +15,7 @@ OPT_PAIRED_LAYOUT = 2
 OPT_TABLE_WORKSPACE = 3
 OPT_SPLIT_PHASES = 4
 OPT_SUBGROUP_CHECK = 5
+OPT_COOP_PAIRING = 6
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -165,6 +166,10 @@ class Context:
     def set_subgroup_check(self, on):
         """ELP_OPT_SUBGROUP_CHECK (default on; BLS12-381): prover-supplied G1 points outside the order-r subgroup reject the item."""
         self._chk(self.lib.elp_set_option(self.h, OPT_SUBGROUP_CHECK, int(bool(on))))
+
+    def set_coop_pairing(self, on):
+        """ELP_OPT_COOP_PAIRING: 0 = off, 1 = cooperative pairing check for batches of <= 8192 items and the aggregated tail (default), > 1 = that batch limit."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_COOP_PAIRING, int(on)))
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default on): one-lane-per-item verify_id as two kernels (NIZK half with two job lanes per item, then the pairing)."""

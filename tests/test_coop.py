@@ -1,0 +1,62 @@
+"""Cooperative pairing check (csrc/elp/coop.h + the level-scheduled programs of tools/gen_coop.py) on the CPU: the host twin interprets the SAME program tables
+the kernels k_pair_coop / k_agg_final_coop carry, slot by slot, and the resulting GT element must equal the model's  e(sig1, K) e(-sig2, gg)  bit for bit
+(the model computes pairings with affine formulas and a plain final exponentiation); verdicts on PS signatures issued through the reference's protocol."""
+import base64
+import ctypes
+
+import pytest
+
+from elp_testlib import BN254, Codec, Mcl, Protocol, fb, g1_bases, g1b, g2_bases, g2b, load_golden, scalar_stream, twin
+
+M = Mcl(BN254)
+G, CD, PR = M.G, Codec(M), Protocol(M)
+
+
+@pytest.fixture(scope="module")
+def env():
+    L = twin()
+    d = load_golden("bn254_oracle_flows.json")
+    pk = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
+    L.twin_bn254_ctx_new.restype = ctypes.c_void_p
+    h = L.twin_bn254_ctx_new(len(pk.Yi), 4, g1_bases(M, pk, svc=b"svc"), g2_bases(M, pk))
+    assert h
+    return L, ctypes.c_void_p(h), pk
+
+
+def _gt_bytes(e):
+    return b"".join(fb(e[k][0]) + fb(e[k][1]) for k in [0, 2, 4, 1, 3, 5])
+
+
+def test_program_value_equals_model_pairing_product(env):
+    L, ctx, pk = env
+    g1 = M.hash_to_g1("abc")
+    out = ctypes.create_string_buffer(384)
+    for a, b, k in ((424242, 171717, 987654321), (1, 1, 1), (M.r - 1, 2, M.r - 2)):
+        P1, P2, K = G.g1_mul(g1, a), G.g1_mul(g1, b), G.g2_mul(pk.gg, k)
+        want = _gt_bytes(G.F.f12_mul(G.pairing(P1, K), G.pairing(G.g1_neg(P2), pk.gg)))
+        for mode in (0, 1):          # 0: check program (variable + fixed pair), 1: tail program (F given, fixed pair)
+            r = L.twin_bn254_pair_coop(ctx, g1b(P1), g1b(P2), g2b(K), mode, out)
+            assert out.raw == want and r == int(a * k % M.r == b % M.r)
+
+
+def test_verdicts_on_ps_signatures(env):
+    """e(sig1, K) == e(sig2, gg) for a credential issued by the model's signer (K = XX prod YY_i^{m_i}), and not for a tampered one."""
+    L, ctx, pk0 = env
+    seed, A = 99, 3
+    g = M.hash_to_g1("abc")
+    x, ys = scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)]
+    pk, skX = PR.key_gen(g, pk0.gg, x, ys)
+    h = L.twin_bn254_ctx_new(A, 4, g1_bases(M, pk, svc=b"svc", skX=skX), g2_bases(M, pk))
+    ctx2 = ctypes.c_void_p(h)
+    ms = [M.fr_hash(b"attr-%d" % i) for i in range(A)]
+    u = scalar_stream(seed, 50, M.r)
+    sig1 = G.g1_mul(g, u)
+    sig2 = G.g1_mul(g, u * (x + sum(y * m for y, m in zip(ys, ms))) % M.r)
+    K = pk.XX
+    for i in range(A):
+        K = G.g2_add(K, G.g2_mul(pk.YYi[i], ms[i]))
+    out = ctypes.create_string_buffer(384)
+    one = fb(1) + bytes(352)
+    assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(sig2), g2b(K), 0, out) == 1 and out.raw == one
+    assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(G.g1_add(sig2, g)), g2b(K), 0, out) == 0
+    assert L.twin_bn254_pair_coop(ctx2, g1b(G.g1_mul(sig1, 2)), g1b(sig2), g2b(K), 0, out) == 0

@@ -164,3 +164,54 @@ def test_config5_end_to_end_eight_virtual_ranks(gpu_ctx):
         assert (ofl == flags[idx]).all()
     assert covered == N
     assert total == N - len([i for i in range(N) if i % 97 == 13])
+
+
+def test_cooperative_pairing_small_batches(gpu_ctx):
+    """ELP_OPT_COOP_PAIRING: batches of <= 8192 items run the pairing check on 32 lanes per item (k_pair_coop, level-scheduled program).  Plain PS verification and
+    el_passo_verify_id at n = 1, 63, 64, 65, 4096: verdicts equal the per-lane kernels' (option off), the generator's expectation and the C oracle's; items with
+    sig2 = infinity / tampered signatures / corrupted NIZK take the same verdicts in both modes."""
+    L = oracle()
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=5, window_bits=8)
+    key = _oracle_key(L, wl, gpu_ctx, A)
+    try:
+        for n in (1, 63, 64, 65, 4096):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=3)
+            rsz = len(recs) // n
+            recs = bytearray(recs)
+            if n > 10:
+                recs[9 * rsz + 64:9 * rsz + 128] = recs[8 * rsz + 64:8 * rsz + 128]        # item 9 gets item 8's sig2: NIZK holds, pairing check fails
+                recs[4 * rsz + 64:4 * rsz + 128] = bytes(64)                                # item 4: sig2 = infinity (left to the per-lane kernel)
+            recs = bytes(recs)
+            gpu_ctx.set_coop_pairing(0)
+            f0, c0 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            gpu_ctx.set_coop_pairing(1)
+            f1, c1 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            assert (f0 == f1).all() and c0 == c1 == int(f1.sum())
+            if n > 10:
+                assert f1[9] == 0 and f1[4] == 0 and f1[8] == int(expect[8])
+            ofl = np.zeros(n, dtype=np.uint8)
+            L.elpo_verify_id_batch(key, n, recs, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+            assert (ofl == f1).all()
+        wl3 = synth.Workload(gpu_ctx, 3, seed=6, window_bits=8)
+        for n in (1, 65, 4096):
+            precs, pexpect = wl3.ps_verify_batch(n)
+            gpu_ctx.set_coop_pairing(0)
+            p0, pc0 = gpu_ctx.ps_verify_batch(precs, 3)
+            gpu_ctx.set_coop_pairing(1)
+            p1, pc1 = gpu_ctx.ps_verify_batch(precs, 3)
+            assert (p0 == pexpect).all() and (p1 == pexpect).all() and pc0 == pc1 == int(pexpect.sum())
+        # aggregated verification with the cooperative closing step: fast path and fallback
+        wl = synth.Workload(gpu_ctx, A, seed=5, window_bits=8)
+        recs, mask, expect = wl.verify_id_batch(700, H, with_retrieval=True)
+        fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad)
+        assert held and (fl == expect).all() and cnt == int(expect.sum())
+        rsz = len(recs) // 700
+        bad = bytearray(recs)
+        bad[9 * rsz + 64:9 * rsz + 128] = bad[8 * rsz + 64:8 * rsz + 128]
+        fl2, cnt2, held2 = gpu_ctx.verify_id_batch_aggregated(bytes(bad), mask, True, wl.ad)
+        exp2 = expect.copy()
+        exp2[9] = 0
+        assert not held2 and (fl2 == exp2).all()
+    finally:
+        gpu_ctx.set_coop_pairing(1)

@@ -1,0 +1,855 @@
+#!/usr/bin/env python3
+"""Generator of the level-scheduled programs of the COOPERATIVE pairing kernels (csrc/elp/coop.h, k_pair_coop in csrc/elpasso_impl.h).
+
+Small batches leave the chip idle when one lane (or lane pair) carries a whole pairing: the Miller loop and the final exponentiation are one
+long dependency chain of Fp12 operations.  Inside each Fp12 operation, however, a dozen Fp2 products are independent.  The cooperative kernels
+give every item NP lane pairs and an Fp2 register file in LDS, and run a straight-line PROGRAM of Fp2 operations that this script schedules into
+levels: all operations of a level are independent, lane pair q executes slot q of the level, a barrier separates levels.  A level is either
+a "mul" level (every slot is one Fp2 product, ~420 vector instructions whatever its operands) or a "lin" level (additions, negations,
+xi-multiples, conjugations, loads; ~60 instructions).  The schedule is computed here once (ASAP levels from the data dependencies, then LDS
+registers by linear scan); the kernel is a tiny interpreter.
+
+What is traced (the reference calls it replaces: pairing() + GT== at src/ps-verifier.cc:31-34,134-137):
+    check(P1, Q, P2)  ==  [ f_{Q}(P1) * f_{gg}(P2) ]^((p^12-1)/r) == 1       with the lines of gg precomputed (KeyCtx::gg_lines),
+i.e. e(sig1, K) * e(-sig2, gg) == 1, and the tail of aggregated verification  [ F * f_{gg}(P2) ]^(...) == 1.
+The formulas are the ones of csrc/elp/pairing.h / tower.h in their carried (non-lazy) form; the final exponentiation uses the exact
+Devegili-Scott-Dahab chain so that the value equals the model's GT element bit for bit (validated below against oracle/pymodel.py).
+
+Usage: python tools/gen_coop.py            -> writes ps-signature-and-el-passo_amd/csrc/elp/coop_prog_bn254.h  (after validating against the model)
+"""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from oracle.pymodel import BN254, Groups, Mcl  # noqa: E402
+
+
+def naf(k):      # non-adjacent form, least significant digit first (as tools/gen_params.py, which generates C::ate_naf)
+    out = []
+    while k:
+        if k & 1:
+            d = 2 - (k % 4)
+            k -= d
+        else:
+            d = 0
+        out.append(d)
+        k >>= 1
+    return out
+
+
+NP = 16            # lane pairs per item
+NREG = 128         # Fp2 registers per item in LDS
+
+# ---- operations (SSA).  mul-class: MUL (a*b), MULC (a * constant[c]), MULS (a * Fp scalar = component `sel` of register b)
+#      lin-class: LIN (dst = sum_k M_k x_k: an Fp-linear combination of up to 15 registers, M_k 2x2 matrices of small integers acting on (re, im):
+#                 additions, subtractions, negations, doublings, conjugations and xi-multiples of any depth collapse into ONE such operation),
+#                 LDL (line k, coefficient j of the fixed argument, from global memory), INV (Fp inverse of re(a))
+MUL, MULC, MULS, LIN, LDL, INV, INPUT = range(7)
+MULCLASS = (MUL, MULC, MULS)
+NAMES = ["MUL", "MULC", "MULS", "LIN", "LDL", "INV", "INPUT"]
+MAXTERMS = 31
+MAXCOEF = 7
+
+CONSTS = {}        # name -> id (values are filled in by the kernel's set-up code from the curve parameters)
+
+
+def const_id(name):
+    if name not in CONSTS:
+        CONSTS[name] = len(CONSTS)
+    return CONSTS[name]
+
+
+I2 = (1, 0, 0, 1)
+M_XI = (1, -1, 1, 1)       # (a, b) -> (a - b, a + b) = (a + b i)(1 + i)
+M_CONJ = (1, 0, 0, -1)
+
+
+def mat_mul(m, n):         # m o n
+    return (m[0] * n[0] + m[1] * n[2], m[0] * n[1] + m[1] * n[3], m[2] * n[0] + m[3] * n[2], m[2] * n[1] + m[3] * n[3])
+
+
+def mat_add(m, n):
+    return (m[0] + n[0], m[1] + n[1], m[2] + n[2], m[3] + n[3])
+
+
+class Prog:
+    def __init__(self):
+        self.ops = []          # (op, a, b, aux): a, b = indices of earlier ops (or -1); LIN: aux = tuple of (base index, matrix)
+        self.lin_cache = {}
+
+    def emit(self, op, a=-1, b=-1, aux=0):
+        self.ops.append((op, a, b, aux))
+        return len(self.ops) - 1
+
+    def base(self, idx):
+        return V(self, {idx: I2})
+
+    def input(self, slot):
+        return self.base(self.emit(INPUT, aux=slot))
+
+    def ldl(self, k):
+        return self.base(self.emit(LDL, aux=k))
+
+
+class V:
+    """A symbolic Fp2 value: an Fp-linear combination  sum_k M_k base_k  of materialised values (inputs, loads, products)."""
+
+    def __init__(self, prog, terms):
+        self.p = prog
+        self.terms = {k: m for k, m in terms.items() if m != (0, 0, 0, 0)}
+
+    def mat(self):
+        """The index of an operation whose result is this value (emits a LIN operation unless the value is a plain register)."""
+        t = self.terms
+        if not t:
+            if () not in self.p.lin_cache:
+                self.p.lin_cache[()] = self.p.emit(LIN, aux=())          # the constant 0
+            return self.p.lin_cache[()]
+        if len(t) == 1:
+            (k, m), = t.items()
+            if m == I2:
+                return k
+        key = tuple(sorted(t.items()))
+        # the interpreter accumulates a combination in 64-bit limbs and estimates the quotient by p from the top limb in 64 bits: keep sum |coefficients| small
+        assert sum(max(abs(m[0]) + abs(m[1]), abs(m[2]) + abs(m[3])) for m in t.values()) <= 200
+        if key not in self.p.lin_cache:
+            assert len(key) <= MAXTERMS and all(abs(c) <= MAXCOEF for _, m in key for c in m), key
+            self.p.lin_cache[key] = self.p.emit(LIN, aux=key)
+        return self.p.lin_cache[key]
+
+    def _fits(self, terms):
+        return (len(terms) <= MAXTERMS and all(abs(c) <= MAXCOEF for m in terms.values() for c in m) and
+                sum(max(abs(m[0]) + abs(m[1]), abs(m[2]) + abs(m[3])) for m in terms.values()) <= 200)
+
+    def _combine(self, o, sign):
+        t = dict(self.terms)
+        for k, m in o.terms.items():
+            mm = m if sign > 0 else tuple(-c for c in m)
+            t[k] = mat_add(t[k], mm) if k in t else mm
+        if self._fits(t):
+            return V(self.p, t)
+        # too wide for one operation: materialise the operands first
+        a, b = self.p.base(self.mat()), self.p.base(o.mat())
+        return a._combine(b, sign)
+
+    def _apply(self, m):
+        t = {k: mat_mul(m, n) for k, n in self.terms.items()}
+        if self._fits(t):
+            return V(self.p, t)
+        return self.p.base(self.mat())._apply(m)
+
+    def __mul__(self, o):
+        if not self.terms or not o.terms:
+            return V(self.p, {})                                          # a factor is the constant 0: no operation
+        return self.p.base(self.p.emit(MUL, self.mat(), o.mat()))
+
+    def sqr(self):
+        if not self.terms:
+            return V(self.p, {})
+        a = self.mat()
+        return self.p.base(self.p.emit(MUL, a, a))
+
+    def mulc(self, cname):
+        if not self.terms:
+            return V(self.p, {})
+        return self.p.base(self.p.emit(MULC, self.mat(), -1, const_id(cname)))
+
+    def muls(self, o, sel):      # self * (component sel of o), an Fp scalar
+        if not self.terms:
+            return V(self.p, {})
+        return self.p.base(self.p.emit(MULS, self.mat(), o.mat(), sel))
+
+    def __add__(self, o):
+        return self._combine(o, 1)
+
+    def __sub__(self, o):
+        return self._combine(o, -1)
+
+    def __neg__(self):
+        return self._apply((-1, 0, 0, -1))
+
+    def conj(self):
+        return self._apply(M_CONJ)
+
+    def xi(self):
+        return self._apply(M_XI)
+
+    def dbl(self):
+        return self._apply((2, 0, 0, 2))
+
+    def tpl(self):
+        return self._apply((3, 0, 0, 3))
+
+    def inv_re(self):            # (1 / re(self), 0): self must be a base-field value (im == 0)
+        return self.p.base(self.p.emit(INV, self.mat()))
+
+
+# ---- tower arithmetic on symbolic values (Fp6 = 3 Fp2, Fp12 = (Fp6, Fp6); same conventions as csrc/elp/tower.h)
+def f6_add(a, b):
+    return [a[i] + b[i] for i in range(3)]
+
+
+def f6_sub(a, b):
+    return [a[i] - b[i] for i in range(3)]
+
+
+def f6_neg(a):
+    return [-a[i] for i in range(3)]
+
+
+def f6_mul_v(a):
+    return [a[2].xi(), a[0], a[1]]
+
+
+def f6_mul(a, b):
+    t0, t1, t2 = a[0] * b[0], a[1] * b[1], a[2] * b[2]
+    r0 = t0 + (((a[1] + a[2]) * (b[1] + b[2])) - t1 - t2).xi()
+    r1 = ((a[0] + a[1]) * (b[0] + b[1])) - t0 - t1 + t2.xi()
+    r2 = ((a[0] + a[2]) * (b[0] + b[2])) - t0 - t2 + t1
+    return [r0, r1, r2]
+
+
+def f6_mul_01(a, b0, b1):        # a * (b0 + b1 v)
+    t0, t1 = a[0] * b0, a[1] * b1
+    r0 = t0 + (((a[1] + a[2]) * b1) - t1).xi()
+    r1 = ((a[0] + a[1]) * (b0 + b1)) - t0 - t1
+    r2 = (a[2] * b0) + t1
+    return [r0, r1, r2]
+
+
+def f6_mul_fp2(a, b):
+    return [a[0] * b, a[1] * b, a[2] * b]
+
+
+def f6_sqr(a):
+    return f6_mul(a, a)
+
+
+def f6_inv(x):
+    A = x[0].sqr() - (x[1] * x[2]).xi()
+    B = x[2].sqr().xi() - (x[0] * x[1])
+    Cc = x[1].sqr() - (x[0] * x[2])
+    Fv = (x[0] * A) + ((x[2] * B) + (x[1] * Cc)).xi()
+    Fi = f2_inv(Fv)
+    return [A * Fi, B * Fi, Cc * Fi]
+
+
+def f2_inv(a):                   # conj(a) / norm(a);  norm = a * conj(a) is a base-field value
+    n = a * a.conj()
+    return a.conj() * n.inv_re()
+
+
+def f12_mul(a, b):
+    t0, t1 = f6_mul(a[0], b[0]), f6_mul(a[1], b[1])
+    s = f6_mul(f6_add(a[0], a[1]), f6_add(b[0], b[1]))
+    return [f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(s, t0), t1)]
+
+
+def f12_sqr(a):
+    t = f6_mul(a[0], a[1])
+    s = f6_mul(f6_add(a[0], a[1]), f6_add(a[0], f6_mul_v(a[1])))
+    return [f6_sub(f6_sub(s, t), f6_mul_v(t)), f6_add(t, t)]
+
+
+def f12_conj(a):
+    return [a[0], f6_neg(a[1])]
+
+
+def f12_inv(a):
+    t = f6_sub(f6_sqr(a[0]), f6_mul_v(f6_sqr(a[1])))
+    ti = f6_inv(t)
+    return [f6_mul(a[0], ti), f6_neg(f6_mul(a[1], ti))]
+
+
+def f12_frob(a, n):
+    # coefficient of w^k (k = 2 i + j for v^i w^j) is conjugated n times and scaled by gamma_{n,k}
+    out = [[None] * 3, [None] * 3]
+    for i in range(3):
+        for j in range(2):
+            k = 2 * i + j
+            t = a[j][i].conj() if (n & 1) else a[j][i]
+            out[j][i] = t if k == 0 else t.mulc("frob%d_%d" % (n, k))
+    return out
+
+
+def f12_cyc_sqr(a):
+    # Granger-Scott on the three Fp4 blocks (z0,z1) (z2,z3) (z4,z5) = (c0.c0,c1.c1) (c1.c0,c0.c2) (c0.c1,c1.c2)
+    z0, z4, z3, z2, z1, z5 = a[0][0], a[0][1], a[0][2], a[1][0], a[1][1], a[1][2]
+
+    def fp4_sqr(x0, x1):
+        t0, t1 = x0.sqr(), x1.sqr()
+        return t0 + t1.xi(), ((x0 + x1).sqr() - t0) - t1
+
+    A0, A1 = fp4_sqr(z0, z1)
+    B0, B1 = fp4_sqr(z2, z3)
+    C0, C1 = fp4_sqr(z4, z5)
+    n0 = (A0 - z0).dbl() + A0
+    n1 = (A1 + z1).dbl() + A1
+    xc1 = C1.xi()
+    n2 = (xc1 + z2).dbl() + xc1
+    n3 = (C0 - z3).dbl() + C0
+    n4 = (B0 - z4).dbl() + B0
+    n5 = (B1 + z5).dbl() + B1
+    return [[n0, n4, n3], [n2, n1, n5]]
+
+
+def f12_mul_two_lines_d(f, l1, l2):
+    """f * (a1 + b1 w + c1 w^3) * (a2 + b2 w + c2 w^3), D-type twist (csrc/elp/tower.h fp12_mul_by_two_lines_inl)."""
+    a1, b1, c1 = l1
+    a2, b2, c2 = l2
+    taa, tbb, tcc = a1 * a2, b1 * b2, c1 * c2
+    tbc = (b1 + c1) * (b2 + c2)
+    tab = (a1 + b1) * (a2 + b2)
+    tac = (a1 + c1) * (a2 + c2)
+    L0 = [taa + tcc.xi(), tbb, (tbc - tbb) - tcc]
+    y0 = (tab - taa) - tbb
+    y1 = (tac - taa) - tcc
+    L1s = [L0[0] + y0, L0[1] + y1, L0[2]]
+    t0 = f6_mul(f[0], L0)
+    t1 = f6_mul_01(f[1], y0, y1)
+    t2 = f6_mul(f6_add(f[0], f[1]), L1s)
+    return [f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(t2, t0), t1)]
+
+
+def f12_mul_line_d(f, l):
+    a, b, c = l
+    t0 = f6_mul_fp2(f[0], a)
+    t1 = f6_mul_01(f[1], b, c)
+    t2 = f6_mul_01(f6_add(f[0], f[1]), a + b, c)
+    return [f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(t2, t0), t1)]
+
+
+def ml_dbl_step(T):
+    """Tangent at T (homogeneous projective) and T <- 2T; returns the un-evaluated line (a: times y_P, b: times x_P, c)."""
+    X, Y, Z = T
+    A = (X * Y).mulc("inv2")
+    B, Cz = Y.sqr(), Z.sqr()
+    E = Cz.mulc("twist_3b")
+    Fq = E.tpl()
+    G = (B + Fq).mulc("inv2")
+    H = ((Y + Z).sqr() - B) - Cz
+    J = X.sqr()
+    la, lb, lc = H, -(J.tpl()), B - E
+    X3 = A * (B - Fq)
+    Y3 = G.sqr() - E.sqr().tpl()
+    Z3 = B * H
+    return [X3, Y3, Z3], (la, lb, lc)
+
+
+def ml_add_step(T, xq, yq):
+    X, Y, Z = T
+    theta = Y - (yq * Z)
+    mu = X - (xq * Z)
+    la, lb = mu, -theta
+    lc = (theta * xq) - (mu * yq)
+    Cc, D = theta.sqr(), mu.sqr()
+    E = mu * D
+    Fq = Z * Cc
+    G = X * D
+    H = (E + Fq) - G.dbl()
+    X3 = mu * H
+    Y3 = (theta * (G - H)) - (E * Y)
+    Z3 = Z * E
+    return [X3, Y3, Z3], (la, lb, lc)
+
+
+def eval_line(l, P):             # P = packed (x_P, y_P) in one register: a * y_P, b * x_P, c
+    return (l[0].muls(P, 1), l[1].muls(P, 0), l[2])
+
+
+def fixed_line(p, n, P):         # precomputed line n of the fixed argument, evaluated at P
+    l = (p.ldl(3 * n), p.ldl(3 * n + 1), p.ldl(3 * n + 2))
+    return eval_line(l, P)
+
+
+def f12_pow_z(a, zabs, negz):
+    acc = a
+    for bit in bin(zabs)[3:]:
+        acc = f12_cyc_sqr(acc)
+        if bit == "1":
+            acc = f12_mul(acc, a)
+    return f12_conj(acc) if negz else acc
+
+
+def f12_hold(a):
+    """Values that live long are held as six registers, not as the (up to 18) products their coefficients are linear combinations of."""
+    return [[x.p.base(x.mat()) for x in a[0]], [x.p.base(x.mat()) for x in a[1]]]
+
+
+def final_exp_bn(f, cv):
+    f = f12_hold(f)
+    t0 = f12_inv(f)
+    f = f12_mul(f12_conj(f), t0)
+    f = f12_hold(f12_mul(f12_frob(f, 2), f))
+    zabs, negz = abs(cv.z), cv.z < 0
+    fz = f12_hold(f12_pow_z(f, zabs, negz))
+    fz2 = f12_hold(f12_pow_z(fz, zabs, negz))
+    fz3 = f12_hold(f12_pow_z(fz2, zabs, negz))
+    y0 = f12_mul(f12_mul(f12_frob(f, 1), f12_frob(f, 2)), f12_frob(f, 3))
+    y1 = f12_conj(f)
+    y2 = f12_frob(fz2, 2)
+    y3 = f12_conj(f12_frob(fz, 1))
+    y4 = f12_conj(f12_mul(fz, f12_frob(fz2, 1)))
+    y5 = f12_conj(fz2)
+    y6 = f12_conj(f12_mul(fz3, f12_frob(fz3, 1)))
+    T0 = f12_mul(f12_mul(f12_cyc_sqr(y6), y4), y5)
+    T1 = f12_mul(f12_mul(y3, y5), T0)
+    T0 = f12_mul(T0, y2)
+    T1 = f12_cyc_sqr(f12_mul(f12_cyc_sqr(T1), T0))
+    T0 = f12_mul(T1, y1)
+    T1 = f12_mul(T1, y0)
+    return f12_mul(f12_cyc_sqr(T0), T1)
+
+
+# input slots of the programs (the kernel fills these registers before running)
+IN_P1, IN_P2, IN_QX, IN_QY, IN_ONE = 0, 1, 2, 3, 4
+IN_F0 = 5                        # .. IN_F0 + 5: the Fp12 value F of the aggregated tail (c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2)
+
+
+def trace_check(cv, variable_pair=True):
+    """variable_pair: [f_Q(P1) f_gg(P2)]^e;  else: [F f_gg(P2)]^e.  Returns (prog, outputs = the 6 coefficients of the result)."""
+    p = Prog()
+    P2 = p.input(IN_P2)
+    one = p.input(IN_ONE)
+    dig = list(reversed(naf(cv.ate_loop)[:-1]))
+    f = None
+    n = 0
+    if variable_pair:
+        P1, qx, qy = p.input(IN_P1), p.input(IN_QX), p.input(IN_QY)
+        nqy = -qy
+        T = [qx, qy, one]
+    for i, d in enumerate(dig):
+        if f is not None:
+            f = f12_sqr(f)
+        steps = [0] + ([1] if d != 0 else [])
+        for half in steps:
+            lf = fixed_line(p, n, P2)
+            n += 1
+            if variable_pair:
+                if half == 0:
+                    T, l = ml_dbl_step(T)
+                else:
+                    T, l = ml_add_step(T, qx, qy if d > 0 else nqy)
+                lv = eval_line(l, P1)
+                if f is None:
+                    # f = 1: the product of the two lines itself (the same six products, no pass over f)
+                    zero = one - one
+                    f = f12_mul_two_lines_d([[one, zero, zero], [zero, zero, zero]], lv, lf)
+                else:
+                    f = f12_mul_two_lines_d(f, lv, lf)
+            else:
+                if f is None:
+                    zero = one - one
+                    f = [[lf[0], zero, zero], [lf[1], lf[2], zero]]
+                else:
+                    f = f12_mul_line_d(f, lf)
+    if cv.z < 0:
+        f = f12_conj(f)
+    if cv.is_bn:
+        if variable_pair:
+            T = [T[0], -T[1], T[2]] if cv.z < 0 else T
+            q1x, q1y = qx.conj().mulc("g2frob1_x"), qy.conj().mulc("g2frob1_y")
+            q2x, q2y = qx.mulc("g2frob2_x"), -(qy.mulc("g2frob2_y"))
+            T, l = ml_add_step(T, q1x, q1y)
+            f = f12_mul_two_lines_d(f, eval_line(l, P1), fixed_line(p, n, P2))
+            T, l = ml_add_step(T, q2x, q2y)
+            f = f12_mul_two_lines_d(f, eval_line(l, P1), fixed_line(p, n + 1, P2))
+        else:
+            f = f12_mul_line_d(f, fixed_line(p, n, P2))
+            f = f12_mul_line_d(f, fixed_line(p, n + 1, P2))
+        n += 2
+    if not variable_pair:
+        Fin = [[p.input(IN_F0 + 0), p.input(IN_F0 + 1), p.input(IN_F0 + 2)], [p.input(IN_F0 + 3), p.input(IN_F0 + 4), p.input(IN_F0 + 5)]]
+        f = f12_mul(f, Fin)
+    p.fe_start = len(p.ops)          # everything traced from here on belongs to the final exponentiation (scheduled as late as possible)
+    r = final_exp_bn(f, cv)
+    return p, [x.mat() for x in (r[0][0], r[0][1], r[0][2], r[1][0], r[1][1], r[1][2])], n
+
+
+# ---- dead-code elimination, scheduling into levels, register allocation
+def srcs(op):
+    o, a, b, aux = op
+    if o == LIN:
+        return [k for k, _ in aux]
+    return [x for x in (a, b) if x >= 0]
+
+
+def schedule(prog, outs, ninputs):
+    ops = prog.ops
+    live = [False] * len(ops)
+    stack = list(outs)
+    while stack:
+        i = stack.pop()
+        if live[i]:
+            continue
+        live[i] = True
+        stack.extend(srcs(ops[i]))
+    # ASAP levels; a level holds one class only: lin-class operations on even levels, products on odd ones
+    level = [0] * len(ops)
+    for i, op in enumerate(ops):
+        if not live[i]:
+            continue
+        if op[0] == INPUT:
+            level[i] = -1
+            continue
+        lv = 0
+        for s_ in srcs(op):
+            if ops[s_][0] != INPUT:
+                lv = max(lv, level[s_] + 1)
+        want_mul = 1 if op[0] in MULCLASS else 0
+        if (lv & 1) != want_mul:
+            lv += 1
+        level[i] = lv
+    nlev = max(level) + 1
+    # ALAP: every operation as late as its consumers allow (an ASAP schedule would issue all the line loads and everything else that only depends
+    # on the inputs at once and hold hundreds of registers); the critical path, hence the number of levels, is unchanged
+    users = [[] for _ in ops]
+    for i, op in enumerate(ops):
+        if live[i]:
+            for s_ in srcs(op):
+                users[s_].append(i)
+    outset = set(outs)
+    free_op = [False] * len(ops)       # loads of the fixed lines and what is computed from them and the inputs alone (their evaluation at P2)
+    for i, op in enumerate(ops):
+        if live[i] and op[0] != INPUT:
+            ss = srcs(op)
+            free_op[i] = op[0] == LDL or (any(free_op[s_] for s_ in ss) and all(free_op[s_] or ops[s_][0] == INPUT for s_ in ss))
+    for i in range(len(ops) - 1, -1, -1):
+        if not live[i] or ops[i][0] == INPUT:
+            continue
+        # ... but only the loads of the fixed lines and their evaluation at P2: they are wanted just in time.  Everything else stays as early as
+        # possible, so that the two chains of the Miller loop (the point T and the value f) advance together and lines are consumed at once.
+        # The final exponentiation is one chain with side computations hanging off it (Frobenius images, the y_i of the addition chain): those are
+        # computed when they are needed, not when they become possible.
+        if not free_op[i] and i < getattr(prog, "fe_start", len(ops)):
+            continue
+        want_mul = 1 if ops[i][0] in MULCLASS else 0
+        lim = nlev - 1 if (i in outset or not users[i]) else min(level[u] for u in users[i]) - 1
+        if (lim & 1) != want_mul:
+            lim -= 1
+        assert lim >= level[i], (i, lim, level[i])
+        level[i] = lim
+    by_level = [[] for _ in range(nlev)]
+    for i in range(len(ops)):
+        if live[i] and ops[i][0] != INPUT:
+            by_level[level[i]].append(i)
+    # split levels wider than NP into rounds (each round is one barrier-separated step of the kernel)
+    steps = []
+    for lv, lst in enumerate(by_level):
+        nr = (len(lst) + NP - 1) // NP
+        for k in range(nr):                              # balanced rounds
+            steps.append((lv & 1, lst[k::nr]))
+    step_of = {}
+    for si, (_, lst) in enumerate(steps):
+        for i in lst:
+            step_of[i] = si
+    # last use (in steps) of every value
+    last = {}
+    for i in range(len(ops)):
+        if not live[i] or ops[i][0] == INPUT:
+            continue
+        for s_ in srcs(ops[i]):
+            last[s_] = max(last.get(s_, -1), step_of[i])
+    for o in outs:
+        last[o] = len(steps) + 1
+    # registers: inputs are pinned to their slots for the whole program; values get a register at their step and release it after the
+    # step of their last use (a register freed in step s is reusable from step s + 1 on)
+    reg = {}
+    free = list(range(NREG - 1, ninputs - 1, -1))
+    for i in range(len(ops)):
+        if ops[i][0] == INPUT:
+            reg[i] = ops[i][3]
+    release = [[] for _ in range(len(steps) + 3)]
+    peak = 0
+    for si, (_, lst) in enumerate(steps):
+        for i in lst:
+            if not free:
+                import collections
+                livev = [j for j in reg if ops[j][0] != INPUT and step_of.get(j, 10**9) <= si and last.get(j, -1) >= si]
+                ex = sorted(livev, key=lambda j: step_of[j] - last[j])[:12]
+                for j in ex[:4]:
+                    print("  value %d %s level %d step %d last-use step %d" % (j, NAMES[ops[j][0]], level[j], step_of[j], last[j]), file=sys.stderr)
+                    for u in users[j]:
+                        print("      user %d %s level %d free=%s nterms=%s" % (u, NAMES[ops[u][0]], level[u], free_op[u], len(ops[u][3]) if ops[u][0] == LIN else "-"), file=sys.stderr)
+                hist = collections.Counter((NAMES[ops[j][0]], min(60, (last[j] - step_of[j]) // 10 * 10)) for j in livev)
+                raise RuntimeError("out of LDS registers at step %d; live values by (op, lifetime in steps): %s" % (si, sorted(hist.items())))
+            reg[i] = free.pop()
+            peak = max(peak, NREG - ninputs - len(free))
+            release[min(last.get(i, si), len(steps) + 1)].append(reg[i])
+        for r in release[si]:
+            free.append(r)
+    return steps, reg, list(outs), peak
+
+
+def encode(ops, steps, reg):
+    """Two 32-bit words per (step, slot):  word 0 = op:4 | dst:8 | a:8 | b:8 | aux:4  (LDL / MULC carry their index in b:aux, 12 bits); a LIN descriptor is
+    word 0 = op:4 | dst:8 | nterms:20, word 1 = offset into the term table, one word per term:  reg:8 | m00:4 | m01:4 | m10:4 | m11:4 (two's complement
+    nibbles);  NOP = 0xF."""
+    words, terms = [], []
+    for cls, lst in steps:
+        row = []
+        for i in lst:
+            op, a, b, aux = ops[i]
+            if op == LIN:
+                off = len(terms)
+                assert off < (1 << 20) - 64
+                for k, m in aux:
+                    terms.append((reg[k] << 16) | ((m[0] & 15) << 12) | ((m[1] & 15) << 8) | ((m[2] & 15) << 4) | (m[3] & 15))
+                row += [(op << 28) | (reg[i] << 20) | len(aux), off]
+                continue
+            ra = reg[a] if a >= 0 else 0
+            rb = reg[b] if b >= 0 else 0
+            x = 0
+            if op in (LDL, MULC):
+                rb, x = (aux >> 4) & 0xFF, aux & 0xF
+            elif op == MULS:
+                x = aux
+            row += [(op << 28) | (reg[i] << 20) | (ra << 12) | (rb << 4) | x, 0]
+        row += [0xF0000000, 0] * (NP - len(row) // 2)
+        words.append(row)
+    return words, terms
+
+
+# ---- numeric execution of the SCHEDULED program in Python (validation of tracing + scheduling + register allocation against the model)
+def run_numeric(cv, ops, steps, reg, inputs, lines, consts):
+    G = Groups(cv)
+    F = G.F
+    p = cv.p
+    R = [None] * NREG
+    for slot, v in inputs.items():
+        R[slot] = v
+    for cls, lst in steps:
+        res = []
+        for i in lst:
+            op, a, b, aux = ops[i]
+            A = R[reg[a]] if a >= 0 else None
+            B = R[reg[b]] if b >= 0 else None
+            if op == MUL:
+                v = F.f2_mul(A, B)
+            elif op == MULC:
+                v = F.f2_mul(A, consts[aux])
+            elif op == MULS:
+                v = F.f2_muls(A, B[aux])
+            elif op == LIN:
+                x = y = 0
+                for k, m in aux:
+                    t = R[reg[k]]
+                    x += m[0] * t[0] + m[1] * t[1]
+                    y += m[2] * t[0] + m[3] * t[1]
+                v = (x % p, y % p)
+            elif op == LDL:
+                v = lines[aux]
+            elif op == INV:
+                assert A[1] == 0
+                v = (pow(A[0], -1, p) if A[0] else 0, 0)
+            else:
+                raise RuntimeError(op)
+            res.append((reg[i], v))
+        for r_, v in res:          # all reads of a step happen before its writes
+            R[r_] = v
+    return R
+
+
+def model_lines(cv, Q):
+    """The un-evaluated lines (a, b, c) of the fixed argument in the order the kernels consume them (csrc/elp/pairing.h ml_precompute), as field values."""
+    G = Groups(cv)
+    F = G.F
+    inv2 = pow(2, -1, cv.p)
+    b3 = F.f2_muls(F.b2, 3)
+
+    def dbl(T):
+        X, Y, Z = T
+        A = F.f2_muls(F.f2_mul(X, Y), inv2)
+        B, Cz = F.f2_sqr(Y), F.f2_sqr(Z)
+        E = F.f2_mul(Cz, b3)
+        Fq = F.f2_muls(E, 3)
+        Gv = F.f2_muls(F.f2_add(B, Fq), inv2)
+        H = F.f2_sub(F.f2_sub(F.f2_sqr(F.f2_add(Y, Z)), B), Cz)
+        J = F.f2_sqr(X)
+        l = (H, F.f2_neg(F.f2_muls(J, 3)), F.f2_sub(B, E))
+        X3 = F.f2_mul(A, F.f2_sub(B, Fq))
+        Y3 = F.f2_sub(F.f2_sqr(Gv), F.f2_muls(F.f2_sqr(E), 3))
+        Z3 = F.f2_mul(B, H)
+        return (X3, Y3, Z3), l
+
+    def add(T, xq, yq):
+        X, Y, Z = T
+        theta = F.f2_sub(Y, F.f2_mul(yq, Z))
+        mu = F.f2_sub(X, F.f2_mul(xq, Z))
+        l = (mu, F.f2_neg(theta), F.f2_sub(F.f2_mul(theta, xq), F.f2_mul(mu, yq)))
+        Cc, D = F.f2_sqr(theta), F.f2_sqr(mu)
+        E = F.f2_mul(mu, D)
+        Fq = F.f2_mul(Z, Cc)
+        Gv = F.f2_mul(X, D)
+        H = F.f2_sub(F.f2_add(E, Fq), F.f2_add(Gv, Gv))
+        X3 = F.f2_mul(mu, H)
+        Y3 = F.f2_sub(F.f2_mul(theta, F.f2_sub(Gv, H)), F.f2_mul(E, Y))
+        Z3 = F.f2_mul(Z, E)
+        return (X3, Y3, Z3), l
+
+    out = []
+    T = (Q[0], Q[1], (1, 0))
+    nqy = F.f2_neg(Q[1])
+    for d in reversed(naf(cv.ate_loop)[:-1]):
+        T, l = dbl(T)
+        out.append(l)
+        if d:
+            T, l = add(T, Q[0], Q[1] if d > 0 else nqy)
+            out.append(l)
+    if cv.is_bn:
+        if cv.z < 0:
+            T = (T[0], F.f2_neg(T[1]), T[2])
+        Q1 = G.g2_frob(Q)
+        Q2 = G.g2_neg(G.g2_frob(Q1))
+        T, l = add(T, Q1[0], Q1[1])
+        out.append(l)
+        T, l = add(T, Q2[0], Q2[1])
+        out.append(l)
+    flat = []
+    for l in out:
+        flat += list(l)
+    return flat
+
+
+def const_values(cv):
+    G = Groups(cv)
+    F = G.F
+    p = cv.p
+    vals = {"inv2": (pow(2, -1, p), 0), "twist_3b": F.f2_muls(F.b2, 3)}
+    for n in (1, 2, 3):
+        for k in range(1, 6):
+            vals["frob%d_%d" % (n, k)] = F.f2_pow(cv.xi, k * (p**n - 1) // 6)
+        gx, gy = F.f2_pow(cv.xi, 2 * (p**n - 1) // 6), F.f2_pow(cv.xi, 3 * (p**n - 1) // 6)
+        if cv.twist != "D":
+            gx, gy = F.f2_inv(gx), F.f2_inv(gy)
+        vals["g2frob%d_x" % n], vals["g2frob%d_y" % n] = gx, gy
+    return vals
+
+
+def validate(cv):
+    """The scheduled programs, executed numerically, against the model's pairing (value of e(P1, Q) e(P2, gg), bit for bit)."""
+    M = Mcl(cv)
+    G = M.G
+    F = G.F
+    cvals = const_values(cv)
+    g1 = M.hash_to_g1("abc")
+    gg = G.g2_mul(_bn_g2(cv), 7)
+    Q = G.g2_mul(gg, 123456789)
+    P1, P2 = G.g1_mul(g1, 424242), G.g1_mul(g1, 171717)
+    lines = model_lines(cv, gg)
+    want = F.f12_mul(G.pairing(P1, Q), G.pairing(P2, gg))
+    res = {}
+    for name, variable in (("check", True), ("tail", False)):
+        prog, outs, nlines = trace_check(cv, variable)
+        assert 3 * nlines == len(lines)
+        steps, reg, outs_c, peak = schedule(prog, outs, IN_F0 + 6)
+        consts = [None] * len(CONSTS)
+        for k, v in CONSTS.items():
+            consts[v] = cvals[k]
+        inputs = {IN_P2: (P2[0], P2[1]), IN_ONE: (1, 0)}
+        if variable:
+            inputs.update({IN_P1: (P1[0], P1[1]), IN_QX: Q[0], IN_QY: Q[1]})
+        else:
+            fm = G.miller_loop(P1, Q)           # the tail multiplies a given Miller value in
+            order = [0, 2, 4, 1, 3, 5]          # model coefficient of w^k -> (c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2)
+            for j, k in enumerate(order):
+                inputs[IN_F0 + j] = fm[k]
+        R = run_numeric(cv, prog.ops, steps, reg, inputs, lines, consts)
+        got = [R[reg[o]] for o in outs_c]
+        exp = [want[k] for k in [0, 2, 4, 1, 3, 5]]
+        assert got == exp, "%s: the scheduled program does not reproduce the model's pairing value" % name
+        nmul = sum(len(l) for c, l in steps if c == 1)
+        nlin = sum(len(l) for c, l in steps if c == 0)
+        res[name] = (prog, steps, reg, outs_c, peak, nmul, nlin)
+        print("%s: %d mul ops in %d mul steps, %d lin ops in %d lin steps, peak %d registers (+%d inputs), %d fixed lines" %
+              (name, nmul, sum(1 for c, _ in steps if c == 1), nlin, sum(1 for c, _ in steps if c == 0), peak, IN_F0 + 6, nlines), file=sys.stderr)
+    return res
+
+
+def _bn_g2(cv):
+    """Some point of the order-r subgroup of the twist (deterministic): hash x until on the curve, clear the cofactor."""
+    G = Groups(cv)
+    F = G.F
+    x0 = 1
+    while True:
+        x = (x0, 1)
+        rhs = F.f2_add(F.f2_mul(F.f2_sqr(x), x), F.b2)
+        y = F.f2_sqrt(rhs)
+        if y is not None:
+            cof = (cv.p**2 + 1 - (cv.p + 1 - (6 * cv.z * cv.z + 1)) ** 2 + 2 * cv.p)  # placeholder, replaced below
+            break
+        x0 += 1
+    # order of the twist: #E'(Fp2) = p^2 + 1 - t2 with the twisted trace; simpler: multiply by (#E'/r) computed from the known formula for BN: 2p - r
+    h2 = 2 * cv.p - cv.r
+    Qp = (x, y)
+    R = None
+    for bit in bin(h2)[2:]:
+        R = G.g2_add(R, R)
+        if bit == "1":
+            R = G.g2_add(R, Qp)
+    assert R is not None and G.g2_mul(R, cv.r - 1) == G.g2_neg(R)
+    return R
+
+
+def emit_header(res, path, cvname):
+    out = []
+    A = out.append
+    A("// GENERATED by tools/gen_coop.py -- do not edit.  Level-scheduled Fp2 programs of the cooperative pairing kernels (csrc/elp/coop.h).")
+    A("// Each step holds COOP_NP descriptors of two words (one descriptor per lane pair of an item):  op:4 | dst:8 | a:8 | b:8 | aux:4 , 0   (LIN: op:4 | dst:8 | nterms:20 , term offset;")
+    A("// term = reg:8 | four signed nibbles of the 2x2 matrix acting on (re, im)).  *_CLASS: 1 = every slot of the step is an Fp2 product, 0 = linear class.")
+    A("#pragma once")
+    A("#include <stdint.h>")
+    A("#ifndef ELP_COOP_TABLE")
+    A("#define ELP_COOP_TABLE static   /* the device build of csrc/elpasso_*_coop.hip defines it as static __device__ */")
+    A("#endif")
+    A("namespace elp {")
+    A("namespace coop_%s {" % cvname)
+    A("constexpr int COOP_NP = %d;" % NP)
+    A("constexpr int COOP_NREG = %d;" % NREG)
+    A("enum { OP_MUL = %d, OP_MULC = %d, OP_MULS = %d, OP_LIN = %d, OP_LDL = %d, OP_INV = %d, OP_NOP = 15 };" % (MUL, MULC, MULS, LIN, LDL, INV))
+    A("enum { IN_P1 = %d, IN_P2 = %d, IN_QX = %d, IN_QY = %d, IN_ONE = %d, IN_F0 = %d };" % (IN_P1, IN_P2, IN_QX, IN_QY, IN_ONE, IN_F0))
+    A("constexpr int COOP_NCONST = %d;" % len(CONSTS))
+    A("// constants of the MULC operations: kind 0 = 1/2, 1 = 3 b' (twist), 2 = Frobenius coefficient gamma_{n,k} of Fp12, 3 = coefficient of psi^n on G2 (k = 0: x, 1: y)")
+    kinds = []
+    for name, cid in sorted(CONSTS.items(), key=lambda kv: kv[1]):
+        if name == "inv2":
+            kinds.append((0, 0, 0))
+        elif name == "twist_3b":
+            kinds.append((1, 0, 0))
+        elif name.startswith("frob"):
+            n_, k_ = name[4:].split("_")
+            kinds.append((2, int(n_), int(k_)))
+        else:
+            n_, w_ = name[6:].split("_")
+            kinds.append((3, int(n_), 0 if w_ == "x" else 1))
+    A("ELP_COOP_TABLE const uint8_t CONST_KIND[%d][3] = {%s};" % (len(kinds), ",".join("{%d,%d,%d}" % k for k in kinds)))
+    for name, (prog, steps, reg, outs_c, peak, nmul, nlin) in res.items():
+        words, terms = encode(prog.ops, steps, reg)
+        U = name.upper()
+        A("// %s: %d steps (%d products, %d linear-class operations, %d terms), peak %d registers" % (name, len(steps), nmul, nlin, len(terms), peak))
+        A("constexpr int %s_NSTEPS = %d;" % (U, len(steps)))
+        A("constexpr int %s_NTERMS = %d;" % (U, len(terms)))
+        A("constexpr int %s_OUT[6] = {%s};" % (U, ", ".join(str(reg[o]) for o in outs_c)))
+        A("ELP_COOP_TABLE const uint8_t %s_CLASS[%d] = {%s};" % (U, len(steps), ",".join(str(c) for c, _ in steps)))
+        A("ELP_COOP_TABLE const uint32_t %s_PROG[%d] = {" % (U, len(steps) * NP * 2))
+        for row in words:
+            A("  " + ",".join("0x%08xu" % w for w in row) + ",")
+        A("};")
+        A("ELP_COOP_TABLE const uint32_t %s_TERMS[%d] = {" % (U, max(1, len(terms))))
+        for k in range(0, len(terms), 16):
+            A("  " + ",".join("0x%08xu" % w for w in terms[k:k + 16]) + ",")
+        if not terms:
+            A("  0")
+        A("};")
+    A("}  // namespace coop_%s" % cvname)
+    A("}  // namespace elp")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    sys.setrecursionlimit(100000)
+    res = validate(BN254)
+    emit_header(res, os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bn254.h"), "bn254")
+    print("written", file=sys.stderr)
