@@ -21,7 +21,18 @@ struct CoopProg {        // one scheduled program (device pointers on the device
   const u32* terms;      // term table of the LIN operations
   int nsteps;
   int out[6];            // registers of the result (c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2)
+  const u32* chunk_off = nullptr;   // first term of every chunk of COOP_CHUNK steps (+ end): the kernels stage descriptors and terms through LDS chunk by chunk
 };
+
+// The register file and the staged program live in LDS: on the device the interpreter takes LDS-address-space pointers, so that every access is a DS
+// instruction (through generic pointers they become FLAT loads: measured 53 % of the kernel's wave-cycles waiting on them)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) i32 coop_i32;
+typedef __attribute__((address_space(3))) u32 coop_u32;
+#else
+typedef i32 coop_i32;
+typedef u32 coop_u32;
+#endif
 
 enum { COOP_OP_MUL = 0, COOP_OP_MULC = 1, COOP_OP_MULS = 2, COOP_OP_LIN = 3, COOP_OP_LDL = 4, COOP_OP_INV = 5, COOP_OP_NOP = 15 };
 
@@ -29,16 +40,16 @@ enum { COOP_OP_MUL = 0, COOP_OP_MULC = 1, COOP_OP_MULS = 2, COOP_OP_LIN = 3, COO
 template <class C>
 ELP_HD constexpr int coop_reg_words() { return 2 * C::NL; }
 template <class C>
-ELP_INL Fp<C> coop_ld(const i32* R, int reg, int comp) {
+ELP_INL Fp<C> coop_ld(const coop_i32* R, int reg, int comp) {
   Fp<C> r;
-  const i32* p = R + (reg * 2 + comp) * C::NL;
+  const coop_i32* p = R + (reg * 2 + comp) * C::NL;
   ELP_UNROLL
   for (int i = 0; i < C::NL; i++) r.v[i] = p[i];
   return r;
 }
 template <class C>
-ELP_INL void coop_st(i32* R, int reg, int comp, const Fp<C>& a) {
-  i32* p = R + (reg * 2 + comp) * C::NL;
+ELP_INL void coop_st(coop_i32* R, int reg, int comp, const Fp<C>& a) {
+  coop_i32* p = R + (reg * 2 + comp) * C::NL;
   ELP_UNROLL
   for (int i = 0; i < C::NL; i++) p[i] = a.v[i];
 }
@@ -93,9 +104,18 @@ ELP_HEAVY Fp<C> coop_const(const uint8_t (*kind)[3], int id, int comp) {
 // One slot of one step for the lane of parity `comp`: computes the component `comp` of the slot's result.  Returns the destination register or -1
 // (empty slot).  `consts`: COOP_NCONST Fp2 values in the plain layout (c0 | c1); `lines`: the precomputed lines of the fixed argument as a flat
 // array of Fp2 (a, b, c per line; stored un-carried by ml_precompute, carried here).
+// (inlined into the kernels' step loop: as a call, the result would travel through the lane's private memory -- a global-memory round trip per step)
 template <class C>
-ELP_HEAVY int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, const i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out) {
-  const u32 d0 = P.prog[((size_t)step * 16 + slot) * 2], d1 = P.prog[((size_t)step * 16 + slot) * 2 + 1];
+ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out);
+#if !defined(__HIP_DEVICE_COMPILE__)
+template <class C>
+ELP_INL int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, const i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out) {
+  return coop_exec_desc<C>(P.prog[((size_t)step * 16 + slot) * 2], P.prog[((size_t)step * 16 + slot) * 2 + 1], P.terms, comp, R, consts, lines, out);
+}
+#endif
+// the same from the two descriptor words; `terms[d1 + t]` must be term t of a LIN descriptor (the kernels pass a pointer into their LDS copy of the chunk)
+template <class C>
+ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out) {
   const int op = (int)(d0 >> 28);
   if (op == COOP_OP_NOP) return -1;
   const int dst = (int)((d0 >> 20) & 255);
@@ -124,21 +144,26 @@ ELP_HEAVY int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, co
     const int nt = (int)(d0 & 0xFFFFF);
     i64 acc[C::NL];
     for (int i = 0; i < C::NL; i++) acc[i] = 0;
+    const int sh = comp ? 0 : 8;                  // row of the matrix that produces this lane's component: (m00 m01) or (m10 m11)
+    // four terms per round: the term words first, then all their operands (unconditionally: a zero coefficient costs nothing but the load), then the
+    // multiply-adds -- two LDS round trips per FOUR terms instead of two per term (a lone wave has nothing else to hide them behind)
     ELP_NOUNROLL
-    for (int t = 0; t < nt; t++) {
-      const u32 tw = P.terms[d1 + t];
-      const int r = (int)((tw >> 16) & 255);
-      const int sh = comp ? 0 : 8;                // row of the matrix that produces this lane's component: (m00 m01) or (m10 m11)
-      const i32 c0 = ((i32)((tw >> (sh + 4)) << 28)) >> 28, c1 = ((i32)((tw >> sh) << 28)) >> 28;
-      if (c0 != 0) {
-        const Fp<C> v = coop_ld<C>(R, r, 0);
-        ELP_UNROLL
-        for (int i = 0; i < C::NL; i++) acc[i] += (i64)c0 * v.v[i];
+    for (int t = 0; t < nt; t += 4) {
+      u32 tw[4];
+      ELP_UNROLL
+      for (int q = 0; q < 4; q++) tw[q] = (t + q < nt) ? terms[d1 + t + q] : 0u;      // a zero word: register 0, coefficients 0
+      Fp<C> v0[4], v1[4];
+      ELP_UNROLL
+      for (int q = 0; q < 4; q++) {
+        const int r = (int)((tw[q] >> 16) & 255);
+        v0[q] = coop_ld<C>(R, r, 0);
+        v1[q] = coop_ld<C>(R, r, 1);
       }
-      if (c1 != 0) {
-        const Fp<C> v = coop_ld<C>(R, r, 1);
+      ELP_UNROLL
+      for (int q = 0; q < 4; q++) {
+        const i32 c0 = ((i32)((tw[q] >> (sh + 4)) << 28)) >> 28, c1 = ((i32)((tw[q] >> sh) << 28)) >> 28;
         ELP_UNROLL
-        for (int i = 0; i < C::NL; i++) acc[i] += (i64)c1 * v.v[i];
+        for (int i = 0; i < C::NL; i++) acc[i] += (i64)c0 * v0[q].v[i] + (i64)c1 * v1[q].v[i];
       }
     }
     out = coop_lin_finish<C>(acc);

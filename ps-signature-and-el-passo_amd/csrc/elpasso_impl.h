@@ -235,12 +235,14 @@ template <>
 struct CoopTables<BN254> {
   static __device__ __forceinline__ CoopProg check() {
     using namespace elp::coop_bn254;
-    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}};
+    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}, CHECK_CHUNK_OFF};
   }
   static __device__ __forceinline__ CoopProg tail() {
     using namespace elp::coop_bn254;
-    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}};
+    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}, TAIL_CHUNK_OFF};
   }
+  static constexpr int CHUNK = elp::coop_bn254::COOP_CHUNK;
+  static constexpr int MAX_CHUNK_TERMS = elp::coop_bn254::CHECK_MAX_CHUNK_TERMS > elp::coop_bn254::TAIL_MAX_CHUNK_TERMS ? elp::coop_bn254::CHECK_MAX_CHUNK_TERMS : elp::coop_bn254::TAIL_MAX_CHUNK_TERMS;
   static constexpr int NREG = elp::coop_bn254::COOP_NREG, NP = elp::coop_bn254::COOP_NP, NCONST = elp::coop_bn254::COOP_NCONST;
   static constexpr int IN_P1 = elp::coop_bn254::IN_P1, IN_P2 = elp::coop_bn254::IN_P2, IN_QX = elp::coop_bn254::IN_QX, IN_QY = elp::coop_bn254::IN_QY,
                        IN_ONE = elp::coop_bn254::IN_ONE, IN_F0 = elp::coop_bn254::IN_F0;
@@ -254,21 +256,35 @@ __global__ void ELP_LAUNCH_BOUNDS k_coop_consts(Fp2<C>* out) {
   out[i].c1 = coop_const<C>(CoopTables<C>::kinds(), i, 1);
 }
 // runs program P over the register files of the workgroup's two items; every lane walks all steps (empty slots and inactive items idle)
+// The program itself (descriptors and the terms of the linear combinations) is staged through LDS in chunks of CHUNK steps by all 64 lanes with coalesced
+// loads: read straight from global memory every step would open with a dependent ~1 us load and every term of a combination with another.
 template <class C>
-__device__ __forceinline__ void coop_run_device(const CoopProg& P, i32* R, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines) {
+__device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines) {
+  typedef CoopTables<C> T;
+  constexpr int CH = T::CHUNK, DW = CH * 32;            // descriptor words per chunk (16 slots x 2 words per step)
+  coop_u32* const sd = stage;
+  coop_u32* const stt = stage + DW;
   ELP_NOUNROLL
-  for (int s = 0; s < P.nsteps; s++) {
-    if (active) {
-      Fp<C> out;
-      const int dst = coop_exec_slot<C>(P, s, pair, comp, R, consts, lines, out);
-      if (dst >= 0) coop_st<C>(R, dst, comp, out);     // the register allocation never lets a step write a register that the same step reads
-    }
+  for (int s0 = 0; s0 < P.nsteps; s0 += CH) {
+    const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
+    const u32 t0 = P.chunk_off[s0 / CH], t1 = P.chunk_off[s0 / CH + 1];
+    for (int k = (int)threadIdx.x; k < ns * 32; k += ELP_BLOCK) sd[k] = P.prog[(size_t)s0 * 32 + k];
+    for (u32 k = threadIdx.x; k < t1 - t0; k += ELP_BLOCK) stt[k] = P.terms[t0 + k];
     __syncthreads();
+    ELP_NOUNROLL
+    for (int s = 0; s < ns; s++) {
+      if (active) {
+        Fp<C> out;
+        const int dst = coop_exec_desc<C>(sd[s * 32 + pair * 2], sd[s * 32 + pair * 2 + 1], stt - t0, comp, R, consts, lines, out);
+        if (dst >= 0) coop_st<C>(R, dst, comp, out);     // the register allocation never lets a step write a register that the same step reads
+      }
+      __syncthreads();
+    }
   }
 }
 // is the Fp12 value in registers P.out[0..5] equal to 1?  (lane pair j < 6 tests coefficient j; result through LDS word `flagw`)
 template <class C>
-__device__ __forceinline__ bool coop_is_one(const CoopProg& P, i32* R, bool active, int pair, int comp, i32* flagw) {
+__device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool active, int pair, int comp, coop_i32* flagw) {
   if (pair == 0 && comp == 0) *flagw = 1;
   __syncthreads();
   if (active && pair < 6) {
@@ -286,10 +302,12 @@ __global__ void __launch_bounds__(ELP_BLOCK, 2) k_pair_coop(KeyCtx<C> key, const
                                                             size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n) {
   typedef CoopTables<C> T;
   constexpr int RW = T::NREG * 2 * C::NL;
-  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + 8];
+  constexpr int RPAD = 17;      // the two items run the same program in lockstep: without the offset every access of item 1 would hit the banks of item 0
+  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + RPAD + 8];
+  __shared__ __attribute__((aligned(16))) u32 stage[T::CHUNK * 32 + T::MAX_CHUNK_TERMS];
   const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
-  i32* R = Rall + slot * RW;
-  i32* flagw = Rall + 2 * RW + slot;            // [0..1]: is-one flags, [2..3]: "inputs usable"
+  coop_i32* R = (coop_i32*)Rall + slot * (RW + RPAD);
+  coop_i32* flagw = (coop_i32*)Rall + 2 * RW + RPAD + slot;            // [0..1]: is-one flags, [2..3]: "inputs usable"
   const size_t i = (size_t)blockIdx.x * 2 + slot;
   if (pair == 0 && comp == 0) {
     int usable = 0;
@@ -319,7 +337,7 @@ __global__ void __launch_bounds__(ELP_BLOCK, 2) k_pair_coop(KeyCtx<C> key, const
   __syncthreads();
   const bool active = flagw[2] != 0;
   const CoopProg P = T::check();
-  coop_run_device<C>(P, R, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
+  coop_run_device<C>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
   if (pair == 0 && comp == 0 && active) {
     flags[i] = one ? 1 : 0;
@@ -369,10 +387,12 @@ template <class C>
 __global__ void __launch_bounds__(ELP_BLOCK, 2) k_agg_final_coop(KeyCtx<C> key, const Fp2<C>* consts, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
   typedef CoopTables<C> T;
   constexpr int RW = T::NREG * 2 * C::NL;
-  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + 8];
+  constexpr int RPAD = 17;
+  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + RPAD + 8];
+  __shared__ __attribute__((aligned(16))) u32 stage[T::CHUNK * 32 + T::MAX_CHUNK_TERMS];
   const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
-  i32* R = Rall + slot * RW;
-  i32* flagw = Rall + 2 * RW + slot;
+  coop_i32* R = (coop_i32*)Rall + slot * (RW + RPAD);
+  coop_i32* flagw = (coop_i32*)Rall + 2 * RW + RPAD + slot;
   if (pair == 0 && comp == 0) {
     int state = 0;                                  // 0: run the program, 1: verdict is "false" (bad point)
     if (slot == 0) {
@@ -395,7 +415,7 @@ __global__ void __launch_bounds__(ELP_BLOCK, 2) k_agg_final_coop(KeyCtx<C> key, 
   __syncthreads();
   const bool active = flagw[2] != 0;
   const CoopProg P = T::tail();
-  coop_run_device<C>(P, R, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
+  coop_run_device<C>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
   if (threadIdx.x == 0) *agg_ok = (active && one) ? 1 : 0;
 }

@@ -39,6 +39,7 @@ def naf(k):      # non-adjacent form, least significant digit first (as tools/ge
 
 
 NP = 16            # lane pairs per item
+CHUNK = 16         # steps per program chunk staged through LDS by the kernels
 NREG = 128         # Fp2 registers per item in LDS
 
 # ---- operations (SSA).  mul-class: MUL (a*b), MULC (a * constant[c]), MULS (a * Fp scalar = component `sel` of register b)
@@ -807,6 +808,7 @@ def emit_header(res, path, cvname):
     A("namespace coop_%s {" % cvname)
     A("constexpr int COOP_NP = %d;" % NP)
     A("constexpr int COOP_NREG = %d;" % NREG)
+    A("constexpr int COOP_CHUNK = %d;" % CHUNK)
     A("enum { OP_MUL = %d, OP_MULC = %d, OP_MULS = %d, OP_LIN = %d, OP_LDL = %d, OP_INV = %d, OP_NOP = 15 };" % (MUL, MULC, MULS, LIN, LDL, INV))
     A("enum { IN_P1 = %d, IN_P2 = %d, IN_QX = %d, IN_QY = %d, IN_ONE = %d, IN_F0 = %d };" % (IN_P1, IN_P2, IN_QX, IN_QY, IN_ONE, IN_F0))
     A("constexpr int COOP_NCONST = %d;" % len(CONSTS))
@@ -836,6 +838,17 @@ def emit_header(res, path, cvname):
         for row in words:
             A("  " + ",".join("0x%08xu" % w for w in row) + ",")
         A("};")
+        # the kernels stage the program through LDS in chunks of COOP_CHUNK steps: first term of every chunk (+ end)
+        offs, cnt = [], 0
+        for si, (cls, lst) in enumerate(steps):
+            if si % CHUNK == 0:
+                offs.append(cnt)
+            cnt += sum(len(prog.ops[i][3]) for i in lst if prog.ops[i][0] == LIN)
+        offs.append(cnt)
+        assert cnt == len(terms)
+        mx = max(b - a for a, b in zip(offs, offs[1:]))
+        A("constexpr int %s_MAX_CHUNK_TERMS = %d;" % (U, mx))
+        A("ELP_COOP_TABLE const uint32_t %s_CHUNK_OFF[%d] = {%s};" % (U, len(offs), ",".join(str(o) for o in offs)))
         A("ELP_COOP_TABLE const uint32_t %s_TERMS[%d] = {" % (U, max(1, len(terms))))
         for k in range(0, len(terms), 16):
             A("  " + ",".join("0x%08xu" % w for w in terms[k:k + 16]) + ",")
