@@ -59,9 +59,10 @@ int elp_field_bytes(int curve);               /* F */
  * the commitment A of el_passo_provide_id) must lie in the order-r subgroup, otherwise the item is rejected (one [z^2]P per point, ~9 % of a
  * verification).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
  * pseudonyms or an undecryptable token.  The reference never meets the case (it runs on BN254); mcl's default does not check.  0 = no check.
- * ELP_OPT_COOP_PAIRING (default 1; BN254 builds): batches of at most 8192 items (value > 1: that many) and the closing step of aggregated verification run
+ * ELP_OPT_COOP_PAIRING (default 1; BN254 builds): batches of at most 4096 items (value > 1: that many) and the closing step of aggregated verification run
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
- * (pair) per item: a lone verification takes ~5 ms instead of ~9, 4096 PS verifications ~2 ms instead of 4.6.  Results are identical.  0 = off. */
+ * (pair) per item: measured, a lone PS verification takes 2.9 ms instead of 5.2, 4096 of them 3.8 ms instead of 4.7, a lone el_passo_verify_id 8-9 ms
+ * instead of 9.8, 64..2048 of them 6.7-7.4 ms instead of 9.0.  Results are identical.  0 = off. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
        ELP_OPT_COOP_PAIRING = 6 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
@@ -69,7 +70,7 @@ const char* elp_version(void);
 
 /* ---- key material (builds fixed-base window tables and the Miller-loop lines of gg in HBM) ------------------ */
 /* PSPubKey{g, gg, XX, Yi[A], YYi[A]} (src/ps-encoding.h:111-140) as affine std points. window_bits 0 = default (8), up to 22
- * (table bytes grow as 2^W / W: 2.5 GiB at W = 16, 32 GiB at W = 20 for an 8-attribute BN254 key). */
+ * (signed digits: table bytes grow as 2^(W-1) / W: 1.25 GiB at W = 16, 16 GiB at W = 20 for an 8-attribute BN254 key; elp_key_table_bytes). */
 int elp_set_pubkey(elp_ctx* ctx, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi,
                    const uint8_t* YYi, int window_bits);
 /* RP parameters of el_passo_verify_id (src/ps-verifier.h:45-49): service name (hashAndMapToG1 is evaluated on the GPU),

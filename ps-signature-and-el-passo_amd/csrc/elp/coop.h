@@ -12,6 +12,9 @@
 // hard part): gen_coop.py validates the scheduled program against the big-int model bit for bit, tests/ compare the kernels with the oracle.
 #pragma once
 #include "pairing.h"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <vector>
+#endif
 
 namespace elp {
 
@@ -102,20 +105,20 @@ ELP_HEAVY Fp<C> coop_const(const uint8_t (*kind)[3], int id, int comp) {
 }
 
 // One slot of one step for the lane of parity `comp`: computes the component `comp` of the slot's result.  Returns the destination register or -1
-// (empty slot).  `consts`: COOP_NCONST Fp2 values in the plain layout (c0 | c1); `lines`: the precomputed lines of the fixed argument as a flat
-// array of Fp2 (a, b, c per line; stored un-carried by ml_precompute, carried here).
+// (empty slot).  `consts`: the COOP_NCONST Fp2 constants in the layout of the register file (the kernels keep them in LDS); `lines`: the precomputed
+// lines of the fixed argument as a flat array of Fp2 (a, b, c per line; stored un-carried by ml_precompute, carried here).
 // (inlined into the kernels' step loop: as a call, the result would travel through the lane's private memory -- a global-memory round trip per step)
 template <class C>
-ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out);
+ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const coop_i32* consts, const Fp2<C>* lines, Fp<C>& out);
 #if !defined(__HIP_DEVICE_COMPILE__)
 template <class C>
-ELP_INL int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, const i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out) {
+ELP_INL int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, const i32* R, const i32* consts, const Fp2<C>* lines, Fp<C>& out) {
   return coop_exec_desc<C>(P.prog[((size_t)step * 16 + slot) * 2], P.prog[((size_t)step * 16 + slot) * 2 + 1], P.terms, comp, R, consts, lines, out);
 }
 #endif
 // the same from the two descriptor words; `terms[d1 + t]` must be term t of a LIN descriptor (the kernels pass a pointer into their LDS copy of the chunk)
 template <class C>
-ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const Fp2<C>* consts, const Fp2<C>* lines, Fp<C>& out) {
+ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const coop_i32* consts, const Fp2<C>* lines, Fp<C>& out) {
   const int op = (int)(d0 >> 28);
   if (op == COOP_OP_NOP) return -1;
   const int dst = (int)((d0 >> 20) & 255);
@@ -127,9 +130,8 @@ ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, cons
       b0 = coop_ld<C>(R, rb, 0);
       b1 = coop_ld<C>(R, rb, 1);
     } else if (op == COOP_OP_MULC) {
-      const Fp2<C>& c = consts[(rb << 4) | x];
-      b0 = c.c0;
-      b1 = c.c1;
+      b0 = coop_ld<C>(consts, (rb << 4) | x, 0);
+      b1 = coop_ld<C>(consts, (rb << 4) | x, 1);
     } else {                                     // a * (Fp scalar): b = (s, 0)
       b0 = coop_ld<C>(R, rb, x);
       b1 = fp_zero<C>();
@@ -185,7 +187,13 @@ ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, cons
 // every slot of a step reads the registers as they were BEFORE the step.
 #if !defined(__HIP_DEVICE_COMPILE__)
 template <class C>
-inline void coop_run_host(const CoopProg& P, i32* R, const Fp2<C>* consts, const Fp2<C>* lines) {
+inline void coop_run_host(const CoopProg& P, i32* R, const Fp2<C>* consts2, int nconst, const Fp2<C>* lines) {
+  std::vector<i32> cw((size_t)nconst * coop_reg_words<C>());
+  for (int k = 0; k < nconst; k++) {
+    coop_st<C>(cw.data(), k, 0, consts2[k].c0);
+    coop_st<C>(cw.data(), k, 1, consts2[k].c1);
+  }
+  const i32* consts = cw.data();
   for (int s = 0; s < P.nsteps; s++) {
     Fp<C> res[16][2];
     int dst[16][2];

@@ -258,29 +258,86 @@ __global__ void ELP_LAUNCH_BOUNDS k_coop_consts(Fp2<C>* out) {
 // runs program P over the register files of the workgroup's two items; every lane walks all steps (empty slots and inactive items idle)
 // The program itself (descriptors and the terms of the linear combinations) is staged through LDS in chunks of CHUNK steps by all 64 lanes with coalesced
 // loads: read straight from global memory every step would open with a dependent ~1 us load and every term of a combination with another.
+// Workgroup of the cooperative kernels: COOP_ITEMS items x 32 lanes.  4 items share one staged copy of the program; 4 x 8.6 KB of registers + 4.9 KB of program
+// = 39.5 KB per workgroup, four workgroups (16 items, two waves per SIMD) per CU.
+#define ELP_COOP_ITEMS 4
+#define ELP_COOP_BLOCK (32 * ELP_COOP_ITEMS)
+template <class C>
+struct CoopLds {
+  typedef CoopTables<C> T;
+  static constexpr int RW = T::NREG * 2 * C::NL;      // words of one item's register file
+  static constexpr int RPAD = 17;                     // the items of a wave run the same program in lockstep: without the offset item 1 would hit the banks of item 0 on every access
+  static constexpr int R_WORDS = ELP_COOP_ITEMS * (RW + RPAD) + 2 * ELP_COOP_ITEMS;      // + two flag words per item
+  static constexpr int STAGE_WORDS = T::CHUNK * 32 + T::MAX_CHUNK_TERMS + T::NCONST * 2 * C::NL;
+};
+// orders the LDS traffic of one wave: the lanes of an item sit in one wave and the LDS pipeline serves a wave's accesses in order, so between two steps the
+// program needs no workgroup barrier, only that the compiler keeps the order
+__device__ __forceinline__ void coop_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <class C>
 __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines) {
   typedef CoopTables<C> T;
   constexpr int CH = T::CHUNK, DW = CH * 32;            // descriptor words per chunk (16 slots x 2 words per step)
+  constexpr int ND = DW / ELP_COOP_BLOCK;               // descriptor words per lane and chunk
+  constexpr int NT = (T::MAX_CHUNK_TERMS + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;   // term words per lane and chunk
+  static_assert(DW % ELP_COOP_BLOCK == 0, "a chunk of descriptors is a whole number of words per lane");
   coop_u32* const sd = stage;
   coop_u32* const stt = stage + DW;
+  coop_i32* const cw = (coop_i32*)(stage + DW + T::MAX_CHUNK_TERMS);     // the constants, in the layout of the register file
+  {
+    const i32* src = reinterpret_cast<const i32*>(consts);
+    for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += ELP_COOP_BLOCK) cw[k] = src[k];
+  }
+  // chunk c+1 travels from global memory to registers WHILE chunk c executes (all loads of a chunk in flight together, fixed trip counts):
+  // fetched on demand, every chunk opened with a chain of dependent global round trips of ~1 us on waves that have nothing else to run
+  u32 pd[ND];
+  u32 pt[NT];
+  u32 t0n = 0, t1n = 0;
+  auto fetch = [&](int s0) {
+    const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
+    t0n = P.chunk_off[s0 / CH];
+    t1n = P.chunk_off[s0 / CH + 1];
+    const u32* src = P.prog + (size_t)s0 * 32;
+    ELP_UNROLL
+    for (int j = 0; j < ND; j++) {
+      const int k = (int)threadIdx.x + j * ELP_COOP_BLOCK;
+      pd[j] = k < ns * 32 ? src[k] : ((k & 1) ? 0u : 0xF0000000u);     // past the end: empty slots
+    }
+    ELP_UNROLL
+    for (int j = 0; j < NT; j++) {
+      const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+      pt[j] = k < t1n - t0n ? P.terms[t0n + k] : 0u;
+    }
+  };
+  fetch(0);
   ELP_NOUNROLL
   for (int s0 = 0; s0 < P.nsteps; s0 += CH) {
     const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
-    const u32 t0 = P.chunk_off[s0 / CH], t1 = P.chunk_off[s0 / CH + 1];
-    for (int k = (int)threadIdx.x; k < ns * 32; k += ELP_BLOCK) sd[k] = P.prog[(size_t)s0 * 32 + k];
-    for (u32 k = threadIdx.x; k < t1 - t0; k += ELP_BLOCK) stt[k] = P.terms[t0 + k];
+    const u32 t0 = t0n;
+    __syncthreads();                                   // every wave is done with the previous chunk
+    ELP_UNROLL
+    for (int j = 0; j < ND; j++) sd[(int)threadIdx.x + j * ELP_COOP_BLOCK] = pd[j];
+    ELP_UNROLL
+    for (int j = 0; j < NT; j++) {
+      const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+      if (k < (u32)T::MAX_CHUNK_TERMS) stt[k] = pt[j];
+    }
     __syncthreads();
+    if (s0 + CH < P.nsteps) fetch(s0 + CH);
     ELP_NOUNROLL
     for (int s = 0; s < ns; s++) {
       if (active) {
         Fp<C> out;
-        const int dst = coop_exec_desc<C>(sd[s * 32 + pair * 2], sd[s * 32 + pair * 2 + 1], stt - t0, comp, R, consts, lines, out);
+        const int dst = coop_exec_desc<C>(sd[s * 32 + pair * 2], sd[s * 32 + pair * 2 + 1], stt - t0, comp, R, cw, lines, out);
         if (dst >= 0) coop_st<C>(R, dst, comp, out);     // the register allocation never lets a step write a register that the same step reads
       }
-      __syncthreads();
+      coop_wave_sync();
     }
   }
+  __syncthreads();
 }
 // is the Fp12 value in registers P.out[0..5] equal to 1?  (lane pair j < 6 tests coefficient j; result through LDS word `flagw`)
 template <class C>
@@ -298,17 +355,16 @@ __device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool
 // items [0, n): sig1 | sig2 at the head of the record, K in the workspace (vid_store_k layout); todo[i] != 0 selects the items to check.  An item whose sig1,
 // sig2 or K is the point at infinity (or fails validation) is left to the per-lane kernel: done[i] stays 0.  Otherwise flags[i] = verdict, done[i] = 1.
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK, 2) k_pair_coop(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
+__global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
                                                             size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n) {
   typedef CoopTables<C> T;
-  constexpr int RW = T::NREG * 2 * C::NL;
-  constexpr int RPAD = 17;      // the two items run the same program in lockstep: without the offset every access of item 1 would hit the banks of item 0
-  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + RPAD + 8];
-  __shared__ __attribute__((aligned(16))) u32 stage[T::CHUNK * 32 + T::MAX_CHUNK_TERMS];
+  typedef CoopLds<C> L;
+  __shared__ __attribute__((aligned(16))) i32 Rall[L::R_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
   const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
-  coop_i32* R = (coop_i32*)Rall + slot * (RW + RPAD);
-  coop_i32* flagw = (coop_i32*)Rall + 2 * RW + RPAD + slot;            // [0..1]: is-one flags, [2..3]: "inputs usable"
-  const size_t i = (size_t)blockIdx.x * 2 + slot;
+  coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
+  coop_i32* flagw = (coop_i32*)Rall + ELP_COOP_ITEMS * (L::RW + L::RPAD) + slot;     // [slot]: is-one flag, [ITEMS + slot]: "inputs usable"
+  const size_t i = (size_t)blockIdx.x * ELP_COOP_ITEMS + slot;
   if (pair == 0 && comp == 0) {
     int usable = 0;
     if (i < n && todo[i]) {
@@ -332,10 +388,10 @@ __global__ void __launch_bounds__(ELP_BLOCK, 2) k_pair_coop(KeyCtx<C> key, const
         }
       }
     }
-    flagw[2] = usable;
+    flagw[ELP_COOP_ITEMS] = usable;
   }
   __syncthreads();
-  const bool active = flagw[2] != 0;
+  const bool active = flagw[ELP_COOP_ITEMS] != 0;
   const CoopProg P = T::check();
   coop_run_device<C>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
@@ -384,15 +440,14 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k(KeyCtx<C> key, const u32* recs, int rec
 }
 // closing step of aggregated verification on 32 lanes: [F f_gg(-S2)]^e == 1
 template <class C>
-__global__ void __launch_bounds__(ELP_BLOCK, 2) k_agg_final_coop(KeyCtx<C> key, const Fp2<C>* consts, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
+__global__ void __launch_bounds__(ELP_COOP_BLOCK) k_agg_final_coop(KeyCtx<C> key, const Fp2<C>* consts, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
   typedef CoopTables<C> T;
-  constexpr int RW = T::NREG * 2 * C::NL;
-  constexpr int RPAD = 17;
-  __shared__ __attribute__((aligned(16))) i32 Rall[2 * RW + RPAD + 8];
-  __shared__ __attribute__((aligned(16))) u32 stage[T::CHUNK * 32 + T::MAX_CHUNK_TERMS];
+  typedef CoopLds<C> L;
+  __shared__ __attribute__((aligned(16))) i32 Rall[L::R_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
   const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
-  coop_i32* R = (coop_i32*)Rall + slot * (RW + RPAD);
-  coop_i32* flagw = (coop_i32*)Rall + 2 * RW + RPAD + slot;
+  coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
+  coop_i32* flagw = (coop_i32*)Rall + ELP_COOP_ITEMS * (L::RW + L::RPAD) + slot;
   if (pair == 0 && comp == 0) {
     int state = 0;                                  // 0: run the program, 1: verdict is "false" (bad point)
     if (slot == 0) {
@@ -410,10 +465,10 @@ __global__ void __launch_bounds__(ELP_BLOCK, 2) k_agg_final_coop(KeyCtx<C> key, 
         coop_st<C>(R, T::IN_F0 + j, 1, e[j]->c1);
       }
     }
-    flagw[2] = (slot == 0 && state == 0) ? 1 : 0;
+    flagw[ELP_COOP_ITEMS] = (slot == 0 && state == 0) ? 1 : 0;
   }
   __syncthreads();
-  const bool active = flagw[2] != 0;
+  const bool active = flagw[ELP_COOP_ITEMS] != 0;
   const CoopProg P = T::tail();
   coop_run_device<C>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
@@ -426,7 +481,7 @@ void launch_coop_consts(hipStream_t stream, void* d_consts) {
 template <class B>
 void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
                       uint8_t* d_flags, uint8_t* done, void* d_accepted) {
-  hipLaunchKernelGGL((k_pair_coop<B>), dim3((unsigned)((n + 1) / 2)), dim3(ELP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
+  hipLaunchKernelGGL((k_pair_coop<B>), dim3((unsigned)((n + ELP_COOP_ITEMS - 1) / ELP_COOP_ITEMS)), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
                      d_flags, done, (unsigned long long*)d_accepted, n);
   hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, todo, (const uint8_t*)done, kws, kstride, d_flags,
                      (unsigned long long*)d_accepted, n);
@@ -437,7 +492,7 @@ void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void*
 }
 template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok) {
-  hipLaunchKernelGGL((k_agg_final_coop<B>), dim3(1), dim3(ELP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const Fp12<B>*)F, (const u32*)s2_std, agg_ok);
+  hipLaunchKernelGGL((k_agg_final_coop<B>), dim3(1), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const Fp12<B>*)F, (const u32*)s2_std, agg_ok);
 }
 #else
 template <class B>
@@ -1103,7 +1158,7 @@ struct elp_ctx {
   int split = 0;              // ELP_OPT_SPLIT_PHASES: 1 = el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them; 2 = the two jobs
                               // of the first phase as concurrent kernels on two streams (k_vid_g2 || k_vid_g1, then k_vid_pair2)
   int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
-  size_t coop_max = 8192;
+  size_t coop_max = 4096;     // 16 items per CU x 256 CUs: one round of the cooperative kernel; measured cross-over against the per-lane kernels between 4096 and 8192 items
   void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
   hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
   hipEvent_t jev[2] = {nullptr, nullptr};

@@ -484,7 +484,7 @@ extern "C" int twin_bn254_pair_coop(void* cv, const u32* sig1w, const u32* sig2w
     }
     P = CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}};
   }
-  coop_run_host<C>(P, R.data(), consts.data(), reinterpret_cast<const Fp2<C>*>(c->lines.data()));
+  coop_run_host<C>(P, R.data(), consts.data(), (int)consts.size(), reinterpret_cast<const Fp2<C>*>(c->lines.data()));
   Fp12<C> g;
   Fp2<C>* o[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
   for (int j = 0; j < 6; j++) {
@@ -519,7 +519,7 @@ extern "C" int twin_bn254_coop_debug(void* cv, const u32* sig1w, const u32* sig2
   coop_st<C>(R.data(), IN_QY, 0, K.y.c0);
   coop_st<C>(R.data(), IN_QY, 1, K.y.c1);
   CoopProg P{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, nsteps, {0, 0, 0, 0, 0, 0}};
-  coop_run_host<C>(P, R.data(), consts.data(), reinterpret_cast<const Fp2<C>*>(c->lines.data()));
+  coop_run_host<C>(P, R.data(), consts.data(), (int)consts.size(), reinterpret_cast<const Fp2<C>*>(c->lines.data()));
   for (int r = 0; r < COOP_NREG; r++)
     for (int cc = 0; cc < 2; cc++) fp_store_w<C>(regs_out + (r * 2 + cc) * C::N, fp_to_std<C>(coop_ld<C>(R.data(), r, cc)));
   return 0;

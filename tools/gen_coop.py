@@ -39,8 +39,8 @@ def naf(k):      # non-adjacent form, least significant digit first (as tools/ge
 
 
 NP = 16            # lane pairs per item
-CHUNK = 16         # steps per program chunk staged through LDS by the kernels
-NREG = 128         # Fp2 registers per item in LDS
+CHUNK = 8          # steps per program chunk staged through LDS by the kernels
+NREG = 120         # Fp2 registers per item in LDS
 
 # ---- operations (SSA).  mul-class: MUL (a*b), MULC (a * constant[c]), MULS (a * Fp scalar = component `sel` of register b)
 #      lin-class: LIN (dst = sum_k M_k x_k: an Fp-linear combination of up to 15 registers, M_k 2x2 matrices of small integers acting on (re, im):
@@ -834,7 +834,7 @@ def emit_header(res, path, cvname):
         A("constexpr int %s_NTERMS = %d;" % (U, len(terms)))
         A("constexpr int %s_OUT[6] = {%s};" % (U, ", ".join(str(reg[o]) for o in outs_c)))
         A("ELP_COOP_TABLE const uint8_t %s_CLASS[%d] = {%s};" % (U, len(steps), ",".join(str(c) for c, _ in steps)))
-        A("ELP_COOP_TABLE const uint32_t %s_PROG[%d] = {" % (U, len(steps) * NP * 2))
+        A("alignas(16) ELP_COOP_TABLE const uint32_t %s_PROG[%d] = {" % (U, len(steps) * NP * 2))
         for row in words:
             A("  " + ",".join("0x%08xu" % w for w in row) + ",")
         A("};")

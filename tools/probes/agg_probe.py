@@ -14,6 +14,8 @@ dev = torch.device("cuda", 0)
 ctx = pkg.Context(pkg.CURVE_BN254, 0)
 wl = synth.Workload(ctx, 8, seed=20211, window_bits=16)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+if len(sys.argv) > 3:
+    os.environ["ELP_COOP"] = sys.argv[3]
 recs, mask, expect = wl.verify_id_batch(B, 4, with_retrieval=True)
 d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)
 d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
