@@ -438,6 +438,61 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k(KeyCtx<C> key, const u32* recs, int rec
   jac_to_aff<F2<C>>(aK, K);
   vid_store_k<C>(kws, kstride, i, aK);
 }
+// The same on ELP_PSK_LANES lanes per item: the A x nwin table entries of the sum are dealt round-robin to the lanes (each recomputes the signed digit of its
+// window from the scalar: the carry chain is a few integer operations per window), partial sums are folded through lane shuffles with complete Jacobian
+// additions.  48 sequential mixed additions (A = 3, W = 16) become 6 + 3 full ones; the one inversion of the affine result stays.
+#define ELP_PSK_LANES 8
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+  typedef F2<C> G;
+  constexpr int J = ELP_PSK_LANES;
+  const int sub = (int)(threadIdx.x & (J - 1));
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / J;
+  bool ok = false;
+  Jac<G> K;
+  jac_set_inf(K);
+  if (i < n) {
+    const u32* rec = recs + i * (size_t)rec_words;
+    Aff<F1<C>> s1, s2;
+    ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && !aff_is_inf(s1);       // every lane of the item decides the same
+    if (ok) {
+      if (sub == 0) jac_from_aff(K, aff_from_mem<G>(key.b2[G2_BASE_XX]));
+      const int W = key.W, nwin = key.nwin, total = nattr * nwin;
+      ELP_NOUNROLL
+      for (int t = sub; t < total; t += J) {
+        const int a = t / nwin, j = t - a * nwin;
+        const Scalar k = scalar_mod_r<C>(scalar_load_w(rec + 4 * C::N + 8 * a));
+        int carry = 0, d = 0;
+        for (int jj = 0; jj <= j; jj++) d = fixed_base_digit(k, jj, W, carry);
+        if (d != 0) {
+          Aff<G> e = aff_from_mem<G>(key.t2[((size_t)(G2_BASE_YY0 + a) * nwin + j) * key.per + ((d < 0 ? -d : d) - 1)]);
+          if (d < 0) e.y = G::neg(e.y);
+          jac_madd<G>(K, K, e);
+        }
+      }
+    }
+  }
+  ELP_NOUNROLL
+  for (int m = 1; m < J; m <<= 1) {
+    Jac<G> o;
+    {
+      constexpr int NW = (int)(sizeof(Jac<G>) / 4);
+      const i32* src = reinterpret_cast<const i32*>(&K);
+      i32* dst = reinterpret_cast<i32*>(&o);
+      ELP_UNROLL
+      for (int w = 0; w < NW; w++) dst[w] = __shfl_xor(src[w], m);
+    }
+    if (ok && (sub & (2 * m - 1)) == 0) jac_add<G>(K, K, o);
+  }
+  if (i < n && sub == 0) {
+    todo[i] = ok ? 1 : 0;
+    if (ok) {
+      Aff<G> aK;
+      jac_to_aff<G>(aK, K);
+      vid_store_k<C>(kws, kstride, i, aK);
+    }
+  }
+}
 // closing step of aggregated verification on 32 lanes: [F f_gg(-S2)]^e == 1
 template <class C>
 __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_agg_final_coop(KeyCtx<C> key, const Fp2<C>* consts, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
@@ -488,7 +543,7 @@ void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_co
 }
 template <class B>
 void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride) {
-  hipLaunchKernelGGL((k_ps_k<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, nattr, todo, kws, kstride, n);
+  hipLaunchKernelGGL((k_ps_k_coop<B>), dim3(grid_for(n * ELP_PSK_LANES)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, nattr, todo, kws, kstride, n);
 }
 template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok) {

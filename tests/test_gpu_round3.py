@@ -194,13 +194,20 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
             L.elpo_verify_id_batch(key, n, recs, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
             assert (ofl == f1).all()
         wl3 = synth.Workload(gpu_ctx, 3, seed=6, window_bits=8)
-        for n in (1, 65, 4096):
-            precs, pexpect = wl3.ps_verify_batch(n)
-            gpu_ctx.set_coop_pairing(0)
-            p0, pc0 = gpu_ctx.ps_verify_batch(precs, 3)
-            gpu_ctx.set_coop_pairing(1)
-            p1, pc1 = gpu_ctx.ps_verify_batch(precs, 3)
-            assert (p0 == pexpect).all() and (p1 == pexpect).all() and pc0 == pc1 == int(pexpect.sum())
+        key3 = _oracle_key(L, wl3, gpu_ctx, 3)
+        try:
+            for n in (1, 63, 64, 65, 4096):
+                precs, pexpect = wl3.ps_verify_batch(n)
+                gpu_ctx.set_coop_pairing(0)
+                p0, pc0 = gpu_ctx.ps_verify_batch(precs, 3)
+                gpu_ctx.set_coop_pairing(1)         # K on 8 lanes per item (k_ps_k_coop), pairing check on 32 (k_pair_coop)
+                p1, pc1 = gpu_ctx.ps_verify_batch(precs, 3)
+                assert (p0 == pexpect).all() and (p1 == pexpect).all() and pc0 == pc1 == int(pexpect.sum())
+                prsz = len(precs) // n
+                for i in range(0, n, 1 if n < 100 else 37):
+                    assert L.elpo_ps_verify(key3, precs[i * prsz:(i + 1) * prsz], 3) == int(p1[i])
+        finally:
+            L.elpo_key_free(key3)
         # aggregated verification with the cooperative closing step: fast path and fallback
         wl = synth.Workload(gpu_ctx, A, seed=5, window_bits=8)
         recs, mask, expect = wl.verify_id_batch(700, H, with_retrieval=True)
