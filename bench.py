@@ -368,12 +368,12 @@ def valu_bound(ctx, ops_key, window, B, kern_ms, macs_per_mul):
                 vb.update({"fp_mul_equivalents_per_verification": per_item, "multiply_adds_per_verification": ops[key]["multiply_adds"],
                            "op_count_source": "profiles/op_counts.json[%s][%s]%s" % (ops_key, key, " (extrapolated)" if ops[key].get("extrapolated") else " (counted)"),
                            "achieved": ach, "frac": ach / peak})
-        pj = os.path.join(ROOT, "profiles", "r02_summary.json")
-        if ops_key == "verify_id" and os.path.exists(pj):
+        pj = next((q for q in (os.path.join(ROOT, "profiles", t + "_summary.json") for t in ("r03", "r02")) if os.path.exists(q)), "")
+        if ops_key == "verify_id" and pj:
             try:
                 pm = json.load(open(pj))
                 iv, waves = pm["pmc_per_launch"]["SQ_INSTS_VALU"], pm["pmc_per_launch"]["SQ_WAVES"]
-                vb["issue_model"] = {"valu_wave_instructions_per_launch": iv, "waves": waves, "source": "profiles/r02_summary.json (round PMC pass, W = %s)" % pm.get("window"),
+                vb["issue_model"] = {"valu_wave_instructions_per_launch": iv, "waves": waves, "source": "profiles/%s (round PMC pass, W = %s)" % (os.path.basename(pj), pm.get("window")),
                                      "ns_per_valu_instruction_per_wave": kern_ms * 1e6 / (iv / waves),
                                      "note": "one resident wave per SIMD: the wave issues one vector instruction every ~5 cycles whatever its type "
                                              "(profiles/r01_ubench_valu.log), so kernel time = instructions per wave x issue interval; see DESIGN.md section 5"}
@@ -492,7 +492,31 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
     res["ps_verify_4096x3attrs"] = {"value": n / (ms * 1e-3), "unit": "verifications/s", "kernel_ms": ms,
-                                    "parity_ok": bool((d_fl.cpu().numpy() == expect).all())}
+                                    "parity_ok": bool((d_fl.cpu().numpy() == expect).all()),
+                                    "path": "cooperative kernels (k_ps_k_coop: K on 8 lanes per item; k_pair_coop: pairing check on 32 lanes per item)"}
+    # small batches and lone items, cooperative kernels on / off (ELP_OPT_COOP_PAIRING): latency, not throughput
+    lat = {}
+    for coop in (1, 0):
+        ctx.set_coop_pairing(coop)
+        for m in (1, 1024, 4096):
+            ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, m, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
+            lat["ps_verify_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms
+    ctx.set_coop_pairing(1)
+    ctx.close()
+    ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
+    wl = synth.Workload(ctx, 8, seed=20211, window_bits=window)
+    nl = 4096
+    vrecs, vmask, vexpect = wl.verify_id_batch(nl, 4, with_retrieval=True)
+    d_vrec = torch.from_numpy(np.frombuffer(vrecs, dtype=np.uint8).copy()).to(dev)
+    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    for coop in (1, 0):
+        ctx.set_coop_pairing(coop)
+        for m in (1, 64, 1024, 4096):
+            ms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_vrec.data_ptr(), vmask, 1, d_ad.data_ptr(), None, len(wl.ad),
+                                                                         d_fl.data_ptr(), d_cnt.data_ptr())))
+            lat["verify_id_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms
+    lat["parity_ok"] = bool((d_fl.cpu().numpy()[:nl] == vexpect).all())
+    res["small_batches"] = lat
     ctx.close()
     ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
     wl = synth.Workload(ctx, 8, seed=20211, window_bits=window)

@@ -237,7 +237,7 @@ int elp_provide_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_r
 int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad,
                         const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
   int rc = check_fused(c, mask, need_rp(retr));
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
   if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
@@ -251,7 +251,7 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   HIPCHK(c, dcnt.alloc(8));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   const size_t round = (size_t)64 * c->simds;
   std::vector<hipEvent_t> ev;
   int status = ELP_OK;
@@ -303,7 +303,7 @@ int elp_request_id_batch_dev(elp_ctx* c, void* stream, size_t n, const void* d_r
 int elp_prove_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad, const uint32_t* ad_off,
                        size_t ad_len, uint8_t* proofs, uint8_t* flags, uint64_t* produced) {
   int rc = check_fused(c, mask, need_rp(retr));
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (produced) *produced = 0;
   if (n == 0) return ELP_OK;
   if (!records || !flags || !proofs || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
@@ -319,9 +319,9 @@ int elp_prove_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t ma
   HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   rc = elp_prove_id_batch_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, dout.p, dfl.p, dcnt.p);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   uint64_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(proofs, dout.p, n * osz, hipMemcpyDeviceToHost, c->stream));
@@ -333,7 +333,7 @@ int elp_prove_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t ma
 int elp_request_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
                          size_t ad_len, uint8_t* requests) {
   int rc = check_fused(c, mask);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (n == 0) return ELP_OK;
   if (!records || !requests || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
@@ -345,9 +345,9 @@ int elp_request_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t 
   HIPCHK(c, dout.alloc(n * osz));
   HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   rc = elp_request_id_batch_dev(c, c->stream, n, drec.p, mask, pad, poff, ad_len, dout.p);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   HIPCHK(c, hipMemcpyAsync(requests, dout.p, n * osz, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ELP_OK;
@@ -356,7 +356,7 @@ int elp_request_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t 
 int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const uint32_t* msg_off, int retr, const uint8_t* ad,
                              const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted) {
   int rc = check_fused(c, 0, need_rp(retr));
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
   if (!msgs || !msg_off || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
@@ -371,9 +371,9 @@ int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const ui
   HIPCHK(c, hipMemcpyAsync(dmoff.p, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   rc = elp_verify_id_wire_batch_dev(c, c->stream, n, dmsg.p, dmoff.p, retr, pad, poff, ad_len, dfl.p, dcnt.p);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   uint64_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -384,7 +384,7 @@ int elp_verify_id_wire_batch(elp_ctx* c, size_t n, const uint8_t* msgs, const ui
 
 int elp_ps_verify_batch(elp_ctx* c, size_t n, const uint8_t* records, int nattr, uint8_t* flags, uint64_t* accepted) {
   int rc = check_fused(c, 0);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
   if (!records || !flags) return ELP_ERR_ARG;
@@ -397,7 +397,7 @@ int elp_ps_verify_batch(elp_ctx* c, size_t n, const uint8_t* records, int nattr,
   HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
   rc = elp_ps_verify_batch_dev(c, c->stream, n, drec.p, nattr, dfl.p, dcnt.p);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   uint64_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&cnt, dcnt.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -438,7 +438,7 @@ int elp_time_verify_id_dev(elp_ctx* c, void* stream, int reps, size_t n, const v
   HIPCHK(c, hipEventRecord(e0, (hipStream_t)stream));
   for (int r = 0; r < reps; r++) {
     int rc = elp_verify_id_batch_dev(c, stream, n, d_records, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted);
-    if (rc) return rc;
+    if (rc) return sync_fail(rc);
   }
   HIPCHK(c, hipEventRecord(e1, (hipStream_t)stream));
   HIPCHK(c, hipEventSynchronize(e1));
@@ -480,7 +480,7 @@ int elp_verify_id_batch_aggregated(elp_ctx* c, size_t n, const uint8_t* records,
                                    const uint32_t* ad_off, size_t ad_len, const uint8_t* seed32, uint8_t* flags, uint64_t* accepted,
                                    int* batch_equation_held) {
   int rc = check_fused(c, mask, need_rp(retr));
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (accepted) *accepted = 0;
   if (batch_equation_held) *batch_equation_held = 1;
   if (n == 0) return ELP_OK;
@@ -495,9 +495,9 @@ int elp_verify_id_batch_aggregated(elp_ctx* c, size_t n, const uint8_t* records,
   HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   rc = elp_verify_id_batch_aggregated_dev(c, c->stream, n, drec.p, mask, retr, pad, poff, ad_len, seed32, dfl.p, dcnt.p);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   uint64_t cnt = 0;
   int held = 0;
   HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));

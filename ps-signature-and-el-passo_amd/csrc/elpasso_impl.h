@@ -2200,11 +2200,17 @@ static inline int stage_ad(elp_ctx* c, size_t n, const uint8_t* ad, const uint32
   return ELP_OK;
 }
 
+// error exit of a host-buffer entry point: copies and kernels may already be queued on the context's stream(s) and still use the DevBufs that the exit returns to
+// the process-wide block cache (another context could be handed the block at once), so drain the device first
+static inline int sync_fail(int rc) {
+  (void)hipDeviceSynchronize();
+  return rc;
+}
 template <class C>
 int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_t mask, const uint8_t* ad, const uint32_t* ad_off,
                          size_t ad_len, uint8_t* sigs, uint8_t* flags, uint64_t* accepted) {
   int rc = check_fused(c, mask, NEED_SK);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
   if (!records || !flags || !sigs || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
@@ -2219,9 +2225,9 @@ int elp_provide_id_batch_t(elp_ctx* c, size_t n, const uint8_t* records, uint64_
   HIPCHK(c, hipMemcpyAsync(drec.p, records, n * rsz, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 8, c->stream));
   rc = stage_ad(c, n, ad, ad_off, ad_len, dad, doff, &pad, &poff);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   rc = elp_provide_id_batch_dev(c, c->stream, n, drec.p, mask, pad, poff, ad_len, dsig.p, dfl.p, dcnt.p);
-  if (rc) return rc;
+  if (rc) return sync_fail(rc);
   uint64_t cnt = 0;
   HIPCHK(c, hipMemcpyAsync(flags, dfl.p, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(sigs, dsig.p, n * 2 * Sizes<C>::G1, hipMemcpyDeviceToHost, c->stream));

@@ -24,7 +24,7 @@ def elp():
 def gpu_ctx(elp):
     ctx = elp.Context(elp.CURVE_BN254, 0)   # raises without a GPU or without the built .so: no fallback
     # parity tests compare with the reference's verdicts bit for bit, including its acceptance of sig1 = sig2 = infinity (golden
-    # case "sig_both_zero"); the library's default rejects that forgery (ELP_OPT_STRICT_SIGNATURE, tested in test_gpu_strict.py)
+    # case "sig_both_zero"); the library's default rejects that forgery (ELP_OPT_STRICT_SIGNATURE, tested in test_gpu_round2.py::test_strict_signature_default_and_state_checks and test_gpu_host_layer.py::test_default_strict_signature_through_reference_api)
     ctx.set_strict_signature(False)
     yield ctx
     ctx.close()

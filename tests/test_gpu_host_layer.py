@@ -28,7 +28,7 @@ def host():
     L.elph_prove_id_b64.argtypes = [cp, cp, cp, cp, cp, c, cp, cp, cp, cp, sz, cp, sz]
     L.elph_request_id_b64.argtypes = [cp, cp, cp, cp, sz, cp, sz]
     assert L.elph_init(0) == 0, L.elph_last_error()
-    L.elph_set_strict_signature(0)      # bit-for-bit reference verdicts (golden case sig_both_zero); default-strict: test_gpu_strict.py
+    L.elph_set_strict_signature(0)      # bit-for-bit reference verdicts (golden case sig_both_zero); default-strict: test_default_strict_signature_through_reference_api below
     return L
 
 

@@ -7,11 +7,13 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles")
 shutil.copy(f"{src}/bench_n1.json", f"{dst}/{tag}_bench_n1.json")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/{tag}_bench_under_rocprof.json")
+if os.path.exists(f"{src}/bench_headline.json"):
+    shutil.copy(f"{src}/bench_headline.json", f"{dst}/{tag}_bench_headline.json")
 shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/summary.json", f"{dst}/{tag}_summary.json")
 
@@ -26,10 +28,12 @@ def filt(inp, out):
 filt(f"{src}/trace/{tag}_kernel_trace.csv", f"{dst}/{tag}_kernel_trace_k_verify_id.csv")
 filt(f"{src}/pmc_a/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_a_k_verify_id.csv")
 filt(f"{src}/pmc_b/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_b_k_verify_id.csv")
+if os.path.exists(f"{src}/pmc_c/{tag}_counter_collection.csv"):
+    filt(f"{src}/pmc_c/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_c_k_verify_id.csv")
 s = json.load(open(f"{src}/summary.json"))
 h = {"kernel": "k_verify_id<BN254>", "items_per_launch": s["k_verify_id"]["grid"],
      "tag": tag, "window": s.get("window"),
-     "build": "round-2 (29-bit limbs, single-reduction Fp2 products, lazy sums, LDS hot slot, fused loops; plain layout, W = %s tables)" % s.get("window"),
+     "build": "round-3 (29-bit limbs, single-reduction Fp2 products, lazy sums, LDS hot slot, fused loops; plain layout, signed-digit W = %s tables)" % s.get("window"),
      "FETCH_SIZE_KiB": s["pmc_per_launch"]["FETCH_SIZE"], "WRITE_SIZE_KiB": s["pmc_per_launch"]["WRITE_SIZE"],
      "k_verify_id_bytes_per_launch": s["k_verify_id_bytes_per_launch"],
      "k_verify_id_bytes_per_launch_uncorrected": s["k_verify_id_bytes_per_launch_uncorrected"], "l2_hit_rate": s["l2_hit_rate"],

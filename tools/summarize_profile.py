@@ -13,12 +13,17 @@ out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_m
                        for r in rows[:12]]
 pmc = {}
 meta = {}
-for sub in ("pmc_a", "pmc_b"):
-    rr = list(csv.DictReader(open(os.path.join(d, sub, tag + "_counter_collection.csv"))))
+dur = {}
+for sub in ("pmc_a", "pmc_b", "pmc_c"):
+    f = os.path.join(d, sub, tag + "_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    rr = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(list)
     for r in rr:
         if "k_verify_id<elp::BN254>" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.setdefault(sub, {})[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
             meta = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "scratch_bytes_per_lane": int(r["Scratch_Size"]),
                     "grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"])}
     for k, v in agg.items():
@@ -32,5 +37,28 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     out["k_verify_id_bytes_per_launch_uncorrected"] = int((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
 if "TCC_HIT_sum" in pmc:
     out["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+if "GRBM_GUI_ACTIVE" in pmc and dur.get("pmc_c"):
+    ms_c = sum(dur["pmc_c"].values()) / len(dur["pmc_c"])
+    out["clock_ghz"] = pmc["GRBM_GUI_ACTIVE"] / ms_c / 1e6
+    out["kernel_ms_in_clock_pass"] = ms_c
+if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
+    out["valu_instructions_per_wave"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
+    out["wait_fraction_of_wave_cycles"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
+# same-lease agreement: the average of ALL k_verify_id dispatches under rocprofv3 (--headline-only: each one is a launch of the headline size) against the
+# ms_per_step of the plain bench line taken minutes earlier on the same box
+ok = True
+try:
+    line = json.loads(open(os.path.join(d, "bench_headline.json")).read().strip().splitlines()[-1])
+    kv = [r for r in rows if "k_verify_id<elp::BN254>" in r["Name"]]
+    if kv:
+        avg = float(kv[0]["AverageNs"]) / 1e6
+        ok = avg <= 1.02 * line["ms_per_step"]
+        out["same_lease_agreement"] = {"rocprof_avg_ms": avg, "rocprof_calls": int(kv[0]["Calls"]), "bench_ms_per_step": line["ms_per_step"],
+                                       "bench_kernel_ms": line.get("roofline", {}).get("kernel_ms"), "ratio": avg / line["ms_per_step"], "ok": ok,
+                                       "rule": "rocprof avg <= 1.02 x ms_per_step"}
+except (OSError, ValueError, KeyError, IndexError) as e:
+    out["same_lease_agreement"] = {"error": str(e)}
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
+if not ok:
+    sys.exit("rocprof average of k_verify_id exceeds 1.02 x ms_per_step of the same lease's bench line")
