@@ -542,7 +542,7 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
 //     prod_i [ e(sig1_i, K_i) e(-sig2_i, gg) ]^{d_i} == 1   <=>   prod_i e(d_i sig1_i, K_i) * e(-sum_i d_i sig2_i, gg) == 1
 // with verifier-chosen 128-bit d_i: ONE final exponentiation and ONE Miller loop against gg for the whole batch; sum d_i sig2_i is
 // a Pippenger MSM.  This per-item part returns the item's Miller value f_i = f(d_i sig1_i, K_i) (1 for rejected items), its
-// multiplier d_i and a copy of sig2_i.  If the batch equation fails, the caller falls back to the per-item check, so verdicts
+// multiplier d_i (as the pair (a_i, b_i) of d_i = a_i + b_i lam) and a copy of sig2_i.  If the batch equation fails, the caller falls back to the per-item check, so verdicts
 // stay exact; a wrong accept needs a 2^-128 event.
 ELP_HD inline Scalar agg_multiplier(const uint8_t seed[32], u64 index) {
   Sha256 s;
@@ -571,9 +571,37 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
   if (!verify_id_nizk<C, RecordSrc<C>>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
+  // multiplier d = a + b lam (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [d]sig1 = [a]sig1 + [b]phi(sig1) over the affine multiples
+  // 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private memory
   const Scalar d = agg_multiplier(seed, index);
   Jac<F1<C>> P;
-  jac_mul_var<F1<C>>(P, sig1, d, 32);
+  if (aff_is_inf(sig1)) {
+    jac_set_inf(P);
+  } else {
+    typedef F1<C> G1F;
+    Aff<G1F> tab[8];
+    {
+      Jac<G1F> jm[8];
+      jac_multiples8<G1F>(jm, sig1);
+      Fp<C> pre[7];                       // Montgomery's trick over Z(2P) .. Z(8P); none is zero (sig1 has prime order r > 8)
+      pre[0] = jm[1].Z;
+      for (int i = 1; i < 7; i++) pre[i] = fp_mul<C>(pre[i - 1], jm[i + 1].Z);
+      Fp<C> inv = fp_inv<C>(pre[6]);
+      tab[0] = sig1;
+      for (int i = 6; i >= 1; i--) {
+        jac_to_aff_with_zinv<G1F>(tab[i + 1], jm[i + 1], fp_mul<C>(inv, pre[i - 1]));
+        inv = fp_mul<C>(inv, jm[i + 1].Z);
+      }
+      jac_to_aff_with_zinv<G1F>(tab[1], jm[1], inv);
+    }
+    u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
+    if (ws1) {
+      for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1, i, tab[i]);
+      g1_mul_pair64_with<C, WsTab<G1F>>(P, WsTab<G1F>{ws1}, d);
+    } else {
+      g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
+    }
+  }
   Aff<F1<C>> aP;
   jac_to_aff<F1<C>>(aP, P);
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);

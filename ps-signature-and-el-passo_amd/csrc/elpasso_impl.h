@@ -926,6 +926,36 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S,
   if (tid == 0) win[w] = acc;
 }
 
+// Closing step for the multipliers of aggregated verification, d_i = a_i + b_i lam with a_i in scalar bytes 0-7 and b_i in bytes 8-15 (pipeline.h
+// verify_id_agg_item): windows 0-7 hold the bucket sums of sum a_i P_i =: A, windows 8-15 those of sum b_i P_i =: B; the result is A + phi(B).  The two Horner
+// chains (56 doublings each) run on two lanes.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_msm_final_glv(const void* win_, u32* out) {
+  typedef F1<C> F;
+  __shared__ Jac<F> half[2];
+  if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+  const Jac<F>* win = (const Jac<F>*)win_ + 8 * threadIdx.x;
+  Jac<F> r = win[7];
+  for (int w = 6; w >= 0; w--) {
+    for (int k = 0; k < 8; k++) jac_dbl<F>(r, r);
+    jac_add<F>(r, r, win[w]);
+  }
+  if (threadIdx.x == 1) {
+    Fp<C> beta;
+    ELP_LOAD_FP(beta, C::glv_beta(i_));
+    r.X = fp_mul<C>(r.X, beta);
+  }
+  half[threadIdx.x] = r;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (threadIdx.x == 0) {
+    jac_add<F>(r, half[0], half[1]);
+    Aff<F> a;
+    jac_to_aff<F>(a, r);
+    g1_store<C>(out, a);
+  }
+}
 template <class C, int G>
 __global__ void ELP_LAUNCH_BOUNDS k_msm_final(const void* win_, u32* out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -1767,10 +1797,11 @@ static size_t msm_ws_bytes(size_t n) {
   return ((n * AFF + 255) & ~(size_t)255) + ((32 * S * 256 * JAC + 255) & ~(size_t)255) + ((32 * JAC + 255) & ~(size_t)255) + 256;
 }
 template <class C, int G>
-static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws) {
+static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs = false) {
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
   const int S = (int)((n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE);
+  const int NWL = glv_pairs ? 16 : 32;            // scalar bytes in use: the pairs (a, b) of aggregated verification fill 16
   uint8_t* aff = ws;
   uint8_t* part = aff + ((n * AFF + 255) & ~(size_t)255);
   uint8_t* win = part + (((size_t)32 * S * 256 * JAC + 255) & ~(size_t)255);
@@ -1779,12 +1810,18 @@ static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, cons
   hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, (const u32*)d_pts_std, (void*)aff, bad, n);
   if (G == 1) {
     typedef F1<C> F;
-    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
-    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NWL * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
+    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(NWL), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
   } else {
     typedef F2<C> F;
-    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
-    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NWL * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
+    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(NWL), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+  }
+  if constexpr (G == 1) {
+    if (glv_pairs) {
+      hipLaunchKernelGGL((k_msm_final_glv<C>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
+      return;
+    }
   }
   hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
 }
@@ -1861,7 +1898,7 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   }
   F = (const Fp12<C>*)cur;
   // S2 = sum d_i sig2_i
-  msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm);
+  msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm, true);
   bool tail_done = false;
   if constexpr (CoopBuild<C>::value) {
     if (c->coop) {                                            // the serial tail on 32 lanes (level-scheduled program): ~4x faster than a lane pair
