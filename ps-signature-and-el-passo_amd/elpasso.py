@@ -26,6 +26,8 @@ _SIGS = {
     "elp_field_bytes": (_c.c_int, [_c.c_int]),
     "elp_set_option": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     "elp_key_table_bytes": (_c.c_size_t, [_c.c_void_p]),
+    "elp_host_alloc": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "elp_host_free": (None, [_c.c_void_p, _c.c_void_p]),
     "elp_version": (_c.c_char_p, []),
     "elp_set_pubkey": (_c.c_int, [_c.c_void_p, _c.c_int, _u8p, _u8p, _u8p, _u8p, _u8p, _c.c_int]),
     "elp_set_rp": (_c.c_int, [_c.c_void_p, _u8p, _c.c_size_t, _u8p, _u8p, _u8p]),
