@@ -53,8 +53,9 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_TABLE_WORKSPACE (default 1): the verify_id kernels keep the per-item tables of their variable-base multiplications in a
  * launch workspace in device memory (3 KB per item, see the *_dev entry points) instead of the lanes' private memory; results are
  * identical, 0 saves the memory at a few per cent of throughput.
- * ELP_OPT_SPLIT_PHASES (default 1): the one-lane-per-item el_passo_verify_id runs as two kernels -- the NIZK half with two job lanes per
- * item (two waves per SIMD), then the pairing check -- instead of one fused kernel; results are identical (BN254 builds).
+ * ELP_OPT_SPLIT_PHASES (default 0; BN254 builds): 1 = the one-lane-per-item el_passo_verify_id runs as two kernels -- the NIZK half as independent jobs on two
+ * job waves per workgroup, then the pairing check; 2 = the G2 job and the G1 jobs as concurrent kernels on two streams, then the pairing check.  Results are
+ * identical; measured not faster than the fused kernel at full batches, faster at a light load.
  * ELP_OPT_SUBGROUP_CHECK (default 1; BLS12-381 only, BN254 has G1 cofactor 1): the prover-supplied G1 points of a proof or request (phi, E1, E2;
  * the commitment A of el_passo_provide_id) must lie in the order-r subgroup, otherwise the item is rejected (one [z^2]P per point, ~9 % of a
  * verification).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
@@ -62,9 +63,13 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_COOP_PAIRING (default 1; BN254 builds): batches of at most 4096 items (value > 1: that many) and the closing step of aggregated verification run
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
  * (pair) per item: measured, a lone PS verification takes 2.9 ms instead of 5.2, 4096 of them 3.8 ms instead of 4.7, a lone el_passo_verify_id 8-9 ms
- * instead of 9.8, 64..2048 of them 6.7-7.4 ms instead of 9.0.  Results are identical.  0 = off. */
+ * instead of 9.8, 64..2048 of them 6.7-7.4 ms instead of 9.0.  Results are identical.  0 = off.
+ * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
+ * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.
+ * Needs records of a multiple of 16 bytes, at most 1152, at a 16-byte aligned address; otherwise the in-place kernel runs.  Results are identical and so is the
+ * kernel time (measured: 17.3 ms either way at 65 536 items).  0 = read in place. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
-       ELP_OPT_COOP_PAIRING = 6 };
+       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

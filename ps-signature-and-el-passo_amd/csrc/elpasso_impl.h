@@ -66,6 +66,56 @@ __global__ void ELP_LAUNCH_BOUNDS k_verify_id(KeyCtx<C> key, const u32* recs, in
   count_accept(ok, accepted);
 }
 
+// The same with COALESCED record loads (north_star: "coalesced HBM loads"; ELP_OPT_COALESCED_RECORDS): the workgroup's 64 records are one contiguous
+// 64 x rec_words block of the input; all lanes fetch it with 16-byte loads (a wave instruction covers 1 KB of consecutive addresses) into the LDS area
+// that later serves as the hot slots, P records at a time with an odd word stride per record, and every lane copies ITS record out of LDS into private
+// memory, which the hardware interleaves by lane.  The body then reads the record through that private copy.  (As handed over, lane l reads words at
+// recs + l * rec_words: 64 different cache lines per load instruction.)
+#define ELP_STAGE_CAP 288      // words of the private copy: records up to 1152 bytes (A = 16, H = 4 with id-retrieval: 265 words)
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_verify_id_staged(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+                                                                const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
+                                                                unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP(key);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
+  u32 myrec[ELP_STAGE_CAP];
+  {
+    u32* const tile = elp_hot_lds;
+    const int stride = rec_words | 1;                              // odd: the per-lane copy below walks 32 banks without conflicts
+    int P = ELP_BLOCK;
+    while (P * stride > ELP_BLOCK * elp::ELP_HOT_WORDS) P >>= 1;   // records per pass that fit the area
+    const size_t wg0 = (size_t)blockIdx.x * blockDim.x;
+    const int lane = (int)threadIdx.x;
+    for (int base = 0; base < ELP_BLOCK; base += P) {
+      const size_t first = wg0 + base;
+      const int avail = first < n ? (int)((n - first) < (size_t)P ? (n - first) : (size_t)P) : 0;
+      const int total = avail * rec_words;                         // words of this pass, contiguous from recs + first * rec_words
+      const uint4* src = reinterpret_cast<const uint4*>(recs + first * (size_t)rec_words);
+      for (int k = lane * 4; k < total; k += ELP_BLOCK * 4) {      // rec_words % 4 == 0 (checked by the launcher): a 16-byte word never straddles two records
+        const uint4 v = src[k >> 2];
+        const int r = k / rec_words, w = k - r * rec_words;
+        u32* d = tile + r * stride + w;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+      __syncthreads();
+      if (lane >= base && lane < base + avail) {
+        const u32* mine = tile + (lane - base) * stride;
+        for (int w = 0; w < rec_words; w++) myrec[w] = mine[w];
+      }
+      __syncthreads();
+    }
+  }
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    ok = verify_id_item<C>(key, myrec, mask, retr != 0, a, al);
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
+
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_verify_id_wire(KeyCtx<C> key, const uint8_t* msgs, const u32* msg_off, int retr,
                                                               const uint8_t* ad, const u32* ad_off, u32 ad_len, uint8_t* flags,
@@ -1242,6 +1292,7 @@ struct elp_ctx {
   int use_vtab = 1;           // ELP_VTAB=0 in the environment keeps the tables in private memory (A/B measurements)
   int split = 0;              // ELP_OPT_SPLIT_PHASES: 1 = el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them; 2 = the two jobs
                               // of the first phase as concurrent kernels on two streams (k_vid_g2 || k_vid_g1, then k_vid_pair2)
+  int stage_records = 1;      // ELP_OPT_COALESCED_RECORDS: k_verify_id_staged (records through LDS into a private copy) instead of k_verify_id; measured equal in time
   int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
   size_t coop_max = 4096;     // 16 items per CU x 256 CUs: one round of the cooperative kernel; measured cross-over against the per-lane kernels between 4096 and 8192 items
   void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
@@ -1990,6 +2041,15 @@ template <class B>
 void launch_vid_g1(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<B>& key) {
   hipLaunchKernelGGL((k_vid_g1<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, ws, stride, n);
 }
+template <class B>
+void launch_verify_id_staged(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off,
+                             size_t ad_len, void* d_flags, void* d_accepted, const KeyCtx<B>& key) {
+  hipLaunchKernelGGL((k_verify_id_staged<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+}
+#ifndef ELP_STAGE_TU
+extern template void launch_verify_id_staged<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted, const KeyCtx<BN254>& key);
+#endif
 #ifndef ELP_G2JOB_TU
 extern template void launch_vid_g2<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, uint8_t* ok_g2, u32* ws, size_t stride, const KeyCtx<BN254>& key);
 #endif
@@ -2099,6 +2159,14 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       key.vtab = nullptr;
       hipLaunchKernelGGL((k_vid_pair<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, key, (const u32*)d_records, words,
                          (const uint8_t*)nizk_ok, (const u32*)kws, lanes, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+      HIPCHK(c, hipGetLastError());
+      return ELP_OK;
+    }
+  }
+  if constexpr (SplitBuild<C>::value) {
+    if (c->stage_records && words <= ELP_STAGE_CAP && (words & 3) == 0 && ((uintptr_t)d_records & 15) == 0) {
+      launch_verify_id_staged<C>((hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, d_flags, d_accepted,
+                                 make_key_ws<C>(c, (hipStream_t)stream, (size_t)grid_for(n) * ELP_BLOCK));
       HIPCHK(c, hipGetLastError());
       return ELP_OK;
     }

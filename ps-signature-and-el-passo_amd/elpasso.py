@@ -16,6 +16,7 @@ OPT_TABLE_WORKSPACE = 3
 OPT_SPLIT_PHASES = 4
 OPT_SUBGROUP_CHECK = 5
 OPT_COOP_PAIRING = 6
+OPT_COALESCED_RECORDS = 7
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -170,11 +171,15 @@ class Context:
         self._chk(self.lib.elp_set_option(self.h, OPT_SUBGROUP_CHECK, int(bool(on))))
 
     def set_coop_pairing(self, on):
-        """ELP_OPT_COOP_PAIRING: 0 = off, 1 = cooperative pairing check for batches of <= 8192 items and the aggregated tail (default), > 1 = that batch limit."""
+        """ELP_OPT_COOP_PAIRING: 0 = off, 1 = cooperative pairing check for batches of <= 4096 items and the aggregated tail (default), > 1 = that batch limit."""
         self._chk(self.lib.elp_set_option(self.h, OPT_COOP_PAIRING, int(on)))
 
+    def set_coalesced_records(self, on):
+        """ELP_OPT_COALESCED_RECORDS: verify_id records fetched per workgroup with coalesced 16-byte loads through LDS into a private copy (k_verify_id_staged)."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_COALESCED_RECORDS, int(bool(on))))
+
     def set_split_phases(self, on):
-        """ELP_OPT_SPLIT_PHASES (default on): one-lane-per-item verify_id as two kernels (NIZK half with two job lanes per item, then the pairing)."""
+        """ELP_OPT_SPLIT_PHASES (default 0): 1 / 2 = one-lane-per-item verify_id as phase-split kernels (NIZK jobs, then the pairing); identical results."""
         self._chk(self.lib.elp_set_option(self.h, OPT_SPLIT_PHASES, int(on)))
 
     def set_pubkey(self, g, gg, XX, Yi, YYi, window_bits=0):

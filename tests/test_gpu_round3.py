@@ -222,3 +222,44 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
         assert not held2 and (fl2 == exp2).all()
     finally:
         gpu_ctx.set_coop_pairing(1)
+
+
+@pytest.mark.gpu
+def test_coalesced_record_loads_equal_in_place_reads(gpu_ctx):
+    """ELP_OPT_COALESCED_RECORDS (default on): k_verify_id_staged fetches the 64 records of a workgroup as one contiguous block through LDS into a private copy;
+    verdicts equal the in-place kernel's, the generator's expectation and the oracle's at ragged sizes (last workgroup partly empty, a lone item), with corrupted
+    and degenerate items; records larger than the private copy (A = 24: 1312 bytes) silently take the in-place kernel."""
+    L = oracle()
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=11, window_bits=8)
+    key = _oracle_key(L, wl, gpu_ctx, A)
+    gpu_ctx.set_paired_layout(0)
+    gpu_ctx.set_coop_pairing(0)            # small batches through the fused kernel too
+    try:
+        for n in (1, 63, 65, 777, 5000):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=5, corrupt_at=2, degenerate_items=(3,) if n > 10 else ())
+            gpu_ctx.set_coalesced_records(0)
+            f0, c0 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            gpu_ctx.set_coalesced_records(1)
+            f1, c1 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            assert (f0 == f1).all() and (f1 == expect).all() and c0 == c1 == int(expect.sum())
+            rsz = len(recs) // n
+            ofl = np.zeros(n, dtype=np.uint8)
+            m = min(n, 400)
+            L.elpo_verify_id_batch(key, m, recs[:m * rsz], rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+            assert (ofl[:m] == f1[:m]).all()
+        # without id-retrieval (672-byte records at A = 8, H = 4)
+        recs, mask, expect = wl.verify_id_batch(300, H, with_retrieval=False, corrupt_every=9, corrupt_at=1)
+        f1, c1 = gpu_ctx.verify_id_batch(recs, mask, False, wl.ad)
+        assert (f1 == expect).all()
+        # 1056-byte records (A = 16): four passes of 16 records through the LDS area; 1312-byte records (A = 24) exceed the private copy: in-place kernel
+        for A2, seed in ((16, 12), (24, 13)):
+            wl2 = synth.Workload(gpu_ctx, A2, seed=seed, window_bits=8)
+            recs, mask, expect = wl2.verify_id_batch(130, H, with_retrieval=True, corrupt_every=6, corrupt_at=1)
+            assert len(recs) // 130 == 672 + 32 * (A2 - H)
+            f2, c2 = gpu_ctx.verify_id_batch(recs, mask, True, wl2.ad)
+            assert (f2 == expect).all() and c2 == int(expect.sum())
+    finally:
+        L.elpo_key_free(key)
+        gpu_ctx.set_paired_layout(2)
+        gpu_ctx.set_coop_pairing(1)
