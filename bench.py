@@ -498,7 +498,7 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     lat = {}
     for coop in (1, 0):
         ctx.set_coop_pairing(coop)
-        for m in (1, 1024, 4096):
+        for m in (4096, 1, 1024, 4096):       # the first entry warms tables and TLBs for this mode (its time is overwritten by the last)
             ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, m, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
             lat["ps_verify_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms
     ctx.set_coop_pairing(1)
@@ -511,7 +511,7 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
     for coop in (1, 0):
         ctx.set_coop_pairing(coop)
-        for m in (1, 64, 1024, 4096):
+        for m in (4096, 1, 64, 1024, 4096):
             ms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_vrec.data_ptr(), vmask, 1, d_ad.data_ptr(), None, len(wl.ad),
                                                                          d_fl.data_ptr(), d_cnt.data_ptr())))
             lat["verify_id_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms

@@ -672,8 +672,10 @@ ELP_INL Scalar scalar_one_minus(const Scalar& c) {   // 1 - c mod r (c >= r cann
   return scalar_sub_mod_r<C>(one, cred);
 }
 // G2 job.  `vk` receives the wire bytes of V_k (as words).
+// `pre` (optional): the fixed-base part of V_k, sum rs_j YY_i + r_t gg + (1 - c) XX, as a Jacobian point computed beforehand by the cooperative kernel
+// k_vid_fixed_coop (8 lanes per sum); without it the job walks the tables itself.
 template <class C, class Src>
-ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F2<C>>& kk, const Scalar& c, u32* vk) {
+ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F2<C>>& kk, const Scalar& c, u32* vk, const Jac<F2<C>>* pre = nullptr) {
   typedef F2<C> G2F;
   const int A = key.A;
   const int nrs = src.nrs();
@@ -699,16 +701,19 @@ ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F
       g2_mul_gls_tab<C>(Vk, tabk, c);
     }
   }
-  {
+  if (pre) {
+    Jac<G2F> S = *pre;
+    jac_add<G2F>(Vk, Vk, S);
+  } else {
     int jh = 0;
     for (int i = 0; i < A; i++)
       if (src.hidden(i)) {
         acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, src.rs(jh));
         jh++;
       }
+    acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
+    acc_fixed_g2<C>(Vk, key, G2_BASE_XX, scalar_one_minus<C>(c));
   }
-  acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
-  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, scalar_one_minus<C>(c));
   Aff<G2F> aVk;
   jac_to_aff<G2F>(aVk, Vk);
   uint8_t b[2 * C::FBYTES];
@@ -716,13 +721,19 @@ ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F
   bytes_to_words(vk, b, 2 * C::FBYTES);
 }
 // K = k prod_{revealed} YY_i^{m_i}, affine (src/ps-verifier.cc:214-229): four fixed-base terms at A = 8, H = 4; whichever job has the time takes it
+// `pre` (optional): sum over the revealed attributes of m_i YY_i as a Jacobian point (k_vid_fixed_coop)
 template <class C, class Src>
-ELP_HEAVY void vid_job_k(const KeyCtx<C>& key, Src& src, const Aff<F2<C>>& kk, Aff<F2<C>>& aK) {
+ELP_HEAVY void vid_job_k(const KeyCtx<C>& key, Src& src, const Aff<F2<C>>& kk, Aff<F2<C>>& aK, const Jac<F2<C>>* pre = nullptr) {
   typedef F2<C> G2F;
   Jac<G2F> K;
-  jac_from_aff(K, kk);
-  for (int i = 0; i < key.A; i++)
-    if (!src.hidden(i)) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
+  if (pre) {
+    K = *pre;
+    jac_madd<G2F>(K, K, kk);
+  } else {
+    jac_from_aff(K, kk);
+    for (int i = 0; i < key.A; i++)
+      if (!src.hidden(i)) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
+  }
   jac_to_aff<G2F>(aK, K);
 }
 // G1 job.  `v1` receives the wire bytes of V_phi, V_E1, V_E2 (as words).
@@ -781,6 +792,49 @@ ELP_HEAVY void vid_job_g1(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F
     bytes_to_words(v1[t], b, C::FBYTES);
   }
 }
+// ONE of the three G1 commitments (which = 0: V_phi = [c]phi + [rs_0]hs; 1: V_E1 = [c]E1 + [r_e]g_eg; 2: V_E2 = [c]E2 + [r_e]apk + [rs_1]h) with its own
+// table of multiples and inversions: the form in which the commitments spread over three lanes of an item (k_vid_nizk4).  `vtab_slot`: this commitment's
+// 8-entry slice of the launch workspace or null.
+template <class C, class Src>
+ELP_HEAVY void vid_job_g1_one(const KeyCtx<C>& key, Src& src, int which, const Aff<F1<C>>& P, const Scalar& c, u32* vrow, u32* vtab_slot) {
+  typedef F1<C> G1F;
+  const int nrs = src.nrs();
+  Jac<G1F> V;
+  {
+    Aff<G1F> tab[8];
+    {
+      Jac<G1F> jm[8];
+      jac_multiples8<G1F>(jm, P);
+      Fp<C> z[7], zi[7];
+      for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
+      batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
+      tab[0] = P;
+      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
+    }
+    if (vtab_slot) {
+      for (int i = 0; i < 8; i++) vtab_store<G1F>(vtab_slot, i, tab[i]);
+      g1_mul_glv_with<C, WsTab<G1F>>(V, WsTab<G1F>{vtab_slot}, c);
+    } else {
+      g1_mul_glv_tab<C>(V, tab, c);
+    }
+  }
+  if (which == 0) {
+    acc_fixed_g1<C>(V, key, g1_base_hs(key), src.rs(0));
+  } else {
+    const Scalar r_e = src.rs(nrs - 1);
+    if (which == 1) {
+      acc_fixed_g1<C>(V, key, g1_base_geg(key), r_e);
+    } else {
+      acc_fixed_g1<C>(V, key, g1_base_apk(key), r_e);
+      acc_fixed_g1<C>(V, key, g1_base_h(key), src.rs(1));
+    }
+  }
+  Aff<G1F> a;
+  jac_to_aff<G1F>(a, V);
+  uint8_t b[C::FBYTES];
+  g1_serialize<C>(b, a);
+  bytes_to_words(vrow, b, C::FBYTES);
+}
 // closing step of phase 1: c == Hr(SHA256(hex k | hex phi | [hex E1 | hex E2] | hex V_k | hex V_phi | [hex V_E1 | hex V_E2] | ad))
 // (src/ps-verifier.cc:111-130); the input points come from the source's own serialisations (ser_k / ser_g1)
 template <class C, class Src>
@@ -829,21 +883,46 @@ struct VidNizkState {      // what a lane keeps across the barrier
 };
 template <class C>
 ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64 hidden_mask, bool retr, VidShared<C>& sh, VidNizkState<C>& st,
-                             Aff<F2<C>>& aK) {
+                             Aff<F2<C>>& aK, const Jac<F2<C>>* pre = nullptr) {      // pre: {fixed part of V_k, fixed part of K} of this item, or null
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
   Aff<F2<C>> kk;
   st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
   if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
   if (role == 0) {
-    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk);
+    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre);
   } else {
     sh.ok_g1 = st.ok ? 1u : 0u;
     aff_set_inf(aK);
     if (st.ok) {
       vid_job_g1<C, RecordSrc<C>>(key, st.src, retr, phi, E1, E2, st.c, sh.v1);
-      vid_job_k<C, RecordSrc<C>>(key, st.src, kk, aK);
+      vid_job_k<C, RecordSrc<C>>(key, st.src, kk, aK, pre ? pre + 1 : nullptr);
     }
+  }
+}
+// The same phase with FOUR roles per item (small batches: the jobs of an item in parallel): 0 = G2 job + closing step, 1 = V_phi and K, 2 = V_E1, 3 = V_E2.
+// `pre` (the fixed-base sums of k_vid_fixed_coop) is required.
+template <class C>
+ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u64 hidden_mask, bool retr, VidShared<C>& sh, VidNizkState<C>& st,
+                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre) {
+  Aff<F1<C>> sig1, sig2, phi, E1, E2;
+  Aff<F2<C>> kk;
+  st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
+  st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
+  u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
+  if (role == 0) {
+    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre);
+  } else if (role == 1) {
+    sh.ok_g1 = st.ok ? 1u : 0u;
+    aff_set_inf(aK);
+    if (st.ok) {
+      vid_job_g1_one<C, RecordSrc<C>>(key, st.src, 0, phi, st.c, sh.v1[0], ws1);
+      vid_job_k<C, RecordSrc<C>>(key, st.src, kk, aK, pre + 1);
+    }
+  } else if (retr && st.ok) {
+    const int t = role - 1;
+    vid_job_g1_one<C, RecordSrc<C>>(key, st.src, t, t == 1 ? E1 : E2, st.c, sh.v1[t], ws1 ? ws1 + t * 8 * vtab_entry_words<F1<C>>() : nullptr);
   }
 }
 template <class C>

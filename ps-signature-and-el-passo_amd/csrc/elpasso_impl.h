@@ -153,7 +153,8 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_verify(KeyCtx<C> key, const u32* recs, in
 #define ELP_NIZK_BLOCK 128
 template <class C>
 __global__ void __launch_bounds__(ELP_NIZK_BLOCK, 2) k_vid_nizk(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
-                                                                const u32* ad_off, u32 ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n) {
+                                                                const u32* ad_off, u32 ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n,
+                                                                const Jac<F2<C>>* pre) {      // pre: two sums per item from k_vid_fixed_coop, or null
   constexpr int HOTW = (int)(sizeof(Jac<F2<C>>) / 4);      // the only users of the slot in this kernel are the running sums of jac_acc_fixed
   __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_NIZK_BLOCK * HOTW];
   __shared__ VidShared<C> sh[64];
@@ -165,7 +166,33 @@ __global__ void __launch_bounds__(ELP_NIZK_BLOCK, 2) k_vid_nizk(KeyCtx<C> key, c
   st.ok = false;
   if (i < n) {
     Aff<F2<C>> aK;
-    vid_nizk_jobs<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK);
+    vid_nizk_jobs<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre ? pre + 2 * i : nullptr);
+    if (role == 1) vid_store_k<C>(kws, kstride, i, aK);
+  }
+  __syncthreads();
+  if (role == 0 && i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    const size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    nizk_ok[i] = vid_nizk_finish<C>(sh[lane], st, retr != 0, a, al) ? 1 : 0;
+  }
+}
+// Phase 1 with four job waves per 64 items (vid_nizk_jobs4) for small batches: G2 job | V_phi + K | V_E1 | V_E2 side by side.  The G2 job runs without a hot
+// slot (its fixed-base part arrives precomputed), the G1 jobs keep a Jac<F1>-sized one.
+template <class C>
+__global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
+                                                  uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre) {
+  constexpr int HOTW = (int)(sizeof(Jac<F1<C>>) / 4);
+  __shared__ __attribute__((aligned(16))) u32 hot_lds[192 * HOTW];
+  __shared__ VidShared<C> sh[64];
+  const int role = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  key.hot = role == 0 ? nullptr : hot_lds + (threadIdx.x - 64) * HOTW;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  if (key.vtab) key.vtab += i * (size_t)vtab_words<C>();     // one slice per item: the G2 job uses its first part, each G1 job its own third of the rest
+  VidNizkState<C> st;
+  st.ok = false;
+  if (i < n) {
+    Aff<F2<C>> aK;
+    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i);
     if (role == 1) vid_store_k<C>(kws, kstride, i, aK);
   }
   __syncthreads();
@@ -488,37 +515,29 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k(KeyCtx<C> key, const u32* recs, int rec
   jac_to_aff<F2<C>>(aK, K);
   vid_store_k<C>(kws, kstride, i, aK);
 }
-// The same on ELP_PSK_LANES lanes per item: the A x nwin table entries of the sum are dealt round-robin to the lanes (each recomputes the signed digit of its
-// window from the scalar: the carry chain is a few integer operations per window), partial sums are folded through lane shuffles with complete Jacobian
-// additions.  48 sequential mixed additions (A = 3, W = 16) become 6 + 3 full ones; the one inversion of the affine result stays.
+// Fixed-base sums on ELP_PSK_LANES lanes: the nterms x nwin table entries of  sum_t k_t B_t  are dealt round-robin to the lanes (each recomputes the signed digit
+// of its window from the scalar: the carry chain is a few integer operations per window), partial sums are folded through lane shuffles with complete Jacobian
+// additions.  `term(t, base, k)` names term t.  All 64 lanes of the wave must call (the shuffles); lane 0 of every group of 8 returns the sum.
 #define ELP_PSK_LANES 8
-template <class C>
-__global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+template <class C, class TermFn>
+__device__ __forceinline__ void coop_fixed_sum_g2(Jac<F2<C>>& K, const KeyCtx<C>& key, int sub, int nterms, bool live, TermFn term) {
   typedef F2<C> G;
   constexpr int J = ELP_PSK_LANES;
-  const int sub = (int)(threadIdx.x & (J - 1));
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / J;
-  bool ok = false;
-  Jac<G> K;
-  jac_set_inf(K);
-  if (i < n) {
-    const u32* rec = recs + i * (size_t)rec_words;
-    Aff<F1<C>> s1, s2;
-    ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && !aff_is_inf(s1);       // every lane of the item decides the same
-    if (ok) {
-      if (sub == 0) jac_from_aff(K, aff_from_mem<G>(key.b2[G2_BASE_XX]));
-      const int W = key.W, nwin = key.nwin, total = nattr * nwin;
-      ELP_NOUNROLL
-      for (int t = sub; t < total; t += J) {
-        const int a = t / nwin, j = t - a * nwin;
-        const Scalar k = scalar_mod_r<C>(scalar_load_w(rec + 4 * C::N + 8 * a));
-        int carry = 0, d = 0;
-        for (int jj = 0; jj <= j; jj++) d = fixed_base_digit(k, jj, W, carry);
-        if (d != 0) {
-          Aff<G> e = aff_from_mem<G>(key.t2[((size_t)(G2_BASE_YY0 + a) * nwin + j) * key.per + ((d < 0 ? -d : d) - 1)]);
-          if (d < 0) e.y = G::neg(e.y);
-          jac_madd<G>(K, K, e);
-        }
+  if (live) {
+    const int W = key.W, nwin = key.nwin, total = nterms * nwin;
+    ELP_NOUNROLL
+    for (int t = sub; t < total; t += J) {
+      const int a = t / nwin, j = t - a * nwin;
+      int base;
+      Scalar kraw;
+      term(a, base, kraw);
+      const Scalar k = scalar_mod_r<C>(kraw);
+      int carry = 0, d = 0;
+      for (int jj = 0; jj <= j; jj++) d = fixed_base_digit(k, jj, W, carry);
+      if (d != 0) {
+        Aff<G> e = aff_from_mem<G>(key.t2[((size_t)base * nwin + j) * key.per + ((d < 0 ? -d : d) - 1)]);
+        if (d < 0) e.y = G::neg(e.y);
+        jac_madd<G>(K, K, e);
       }
     }
   }
@@ -532,8 +551,30 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
       ELP_UNROLL
       for (int w = 0; w < NW; w++) dst[w] = __shfl_xor(src[w], m);
     }
-    if (ok && (sub & (2 * m - 1)) == 0) jac_add<G>(K, K, o);
+    if (live && (sub & (2 * m - 1)) == 0) jac_add<G>(K, K, o);
   }
+}
+// K of a plain PS verification on 8 lanes per item: 48 sequential mixed additions (A = 3, W = 16) become 6 + 3 full ones; the one inversion of the affine
+// result stays.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+  typedef F2<C> G;
+  constexpr int J = ELP_PSK_LANES;
+  const int sub = (int)(threadIdx.x & (J - 1));
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / J;
+  bool ok = false;
+  Jac<G> K;
+  jac_set_inf(K);
+  const u32* rec = recs + (i < n ? i : 0) * (size_t)rec_words;
+  if (i < n) {
+    Aff<F1<C>> s1, s2;
+    ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && !aff_is_inf(s1);       // every lane of the item decides the same
+    if (ok && sub == 0) jac_from_aff(K, aff_from_mem<G>(key.b2[G2_BASE_XX]));
+  }
+  coop_fixed_sum_g2<C>(K, key, sub, nattr, ok, [&](int a, int& base, Scalar& k) {
+    base = G2_BASE_YY0 + a;
+    k = scalar_load_w(rec + 4 * C::N + 8 * a);
+  });
   if (i < n && sub == 0) {
     todo[i] = ok ? 1 : 0;
     if (ok) {
@@ -542,6 +583,57 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
       vid_store_k<C>(kws, kstride, i, aK);
     }
   }
+}
+// The fixed-base halves of el_passo_verify_id's G2 work for small batches, 16 lanes per item (src/ps-verifier.cc:76-88,220-227): lanes 0-7 compute
+//     out[2 i]     = sum_{hidden} rs_j YY_i + r_t gg + (1 - c) XX          (V_k without its [c]k term)
+// and lanes 8-15
+//     out[2 i + 1] = sum_{revealed} m_i YY_i                               (K without k)
+// from the record's scalars alone (any 256-bit value is a valid scalar: nothing to validate here; k_vid_nizk validates the points and ignores the sums of an
+// invalid record).  Jacobian results: the NIZK jobs add them with complete additions.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, size_t n) {
+  typedef F2<C> G;
+  constexpr int J = ELP_PSK_LANES;
+  const int sub = (int)(threadIdx.x & (J - 1)), which = (int)((threadIdx.x >> 3) & 1);
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / (2 * J);
+  const bool live = i < n;
+  PairedRecordSrc<C> src;
+  src.init(recs + (live ? i : 0) * (size_t)rec_words, mask, key.A, retr != 0);
+  int H = 0;
+  for (int a = 0; a < key.A; a++) H += (int)((mask >> a) & 1);
+  const int nterms = which == 0 ? H + 2 : key.A - H;
+  Jac<G> S;
+  jac_set_inf(S);
+  coop_fixed_sum_g2<C>(S, key, sub, nterms, live, [&](int t, int& base, Scalar& k) {
+    if (which == 0) {
+      if (t < H) {                                  // t-th hidden attribute: response rs_t on YY_a
+        int a = 0, seen = 0;
+        for (; a < key.A; a++)
+          if ((mask >> a) & 1) {
+            if (seen == t) break;
+            seen++;
+          }
+        base = G2_BASE_YY0 + a;
+        k = src.rs(t);
+      } else if (t == H) {
+        base = G2_BASE_GG;
+        k = src.rs(retr ? src.nrs() - 2 : src.nrs() - 1);
+      } else {
+        base = G2_BASE_XX;
+        k = scalar_one_minus<C>(scalar_load_w(src.w_k_ + 4 * C::N));
+      }
+    } else {                                        // t-th revealed attribute: its hash on YY_a
+      int a = 0, seen = 0;
+      for (; a < key.A; a++)
+        if (!((mask >> a) & 1)) {
+          if (seen == t) break;
+          seen++;
+        }
+      base = G2_BASE_YY0 + a;
+      k = scalar_load_w(src.w_ms_ + 8 * t);
+    }
+  });
+  if (live && sub == 0) out[2 * i + which] = S;
 }
 // closing step of aggregated verification on 32 lanes: [F f_gg(-S2)]^e == 1
 template <class C>
@@ -596,6 +688,11 @@ void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void*
   hipLaunchKernelGGL((k_ps_k_coop<B>), dim3(grid_for(n * ELP_PSK_LANES)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, nattr, todo, kws, kstride, n);
 }
 template <class B>
+void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre) {
+  hipLaunchKernelGGL((k_vid_fixed_coop<B>), dim3(grid_for(n * 2 * ELP_PSK_LANES)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (Jac<F2<B>>*)pre, n);
+}
+template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok) {
   hipLaunchKernelGGL((k_agg_final_coop<B>), dim3(1), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const Fp12<B>*)F, (const u32*)s2_std, agg_ok);
 }
@@ -609,6 +706,8 @@ template <class B>
 void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
 template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
+template <class B>
+void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre);
 #endif
 // which curves have the cooperative kernels (their own translation unit, elpasso_<curve>_coop.hip)
 template <class B>
@@ -624,6 +723,7 @@ extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_const
 extern template void launch_pair_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
 extern template void launch_ps_k<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
 extern template void launch_agg_final_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
+extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre);
 #endif
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
@@ -2028,9 +2128,15 @@ struct SplitBuild<BN254> {
 };
 template <class B>
 void launch_vid_nizk(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
-                     const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<B>& key) {
+                     const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<B>& key, const void* pre) {
   hipLaunchKernelGGL((k_vid_nizk<B>), dim3(grid_for(n)), dim3(ELP_NIZK_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
-                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n);
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n, (const Jac<F2<B>>*)pre);
+}
+template <class B>
+void launch_vid_nizk4(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                      const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<B>& key, const void* pre) {
+  hipLaunchKernelGGL((k_vid_nizk4<B>), dim3(grid_for(n)), dim3(256), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n, (const Jac<F2<B>>*)pre);
 }
 template <class B>
 void launch_vid_g2(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, uint8_t* ok_g2, u32* ws, size_t stride,
@@ -2057,7 +2163,8 @@ extern template void launch_vid_g2<BN254>(hipStream_t stream, size_t n, const vo
 extern template void launch_vid_g1<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<BN254>& key);
 #endif
 #ifndef ELP_NIZK_TU
-extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key);
+extern template void launch_vid_nizk4<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre);
+extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre);
 #endif
 #ifndef ELP_PAIR_TU
 extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
@@ -2086,13 +2193,16 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
       void* extra = nullptr;
-      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + 2 * lanes, &extra);
+      const size_t pre_bytes = (lanes * 2 * sizeof(Jac<F2<C>>) + 255) & ~(size_t)255;      // fixed-base parts of V_k and K per item (k_vid_fixed_coop)
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + pre_bytes + 2 * lanes, &extra);
       if (consts && extra) {
         u32* kws = (u32*)extra;
-        uint8_t* nizk_ok = (uint8_t*)extra + k_bytes;
+        void* pre = (uint8_t*)extra + k_bytes;
+        uint8_t* nizk_ok = (uint8_t*)extra + k_bytes + pre_bytes;
         uint8_t* done = nizk_ok + lanes;
         HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
-        launch_vid_nizk<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key);
+        launch_vid_fixed_coop<C>((hipStream_t)stream, key, n, d_records, words, mask, retr, pre);
+        launch_vid_nizk4<C>((hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre);
         key.vtab = nullptr;
         launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, nizk_ok, kws, lanes, (uint8_t*)d_flags, done, d_accepted);
         HIPCHK(c, hipGetLastError());
@@ -2155,7 +2265,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       }
       u32* kws = (u32*)extra;
       uint8_t* nizk_ok = (uint8_t*)extra + k_bytes;
-      launch_vid_nizk<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key);
+      launch_vid_nizk<C>(c, (hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, nullptr);
       key.vtab = nullptr;
       hipLaunchKernelGGL((k_vid_pair<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, (hipStream_t)stream, key, (const u32*)d_records, words,
                          (const uint8_t*)nizk_ok, (const u32*)kws, lanes, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
