@@ -251,7 +251,7 @@ def main():
                            "set_pubkey_ms": wl.t_set_pubkey_ms, "set_rp_and_secret_ms": wl.t_set_params_ms,
                            "note": "signed-digit fixed-base window tables of the key's 14 G1 and 10 G2 bases, per key and per GPU; built on the GPU (k_window_bases, k_table_fill)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_verify_id", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_verify_id_staged (k_verify_id with coalesced record loads, ELP_OPT_COALESCED_RECORDS default)", "kernel_ms": kern_ms, "algorithmic_bytes_per_item": algo_bytes_per_item,
                          "note": "integer-VALU bound path: see valu_bound"},
         }
         out["valu_bound"] = valu_bound(ctx, "verify_id" if (args.curve == "bn254" and A == 8 and H == 4) else None, args.window, B, kern_ms, 162)

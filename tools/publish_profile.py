@@ -7,6 +7,9 @@ import os
 import shutil
 import sys
 
+# the dominant kernel: k_verify_id_staged (coalesced record loads, the default since round 3) or k_verify_id (records read in place)
+DOMINANT = ("k_verify_id<elp::BN254>", "k_verify_id_staged<elp::BN254>")
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles")
@@ -21,7 +24,7 @@ shutil.copy(f"{src}/summary.json", f"{dst}/{tag}_summary.json")
 def filt(inp, out):
     rows = list(csv.reader(open(inp)))
     ki = rows[0].index("Kernel_Name")
-    keep = [rows[0]] + [r for r in rows[1:] if "k_verify_id<elp::BN254>" in r[ki]]
+    keep = [rows[0]] + [r for r in rows[1:] if any(k in r[ki] for k in DOMINANT)]
     csv.writer(open(out, "w", newline="")).writerows(keep)
 
 

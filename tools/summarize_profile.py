@@ -6,6 +6,9 @@ import json
 import os
 import sys
 
+# the dominant kernel: k_verify_id_staged (coalesced record loads, the default since round 3) or k_verify_id (records read in place)
+DOMINANT = ("k_verify_id<elp::BN254>", "k_verify_id_staged<elp::BN254>")
+
 d, tag = sys.argv[1], sys.argv[2]
 out = {"tag": tag, "window": int(sys.argv[3]) if len(sys.argv) > 3 else None}
 rows = list(csv.DictReader(open(os.path.join(d, "trace", tag + "_kernel_stats.csv"))))
@@ -21,7 +24,7 @@ for sub in ("pmc_a", "pmc_b", "pmc_c"):
     rr = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(list)
     for r in rr:
-        if "k_verify_id<elp::BN254>" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in DOMINANT):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.setdefault(sub, {})[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
             meta = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "scratch_bytes_per_lane": int(r["Scratch_Size"]),
@@ -49,7 +52,7 @@ if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
 ok = True
 try:
     line = json.loads(open(os.path.join(d, "bench_headline.json")).read().strip().splitlines()[-1])
-    kv = [r for r in rows if "k_verify_id<elp::BN254>" in r["Name"]]
+    kv = [r for r in rows if any(k in r["Name"] for k in DOMINANT)]
     if kv:
         avg = float(kv[0]["AverageNs"]) / 1e6
         ok = avg <= 1.02 * line["ms_per_step"]
