@@ -314,6 +314,48 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     vid_load_k<C>(k2, ws.data(), 3, 1);                                                                                \
     return vid_pair_item<C>(c->key, rec, k2) ? 1 : 0;                                                                  \
   }                                                                                                                    \
+  /* the small-batch form (k_vid_fixed_coop + k_vid_nizk4 + pairing): the fixed-base sums computed first (here sequentially), the four job roles in turn */ \
+  int pfx##_verify_id_jobs4(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {        \
+    TwinCtx<C>* c = (TwinCtx<C>*)cv;                                                                                   \
+    Jac<F2<C>> pre[2];                                                                                                 \
+    jac_set_inf(pre[0]);                                                                                               \
+    jac_set_inf(pre[1]);                                                                                               \
+    {                                                                                                                  \
+      PairedRecordSrc<C> ps;                                                                                           \
+      ps.init(rec, mask, c->key.A, retr != 0);                                                                         \
+      int jh = 0, jr = 0;                                                                                              \
+      for (int i = 0; i < c->key.A; i++) {                                                                             \
+        if ((mask >> i) & 1) acc_fixed_g2<C>(pre[0], c->key, G2_BASE_YY0 + i, ps.rs(jh++));                             \
+        else acc_fixed_g2<C>(pre[1], c->key, G2_BASE_YY0 + i, scalar_load_w(ps.w_ms_ + 8 * jr++));                      \
+      }                                                                                                                \
+      acc_fixed_g2<C>(pre[0], c->key, G2_BASE_GG, ps.rs(retr ? ps.nrs() - 2 : ps.nrs() - 1));                           \
+      acc_fixed_g2<C>(pre[0], c->key, G2_BASE_XX, scalar_one_minus<C>(scalar_load_w(ps.w_k_ + 4 * C::N)));              \
+    }                                                                                                                  \
+    VidShared<C> sh;                                                                                                   \
+    memset(&sh, 0xa5, sizeof sh);                                                                                      \
+    VidNizkState<C> st[4];                                                                                             \
+    Aff<F2<C>> aK, unused;                                                                                             \
+    for (int role = 0; role < 4; role++) vid_nizk_jobs4<C>(c->key, role, rec, mask, retr != 0, sh, st[role], role == 1 ? aK : unused, pre); \
+    if (!vid_nizk_finish<C>(sh, st[0], retr != 0, ad, adlen)) return 0;                                                \
+    return vid_pair_item<C>(c->key, rec, aK) ? 1 : 0;                                                                  \
+  }                                                                                                                    \
+  /* [a]P + [b]phi(P) with a = k[0..1], b = k[2..3] (curve.h g1_mul_pair64_with: the multiplier of aggregated verification); 0 = P is not on the curve */ \
+  int pfx##_g1_mul_pair64(const u32* P, const u32* k, u32* out) {                                                      \
+    Aff<F1<C>> p;                                                                                                      \
+    if (!g1_load<C>(p, P)) return 0;                                                                                   \
+    Aff<F1<C>> tab[8];                                                                                                 \
+    Jac<F1<C>> jm[8];                                                                                                  \
+    jac_multiples8<F1<C>>(jm, p);                                                                                      \
+    for (int i = 0; i < 8; i++) jac_to_aff<F1<C>>(tab[i], jm[i]);                                                      \
+    Scalar d;                                                                                                          \
+    for (int i = 0; i < 8; i++) d.v[i] = i < 4 ? k[i] : 0;                                                             \
+    Jac<F1<C>> r;                                                                                                      \
+    g1_mul_pair64_with<C, PrivTab<F1<C>>>(r, PrivTab<F1<C>>{tab}, d);                                                  \
+    Aff<F1<C>> a;                                                                                                      \
+    jac_to_aff<F1<C>>(a, r);                                                                                           \
+    g1_store<C>(out, a);                                                                                               \
+    return 1;                                                                                                          \
+  }                                                                                                                    \
   int pfx##_verify_id_wire(void* c, const uint8_t* msg, size_t len, int retr, const uint8_t* ad, size_t adlen) {          \
     return verify_id_wire_item<C>(((TwinCtx<C>*)c)->key, msg, len, retr != 0, ad, adlen) ? 1 : 0;                      \
   }                                                                                                                    \

@@ -114,6 +114,9 @@ def test_verify_id_golden(L):
                 # the two-phase form (two job roles + pairing phase) gives the same verdict
                 got = L.twin_bn254_verify_id_split(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
                 assert bool(got) == c["expect"], ("split", s["name"], c["label"])
+                # the small-batch form (fixed-base sums first, four job roles, pairing phase) as well
+                got = L.twin_bn254_verify_id_jobs4(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
+                assert bool(got) == c["expect"], ("jobs4", s["name"], c["label"])
                 n += 1
     assert n > 80
 
@@ -129,6 +132,7 @@ def test_verify_id_with_retrieval_golden(L):
         for ad, exp in ((b"hello", 1), (b"hellO", 0)):
             assert L.twin_bn254_verify_id(ctx, rec, ctypes.c_uint64(hidden_mask(P.attributes)), 1, ad, len(ad)) == exp
             assert L.twin_bn254_verify_id_split(ctx, rec, ctypes.c_uint64(hidden_mask(P.attributes)), 1, ad, len(ad)) == exp
+            assert L.twin_bn254_verify_id_jobs4(ctx, rec, ctypes.c_uint64(hidden_mask(P.attributes)), 1, ad, len(ad)) == exp
 
 
 def test_ps_verify_and_provide_id(L):
@@ -364,3 +368,40 @@ def test_paired_layout_wire_ingest(L):
     assert L.twin_bn254p_verify_id_wire(ctx, raw, len(raw), 1, b"hellO", 5) == 0
     for cut in (1, 2, 35, 100, len(raw) - 1):
         assert L.twin_bn254p_verify_id_wire(ctx, raw[:cut], cut, 1, b"hello", 5) == 0
+
+
+def test_aggregation_multiplier_in_glv_form(L):
+    """g1_mul_pair64_with (the multiplier a + b lam of aggregated verification, 64 shared doublings): the result equals [a]P + [b]phi(P) computed by the model,
+    phi(x, y) = (beta x, y) for ONE of the two primitive cube roots of unity (the same one for every input), on both curves; edge multipliers included."""
+    from elp_testlib import BLS12_381
+    for pfx, curve, N in (("twin_bn254", BN254, 32), ("twin_bls", BLS12_381, 48)):
+        Mc = Mcl(curve)
+        G = Mc.G
+        p = curve.p
+        betas = [b for b in (pow(g, (p - 1) // 3, p) for g in range(2, 12)) if b != 1][:1]
+        betas.append(betas[0] * betas[0] % p)
+        fn = getattr(L, pfx + "_g1_mul_pair64")
+        which = None
+        P0 = Mc.hash_to_g1("pair64")
+        cases = [(1, 0), (0, 1), (2**64 - 1, 2**64 - 1), (0x8888888888888888, 0x7777777777777777), (0, 0)]
+        cases += [(scalar_stream(5, 2 * i, 2**64), scalar_stream(5, 2 * i + 1, 2**64)) for i in range(6)]
+        for j, (a, b) in enumerate(cases):
+            P = G.g1_mul(P0, j + 1)
+            k = (ctypes.c_uint32 * 4)(a & 0xFFFFFFFF, a >> 32, b & 0xFFFFFFFF, b >> 32)
+            out = ctypes.create_string_buffer(2 * N)
+            assert fn(g1b(P, N), k, out) == 1
+            got = out.raw
+            want = []
+            for beta in betas:
+                Q = (P[0] * beta % p, P[1])
+                want.append(g1b(G.g1_add(G.g1_mul(P, a), G.g1_mul(Q, b)), N))
+            if a == 0 and b == 0:
+                assert got == bytes(2 * N)
+                continue
+            if which is None and want[0] != want[1]:
+                which = 0 if got == want[0] else 1
+            if which is not None:
+                assert got == want[which], (pfx, j)
+            else:
+                assert got in want
+        assert which is not None
