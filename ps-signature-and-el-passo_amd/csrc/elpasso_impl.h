@@ -495,26 +495,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_pair_rest(KeyCtx<C> key, const u32* recs, in
   }
   count_accept(ok, accepted);
 }
-// K of a plain PS verification (src/ps-verifier.cc:20-29: XX prod YY_i^{m_i}), affine, into the workspace; todo[i] = the record decodes and sig1 != infinity (:16-18)
-template <class C>
-__global__ void ELP_LAUNCH_BOUNDS k_ps_k(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
-  constexpr int HOTW = (int)(sizeof(Jac<F2<C>>) / 4);
-  __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_BLOCK * HOTW];
-  key.hot = hot_lds + threadIdx.x * HOTW;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u32* rec = recs + i * (size_t)rec_words;
-  Aff<F1<C>> s1, s2;
-  const bool ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && !aff_is_inf(s1);
-  todo[i] = ok ? 1 : 0;
-  if (!ok) return;
-  Jac<F2<C>> K;
-  jac_from_aff(K, aff_from_mem<F2<C>>(key.b2[G2_BASE_XX]));
-  for (int a = 0; a < nattr; a++) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + a, scalar_load_w(rec + 4 * C::N + 8 * a));
-  Aff<F2<C>> aK;
-  jac_to_aff<F2<C>>(aK, K);
-  vid_store_k<C>(kws, kstride, i, aK);
-}
+// K of a plain PS verification (src/ps-verifier.cc:20-29: XX prod YY_i^{m_i}), affine, into the workspace; todo[i] = the record decodes and sig1 != infinity (:16-18).
 // Fixed-base sums on ELP_PSK_LANES lanes: the nterms x nwin table entries of  sum_t k_t B_t  are dealt round-robin to the lanes (each recomputes the signed digit
 // of its window from the scalar: the carry chain is a few integer operations per window), partial sums are folded through lane shuffles with complete Jacobian
 // additions.  `term(t, base, k)` names term t.  All 64 lanes of the wave must call (the shuffles); lane 0 of every group of 8 returns the sum.

@@ -31,3 +31,11 @@ for it in range(4):
     e1.record()
     torch.cuda.synchronize()
     print("agg call %d: %.3f ms  ok=%s" % (it, e0.elapsed_time(e1), bool((d_flags.cpu().numpy() == expect).all())), flush=True)
+for it in range(4):      # per-item calls beside them (same lease: clock and cycles per instruction compared in one rocprofv3 pass)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, B, d_rec.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(wl.ad), d_flags.data_ptr(), d_cnt.data_ptr()))
+    e1.record()
+    torch.cuda.synchronize()
+    print("per-item call %d: %.3f ms" % (it, e0.elapsed_time(e1)), flush=True)
+ctx.close()
