@@ -63,7 +63,7 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_COOP_PAIRING (default 1; BN254 builds): batches of at most 4096 items (value > 1: that many) and the closing step of aggregated verification run
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
  * (pair) per item, and the NIZK half of el_passo_verify_id spreads its jobs over four waves per 64 items with the fixed-base G2 sums on 8 lanes each: measured, a
- * lone PS verification takes 2.3 ms instead of 5.1, 4096 of them 3.3 ms instead of 4.6, 64..1024 el_passo_verify_id 4.9 ms instead of 8.8, 4096 of them 6.0 ms.
+ * lone PS verification takes 1.8 ms instead of 5.1, 4096 of them 3.3 ms instead of 4.6, 64..1024 el_passo_verify_id 4.9 ms instead of 8.8, 4096 of them 6.0 ms.
  * Results are identical.  0 = off.
  * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
  * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.

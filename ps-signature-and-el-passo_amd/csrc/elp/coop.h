@@ -1,4 +1,4 @@
-// Cooperative pairing check: one item on COOP_NP lane pairs with an Fp2 register file in LDS, interpreting the level-scheduled programs that
+// Cooperative pairing check: one item on 16 or 32 lane pairs with an Fp2 register file in LDS, interpreting the level-scheduled programs that
 // tools/gen_coop.py generates (elp/coop_prog_<curve>.h).  Replaces, for SMALL batches and for the tail of aggregated verification, the
 // one-lane(-pair)-per-item evaluation of  pairing() + GT==  (src/ps-verifier.cc:31-34,134-137):
 //     check: [ f_Q(P1) f_gg(P2) ]^((p^12-1)/r) == 1      (P1 = sig1, Q = K, P2 = -sig2; the lines of gg come precomputed from the key)
@@ -25,6 +25,7 @@ struct CoopProg {        // one scheduled program (device pointers on the device
   int nsteps;
   int out[6];            // registers of the result (c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2)
   const u32* chunk_off = nullptr;   // first term of every chunk of COOP_CHUNK steps (+ end): the kernels stage descriptors and terms through LDS chunk by chunk
+  int np = 16;                      // lane pairs per item the program was scheduled for (descriptors per step); the kernels know it at compile time
 };
 
 // The register file and the staged program live in LDS: on the device the interpreter takes LDS-address-space pointers, so that every access is a DS
@@ -113,7 +114,7 @@ ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, cons
 #if !defined(__HIP_DEVICE_COMPILE__)
 template <class C>
 ELP_INL int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, const i32* R, const i32* consts, const Fp2<C>* lines, Fp<C>& out) {
-  return coop_exec_desc<C>(P.prog[((size_t)step * 16 + slot) * 2], P.prog[((size_t)step * 16 + slot) * 2 + 1], P.terms, comp, R, consts, lines, out);
+  return coop_exec_desc<C>(P.prog[((size_t)step * P.np + slot) * 2], P.prog[((size_t)step * P.np + slot) * 2 + 1], P.terms, comp, R, consts, lines, out);
 }
 #endif
 // the same from the two descriptor words; `terms[d1 + t]` must be term t of a LIN descriptor (the kernels pass a pointer into their LDS copy of the chunk)
@@ -195,11 +196,11 @@ inline void coop_run_host(const CoopProg& P, i32* R, const Fp2<C>* consts2, int 
   }
   const i32* consts = cw.data();
   for (int s = 0; s < P.nsteps; s++) {
-    Fp<C> res[16][2];
-    int dst[16][2];
-    for (int q = 0; q < 16; q++)
+    Fp<C> res[32][2];
+    int dst[32][2];
+    for (int q = 0; q < P.np; q++)
       for (int c = 0; c < 2; c++) dst[q][c] = coop_exec_slot<C>(P, s, q, c, R, consts, lines, res[q][c]);
-    for (int q = 0; q < 16; q++)
+    for (int q = 0; q < P.np; q++)
       for (int c = 0; c < 2; c++)
         if (dst[q][c] >= 0) coop_st<C>(R, dst[q][c], c, res[q][c]);
   }

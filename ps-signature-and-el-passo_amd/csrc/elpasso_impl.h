@@ -314,13 +314,22 @@ struct CoopTables<BN254> {
     using namespace elp::coop_bn254;
     return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}, CHECK_CHUNK_OFF};
   }
-  static __device__ __forceinline__ CoopProg tail() {
+  static __device__ __forceinline__ CoopProg check32() {      // the same check scheduled for 32 lane pairs (one item per wave)
+    using namespace elp::coop_bn254;
+    return CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}, CHECK32_CHUNK_OFF};
+  }
+  static __device__ __forceinline__ CoopProg tail() {         // 32 lane pairs
     using namespace elp::coop_bn254;
     return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}, TAIL_CHUNK_OFF};
   }
+  static_assert(elp::coop_bn254::CHECK_NP == 16 && elp::coop_bn254::CHECK32_NP == 32 && elp::coop_bn254::TAIL_NP == 32, "lane pairs per item of the generated programs");
   static constexpr int CHUNK = elp::coop_bn254::COOP_CHUNK;
-  static constexpr int MAX_CHUNK_TERMS = elp::coop_bn254::CHECK_MAX_CHUNK_TERMS > elp::coop_bn254::TAIL_MAX_CHUNK_TERMS ? elp::coop_bn254::CHECK_MAX_CHUNK_TERMS : elp::coop_bn254::TAIL_MAX_CHUNK_TERMS;
-  static constexpr int NREG = elp::coop_bn254::COOP_NREG, NP = elp::coop_bn254::COOP_NP, NCONST = elp::coop_bn254::COOP_NCONST;
+  template <int NP_>
+  static constexpr int max_chunk_terms() {
+    using namespace elp::coop_bn254;
+    return NP_ == 16 ? CHECK_MAX_CHUNK_TERMS : (CHECK32_MAX_CHUNK_TERMS > TAIL_MAX_CHUNK_TERMS ? CHECK32_MAX_CHUNK_TERMS : TAIL_MAX_CHUNK_TERMS);
+  }
+  static constexpr int NREG = elp::coop_bn254::COOP_NREG, NCONST = elp::coop_bn254::COOP_NCONST;
   static constexpr int IN_P1 = elp::coop_bn254::IN_P1, IN_P2 = elp::coop_bn254::IN_P2, IN_QX = elp::coop_bn254::IN_QX, IN_QY = elp::coop_bn254::IN_QY,
                        IN_ONE = elp::coop_bn254::IN_ONE, IN_F0 = elp::coop_bn254::IN_F0;
   static __device__ __forceinline__ const uint8_t (*kinds())[3] { return elp::coop_bn254::CONST_KIND; }
@@ -335,17 +344,20 @@ __global__ void ELP_LAUNCH_BOUNDS k_coop_consts(Fp2<C>* out) {
 // runs program P over the register files of the workgroup's two items; every lane walks all steps (empty slots and inactive items idle)
 // The program itself (descriptors and the terms of the linear combinations) is staged through LDS in chunks of CHUNK steps by all 64 lanes with coalesced
 // loads: read straight from global memory every step would open with a dependent ~1 us load and every term of a combination with another.
-// Workgroup of the cooperative kernels: COOP_ITEMS items x 32 lanes.  4 items share one staged copy of the program; 4 x 8.6 KB of registers + 4.9 KB of program
-// = 39.5 KB per workgroup, four workgroups (16 items, two waves per SIMD) per CU.
-#define ELP_COOP_ITEMS 4
-#define ELP_COOP_BLOCK (32 * ELP_COOP_ITEMS)
-template <class C>
+// Workgroup of the cooperative kernels: 128 lanes = 4 items x 16 lane pairs (batches: the items share one staged copy of the program; 4 x 8.6 KB of registers +
+// 4.9 KB of program = 39.5 KB per workgroup, four workgroups -- 16 items, two waves per SIMD -- per CU) or 2 items x 32 lane pairs (one item per wave: lone items,
+// batches that leave SIMDs idle anyway, the one closing pairing of aggregated verification: a quarter fewer steps).
+#define ELP_COOP_BLOCK 128
+template <class C, int NP>
 struct CoopLds {
   typedef CoopTables<C> T;
+  static constexpr int LANES = 2 * NP;                // lanes of one item
+  static constexpr int ITEMS = ELP_COOP_BLOCK / LANES;
   static constexpr int RW = T::NREG * 2 * C::NL;      // words of one item's register file
   static constexpr int RPAD = 17;                     // the items of a wave run the same program in lockstep: without the offset item 1 would hit the banks of item 0 on every access
-  static constexpr int R_WORDS = ELP_COOP_ITEMS * (RW + RPAD) + 2 * ELP_COOP_ITEMS;      // + two flag words per item
-  static constexpr int STAGE_WORDS = T::CHUNK * 32 + T::MAX_CHUNK_TERMS + T::NCONST * 2 * C::NL;
+  static constexpr int R_WORDS = ITEMS * (RW + RPAD) + 2 * ITEMS;      // + two flag words per item
+  static constexpr int MAXT = T::template max_chunk_terms<NP>();
+  static constexpr int STAGE_WORDS = T::CHUNK * NP * 2 + MAXT + T::NCONST * 2 * C::NL;
 };
 // orders the LDS traffic of one wave: the lanes of an item sit in one wave and the LDS pipeline serves a wave's accesses in order, so between two steps the
 // program needs no workgroup barrier, only that the compiler keeps the order
@@ -354,16 +366,18 @@ __device__ __forceinline__ void coop_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <class C>
+template <class C, int NP>
 __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines) {
   typedef CoopTables<C> T;
-  constexpr int CH = T::CHUNK, DW = CH * 32;            // descriptor words per chunk (16 slots x 2 words per step)
+  constexpr int MAXT = CoopLds<C, NP>::MAXT;
+  constexpr int SW = NP * 2;                            // descriptor words per step (two per lane pair)
+  constexpr int CH = T::CHUNK, DW = CH * SW;            // descriptor words per chunk
   constexpr int ND = DW / ELP_COOP_BLOCK;               // descriptor words per lane and chunk
-  constexpr int NT = (T::MAX_CHUNK_TERMS + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;   // term words per lane and chunk
+  constexpr int NT = (MAXT + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;   // term words per lane and chunk
   static_assert(DW % ELP_COOP_BLOCK == 0, "a chunk of descriptors is a whole number of words per lane");
   coop_u32* const sd = stage;
   coop_u32* const stt = stage + DW;
-  coop_i32* const cw = (coop_i32*)(stage + DW + T::MAX_CHUNK_TERMS);     // the constants, in the layout of the register file
+  coop_i32* const cw = (coop_i32*)(stage + DW + MAXT);     // the constants, in the layout of the register file
   {
     const i32* src = reinterpret_cast<const i32*>(consts);
     for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += ELP_COOP_BLOCK) cw[k] = src[k];
@@ -377,11 +391,11 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
     const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
     t0n = P.chunk_off[s0 / CH];
     t1n = P.chunk_off[s0 / CH + 1];
-    const u32* src = P.prog + (size_t)s0 * 32;
+    const u32* src = P.prog + (size_t)s0 * SW;
     ELP_UNROLL
     for (int j = 0; j < ND; j++) {
       const int k = (int)threadIdx.x + j * ELP_COOP_BLOCK;
-      pd[j] = k < ns * 32 ? src[k] : ((k & 1) ? 0u : 0xF0000000u);     // past the end: empty slots
+      pd[j] = k < ns * SW ? src[k] : ((k & 1) ? 0u : 0xF0000000u);     // past the end: empty slots
     }
     ELP_UNROLL
     for (int j = 0; j < NT; j++) {
@@ -400,7 +414,7 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
     ELP_UNROLL
     for (int j = 0; j < NT; j++) {
       const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
-      if (k < (u32)T::MAX_CHUNK_TERMS) stt[k] = pt[j];
+      if (k < (u32)MAXT) stt[k] = pt[j];
     }
     __syncthreads();
     if (s0 + CH < P.nsteps) fetch(s0 + CH);
@@ -408,7 +422,7 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
     for (int s = 0; s < ns; s++) {
       if (active) {
         Fp<C> out;
-        const int dst = coop_exec_desc<C>(sd[s * 32 + pair * 2], sd[s * 32 + pair * 2 + 1], stt - t0, comp, R, cw, lines, out);
+        const int dst = coop_exec_desc<C>(sd[s * SW + pair * 2], sd[s * SW + pair * 2 + 1], stt - t0, comp, R, cw, lines, out);
         if (dst >= 0) coop_st<C>(R, dst, comp, out);     // the register allocation never lets a step write a register that the same step reads
       }
       coop_wave_sync();
@@ -431,17 +445,17 @@ __device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool
 }
 // items [0, n): sig1 | sig2 at the head of the record, K in the workspace (vid_store_k layout); todo[i] != 0 selects the items to check.  An item whose sig1,
 // sig2 or K is the point at infinity (or fails validation) is left to the per-lane kernel: done[i] stays 0.  Otherwise flags[i] = verdict, done[i] = 1.
-template <class C>
+template <class C, int NP>
 __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
                                                             size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n) {
   typedef CoopTables<C> T;
-  typedef CoopLds<C> L;
+  typedef CoopLds<C, NP> L;
   __shared__ __attribute__((aligned(16))) i32 Rall[L::R_WORDS];
   __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
-  const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
+  const int slot = (int)(threadIdx.x / L::LANES), pair = (int)((threadIdx.x % L::LANES) >> 1), comp = (int)(threadIdx.x & 1);
   coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
-  coop_i32* flagw = (coop_i32*)Rall + ELP_COOP_ITEMS * (L::RW + L::RPAD) + slot;     // [slot]: is-one flag, [ITEMS + slot]: "inputs usable"
-  const size_t i = (size_t)blockIdx.x * ELP_COOP_ITEMS + slot;
+  coop_i32* flagw = (coop_i32*)Rall + L::ITEMS * (L::RW + L::RPAD) + slot;     // [slot]: is-one flag, [ITEMS + slot]: "inputs usable"
+  const size_t i = (size_t)blockIdx.x * L::ITEMS + slot;
   if (pair == 0 && comp == 0) {
     int usable = 0;
     if (i < n && todo[i]) {
@@ -465,12 +479,12 @@ __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, con
         }
       }
     }
-    flagw[ELP_COOP_ITEMS] = usable;
+    flagw[L::ITEMS] = usable;
   }
   __syncthreads();
-  const bool active = flagw[ELP_COOP_ITEMS] != 0;
-  const CoopProg P = T::check();
-  coop_run_device<C>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
+  const bool active = flagw[L::ITEMS] != 0;
+  const CoopProg P = NP == 16 ? T::check() : T::check32();
+  coop_run_device<C, NP>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
   if (pair == 0 && comp == 0 && active) {
     flags[i] = one ? 1 : 0;
@@ -616,16 +630,16 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* rec
   });
   if (live && sub == 0) out[2 * i + which] = S;
 }
-// closing step of aggregated verification on 32 lanes: [F f_gg(-S2)]^e == 1
+// closing step of aggregated verification on one wave (32 lane pairs): [F f_gg(-S2)]^e == 1
 template <class C>
 __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_agg_final_coop(KeyCtx<C> key, const Fp2<C>* consts, const Fp12<C>* F, const u32* s2_std, int* agg_ok) {
   typedef CoopTables<C> T;
-  typedef CoopLds<C> L;
+  typedef CoopLds<C, 32> L;
   __shared__ __attribute__((aligned(16))) i32 Rall[L::R_WORDS];
   __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
-  const int slot = (int)(threadIdx.x >> 5), pair = (int)((threadIdx.x & 31) >> 1), comp = (int)(threadIdx.x & 1);
+  const int slot = (int)(threadIdx.x / L::LANES), pair = (int)((threadIdx.x % L::LANES) >> 1), comp = (int)(threadIdx.x & 1);
   coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
-  coop_i32* flagw = (coop_i32*)Rall + ELP_COOP_ITEMS * (L::RW + L::RPAD) + slot;
+  coop_i32* flagw = (coop_i32*)Rall + L::ITEMS * (L::RW + L::RPAD) + slot;
   if (pair == 0 && comp == 0) {
     int state = 0;                                  // 0: run the program, 1: verdict is "false" (bad point)
     if (slot == 0) {
@@ -643,12 +657,12 @@ __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_agg_final_coop(KeyCtx<C> key
         coop_st<C>(R, T::IN_F0 + j, 1, e[j]->c1);
       }
     }
-    flagw[ELP_COOP_ITEMS] = (slot == 0 && state == 0) ? 1 : 0;
+    flagw[L::ITEMS] = (slot == 0 && state == 0) ? 1 : 0;
   }
   __syncthreads();
-  const bool active = flagw[ELP_COOP_ITEMS] != 0;
+  const bool active = flagw[L::ITEMS] != 0;
   const CoopProg P = T::tail();
-  coop_run_device<C>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
+  coop_run_device<C, 32>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
   if (threadIdx.x == 0) *agg_ok = (active && one) ? 1 : 0;
 }
@@ -659,8 +673,13 @@ void launch_coop_consts(hipStream_t stream, void* d_consts) {
 template <class B>
 void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
                       uint8_t* d_flags, uint8_t* done, void* d_accepted) {
-  hipLaunchKernelGGL((k_pair_coop<B>), dim3((unsigned)((n + ELP_COOP_ITEMS - 1) / ELP_COOP_ITEMS)), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
-                     d_flags, done, (unsigned long long*)d_accepted, n);
+  // up to 1024 items (one wave per SIMD or fewer): one item per wave, 32 lane pairs, 982 steps; above: two items per wave, 16 lane pairs each, 1293 steps
+  if (n <= 1024)
+    hipLaunchKernelGGL((k_pair_coop<B, 32>), dim3((unsigned)((n + 1) / 2)), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
+                       d_flags, done, (unsigned long long*)d_accepted, n);
+  else
+    hipLaunchKernelGGL((k_pair_coop<B, 16>), dim3((unsigned)((n + 3) / 4)), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
+                       d_flags, done, (unsigned long long*)d_accepted, n);
   hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, todo, (const uint8_t*)done, kws, kstride, d_flags,
                      (unsigned long long*)d_accepted, n);
 }

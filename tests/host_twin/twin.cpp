@@ -488,8 +488,9 @@ int twin_blsp_pairing(const u32* P, const u32* Q, u32* o) {
 }
 #endif
 #if !defined(TWIN_PART) || TWIN_PART == 1
-// Cooperative pairing check (elp/coop.h): the level-scheduled program executed slot by slot on the host.  mode 0: [f_K(sig1) f_gg(-sig2)]^e, mode 1 (the tail
-// of aggregated verification): [F f_gg(-sig2)]^e with F = f_K(sig1) computed here by the ordinary Miller loop.  Writes the GT bytes; returns 1 iff the value is 1.
+// Cooperative pairing check (elp/coop.h): the level-scheduled program executed slot by slot on the host.  mode 0: [f_K(sig1) f_gg(-sig2)]^e by the 16-pair
+// program, mode 2: the same by the 32-pair program, mode 1 (the tail of aggregated verification, 32 pairs): [F f_gg(-sig2)]^e with F = f_K(sig1) computed here
+// by the ordinary Miller loop.  Writes the GT bytes; returns 1 iff the value is 1.
 extern "C" int twin_bn254_pair_coop(void* cv, const u32* sig1w, const u32* sig2w, const u32* Kw, int mode, u32* gt_out) {
   typedef BN254 C;
   using namespace elp::coop_bn254;
@@ -508,14 +509,20 @@ extern "C" int twin_bn254_pair_coop(void* cv, const u32* sig1w, const u32* sig2w
   coop_st<C>(R.data(), IN_ONE, 0, fp_one<C>());
   coop_st<C>(R.data(), IN_ONE, 1, fp_zero<C>());
   CoopProg P;
-  if (mode == 0) {
+  if (mode == 0 || mode == 2) {
     coop_st<C>(R.data(), IN_P1, 0, s1.x);
     coop_st<C>(R.data(), IN_P1, 1, s1.y);
     coop_st<C>(R.data(), IN_QX, 0, K.x.c0);
     coop_st<C>(R.data(), IN_QX, 1, K.x.c1);
     coop_st<C>(R.data(), IN_QY, 0, K.y.c0);
     coop_st<C>(R.data(), IN_QY, 1, K.y.c1);
-    P = CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}};
+    if (mode == 0) {
+      P = CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}};
+      P.np = CHECK_NP;
+    } else {
+      P = CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}};
+      P.np = CHECK32_NP;
+    }
   } else {
     Fp12<C> F;
     miller_loop<C, 1, 0>(F, &s1, &K, &s1, (const LineMem<C>* const*)0);
@@ -525,6 +532,7 @@ extern "C" int twin_bn254_pair_coop(void* cv, const u32* sig1w, const u32* sig2w
       coop_st<C>(R.data(), IN_F0 + j, 1, e[j]->c1);
     }
     P = CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}};
+    P.np = TAIL_NP;
   }
   coop_run_host<C>(P, R.data(), consts.data(), (int)consts.size(), reinterpret_cast<const Fp2<C>*>(c->lines.data()));
   Fp12<C> g;

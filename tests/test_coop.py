@@ -34,7 +34,7 @@ def test_program_value_equals_model_pairing_product(env):
     for a, b, k in ((424242, 171717, 987654321), (1, 1, 1), (M.r - 1, 2, M.r - 2)):
         P1, P2, K = G.g1_mul(g1, a), G.g1_mul(g1, b), G.g2_mul(pk.gg, k)
         want = _gt_bytes(G.F.f12_mul(G.pairing(P1, K), G.pairing(G.g1_neg(P2), pk.gg)))
-        for mode in (0, 1):          # 0: check program (variable + fixed pair), 1: tail program (F given, fixed pair)
+        for mode in (0, 2, 1):       # 0 / 2: check program for 16 / 32 lane pairs (variable + fixed pair), 1: tail program (F given, fixed pair; 32 lane pairs)
             r = L.twin_bn254_pair_coop(ctx, g1b(P1), g1b(P2), g2b(K), mode, out)
             assert out.raw == want and r == int(a * k % M.r == b % M.r)
 
@@ -57,6 +57,7 @@ def test_verdicts_on_ps_signatures(env):
         K = G.g2_add(K, G.g2_mul(pk.YYi[i], ms[i]))
     out = ctypes.create_string_buffer(384)
     one = fb(1) + bytes(352)
-    assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(sig2), g2b(K), 0, out) == 1 and out.raw == one
-    assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(G.g1_add(sig2, g)), g2b(K), 0, out) == 0
-    assert L.twin_bn254_pair_coop(ctx2, g1b(G.g1_mul(sig1, 2)), g1b(sig2), g2b(K), 0, out) == 0
+    for mode in (0, 2):
+        assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(sig2), g2b(K), mode, out) == 1 and out.raw == one
+        assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(G.g1_add(sig2, g)), g2b(K), mode, out) == 0
+        assert L.twin_bn254_pair_coop(ctx2, g1b(G.g1_mul(sig1, 2)), g1b(sig2), g2b(K), mode, out) == 0

@@ -476,7 +476,8 @@ def srcs(op):
     return [x for x in (a, b) if x >= 0]
 
 
-def schedule(prog, outs, ninputs):
+def schedule(prog, outs, ninputs, np_=None):
+    NP_ = np_ or NP
     ops = prog.ops
     live = [False] * len(ops)
     stack = list(outs)
@@ -538,7 +539,7 @@ def schedule(prog, outs, ninputs):
     # split levels wider than NP into rounds (each round is one barrier-separated step of the kernel)
     steps = []
     for lv, lst in enumerate(by_level):
-        nr = (len(lst) + NP - 1) // NP
+        nr = (len(lst) + NP_ - 1) // NP_
         for k in range(nr):                              # balanced rounds
             steps.append((lv & 1, lst[k::nr]))
     step_of = {}
@@ -583,7 +584,7 @@ def schedule(prog, outs, ninputs):
     return steps, reg, list(outs), peak
 
 
-def encode(ops, steps, reg):
+def encode(ops, steps, reg, np_=None):
     """Two 32-bit words per (step, slot):  word 0 = op:4 | dst:8 | a:8 | b:8 | aux:4  (LDL / MULC carry their index in b:aux, 12 bits); a LIN descriptor is
     word 0 = op:4 | dst:8 | nterms:20, word 1 = offset into the term table, one word per term:  reg:8 | m00:4 | m01:4 | m10:4 | m11:4 (two's complement
     nibbles);  NOP = 0xF."""
@@ -607,7 +608,7 @@ def encode(ops, steps, reg):
             elif op == MULS:
                 x = aux
             row += [(op << 28) | (reg[i] << 20) | (ra << 12) | (rb << 4) | x, 0]
-        row += [0xF0000000, 0] * (NP - len(row) // 2)
+        row += [0xF0000000, 0] * ((np_ or NP) - len(row) // 2)
         words.append(row)
     return words, terms
 
@@ -741,10 +742,12 @@ def validate(cv):
     lines = model_lines(cv, gg)
     want = F.f12_mul(G.pairing(P1, Q), G.pairing(P2, gg))
     res = {}
-    for name, variable in (("check", True), ("tail", False)):
+    # check: 16 lane pairs per item (two items per wave: batches); check32 / tail: 32 lane pairs (one item per wave: lone items, small batches, the one
+    # closing pairing of aggregated verification) -- fewer, wider steps where the dependency depth allows
+    for name, variable, np_ in (("check", True, 16), ("check32", True, 32), ("tail", False, 32)):
         prog, outs, nlines = trace_check(cv, variable)
         assert 3 * nlines == len(lines)
-        steps, reg, outs_c, peak = schedule(prog, outs, IN_F0 + 6)
+        steps, reg, outs_c, peak = schedule(prog, outs, IN_F0 + 6, np_)
         consts = [None] * len(CONSTS)
         for k, v in CONSTS.items():
             consts[v] = cvals[k]
@@ -762,7 +765,7 @@ def validate(cv):
         assert got == exp, "%s: the scheduled program does not reproduce the model's pairing value" % name
         nmul = sum(len(l) for c, l in steps if c == 1)
         nlin = sum(len(l) for c, l in steps if c == 0)
-        res[name] = (prog, steps, reg, outs_c, peak, nmul, nlin)
+        res[name] = (prog, steps, reg, outs_c, peak, nmul, nlin, np_)
         print("%s: %d mul ops in %d mul steps, %d lin ops in %d lin steps, peak %d registers (+%d inputs), %d fixed lines" %
               (name, nmul, sum(1 for c, _ in steps if c == 1), nlin, sum(1 for c, _ in steps if c == 0), peak, IN_F0 + 6, nlines), file=sys.stderr)
     return res
@@ -797,7 +800,7 @@ def emit_header(res, path, cvname):
     out = []
     A = out.append
     A("// GENERATED by tools/gen_coop.py -- do not edit.  Level-scheduled Fp2 programs of the cooperative pairing kernels (csrc/elp/coop.h).")
-    A("// Each step holds COOP_NP descriptors of two words (one descriptor per lane pair of an item):  op:4 | dst:8 | a:8 | b:8 | aux:4 , 0   (LIN: op:4 | dst:8 | nterms:20 , term offset;")
+    A("// Each step holds <program>_NP descriptors of two words (one descriptor per lane pair of an item):  op:4 | dst:8 | a:8 | b:8 | aux:4 , 0   (LIN: op:4 | dst:8 | nterms:20 , term offset;")
     A("// term = reg:8 | four signed nibbles of the 2x2 matrix acting on (re, im)).  *_CLASS: 1 = every slot of the step is an Fp2 product, 0 = linear class.")
     A("#pragma once")
     A("#include <stdint.h>")
@@ -806,7 +809,7 @@ def emit_header(res, path, cvname):
     A("#endif")
     A("namespace elp {")
     A("namespace coop_%s {" % cvname)
-    A("constexpr int COOP_NP = %d;" % NP)
+    A("constexpr int COOP_NP = %d;   // lane pairs per item of the batch program (CHECK); CHECK32 / TAIL: their own *_NP" % NP)
     A("constexpr int COOP_NREG = %d;" % NREG)
     A("constexpr int COOP_CHUNK = %d;" % CHUNK)
     A("enum { OP_MUL = %d, OP_MULC = %d, OP_MULS = %d, OP_LIN = %d, OP_LDL = %d, OP_INV = %d, OP_NOP = 15 };" % (MUL, MULC, MULS, LIN, LDL, INV))
@@ -826,15 +829,16 @@ def emit_header(res, path, cvname):
             n_, w_ = name[6:].split("_")
             kinds.append((3, int(n_), 0 if w_ == "x" else 1))
     A("ELP_COOP_TABLE const uint8_t CONST_KIND[%d][3] = {%s};" % (len(kinds), ",".join("{%d,%d,%d}" % k for k in kinds)))
-    for name, (prog, steps, reg, outs_c, peak, nmul, nlin) in res.items():
-        words, terms = encode(prog.ops, steps, reg)
+    for name, (prog, steps, reg, outs_c, peak, nmul, nlin, np_) in res.items():
+        words, terms = encode(prog.ops, steps, reg, np_)
         U = name.upper()
+        A("constexpr int %s_NP = %d;" % (U, np_))
         A("// %s: %d steps (%d products, %d linear-class operations, %d terms), peak %d registers" % (name, len(steps), nmul, nlin, len(terms), peak))
         A("constexpr int %s_NSTEPS = %d;" % (U, len(steps)))
         A("constexpr int %s_NTERMS = %d;" % (U, len(terms)))
         A("constexpr int %s_OUT[6] = {%s};" % (U, ", ".join(str(reg[o]) for o in outs_c)))
         A("ELP_COOP_TABLE const uint8_t %s_CLASS[%d] = {%s};" % (U, len(steps), ",".join(str(c) for c, _ in steps)))
-        A("alignas(16) ELP_COOP_TABLE const uint32_t %s_PROG[%d] = {" % (U, len(steps) * NP * 2))
+        A("alignas(16) ELP_COOP_TABLE const uint32_t %s_PROG[%d] = {" % (U, len(steps) * np_ * 2))
         for row in words:
             A("  " + ",".join("0x%08xu" % w for w in row) + ",")
         A("};")
