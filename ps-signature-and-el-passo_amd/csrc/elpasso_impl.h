@@ -2034,22 +2034,32 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
                      (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
                      (Fp12<C>*)(ws + o_f1), n);
   key.vtab = nullptr;   // the kernels below do not advance the pointer to their lane (the rare per-item fallback keeps its tables in private memory)
-  // product of the per-wave Miller values: nw -> nw2 -> 1
-  hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nw2), dim3(ELP_BLOCK), 0, stream, (const Fp12<C>*)(ws + o_f1), nw, (Fp12<C>*)(ws + o_f2));
+  // The two halves of the tail are independent -- the product of the per-wave Miller values (nw -> nw2 -> 1) and S2 = sum d_i sig2_i (Pippenger) -- and
+  // neither fills the chip: the product runs on the context's second stream beside the sum.
+  if (!c->jstream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->jstream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->jev[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->jev[1], hipEventDisableTiming));
+  }
+  HIPCHK(c, hipEventRecord(c->jev[0], stream));
+  HIPCHK(c, hipStreamWaitEvent(c->jstream, c->jev[0], 0));
+  hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nw2), dim3(ELP_BLOCK), 0, c->jstream, (const Fp12<C>*)(ws + o_f1), nw, (Fp12<C>*)(ws + o_f2));
   const Fp12<C>* F = (const Fp12<C>*)(ws + o_f2);
   size_t left = nw2;
   uint8_t *cur = ws + o_f2, *nxt = ws + o_f1;   // ping-pong (o_f1 is free again after the first reduction)
   while (left > 1) {
     size_t nl = grid_for(left);
-    hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nl), dim3(ELP_BLOCK), 0, stream, (const Fp12<C>*)cur, left, (Fp12<C>*)nxt);
+    hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nl), dim3(ELP_BLOCK), 0, c->jstream, (const Fp12<C>*)cur, left, (Fp12<C>*)nxt);
     uint8_t* t = cur;
     cur = nxt;
     nxt = t;
     left = nl;
   }
   F = (const Fp12<C>*)cur;
+  HIPCHK(c, hipEventRecord(c->jev[1], c->jstream));
   // S2 = sum d_i sig2_i
   msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm, true);
+  HIPCHK(c, hipStreamWaitEvent(stream, c->jev[1], 0));
   bool tail_done = false;
   if constexpr (CoopBuild<C>::value) {
     if (c->coop) {                                            // the serial tail on 32 lanes (level-scheduled program): ~4x faster than a lane pair
