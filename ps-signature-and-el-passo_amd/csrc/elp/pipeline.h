@@ -904,7 +904,7 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
 // `pre` (the fixed-base sums of k_vid_fixed_coop) is required.
 template <class C>
 ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u64 hidden_mask, bool retr, VidShared<C>& sh, VidNizkState<C>& st,
-                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre) {
+                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre, bool k_done = false) {      // k_done: K was already completed by the kernel that made `pre`
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
   Aff<F2<C>> kk;
   st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
@@ -918,7 +918,7 @@ ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u6
     aff_set_inf(aK);
     if (st.ok) {
       vid_job_g1_one<C, RecordSrc<C>>(key, st.src, 0, phi, st.c, sh.v1[0], ws1);
-      vid_job_k<C, RecordSrc<C>>(key, st.src, kk, aK, pre + 1);
+      if (!k_done) vid_job_k<C, RecordSrc<C>>(key, st.src, kk, aK, pre + 1);
     }
   } else if (retr && st.ok) {
     const int t = role - 1;

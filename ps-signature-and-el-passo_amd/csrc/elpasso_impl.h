@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(ELP_NIZK_BLOCK, 2) k_vid_nizk(KeyCtx<C> key, c
 // slot (its fixed-base part arrives precomputed), the G1 jobs keep a Jac<F1>-sized one.
 template <class C>
 __global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
-                                                  uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre) {
+                                                  uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre, int k_done) {
   constexpr int HOTW = (int)(sizeof(Jac<F1<C>>) / 4);
   __shared__ __attribute__((aligned(16))) u32 hot_lds[192 * HOTW];
   __shared__ VidShared<C> sh[64];
@@ -192,8 +192,8 @@ __global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* rec
   st.ok = false;
   if (i < n) {
     Aff<F2<C>> aK;
-    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i);
-    if (role == 1) vid_store_k<C>(kws, kstride, i, aK);
+    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i, k_done != 0);
+    if (role == 1 && !k_done) vid_store_k<C>(kws, kstride, i, aK);
   }
   __syncthreads();
   if (role == 0 && i < n) {
@@ -586,7 +586,8 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
 // from the record's scalars alone (any 256-bit value is a valid scalar: nothing to validate here; k_vid_nizk validates the points and ignores the sums of an
 // invalid record).  Jacobian results: the NIZK jobs add them with complete additions.
 template <class C>
-__global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride,
+                                                   uint8_t* kvalid, size_t n) {
   typedef F2<C> G;
   constexpr int J = ELP_PSK_LANES;
   const int sub = (int)(threadIdx.x & (J - 1)), which = (int)((threadIdx.x >> 3) & 1);
@@ -628,7 +629,32 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* rec
       k = scalar_load_w(src.w_ms_ + 8 * t);
     }
   });
-  if (live && sub == 0) out[2 * i + which] = S;
+  if (live && sub == 0) {
+    out[2 * i + which] = S;
+    if (which == 1) {
+      // K = k + that sum, affine, straight into the workspace (vid_store_k layout): the pairing check of the item can start while its NIZK half is still
+      // being verified (k_pair_coop on a second stream).  kvalid[i] = the record's k decodes (on the twist); everything else is the NIZK kernel's business.
+      Aff<G> kk, aK;
+      const bool okk = g2_load<C>(kk, src.w_k_);
+      aff_set_inf(aK);
+      if (okk) {
+        jac_madd<G>(S, S, kk);
+        jac_to_aff<G>(aK, S);
+      }
+      vid_store_k<C>(kws, kstride, i, aK);
+      kvalid[i] = okk ? 1 : 0;
+    }
+  }
+}
+// verdict of a small-batch el_passo_verify_id = its NIZK half (k_vid_nizk4) AND its pairing check (k_pair_coop / k_pair_rest), which ran side by side
+__global__ void ELP_LAUNCH_BOUNDS k_vid_combine(const uint8_t* nizk_ok, const uint8_t* pair_ok, uint8_t* flags, unsigned long long* accepted, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    ok = nizk_ok[i] != 0 && pair_ok[i] != 0;
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
 }
 // closing step of aggregated verification on one wave (32 lane pairs): [F f_gg(-S2)]^e == 1
 template <class C>
@@ -673,8 +699,9 @@ void launch_coop_consts(hipStream_t stream, void* d_consts) {
 template <class B>
 void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
                       uint8_t* d_flags, uint8_t* done, void* d_accepted) {
-  // up to 1024 items (one wave per SIMD or fewer): one item per wave, 32 lane pairs, 982 steps; above: two items per wave, 16 lane pairs each, 1293 steps
-  if (n <= 1024)
+  // up to 512 items (half the SIMDs: the other half is free for the kernel that runs beside this one): one item per wave, 32 lane pairs, 982 steps; above: two
+  // items per wave, 16 lane pairs each, 1293 steps
+  if (n <= 512)
     hipLaunchKernelGGL((k_pair_coop<B, 32>), dim3((unsigned)((n + 1) / 2)), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
                        d_flags, done, (unsigned long long*)d_accepted, n);
   else
@@ -688,9 +715,14 @@ void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void*
   hipLaunchKernelGGL((k_ps_k_coop<B>), dim3(grid_for(n * ELP_PSK_LANES)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, nattr, todo, kws, kstride, n);
 }
 template <class B>
-void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre) {
+void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
+                           uint8_t* kvalid) {
   hipLaunchKernelGGL((k_vid_fixed_coop<B>), dim3(grid_for(n * 2 * ELP_PSK_LANES)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
-                     (Jac<F2<B>>*)pre, n);
+                     (Jac<F2<B>>*)pre, kws, kstride, kvalid, n);
+}
+template <class B>
+void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted) {
+  hipLaunchKernelGGL(k_vid_combine, dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, nizk_ok, pair_ok, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
 template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok) {
@@ -707,7 +739,10 @@ void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void*
 template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
 template <class B>
-void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre);
+void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
+                           uint8_t* kvalid);
+template <class B>
+void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
 #endif
 // which curves have the cooperative kernels (their own translation unit, elpasso_<curve>_coop.hip)
 template <class B>
@@ -723,7 +758,8 @@ extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_const
 extern template void launch_pair_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
 extern template void launch_ps_k<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
 extern template void launch_agg_final_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
-extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre);
+extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
+extern template void launch_vid_combine<BN254>(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
 #endif
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
@@ -2144,9 +2180,9 @@ void launch_vid_nizk(elp_ctx* c, hipStream_t stream, size_t n, const void* d_rec
 }
 template <class B>
 void launch_vid_nizk4(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
-                      const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<B>& key, const void* pre) {
+                      const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<B>& key, const void* pre, int k_done) {
   hipLaunchKernelGGL((k_vid_nizk4<B>), dim3(grid_for(n)), dim3(256), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
-                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n, (const Jac<F2<B>>*)pre);
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kws, kstride, n, (const Jac<F2<B>>*)pre, k_done);
 }
 template <class B>
 void launch_vid_g2(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, uint8_t* ok_g2, u32* ws, size_t stride,
@@ -2173,7 +2209,7 @@ extern template void launch_vid_g2<BN254>(hipStream_t stream, size_t n, const vo
 extern template void launch_vid_g1<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<BN254>& key);
 #endif
 #ifndef ELP_NIZK_TU
-extern template void launch_vid_nizk4<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre);
+extern template void launch_vid_nizk4<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre, int k_done);
 extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre);
 #endif
 #ifndef ELP_PAIR_TU
@@ -2204,17 +2240,32 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
       void* extra = nullptr;
       const size_t pre_bytes = (lanes * 2 * sizeof(Jac<F2<C>>) + 255) & ~(size_t)255;      // fixed-base parts of V_k and K per item (k_vid_fixed_coop)
-      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + pre_bytes + 2 * lanes, &extra);
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + pre_bytes + 4 * lanes, &extra);
       if (consts && extra) {
+        // k_vid_fixed_coop (fixed-base sums, K) -> { k_vid_nizk4 on the caller's stream  ||  k_pair_coop on the context's second stream } -> k_vid_combine:
+        // the pairing check only needs K, which is ready after the first kernel, so the two long kernels of a small batch overlap
+        hipStream_t st = (hipStream_t)stream;
+        if (!c->jstream) {
+          HIPCHK(c, hipStreamCreateWithFlags(&c->jstream, hipStreamNonBlocking));
+          HIPCHK(c, hipEventCreateWithFlags(&c->jev[0], hipEventDisableTiming));
+          HIPCHK(c, hipEventCreateWithFlags(&c->jev[1], hipEventDisableTiming));
+        }
         u32* kws = (u32*)extra;
         void* pre = (uint8_t*)extra + k_bytes;
         uint8_t* nizk_ok = (uint8_t*)extra + k_bytes + pre_bytes;
         uint8_t* done = nizk_ok + lanes;
-        HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
-        launch_vid_fixed_coop<C>((hipStream_t)stream, key, n, d_records, words, mask, retr, pre);
-        launch_vid_nizk4<C>((hipStream_t)stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre);
+        uint8_t* kvalid = done + lanes;
+        uint8_t* pair_ok = kvalid + lanes;
+        HIPCHK(c, hipMemsetAsync(done, 0, lanes, st));
+        launch_vid_fixed_coop<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);
+        HIPCHK(c, hipEventRecord(c->jev[0], st));
+        HIPCHK(c, hipStreamWaitEvent(c->jstream, c->jev[0], 0));
+        launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
         key.vtab = nullptr;
-        launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, nizk_ok, kws, lanes, (uint8_t*)d_flags, done, d_accepted);
+        launch_pair_coop<C>(c->jstream, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
+        HIPCHK(c, hipEventRecord(c->jev[1], c->jstream));
+        HIPCHK(c, hipStreamWaitEvent(st, c->jev[1], 0));
+        launch_vid_combine<C>(st, n, nizk_ok, pair_ok, d_flags, d_accepted);
         HIPCHK(c, hipGetLastError());
         return ELP_OK;
       }
