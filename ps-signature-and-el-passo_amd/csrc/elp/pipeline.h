@@ -675,13 +675,16 @@ ELP_INL Scalar scalar_one_minus(const Scalar& c) {   // 1 - c mod r (c >= r cann
 // `pre` (optional): the fixed-base part of V_k, sum rs_j YY_i + r_t gg + (1 - c) XX, as a Jacobian point computed beforehand by the cooperative kernel
 // k_vid_fixed_coop (8 lanes per sum); without it the job walks the tables itself.
 template <class C, class Src>
-ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F2<C>>& kk, const Scalar& c, u32* vk, const Jac<F2<C>>* pre = nullptr) {
+ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F2<C>>& kk, const Scalar& c, u32* vk, const Jac<F2<C>>* pre = nullptr,
+                          bool table_ready = false) {      // table_ready: the multiples 1k .. 8k already sit in the lane's workspace slice (k_vid_ktab)
   typedef F2<C> G2F;
   const int A = key.A;
   const int nrs = src.nrs();
   const Scalar r_t = src.rs(retr ? nrs - 2 : nrs - 1);
   Jac<G2F> Vk;
-  {
+  if (table_ready && key.vtab) {
+    g2_mul_gls_with<C, WsTab<G2F>>(Vk, WsTab<G2F>{key.vtab}, c);
+  } else {
     // 1k .. 8k: Jacobian multiples, one inversion (of the product of the norms) for the seven that need it
     Aff<G2F> tabk[8];
     {
@@ -904,7 +907,7 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
 // `pre` (the fixed-base sums of k_vid_fixed_coop) is required.
 template <class C>
 ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u64 hidden_mask, bool retr, VidShared<C>& sh, VidNizkState<C>& st,
-                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre, bool k_done = false) {      // k_done: K was already completed by the kernel that made `pre`
+                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre, bool k_done = false, bool table_ready = false) {      // k_done: K and the table of multiples of k were already made by the kernels that ran before (k_vid_fixed_coop, k_vid_ktab)
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
   Aff<F2<C>> kk;
   st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
@@ -912,7 +915,7 @@ ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u6
   if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
   u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
   if (role == 0) {
-    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre);
+    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre, table_ready);
   } else if (role == 1) {
     sh.ok_g1 = st.ok ? 1u : 0u;
     aff_set_inf(aK);

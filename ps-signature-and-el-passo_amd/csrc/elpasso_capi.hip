@@ -109,7 +109,7 @@ void elp_destroy(elp_ctx* c) {
   if (c->agg_ok) (void)hipFree(c->agg_ok);
   if (c->coop_consts) (void)hipFree(c->coop_consts);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 4; i++)
     if (c->jev[i]) (void)hipEventDestroy(c->jev[i]);
   (void)hipStreamDestroy(c->stream);
   delete c;

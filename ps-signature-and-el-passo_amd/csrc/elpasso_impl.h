@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* rec
   st.ok = false;
   if (i < n) {
     Aff<F2<C>> aK;
-    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i, k_done != 0);
+    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i, k_done != 0, k_done == 1);
     if (role == 1 && !k_done) vid_store_k<C>(kws, kstride, i, aK);
   }
   __syncthreads();
@@ -646,6 +646,33 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* rec
     }
   }
 }
+// The table of multiples 1k .. 8k of an item's commitment k (affine, one inversion), into the G2 part of the item's workspace slice, where the GLS multiplication
+// of k_vid_nizk4 reads it: one lane per item, beside k_vid_fixed_coop on the second stream.  A record whose k does not decode leaves its slice alone (the NIZK
+// kernel rejects the item before it would read it).
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_vid_ktab(KeyCtx<C> key, const u32* recs, int rec_words, int retr, size_t n) {
+  typedef F2<C> G;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !key.vtab) return;
+  u32* const w = key.vtab + i * (size_t)vtab_words<C>();
+  Aff<G> kk;
+  if (!g2_load<C>(kk, recs + i * (size_t)rec_words + (retr ? 5 : 3) * 2 * C::N)) return;
+  if (aff_is_inf(kk)) {                     // k = O: every multiple is O (the multiplication then contributes nothing, as with a table built in place)
+    for (int q = 0; q < 8; q++) vtab_store<G>(w, q, kk);
+    return;
+  }
+  Jac<G> jk[8];
+  jac_multiples8<G>(jk, kk);
+  Fp2<C> z2[7], zi2[7];
+  for (int q = 1; q < 8; q++) z2[q - 1] = jk[q].Z;
+  batch_zinv<C, 0, 7>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
+  vtab_store<G>(w, 0, kk);
+  for (int q = 1; q < 8; q++) {
+    Aff<G> a;
+    jac_to_aff_with_zinv<G>(a, jk[q], zi2[q - 1]);
+    vtab_store<G>(w, q, a);
+  }
+}
 // verdict of a small-batch el_passo_verify_id = its NIZK half (k_vid_nizk4) AND its pairing check (k_pair_coop / k_pair_rest), which ran side by side
 __global__ void ELP_LAUNCH_BOUNDS k_vid_combine(const uint8_t* nizk_ok, const uint8_t* pair_ok, uint8_t* flags, unsigned long long* accepted, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -721,6 +748,10 @@ void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, c
                      (Jac<F2<B>>*)pre, kws, kstride, kvalid, n);
 }
 template <class B>
+void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int retr) {
+  hipLaunchKernelGGL((k_vid_ktab<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, retr, n);
+}
+template <class B>
 void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted) {
   hipLaunchKernelGGL(k_vid_combine, dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, nizk_ok, pair_ok, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
@@ -743,6 +774,8 @@ void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, c
                            uint8_t* kvalid);
 template <class B>
 void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
+template <class B>
+void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int retr);
 #endif
 // which curves have the cooperative kernels (their own translation unit, elpasso_<curve>_coop.hip)
 template <class B>
@@ -760,6 +793,7 @@ extern template void launch_ps_k<BN254>(hipStream_t stream, const KeyCtx<BN254>&
 extern template void launch_agg_final_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
 extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
 extern template void launch_vid_combine<BN254>(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
+extern template void launch_vid_ktab<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int retr);
 #endif
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
@@ -1433,7 +1467,7 @@ struct elp_ctx {
   size_t coop_max = 4096;     // 16 items per CU x 256 CUs: one round of the cooperative kernel; measured cross-over against the per-lane kernels between 4096 and 8192 items
   void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
   hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
-  hipEvent_t jev[2] = {nullptr, nullptr};
+  hipEvent_t jev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -2256,11 +2290,23 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         uint8_t* done = nizk_ok + lanes;
         uint8_t* kvalid = done + lanes;
         uint8_t* pair_ok = kvalid + lanes;
+        if (!c->jev[2]) {
+          HIPCHK(c, hipEventCreateWithFlags(&c->jev[2], hipEventDisableTiming));
+          HIPCHK(c, hipEventCreateWithFlags(&c->jev[3], hipEventDisableTiming));
+        }
+        // caller's stream:  memset, k_vid_fixed_coop ------------------(e0)  wait(e3) k_vid_nizk4 ............ wait(e1) k_vid_combine
+        // second stream  :  wait(e2) k_vid_ktab (e3)        wait(e0) k_pair_coop, k_pair_rest (e1)
         HIPCHK(c, hipMemsetAsync(done, 0, lanes, st));
+        HIPCHK(c, hipEventRecord(c->jev[2], st));                          // what the caller queued before this call (the records) precedes the second stream's work
+        HIPCHK(c, hipStreamWaitEvent(c->jstream, c->jev[2], 0));
+        static const bool ktab = !getenv("ELP_KTAB") || atoi(getenv("ELP_KTAB")) != 0;      // A/B runs
+        if (ktab) launch_vid_ktab<C>(c->jstream, key, n, d_records, words, retr);
+        HIPCHK(c, hipEventRecord(c->jev[3], c->jstream));
         launch_vid_fixed_coop<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);
         HIPCHK(c, hipEventRecord(c->jev[0], st));
         HIPCHK(c, hipStreamWaitEvent(c->jstream, c->jev[0], 0));
-        launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
+        HIPCHK(c, hipStreamWaitEvent(st, c->jev[3], 0));
+        launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, ktab ? 1 : 2);
         key.vtab = nullptr;
         launch_pair_coop<C>(c->jstream, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
         HIPCHK(c, hipEventRecord(c->jev[1], c->jstream));

@@ -60,7 +60,7 @@ def test_host_twin_reproduces_edge_verdicts():
         got = L.twin_bn254_verify_id_split(ctxs[kk], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
         assert bool(got) == c["expect"], ("two-phase record", c["scenario"], c["label"])
         got = L.twin_bn254_verify_id_jobs4(ctxs[kk], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
-        assert bool(got) == c["expect"], ("four-job record", c["scenario"], c["label"])
+        assert got == int(c["expect"]), ("four-job / five-job record", got, c["scenario"], c["label"])
         got = L.twin_bn254_verify_id_wire(ctxs[kk], raw, len(raw), 0, ad, len(ad))
         assert bool(got) == c["expect"], ("wire", c["scenario"], c["label"])
         # the two-lanes-per-item layout (GLS on a lane pair, decompression split between the lanes)

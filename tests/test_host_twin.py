@@ -116,7 +116,7 @@ def test_verify_id_golden(L):
                 assert bool(got) == c["expect"], ("split", s["name"], c["label"])
                 # the small-batch form (fixed-base sums first, four job roles, pairing phase) as well
                 got = L.twin_bn254_verify_id_jobs4(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
-                assert bool(got) == c["expect"], ("jobs4", s["name"], c["label"])
+                assert got == int(c["expect"]), ("jobs4 / jobs5", got, s["name"], c["label"])
                 n += 1
     assert n > 80
 
