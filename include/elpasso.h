@@ -68,9 +68,14 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
  * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.
  * Needs records of a multiple of 16 bytes, at most 1152, at a 16-byte aligned address; otherwise the in-place kernel runs.  Results are identical and so is the
- * kernel time (measured: 17.3 ms either way at 65 536 items).  0 = read in place. */
+ * kernel time (measured: 17.3 ms either way at 65 536 items).  0 = read in place.
+ * ELP_OPT_STREAM_OVERLAP (default 0): kernels of ONE call that do not depend on each other -- for small batches of el_passo_verify_id the pairing check beside the
+ * NIZK half, for aggregated verification the Fp12 product beside the Pippenger sum -- run on a second stream owned by the context, joined by events before the
+ * call's last kernel; the caller's stream semantics are unchanged.  Measured in a process of its own: 64 verifications 2.6 instead of 4.6 ms, a lone one 3.7
+ * instead of 5.2, aggregated 65 536 17.7 instead of 18.2 ms.  Off by default: inside a process that holds several other contexts and streams (bench.py) the
+ * cross-stream waits were seen to stall for about a second per call on this ROCm release; enable it where the library owns the device. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
-       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7 };
+       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

@@ -74,6 +74,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   c->device = device;
   if (const char* e = getenv("ELP_LAYOUT")) c->paired = !strcmp(e, "plain") ? 0 : !strcmp(e, "paired") ? 1 : 2;     // A/B runs
   if (const char* e = getenv("ELP_SPLIT")) c->split = atoi(e);
+  if (const char* e = getenv("ELP_OVERLAP")) c->overlap = atoi(e) != 0;                                                   // A/B runs: second-stream overlap inside a call
   if (const char* e = getenv("ELP_STAGE")) c->stage_records = atoi(e) != 0;                                              // A/B runs: coalesced record loads
   if (const char* e = getenv("ELP_COOP")) c->coop = atoi(e) != 0;                                                      // A/B runs: cooperative pairing for small batches                                            // A/B runs: one fused kernel per verification
   if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
@@ -132,6 +133,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
       return ELP_OK;
     case ELP_OPT_SUBGROUP_CHECK: c->subgroup_check = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_COALESCED_RECORDS: c->stage_records = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_STREAM_OVERLAP: c->overlap = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
       if (value < 0 || value > 2) return ELP_ERR_ARG;
       c->split = value;

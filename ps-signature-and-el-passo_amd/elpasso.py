@@ -17,6 +17,7 @@ OPT_SPLIT_PHASES = 4
 OPT_SUBGROUP_CHECK = 5
 OPT_COOP_PAIRING = 6
 OPT_COALESCED_RECORDS = 7
+OPT_STREAM_OVERLAP = 8
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -177,6 +178,10 @@ class Context:
     def set_coalesced_records(self, on):
         """ELP_OPT_COALESCED_RECORDS: verify_id records fetched per workgroup with coalesced 16-byte loads through LDS into a private copy (k_verify_id_staged)."""
         self._chk(self.lib.elp_set_option(self.h, OPT_COALESCED_RECORDS, int(bool(on))))
+
+    def set_stream_overlap(self, on):
+        """ELP_OPT_STREAM_OVERLAP (default off): independent kernels of one call on the context's second stream (small-batch verify_id, aggregated tail)."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_STREAM_OVERLAP, int(bool(on))))
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default 0): 1 / 2 = one-lane-per-item verify_id as phase-split kernels (NIZK jobs, then the pairing); identical results."""

@@ -188,6 +188,11 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
             gpu_ctx.set_coop_pairing(1)
             f1, c1 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
             assert (f0 == f1).all() and c0 == c1 == int(f1.sum())
+            gpu_ctx.set_stream_overlap(1)          # ELP_OPT_STREAM_OVERLAP: pairing check beside the NIZK half on the context's second stream
+            f2, c2 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            f3, c3 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            gpu_ctx.set_stream_overlap(0)
+            assert (f2 == f1).all() and (f3 == f1).all() and c2 == c3 == c1
             if n > 10:
                 assert f1[9] == 0 and f1[4] == 0 and f1[8] == int(expect[8])
             ofl = np.zeros(n, dtype=np.uint8)
@@ -212,6 +217,10 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
         wl = synth.Workload(gpu_ctx, A, seed=5, window_bits=8)
         recs, mask, expect = wl.verify_id_batch(700, H, with_retrieval=True)
         fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad)
+        assert held and (fl == expect).all() and cnt == int(expect.sum())
+        gpu_ctx.set_stream_overlap(1)              # Fp12 product beside the Pippenger sum
+        fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad)
+        gpu_ctx.set_stream_overlap(0)
         assert held and (fl == expect).all() and cnt == int(expect.sum())
         rsz = len(recs) // 700
         bad = bytearray(recs)
