@@ -179,14 +179,20 @@ __global__ void __launch_bounds__(ELP_NIZK_BLOCK, 2) k_vid_nizk(KeyCtx<C> key, c
 // Phase 1 with four job waves per 64 items (vid_nizk_jobs4) for small batches: G2 job | V_phi + K | V_E1 | V_E2 side by side.  The G2 job runs without a hot
 // slot (its fixed-base part arrives precomputed), the G1 jobs keep a Jac<F1>-sized one.
 template <class C>
-__global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
-                                                  uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre, int k_done) {
-  constexpr int HOTW = (int)(sizeof(Jac<F1<C>>) / 4);
-  __shared__ __attribute__((aligned(16))) u32 hot_lds[192 * HOTW];
-  __shared__ VidShared<C> sh[64];
+struct Nizk4Lds {
+  static constexpr int HOTW = (int)(sizeof(Jac<F1<C>>) / 4);
+  static constexpr size_t HOT_BYTES = (size_t)192 * HOTW * 4;
+  static constexpr size_t BYTES = HOT_BYTES + 64 * sizeof(VidShared<C>);
+};
+// body of k_vid_nizk4 for workgroup `block` (256 lanes); hot_lds / sh: Nizk4Lds<C>::HOT_BYTES and 64 VidShared of LDS
+template <class C>
+__device__ __forceinline__ void vid_nizk4_body(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
+                                               uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre, int k_done, size_t block, u32* hot_lds,
+                                               VidShared<C>* sh) {
+  constexpr int HOTW = Nizk4Lds<C>::HOTW;
   const int role = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   key.hot = role == 0 ? nullptr : hot_lds + (threadIdx.x - 64) * HOTW;
-  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const size_t i = block * 64 + lane;
   if (key.vtab) key.vtab += i * (size_t)vtab_words<C>();     // one slice per item: the G2 job uses its first part, each G1 job its own third of the rest
   VidNizkState<C> st;
   st.ok = false;
@@ -201,6 +207,13 @@ __global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* rec
     const size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
     nizk_ok[i] = vid_nizk_finish<C>(sh[lane], st, retr != 0, a, al) ? 1 : 0;
   }
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_vid_nizk4(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
+                                                  uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre, int k_done) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Nizk4Lds<C>::BYTES];
+  vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, kws, kstride, n, pre, k_done, blockIdx.x, (u32*)smem,
+                    (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
 }
 // ---- the same phase 1 as two CONCURRENT kernels with asymmetric register budgets (ELP_OPT_SPLIT_PHASES = 2): the G2 job (+ K) on the caller's stream
 // with 384 registers per lane (256 + 128 accumulation registers as spill space: its Fp2 mixed additions do not fit 256), the G1 job on a second stream
@@ -446,16 +459,15 @@ __device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool
 // items [0, n): sig1 | sig2 at the head of the record, K in the workspace (vid_store_k layout); todo[i] != 0 selects the items to check.  An item whose sig1,
 // sig2 or K is the point at infinity (or fails validation) is left to the per-lane kernel: done[i] stays 0.  Otherwise flags[i] = verdict, done[i] = 1.
 template <class C, int NP>
-__global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
-                                                            size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n) {
+__device__ __forceinline__ void pair_coop_body(const KeyCtx<C>& key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
+                                               size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n, size_t block, i32* Rall,
+                                               u32* stage) {      // Rall / stage: CoopLds<C, NP>::R_WORDS / STAGE_WORDS words of LDS; lanes 0..127 of the workgroup
   typedef CoopTables<C> T;
   typedef CoopLds<C, NP> L;
-  __shared__ __attribute__((aligned(16))) i32 Rall[L::R_WORDS];
-  __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
   const int slot = (int)(threadIdx.x / L::LANES), pair = (int)((threadIdx.x % L::LANES) >> 1), comp = (int)(threadIdx.x & 1);
   coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
   coop_i32* flagw = (coop_i32*)Rall + L::ITEMS * (L::RW + L::RPAD) + slot;     // [slot]: is-one flag, [ITEMS + slot]: "inputs usable"
-  const size_t i = (size_t)blockIdx.x * L::ITEMS + slot;
+  const size_t i = block * L::ITEMS + slot;
   if (pair == 0 && comp == 0) {
     int usable = 0;
     if (i < n && todo[i]) {
@@ -490,6 +502,36 @@ __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, con
     flags[i] = one ? 1 : 0;
     done[i] = 1;
     if (one && accepted) atomicAdd(accepted, 1ull);
+  }
+}
+template <class C, int NP>
+__global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
+                                                            size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n) {
+  typedef CoopLds<C, NP> L;
+  __shared__ __attribute__((aligned(16))) i32 Rall[L::R_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
+  pair_coop_body<C, NP>(key, consts, recs, rec_words, todo, kws, kstride, flags, done, accepted, n, blockIdx.x, Rall, stage);
+}
+// Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them, 128
+// of their 256 lanes) of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
+// run them side by side without a second stream.
+template <class C, int NP>
+__global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
+                                                  const u32* ad_off, u32 ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride,
+                                                  uint8_t* pair_ok, uint8_t* done, size_t n, const Jac<F2<C>>* pre, unsigned nb_nizk) {
+  typedef CoopLds<C, NP> L;
+  constexpr size_t PAIR_BYTES = (size_t)(L::R_WORDS + L::STAGE_WORDS) * 4 + 16;
+  constexpr size_t BYTES = PAIR_BYTES > Nizk4Lds<C>::BYTES ? PAIR_BYTES : Nizk4Lds<C>::BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
+  if (blockIdx.x < nb_nizk) {
+    vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
+                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
+  } else {
+    if (threadIdx.x >= ELP_COOP_BLOCK) return;          // the pairing interpreter is laid out for 128 lanes; the other two waves leave (barriers count live waves)
+    KeyCtx<C> k2 = key;
+    k2.vtab = nullptr;
+    pair_coop_body<C, NP>(k2, consts, recs, rec_words, kvalid, kws, kstride, pair_ok, done, nullptr, n, blockIdx.x - nb_nizk, (i32*)smem,
+                          (u32*)(smem + (((size_t)L::R_WORDS * 4 + 15) & ~(size_t)15)));
   }
 }
 // the items k_pair_coop left alone (points at infinity): the ordinary per-lane check
@@ -748,6 +790,22 @@ void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, c
                      (Jac<F2<B>>*)pre, kws, kstride, kvalid, n);
 }
 template <class B>
+void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                      const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
+                      const void* pre) {
+  const unsigned nb_nizk = grid_for(n);
+  if (n <= 512)
+    hipLaunchKernelGGL((k_vid_small<B, 32>), dim3(nb_nizk + (unsigned)((n + 1) / 2)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
+                       retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
+  else
+    hipLaunchKernelGGL((k_vid_small<B, 16>), dim3(nb_nizk + (unsigned)((n + 3) / 4)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
+                       retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
+  KeyCtx<B> k2 = key;
+  k2.vtab = nullptr;
+  hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, k2, (const u32*)d_records, words, kvalid, (const uint8_t*)done, kws, kstride, pair_ok,
+                     (unsigned long long*)nullptr, n);
+}
+template <class B>
 void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int retr) {
   hipLaunchKernelGGL((k_vid_ktab<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, retr, n);
 }
@@ -776,6 +834,10 @@ template <class B>
 void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
 template <class B>
 void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int retr);
+template <class B>
+void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                      const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
+                      const void* pre);
 #endif
 // which curves have the cooperative kernels (their own translation unit, elpasso_<curve>_coop.hip)
 template <class B>
@@ -794,6 +856,7 @@ extern template void launch_agg_final_coop<BN254>(hipStream_t stream, const KeyC
 extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
 extern template void launch_vid_combine<BN254>(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
 extern template void launch_vid_ktab<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int retr);
+extern template void launch_vid_small<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done, const void* pre);
 #endif
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
@@ -2319,12 +2382,21 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
           HIPCHK(c, hipStreamWaitEvent(js, c->jev[0], 0));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[3], 0));
         }
-        launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
-        key.vtab = nullptr;
-        launch_pair_coop<C>(js, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
         if (c->overlap) {
+          launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
+          key.vtab = nullptr;
+          launch_pair_coop<C>(js, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
           HIPCHK(c, hipEventRecord(c->jev[1], js));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[1], 0));
+        } else if (n <= 1024) {
+          // default: NIZK half and pairing check as workgroup ranges of ONE launch (k_vid_small) -- side by side without a second stream.  (Its pairing
+          // workgroups carry the NIZK half's register budget: where the pairing check alone fills the chip that halves their occupancy -- measured, 2048 items take
+          // 7.0 ms in one launch against 5.5 in two.)
+          launch_vid_small<C>(st, key, consts, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kvalid, kws, lanes, pair_ok, done, pre);
+        } else {
+          launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
+          key.vtab = nullptr;
+          launch_pair_coop<C>(st, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
         }
         launch_vid_combine<C>(st, n, nizk_ok, pair_ok, d_flags, d_accepted);
         HIPCHK(c, hipGetLastError());

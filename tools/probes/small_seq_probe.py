@@ -37,7 +37,7 @@ d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 for rnd in range(2):
     for coop in (1, 0):
         ctx.set_coop_pairing(coop)
-        for m in (4096, 1, 64, 1024, 4096, 4096):
+        for m in (4096, 1, 64, 512, 1024, 2048, 4096):
             ms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_vrec.data_ptr(), vmask, 1, d_ad.data_ptr(), None, len(wl.ad),
                                                                          d_fl.data_ptr(), d_cnt.data_ptr())))
             print("round %d coop=%d n=%5d  %.3f ms" % (rnd, coop, m, ms), flush=True)
