@@ -63,7 +63,7 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_COOP_PAIRING (default 1; BN254 builds): batches of at most 4096 items (value > 1: that many) and the closing step of aggregated verification run
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
  * (pair) per item, and the NIZK half of el_passo_verify_id spreads its jobs over four waves per 64 items with the fixed-base G2 sums on 8 lanes each: measured, a
- * lone PS verification takes 1.8 ms instead of 5.1, 4096 of them 3.3 ms instead of 4.6, 64..1024 el_passo_verify_id 4.6-5.0 ms instead of 8.8, 4096 of them 6.2 ms.
+ * lone PS verification takes 1.8 ms instead of 5.1, 4096 of them 3.3 ms instead of 4.6, 64 el_passo_verify_id 2.8 ms and 1024 of them 4.9 ms instead of 8.8 (NIZK half and pairing check in one launch), 4096 of them 6.2 ms.
  * Results are identical.  0 = off.
  * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
  * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.
@@ -71,8 +71,8 @@ int elp_field_bytes(int curve);               /* F */
  * kernel time (measured: 17.3 ms either way at 65 536 items).  0 = read in place.
  * ELP_OPT_STREAM_OVERLAP (default 0): kernels of ONE call that do not depend on each other -- for small batches of el_passo_verify_id the pairing check beside the
  * NIZK half, for aggregated verification the Fp12 product beside the Pippenger sum -- run on a second stream owned by the context, joined by events before the
- * call's last kernel; the caller's stream semantics are unchanged.  Measured in a process of its own: 64 verifications 2.6 instead of 4.6 ms, a lone one 4.0-4.7
- * instead of 5.7, aggregated 65 536 17.5 instead of 17.7-18.2 ms.  Off by default: inside a process that holds several other contexts and streams (bench.py) the
+ * call's last kernel; the caller's stream semantics are unchanged.  Measured in a process of its own: 64 verifications 2.6 instead of 2.8 ms, 2048 of them
+ * 5.0-5.5 instead of 5.7, aggregated 65 536 17.5 instead of 17.7-18.1 ms.  Off by default: inside a process that holds several other contexts and streams (bench.py) the
  * cross-stream waits were seen to stall for about a second per call on this ROCm release; enable it where the library owns the device. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
        ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8 };

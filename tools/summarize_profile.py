@@ -30,7 +30,9 @@ for sub in ("pmc_a", "pmc_b", "pmc_c"):
             meta = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "scratch_bytes_per_lane": int(r["Scratch_Size"]),
                     "grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"])}
     for k, v in agg.items():
-        pmc[k] = sum(v) / len(v)
+        v = sorted(v)
+        pmc[k] = v[len(v) // 2] if len(v) % 2 else (v[len(v) // 2 - 1] + v[len(v) // 2]) / 2      # median over the dispatches: the first dispatch of a pass can carry
+                                                                                                    # cycles counted before it started (GRBM_GUI_ACTIVE)
 out["k_verify_id"] = meta
 out["pmc_per_launch"] = pmc
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -41,7 +43,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 if "TCC_HIT_sum" in pmc:
     out["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
 if "GRBM_GUI_ACTIVE" in pmc and dur.get("pmc_c"):
-    ms_c = sum(dur["pmc_c"].values()) / len(dur["pmc_c"])
+    dv = sorted(dur["pmc_c"].values())
+    ms_c = dv[len(dv) // 2] if len(dv) % 2 else (dv[len(dv) // 2 - 1] + dv[len(dv) // 2]) / 2
     out["clock_ghz"] = pmc["GRBM_GUI_ACTIVE"] / ms_c / 1e6
     out["kernel_ms_in_clock_pass"] = ms_c
 if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
