@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(1536, 48 x cores))")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(4096, 256 x cores))")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config]
     args.batch = args.batch or cfg["batch"]
@@ -271,7 +271,7 @@ def main():
                                  "note": "host records in, verdicts out through elp_verify_id_batch (includes the Python wrapper's buffer handling)"}
         if args.cpu_sample != 0 and args.curve == "bn254":
             ncore = usable_cores()
-            samp = args.cpu_sample if args.cpu_sample > 0 else max(1536, 48 * ncore)
+            samp = args.cpu_sample if args.cpu_sample > 0 else max(4096, 256 * ncore)
             out["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(samp, B))
     if rank == 0 and world == 1 and args.curve == "bn254" and not args.no_second_curve:
         try:

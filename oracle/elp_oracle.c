@@ -1101,6 +1101,13 @@ static int g1_in_subgroup(const g1a* p) {
 static int g1_in_subgroup(const g1a* p) { (void)p; return 1; }     /* BN254: E(Fp) has prime order r */
 #endif
 
+/* sigma_1 must not be the identity of G1 (ps-verifier.cc:16-18).  With a G1 cofactor that is asked of the order-r component: a point whose order divides the
+   cofactor pairs to 1 with everything, so sig1 = T (order 3), sig2 = O would satisfy the pairing equation for any K.  Policy: sig1 != O and sig1 in G1. */
+static int sig1_admissible(const g1a* s) { return !s->inf && g1_in_subgroup(s); }
+/* the library's ELP_OPT_STRICT_SIGNATURE for el_passo_verify_id: 0 (default here) = the reference's behaviour, 1 = sig1 must be admissible as in PSVerifier::verify */
+static int elpo_strict = 0;
+void elpo_set_strict(int on) { elpo_strict = on; }
+
 /* record: sig1 | sig2 | phi | [E1 | E2] | k | c | rs[..] | m[..]   (same as elp_verify_id_batch) */
 int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask, int retr, const uint8_t* ad, size_t adl) {
   const int A = key->A;
@@ -1116,6 +1123,7 @@ int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask
   if (retr) { ok &= g1_load(&E1, p); p += G1B; ok &= g1_load(&E2, p); p += G1B; }
   ok &= g2_load(&kk, p); p += G2B;
   if (!ok) return 0;
+  if (elpo_strict && !sig1_admissible(&sig1)) return 0;
   if (!g1_in_subgroup(&phi) || (retr && (!g1_in_subgroup(&E1) || !g1_in_subgroup(&E2)))) return 0;
   u64 c[4], s[4];
   k_load(c, p); p += 32;
@@ -1179,7 +1187,7 @@ int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask
 int elpo_ps_verify(const elpo_key* key, const uint8_t* rec, int nattr) {
   g1a sig1, sig2;
   if (!g1_load(&sig1, rec) || !g1_load(&sig2, rec + G1B)) return 0;
-  if (sig1.inf) return 0;
+  if (!sig1_admissible(&sig1)) return 0;                                  /* ps-verifier.cc:16-18, in the order-r component */
   g2j K;
   g2_from_aff(&K, &key->XX);
   u64 s[4];

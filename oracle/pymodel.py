@@ -800,11 +800,21 @@ class Protocol:
     def __init__(self, m: Mcl):
         self.m = m
         self.G = m.G
+        # the library's ELP_OPT_STRICT_SIGNATURE for el_passo_verify_id (include/elpasso.h): False = the reference's behaviour (sig1 = sig2 = O passes,
+        # golden case "sig_both_zero"), True = sig1 must be admissible as in PSVerifier::verify
+        self.strict = False
+
+    # sigma_1 must not be the identity of G1 (src/ps-verifier.cc:16-18).  On a curve with a G1 cofactor (BLS12-381) that is asked of the order-r component:
+    # a point of E(Fp) whose order divides the cofactor pairs to 1 with everything, so "sig1 is not the point at infinity" alone admits the forgery
+    # sig1 = T (order 3), sig2 = O for any K.  Project policy (csrc/elp/pipeline.h sig1_admissible): sig1 != O and sig1 in G1.  A no-op beyond the
+    # infinity test on BN254 (E(Fp) = G1), hence invisible to the golden vectors.
+    def sig1_admissible(self, sig1) -> bool:
+        return sig1 is not None and self.in_g1(sig1)
 
     # -- PSVerifier::verify (src/ps-verifier.cc:13-35)
     def ps_verify(self, pk: PubKey, cred: Credential, all_attributes) -> bool:
         m, G = self.m, self.G
-        if cred.sig1 is None:
+        if not self.sig1_admissible(cred.sig1):
             return False
         K = pk.XX
         for i, a in enumerate(all_attributes):
@@ -844,6 +854,8 @@ class Protocol:
         m, G = self.m, self.G
         if not pr.has_E:
             return False
+        if self.strict and not self.sig1_admissible(pr.sig1):
+            return False
         if not (self.in_g1(pr.phi) and self.in_g1(pr.E1) and self.in_g1(pr.E2)):
             return False
         Vk = self._vk(pk, pr, pr.rs[len(pr.rs) - 2])
@@ -864,6 +876,8 @@ class Protocol:
     # -- el_passo_verify_id_without_id_retrieval (src/ps-verifier.cc:140-212)
     def verify_id_noretr(self, pk, pr: IdProof, ad, svc, pairing=True) -> bool:
         m, G = self.m, self.G
+        if self.strict and not self.sig1_admissible(pr.sig1):
+            return False
         if not self.in_g1(pr.phi):
             return False
         Vk = self._vk(pk, pr, pr.rs[len(pr.rs) - 1])

@@ -141,6 +141,25 @@ ELP_HEAVY bool g1_in_subgroup(const Aff<F1<C>>& p) {
     return fp_is_zero<C>(fp_sub_lazy(r.X, t1)) || fp_is_zero<C>(fp_sub_lazy(r.X, t2));
   }
 }
+// sigma_1 of a PS signature must not be the identity OF G1 (src/ps-verifier.cc:16-18 for PSVerifier::verify; for el_passo_verify_id under
+// KEY_STRICT_SIG).  On a curve with a G1 cofactor "not the identity" has to be asked of the order-r component: a point T of E(Fp) whose order divides the
+// cofactor pairs to e(T, Q) = 1 with everything, so sig1 = T, sig2 = O satisfies e(sig1, K) e(-sig2, gg) = 1 for ANY K although sig1 is not the point
+// at infinity -- a universal forgery from the public key alone (round-3 advisor finding).  Rule: sig1 != O and (unless the caller vouches for its inputs with
+// ELP_OPT_SUBGROUP_CHECK = 0) sig1 in G1; then sig1 has order exactly r and e(sig1, .) is non-degenerate.  sig2 needs no test: once sig1 is a generator of
+// G1 the equation pins the order-r component of sig2, and its cofactor component is invisible to every party.  A no-op beyond the infinity test on BN curves.
+template <class C>
+ELP_HEAVY bool sig1_admissible(int key_flags, const Aff<F1<C>>& sig1) {
+  if (aff_is_inf(sig1)) return false;
+  if constexpr (!C::IS_BN) {
+    if (!(key_flags & KEY_NO_SUBGROUP_CHECK) && !g1_in_subgroup<C>(sig1)) return false;
+  }
+  return true;
+}
+// the el_passo_verify_id form of the rule: only under KEY_STRICT_SIG (the reference accepts sig1 = sig2 = O there; the default of this library does not)
+template <class C>
+ELP_INL bool sig1_strict_ok(int key_flags, const Aff<F1<C>>& sig1) {
+  return !(key_flags & KEY_STRICT_SIG) || sig1_admissible<C>(key_flags, sig1);
+}
 template <class C>
 ELP_HEAVY bool g2_load(Aff<F2<C>>& p, const u32* w) {
   if constexpr (is_paired<C>()) {   // each lane takes its own components; validity is agreed on by the pair
@@ -533,7 +552,7 @@ ELP_HEAVY bool verify_id_core(const KeyCtx<C>& key, Src& src, bool retr, const A
                               const Aff<F1<C>>& phi, const Aff<F1<C>>& E1, const Aff<F1<C>>& E2, const Aff<F2<C>>& kk, const Scalar& c,
                               const uint8_t* ad, size_t ad_len) {
   Aff<F2<C>> aK;
-  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
+  if (!sig1_strict_ok<C>(key.flags, sig1)) return false;
   if (!verify_id_nizk<C, Src>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
   return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
@@ -569,7 +588,7 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
   for (int i = 0; i < 8; i++) delta_out[i] = 0;
   for (int i = 0; i < 2 * C::N; i++) sig2_out[i] = 0;
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
-  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
+  if (!sig1_strict_ok<C>(key.flags, sig1)) return false;
   if (!verify_id_nizk<C, RecordSrc<C>>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
   // multiplier d = a + b lam (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [d]sig1 = [a]sig1 + [b]phi(sig1) over the affine multiples
   // 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private memory
@@ -583,16 +602,14 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
     {
       Jac<G1F> jm[8];
       jac_multiples8<G1F>(jm, sig1);
-      Fp<C> pre[7];                       // Montgomery's trick over Z(2P) .. Z(8P); none is zero (sig1 has prime order r > 8)
-      pre[0] = jm[1].Z;
-      for (int i = 1; i < 7; i++) pre[i] = fp_mul<C>(pre[i - 1], jm[i + 1].Z);
-      Fp<C> inv = fp_inv<C>(pre[6]);
+      // Montgomery's trick over Z(2P) .. Z(8P) with batch_zinv's zero guard: without KEY_STRICT_SIG (or with ELP_OPT_SUBGROUP_CHECK = 0) sig1 may have a
+      // small order on a curve with a G1 cofactor and some multiple is the point at infinity (Z = 0); the guarded form keeps every other entry right and
+      // the batch equation / per-item fallback then decide such an item as the per-item path does
+      Fp<C> z[7], zi[7];
+      for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
+      batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
       tab[0] = sig1;
-      for (int i = 6; i >= 1; i--) {
-        jac_to_aff_with_zinv<G1F>(tab[i + 1], jm[i + 1], fp_mul<C>(inv, pre[i - 1]));
-        inv = fp_mul<C>(inv, jm[i + 1].Z);
-      }
-      jac_to_aff_with_zinv<G1F>(tab[1], jm[1], inv);
+      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
     }
     u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
     if (ws1) {
@@ -891,7 +908,7 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
   Aff<F2<C>> kk;
   st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
-  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
+  if (st.ok && !sig1_strict_ok<C>(key.flags, sig1)) st.ok = false;
   if (role == 0) {
     if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre);
   } else {
@@ -912,7 +929,7 @@ ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u6
   Aff<F2<C>> kk;
   st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
-  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
+  if (st.ok && !sig1_strict_ok<C>(key.flags, sig1)) st.ok = false;
   u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
   if (role == 0) {
     if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre, table_ready);
@@ -1145,16 +1162,21 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
     // order-r subgroup membership (g1_in_subgroup): the even lane, which has two of the three multiplications to do, checks phi; the odd lane checks
     // E2 and E1 (handed over by lane exchange)
     if (!(key.flags & KEY_NO_SUBGROUP_CHECK)) {
+      // second test of a lane: the odd lane takes E1, the even lane sig1 under KEY_STRICT_SIG (sig1_admissible above; both lanes hold sig1) -- four tests in
+      // the time of two
       Aff<F1<C>> Q1;
       Q1.x = fp_pair_swap(P1.x);
       Q1.y = fp_pair_swap(P1.y);
-      if (ok) ok = g1_in_subgroup<C>(P0) && (!odd || g1_in_subgroup<C>(Q1));
+      if (!odd) {
+        if (key.flags & KEY_STRICT_SIG) Q1 = sig1; else aff_set_inf(Q1);
+      }
+      if (ok) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(Q1);
     }
   }
   ok = pair_and(ok);
   const bool okk = g2_load<C>(kk, rec + (retr ? 5 : 3) * G1W);
   if (!ok || !okk) return false;
-  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;       // with the subgroup test above: sig1 has order exactly r
   const Scalar c = scalar_load_w(rec + (retr ? 5 : 3) * G1W + 4 * C::N);
   PairedRecordSrc<C> src;
   src.init(rec, hidden_mask, key.A, retr);
@@ -1332,11 +1354,14 @@ ELP_HEAVY bool verify_id_wire_item_paired(const KeyCtx<C>& key, const uint8_t* m
   if (!odd || retr) ok &= g1_deserialize<C>(P0, odd ? src.pe2_ : src.pphi_);
   if (!odd && retr) ok &= g1_deserialize<C>(P1, src.pe1_);
   if constexpr (!C::IS_BN) {
-    if (!(key.flags & KEY_NO_SUBGROUP_CHECK)) {      // as in verify_id_item_paired: even lane phi, odd lane E2 and E1
+    if (!(key.flags & KEY_NO_SUBGROUP_CHECK)) {      // as in verify_id_item_paired: even lane phi and (strict) sig1, odd lane E2 and E1
       Aff<F1<C>> Q1;
       Q1.x = fp_pair_swap(P1.x);
       Q1.y = fp_pair_swap(P1.y);
-      if (ok) ok = g1_in_subgroup<C>(P0) && (!odd || g1_in_subgroup<C>(Q1));
+      if (!odd) {
+        if (key.flags & KEY_STRICT_SIG) Q1 = S; else aff_set_inf(Q1);        // S is sig1 on the even lane
+      }
+      if (ok) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(Q1);
     }
   }
   ok = pair_and(ok);
@@ -1363,7 +1388,7 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   Aff<G1F> sig1, sig2;
   if (!g1_load<C>(sig1, rec)) return false;
   if (!g1_load<C>(sig2, rec + 2 * C::N)) return false;
-  if (aff_is_inf(sig1)) return false;                       // src/ps-verifier.cc:16-18
+  if (!sig1_admissible<C>(key.flags, sig1)) return false;   // src/ps-verifier.cc:16-18 -- asked of the order-r component (BLS12-381: both lanes of a pair hold sig1 and agree)
   const u32* ms = rec + 4 * C::N;
   Jac<G2F> K;
   jac_from_aff(K, aff_from_mem<G2F>(key.b2[G2_BASE_XX]));

@@ -239,7 +239,7 @@ k_vid_g2(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, uint
   RecordSrc<C> src;
   src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
   bool ok = src.open(recs + i * (size_t)rec_words, mask, key.A, retr != 0, sig1, sig2, phi, E1, E2, kk, c);
-  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) ok = false;
+  if (ok && !sig1_strict_ok<C>(key.flags, sig1)) ok = false;
   ok_g2[i] = ok ? 1 : 0;
   if (!ok) return;
   u32 vk[2 * C::FBYTES / 4];
@@ -380,7 +380,8 @@ __device__ __forceinline__ void coop_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <class C, int NP>
-__device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines) {
+__device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines,
+                                                bool member = true) {      // member = false: a lane of a wider workgroup that only keeps the workgroup barriers company (k_vid_small)
   typedef CoopTables<C> T;
   constexpr int MAXT = CoopLds<C, NP>::MAXT;
   constexpr int SW = NP * 2;                            // descriptor words per step (two per lane pair)
@@ -393,7 +394,8 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
   coop_i32* const cw = (coop_i32*)(stage + DW + MAXT);     // the constants, in the layout of the register file
   {
     const i32* src = reinterpret_cast<const i32*>(consts);
-    for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += ELP_COOP_BLOCK) cw[k] = src[k];
+    if (member)
+      for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += ELP_COOP_BLOCK) cw[k] = src[k];
   }
   // chunk c+1 travels from global memory to registers WHILE chunk c executes (all loads of a chunk in flight together, fixed trip counts):
   // fetched on demand, every chunk opened with a chain of dependent global round trips of ~1 us on waves that have nothing else to run
@@ -401,6 +403,7 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
   u32 pt[NT];
   u32 t0n = 0, t1n = 0;
   auto fetch = [&](int s0) {
+    if (!member) return;
     const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
     t0n = P.chunk_off[s0 / CH];
     t1n = P.chunk_off[s0 / CH + 1];
@@ -422,12 +425,14 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
     const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
     const u32 t0 = t0n;
     __syncthreads();                                   // every wave is done with the previous chunk
-    ELP_UNROLL
-    for (int j = 0; j < ND; j++) sd[(int)threadIdx.x + j * ELP_COOP_BLOCK] = pd[j];
-    ELP_UNROLL
-    for (int j = 0; j < NT; j++) {
-      const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
-      if (k < (u32)MAXT) stt[k] = pt[j];
+    if (member) {
+      ELP_UNROLL
+      for (int j = 0; j < ND; j++) sd[(int)threadIdx.x + j * ELP_COOP_BLOCK] = pd[j];
+      ELP_UNROLL
+      for (int j = 0; j < NT; j++) {
+        const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+        if (k < (u32)MAXT) stt[k] = pt[j];
+      }
     }
     __syncthreads();
     if (s0 + CH < P.nsteps) fetch(s0 + CH);
@@ -445,8 +450,8 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
 }
 // is the Fp12 value in registers P.out[0..5] equal to 1?  (lane pair j < 6 tests coefficient j; result through LDS word `flagw`)
 template <class C>
-__device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool active, int pair, int comp, coop_i32* flagw) {
-  if (pair == 0 && comp == 0) *flagw = 1;
+__device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool active, int pair, int comp, coop_i32* flagw, bool member = true) {
+  if (member && pair == 0 && comp == 0) *flagw = 1;
   __syncthreads();
   if (active && pair < 6) {
     Fp<C> v = coop_ld<C>(R, P.out[pair], comp);
@@ -454,7 +459,7 @@ __device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool
     if (!fp_is_zero<C>(v)) *flagw = 0;
   }
   __syncthreads();
-  return *flagw != 0;
+  return member && *flagw != 0;
 }
 // items [0, n): sig1 | sig2 at the head of the record, K in the workspace (vid_store_k layout); todo[i] != 0 selects the items to check.  An item whose sig1,
 // sig2 or K is the point at infinity (or fails validation) is left to the per-lane kernel: done[i] stays 0.  Otherwise flags[i] = verdict, done[i] = 1.
@@ -464,11 +469,15 @@ __device__ __forceinline__ void pair_coop_body(const KeyCtx<C>& key, const Fp2<C
                                                u32* stage) {      // Rall / stage: CoopLds<C, NP>::R_WORDS / STAGE_WORDS words of LDS; lanes 0..127 of the workgroup
   typedef CoopTables<C> T;
   typedef CoopLds<C, NP> L;
-  const int slot = (int)(threadIdx.x / L::LANES), pair = (int)((threadIdx.x % L::LANES) >> 1), comp = (int)(threadIdx.x & 1);
+  // The interpreter is laid out for ELP_COOP_BLOCK lanes.  In a wider workgroup (k_vid_small: 256) the lanes above take part in every workgroup barrier and in
+  // nothing else -- `member` false, no LDS / global access: leaving early instead would rely on the barrier not counting terminated waves, which the HIP
+  // programming model does not promise.
+  const bool member = threadIdx.x < ELP_COOP_BLOCK;
+  const int slot = member ? (int)(threadIdx.x / L::LANES) : 0, pair = (int)((threadIdx.x % L::LANES) >> 1), comp = (int)(threadIdx.x & 1);
   coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
   coop_i32* flagw = (coop_i32*)Rall + L::ITEMS * (L::RW + L::RPAD) + slot;     // [slot]: is-one flag, [ITEMS + slot]: "inputs usable"
   const size_t i = block * L::ITEMS + slot;
-  if (pair == 0 && comp == 0) {
+  if (member && pair == 0 && comp == 0) {
     int usable = 0;
     if (i < n && todo[i]) {
       const u32* rec = recs + i * (size_t)rec_words;
@@ -494,10 +503,10 @@ __device__ __forceinline__ void pair_coop_body(const KeyCtx<C>& key, const Fp2<C
     flagw[L::ITEMS] = usable;
   }
   __syncthreads();
-  const bool active = flagw[L::ITEMS] != 0;
+  const bool active = member && flagw[L::ITEMS] != 0;
   const CoopProg P = NP == 16 ? T::check() : T::check32();
-  coop_run_device<C, NP>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines));
-  const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw);
+  coop_run_device<C, NP>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines), member);
+  const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw, member);
   if (pair == 0 && comp == 0 && active) {
     flags[i] = one ? 1 : 0;
     done[i] = 1;
@@ -527,7 +536,7 @@ __global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* 
     vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
                       (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
   } else {
-    if (threadIdx.x >= ELP_COOP_BLOCK) return;          // the pairing interpreter is laid out for 128 lanes; the other two waves leave (barriers count live waves)
+    // the pairing interpreter is laid out for 128 lanes; the other two waves of the workgroup stay for its barriers only (pair_coop_body, `member`)
     KeyCtx<C> k2 = key;
     k2.vtab = nullptr;
     pair_coop_body<C, NP>(k2, consts, recs, rec_words, kvalid, kws, kstride, pair_ok, done, nullptr, n, blockIdx.x - nb_nizk, (i32*)smem,

@@ -24,6 +24,7 @@ void PSVerifier::useRpAll(const std::string& service, const G1* apk, const G1* g
 std::vector<bool> PSVerifier::verify_batch(const std::vector<PSCredential>& sigs,
                                            const std::vector<std::vector<std::string>>& attrs) const {
   std::vector<bool> out(sigs.size(), false);
+  std::lock_guard<std::mutex> lock(m_stage->mu);            // an elp_ctx serves one call at a time (include/elpasso.h)
   // group by attribute count (the record stride depends on it)
   std::map<size_t, std::vector<size_t>> groups;
   for (size_t i = 0; i < sigs.size(); i++)
@@ -65,7 +66,7 @@ std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, c
     groups[mask].push_back(i);
   }
   const size_t S1 = G1::size(), S2 = G2::size();
-  std::lock_guard<std::mutex> lock(m_stage->mu);
+  // the caller holds m_stage->mu (taken BEFORE useRpAll: the relying-party parameters installed in the contexts belong to this call until its shards are done)
   for (auto& [mask, idx] : groups) {
     // fixed-stride records of the group, packed by several host threads (the record of item j starts at j * rsz; the revealed attributes
     // are hashed here, src/ps-verifier.cc:224); the per-item associated data goes into one blob with offsets
@@ -125,6 +126,7 @@ std::vector<bool> PSVerifier::el_passo_verify_id_batch(const std::vector<IdProof
                                                        const std::string& service_name, const G1& authority_pk, const G1& g,
                                                        const G1& h) const {
   if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
+  std::lock_guard<std::mutex> lock(m_stage->mu);
   useRpAll(service_name, &authority_pk, &g, &h);
   return verifyIdImpl(proofs, ads, true);
 }
@@ -132,6 +134,7 @@ std::vector<bool> PSVerifier::el_passo_verify_id_without_id_retrieval_batch(cons
                                                                             const std::vector<std::string>& ads,
                                                                             const std::string& service_name) const {
   if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
+  std::lock_guard<std::mutex> lock(m_stage->mu);
   useRpAll(service_name, nullptr, nullptr, nullptr);
   return verifyIdImpl(proofs, ads, false);
 }
@@ -140,6 +143,9 @@ std::vector<bool> PSVerifier::el_passo_verify_id_wire_batch(const std::vector<PS
                                                             const G1* h) const {
   if (ads.size() != messages.size()) throw std::runtime_error("associated data count does not match");
   const bool retr = authority_pk != nullptr;
+  // one batch call at a time per verifier, from the installation of the relying-party parameters to the last shard: two threads with different service
+  // names / RP keys would otherwise race on ElpKey::rp_* and on elp_set_rp of the shared contexts and verify against each other's parameters
+  std::lock_guard<std::mutex> lock(m_stage->mu);
   useRpAll(service_name, authority_pk, g, h);
   const size_t n = messages.size();
   std::vector<uint32_t> moff(n + 1, 0), adoff(n + 1, 0);
@@ -147,7 +153,6 @@ std::vector<bool> PSVerifier::el_passo_verify_id_wire_batch(const std::vector<PS
     moff[i + 1] = moff[i] + (uint32_t)messages[i].size();
     adoff[i + 1] = adoff[i] + (uint32_t)ads[i].size();
   }
-  std::lock_guard<std::mutex> lock(m_stage->mu);
   uint8_t* const buf = m_stage->recs.get(m_key->ctx(), moff[n] ? moff[n] : 1);
   uint8_t* const adbuf = m_stage->ads.get(m_key->ctx(), adoff[n] ? adoff[n] : 1);
   uint8_t* const flags = m_stage->flags.get(m_key->ctx(), n ? n : 1);
@@ -178,6 +183,7 @@ uint64_t PSVerifier::el_passo_verify_id_wire_packed(const uint8_t* messages, con
                                                     const std::string& service_name, uint8_t* flags, const G1* authority_pk, const G1* g,
                                                     const G1* h) const {
   const bool retr = authority_pk != nullptr;
+  std::lock_guard<std::mutex> lock(m_stage->mu);            // as above: RP parameters and contexts belong to this call until its shards are done
   useRpAll(service_name, authority_pk, g, h);
   std::vector<uint64_t> acc(m_set->size(), 0);
   const uint8_t zero = 0;

@@ -295,6 +295,7 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
       touch_entries<F2<C>>((Aff<F2<C>>*)c->t2s + base * stride, c->b2[base], c->key.W, c->key.nwin, c->key.per, scalar_load_w(k)); \
   }                                                                                                                    \
   void pfx##_ctx_free(void* c) { delete (TwinCtx<C>*)c; }                                                              \
+  void pfx##_ctx_set_flags(void* c, int flags) { ((TwinCtx<C>*)c)->key.flags = flags; } /* KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2 */ \
   int pfx##_verify_id(void* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {             \
     return verify_id_item<C>(((TwinCtx<C>*)c)->key, rec, mask, retr != 0, ad, adlen) ? 1 : 0;                          \
   }                                                                                                                    \

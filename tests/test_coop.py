@@ -61,3 +61,16 @@ def test_verdicts_on_ps_signatures(env):
         assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(sig2), g2b(K), mode, out) == 1 and out.raw == one
         assert L.twin_bn254_pair_coop(ctx2, g1b(sig1), g1b(G.g1_add(sig2, g)), g2b(K), mode, out) == 0
         assert L.twin_bn254_pair_coop(ctx2, g1b(G.g1_mul(sig1, 2)), g1b(sig2), g2b(K), mode, out) == 0
+
+
+def test_committed_program_header_is_what_the_generator_emits(tmp_path):
+    """csrc/elp/coop_prog_bn254.h (3.4 MB of generated tables) is committed: re-running tools/gen_coop.py must reproduce it byte for byte, so the header cannot
+    drift from its generator (and the generator's own big-integer validation of the program has run on exactly these bytes)."""
+    import os
+    import subprocess
+    import sys
+    from elp_testlib import ROOT
+    out = tmp_path / "coop_prog_bn254.h"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_coop.py"), str(out)])
+    committed = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bn254.h")
+    assert out.read_bytes() == open(committed, "rb").read()

@@ -36,7 +36,7 @@ def _oracle_key(L, wl, ctx, A):
 
 @pytest.mark.parametrize("W", [20, 16])
 def test_headline_window_config4_vs_oracle(gpu_ctx, W):
-    """bench.py's configuration: 8 attributes, 4 hidden, id-retrieval, W = 20 tables (32 GiB, 13 windows of 20-bit digits; W = 16 was round 1's:
+    """bench.py's configuration: 8 attributes, 4 hidden, id-retrieval, W = 20 tables (15.5 GiB of signed-digit entries, 13 windows of 20-bit digits; W = 16 was round 1's:
     2.5 GiB, its own k_table_fill chunking).  2 048 proofs incl. every-97th corrupted and valid proofs that send the group law through P + P at
     this window width, every verdict compared with the C oracle (reference structure, src/ps-verifier.cc:37-138), in both kernel layouts."""
     L = oracle()

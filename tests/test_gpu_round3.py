@@ -108,7 +108,7 @@ def test_cpp_verifier_shards_over_several_contexts(gpu_ctx):
 
 
 def test_headline_batch_full_size_w20_with_4096_oracle_samples(gpu_ctx):
-    """The batch bench.py sells: 65 536 el_passo_verify_id proofs, 8 attributes with 4 hidden, id-retrieval, W = 20 tables (32 GiB), one-lane-per-item
+    """The batch bench.py sells: 65 536 el_passo_verify_id proofs, 8 attributes with 4 hidden, id-retrieval, W = 20 tables (15.5 GiB), one-lane-per-item
     kernel -- every verdict against the generator's expectation, and 4 096+ of them (a stride over the batch + EVERY corrupted item) against the C oracle
     (reference structure, src/ps-verifier.cc:37-138).  Also the two-phase kernels on the same batch."""
     L = oracle()

@@ -171,3 +171,61 @@ def test_off_subgroup_g1_inputs_are_rejected():
     assert L.elpo_provide_id(key, pack_provide_id(M, badrq, u), 3, b"ad", 2, out) == 0
     assert T.twin_bls_provide_id(tctx, pack_provide_id(M, badrq, u), ctypes.c_uint64(3), b"ad", 2, out) == 0
     L.elpo_key_free(key)
+
+
+def test_cofactor_sig1_forgery_is_rejected():
+    """Round-3 advisor finding: on BLS12-381 a point T of E(Fp) whose order divides the G1 cofactor pairs to 1 with everything, so (sig1, sig2) = (T, O) satisfies
+    e(sig1, K) = e(sig2, gg) for ANY K although sig1 is not the point at infinity -- with an honest NIZK over a k built from the public key alone that is a universal
+    forgery.  Rule (csrc/elp/pipeline.h sig1_admissible): sigma_1 must be != O AND in G1 -- always in PSVerifier::verify, under ELP_OPT_STRICT_SIGNATURE (the
+    library's default) in el_passo_verify_id.  Model, C oracle and host twin (both layouts) agree on the crafted inputs; with the option off the reference's
+    lenient behaviour (which BN254's golden vectors pin) is what all of them show."""
+    from elp_testlib import twin
+    L, T = oracle_bls(), twin()
+    seed, A, H = 4242, 4, 2
+    g, gg = M.hash_to_g1("abc"), BLS_G2
+    pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    bases = (g1_bases(M, pk, svc="service", g_eg=g, apk=apk, h=h, skX=skX), g2_bases(M, pk))
+    key = ctypes.c_void_p(L.elpo_key_new(A, *bases))
+    tctx = ctypes.c_void_p(T.twin_bls_ctx_new(A, 4, *bases))
+    T.twin_bls_ctx_set_flags.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.elpo_set_strict.argtypes = [ctypes.c_int]
+    t3 = _small_order_point(3)
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    rq, t1 = PR.request_id(pk, attrs, b"ad", [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)])
+    cred = PR.unblind(PR.provide_id(pk, skX, rq, b"ad", scalar_stream(seed, 99, M.r)), t1)
+    pr = PR.prove_id(pk, cred, attrs, b"sess", b"service", apk, g, h, [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)])
+    mask = hidden_mask(pr.attributes)
+    forged = copy.copy(pr)
+    forged.sig1, forged.sig2 = t3, None                       # needs no credential at all: the NIZK half does not involve the signature
+    mixed = copy.copy(pr)
+    mixed.sig1 = G.g1_add(pr.sig1, t3)                        # honest signature with a cofactor component: pairs like the honest one
+    cases = [(pr, 1, 1), (forged, 1, 0), (mixed, 1, 0)]       # (proof, verdict with the option off, verdict with it on)
+    try:
+        for strict in (0, 1):
+            PR.strict = bool(strict)
+            L.elpo_set_strict(strict)
+            T.twin_bls_ctx_set_flags(tctx, strict)            # KEY_STRICT_SIG = 1
+            for q, lenient, hard in cases:
+                want = hard if strict else lenient
+                rec = pack_verify_id(M, q)
+                assert PR.verify_id(pk, q, b"sess", b"service", apk, g, h) == bool(want)
+                assert L.elpo_verify_id(key, rec, mask, 1, b"sess", 4) == want
+                assert T.twin_bls_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
+                assert T.twin_blsp_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
+        # strict, but the caller vouches for subgroup membership (ELP_OPT_SUBGROUP_CHECK = 0): only the infinity test is left, as documented
+        T.twin_bls_ctx_set_flags(tctx, 1 | 2)
+        assert T.twin_blsp_verify_id(tctx, pack_verify_id(M, forged), ctypes.c_uint64(mask), 1, b"sess", 4) == 1
+    finally:
+        PR.strict = False
+        L.elpo_set_strict(0)
+        T.twin_bls_ctx_set_flags(tctx, 0)
+    # PSVerifier::verify: sigma_1 = T with sigma_2 = O verifies against every attribute set unless the order-r component is asked
+    allattrs = [a for a, _ in attrs]
+    from oracle.pymodel import Credential
+    good, bad = pack_ps_verify(M, cred, allattrs), pack_ps_verify(M, Credential(t3, None), allattrs)
+    assert PR.ps_verify(pk, cred, allattrs) and not PR.ps_verify(pk, Credential(t3, None), allattrs)
+    for fn, ctx in ((L.elpo_ps_verify, key), (T.twin_bls_ps_verify, tctx), (T.twin_blsp_ps_verify, tctx)):
+        assert fn(ctx, good, A) == 1 and fn(ctx, bad, A) == 0
+    L.elpo_key_free(key)
+    T.twin_bls_ctx_free(tctx)

@@ -868,5 +868,7 @@ def emit_header(res, path, cvname):
 if __name__ == "__main__":
     sys.setrecursionlimit(100000)
     res = validate(BN254)
-    emit_header(res, os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bn254.h"), "bn254")
-    print("written", file=sys.stderr)
+    # optional argument: where to write (tests/test_coop.py regenerates into a temporary file and compares with the committed header byte for byte)
+    dest = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bn254.h")
+    emit_header(res, dest, "bn254")
+    print("written", dest, file=sys.stderr)

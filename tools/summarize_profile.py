@@ -45,7 +45,10 @@ if "TCC_HIT_sum" in pmc:
 if "GRBM_GUI_ACTIVE" in pmc and dur.get("pmc_c"):
     dv = sorted(dur["pmc_c"].values())
     ms_c = dv[len(dv) // 2] if len(dv) % 2 else (dv[len(dv) // 2 - 1] + dv[len(dv) // 2]) / 2
-    out["clock_ghz"] = pmc["GRBM_GUI_ACTIVE"] / ms_c / 1e6
+    # GRBM_GUI_ACTIVE is reported once per XCD and the rows of a dispatch are summed above: 8 XCDs on MI355X
+    out["xcds"] = 8
+    out["clock_ghz"] = pmc["GRBM_GUI_ACTIVE"] / out["xcds"] / ms_c / 1e6
+    out["grbm_gui_active_sum_over_xcds"] = pmc["GRBM_GUI_ACTIVE"]
     out["kernel_ms_in_clock_pass"] = ms_c
 if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
     out["valu_instructions_per_wave"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
