@@ -516,6 +516,16 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
                                                                          d_fl.data_ptr(), d_cnt.data_ptr())))
             lat["verify_id_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms
     lat["parity_ok"] = bool((d_fl.cpu().numpy()[:nl] == vexpect).all())
+    if os.environ.get("ELP_BENCH_SMALL_OVERLAP"):      # experiment: the two-stream form of the same calls (ELP_OPT_STREAM_OVERLAP) inside this process
+        ctx.set_coop_pairing(1)
+        ctx.set_stream_overlap(1)
+        for m in (4096, 64, 1024, 4096):
+            t0 = time.perf_counter()
+            ms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_vrec.data_ptr(), vmask, 1, d_ad.data_ptr(), None, len(wl.ad),
+                                                                         d_fl.data_ptr(), d_cnt.data_ptr())))
+            lat["verify_id_n%d_overlap_ms" % m] = ms
+            lat["verify_id_n%d_overlap_wall_ms_4_calls" % m] = (time.perf_counter() - t0) * 1e3
+        ctx.set_stream_overlap(0)
     res["small_batches"] = lat
     ctx.close()
     ctx = pkg.Context(pkg.CURVE_BN254, local_rank)

@@ -245,3 +245,77 @@ def test_off_subgroup_g1_inputs_rejected_on_gpu(bls_ctx):
         assert f2[0] == 1 and f2[6] == 1 and len(f2) == 7
     finally:
         bls_ctx.set_subgroup_check(True)
+
+
+def test_cofactor_sig1_forgery_rejected_on_gpu(bls_ctx):
+    """(sig1, sig2) = (T, O) with T of order 3 -- and an honest sig1 with T added -- under the library's default ELP_OPT_STRICT_SIGNATURE: rejected through the
+    record path and the wire path; with the option off the lenient verdicts of the model come back (tests/test_oracle_bls.py has the CPU side: model, C oracle,
+    host twin).  PSVerifier::verify's sig1 test is asked of the order-r component whatever the option says."""
+    from oracle.pymodel import Credential
+    from test_oracle_bls import _small_order_point
+    seed, A, H = 4242, 4, 2
+    g, gg = M.hash_to_g1("abc"), BLS_G2
+    pk, skX = PR.key_gen(g, gg, scalar_stream(seed, 0, M.r), [scalar_stream(seed, 1 + i, M.r) for i in range(A)])
+    apk, h = M.hash_to_g1("ghi"), M.hash_to_g1("jkl")
+    bls_ctx.set_pubkey(g1b(pk.g, N), g2b(pk.gg, N), g2b(pk.XX, N), b"".join(g1b(P, N) for P in pk.Yi), b"".join(g2b(P, N) for P in pk.YYi), 6)
+    bls_ctx.set_rp(b"service", g1b(apk, N), g1b(g, N), g1b(h, N))
+    attrs = [(b"s-value", True), (b"gamma-value", True), (b"tp", False), (b"other", False)]
+    rq, t1 = PR.request_id(pk, attrs, b"ad", [scalar_stream(seed, 50 + j, M.r) for j in range(2 + H)])
+    cred = PR.unblind(PR.provide_id(pk, skX, rq, b"ad", scalar_stream(seed, 99, M.r)), t1)
+    pr = PR.prove_id(pk, cred, attrs, b"sess", b"service", apk, g, h, [scalar_stream(seed, 200 + j, M.r) for j in range(3 + H + 2)])
+    t3 = _small_order_point(3)
+    forged, mixed = copy.copy(pr), copy.copy(pr)
+    forged.sig1, forged.sig2 = t3, None
+    mixed.sig1 = G.g1_add(pr.sig1, t3)
+    items = [pr, forged, mixed, pr]
+    recs = b"".join(pack_verify_id(M, x) for x in items)
+    mask = hidden_mask(pr.attributes)
+    cd = importlib.import_module("elp_testlib").Codec(M)
+    wires = [cd.proof_encode(x) for x in items]
+    for strict, want in ((True, [1, 0, 0, 1]), (False, [1, 1, 1, 1])):
+        bls_ctx.set_strict_signature(strict)
+        PR.strict = strict
+        try:
+            assert [int(PR.verify_id(pk, x, b"sess", b"service", apk, g, h)) for x in items] == want
+            flags, cnt = bls_ctx.verify_id_batch(recs, mask, True, b"sess")
+            assert list(flags) == want and cnt == sum(want)
+            wflags, _ = bls_ctx.verify_id_wire_batch(wires, True, b"sess")
+            assert list(wflags) == want
+            aflags, acnt, _ = bls_ctx.verify_id_batch_aggregated(recs, mask, True, b"sess", seed=bytes(range(32)))
+            assert list(aflags) == want and acnt == sum(want)
+        finally:
+            PR.strict = False
+            bls_ctx.set_strict_signature(True)
+    allattrs = [a for a, _ in attrs]
+    pflags, pcnt = bls_ctx.ps_verify_batch(pack_ps_verify(M, cred, allattrs) + pack_ps_verify(M, Credential(t3, None), allattrs) +
+                                           pack_ps_verify(M, Credential(G.g1_add(cred.sig1, t3), cred.sig2), allattrs), A)
+    assert list(pflags) == [1, 0, 0] and pcnt == 1
+
+
+def test_headline_size_batch_w20_against_the_c_oracle(bls_ctx):
+    """BLS12-381 at its benchmarked configuration: 65 536 el_passo_verify_id proofs, 8 attributes with 4 hidden, id-retrieval, W = 20 tables,
+    the two-lanes-per-item kernel this curve always uses -- every verdict against the generator's expectation and 1 024+ of them (a stride + EVERY corrupted item)
+    against the C oracle's BLS12-381 build.  PARITY UNPINNED (no reference artefact exists for this curve): the oracle is a second implementation, not the reference."""
+    import ctypes
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    L = oracle_bls()
+    A, H, n = 8, 4, 65536
+    wl = synth.Workload(bls_ctx, A, seed=20211, window_bits=20)
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True)
+    flags, cnt = bls_ctx.verify_id_batch(recs, mask, True, wl.ad)
+    bad = [i for i in range(n) if i % 97 == 13]
+    assert (flags == expect).all() and cnt == int(expect.sum()) == n - len(bad)
+    g1 = wl.g + wl.Yi + bls_ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+    key = ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
+    assert key.value
+    rsz = len(recs) // n
+    idx = sorted(set(list(range(0, n, 149)) + bad))
+    assert len(idx) >= 1024
+    samp = b"".join(recs[i * rsz:(i + 1) * rsz] for i in idx)
+    ofl = np.zeros(len(idx), dtype=np.uint8)
+    import os
+    L.elpo_verify_id_batch(key, len(idx), samp, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, max(1, min(16, len(os.sched_getaffinity(0)))))
+    assert (ofl == flags[idx]).all() and int((ofl == 0).sum()) == len(bad)
+    L.elpo_key_free(key)
+    # leave a small key behind for the tests that follow (22 GiB of W = 20 tables are released with it)
+    synth.Workload(bls_ctx, 3, seed=1, window_bits=4)
