@@ -45,6 +45,7 @@ def parse_args(argv=None):
                     "for the 8-attribute key, 13 table additions per scalar instead of 16 at W = 16: profiles/r02_window_sweep.json); reported in `config` and `key_tables`")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
+    ap.add_argument("--only", default="", help="comma-separated secondary sections to run beside the headline (pcie, w16, config5, aggregated, secondary, host_api, bls); default: all")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(4096, 256 x cores))")
     args = ap.parse_args(argv)
@@ -54,6 +55,9 @@ def parse_args(argv=None):
     args.hidden = args.hidden or cfg["hidden"]
     if args.headline_only:
         args.no_second_curve, args.cpu_sample = True, 0
+    args.only = set(x for x in args.only.split(",") if x)
+    if args.only and "bls" not in args.only:
+        args.no_second_curve = True
     return args
 
 
@@ -256,7 +260,8 @@ def main():
         }
         out["valu_bound"] = valu_bound(ctx, "verify_id" if (args.curve == "bn254" and A == 8 and H == 4) else None, args.window, B, kern_ms, 162)
 
-    if rank == 0 and world == 1 and not args.headline_only:     # profiling runs: every verification dispatch of the process is a timed-region dispatch
+    want = lambda sec: not args.only or sec in args.only      # noqa: E731
+    if rank == 0 and world == 1 and not args.headline_only and want("pcie"):     # profiling runs: every verification dispatch of the process is a timed-region dispatch
         # PCIe-inclusive rate (host buffers in, flags out: elp_verify_id_batch, the path PSVerifier::el_passo_verify_id_batch takes; pinned
         # staging, chunks copied and verified on several streams) -- reported, never the headline value.  One warm-up call, median of 7.
         ts = []
@@ -278,61 +283,27 @@ def main():
             out["bls12_381"] = second_curve(pkg, synth, local_rank, dev, A, H, B, args.window)
         except Exception as e:  # pragma: no cover
             out["bls12_381"] = {"error": str(e)}
-    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and (args.window or 8) != 16:
+    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and (args.window or 8) != 16 and want("w16"):
         try:   # the same workload on the 16-bit tables (1/16 of the memory): what the wide tables buy
             out["w16"] = other_config(pkg, synth, local_rank, dev, 4, 16)
         except Exception as e:  # pragma: no cover
             out["w16"] = {"error": str(e)}
-    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only:
+    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and want("config5"):
         try:   # BASELINE.json config 5 at N = 1: one rank's share (131 072 proofs, 16 attributes) on this GPU
             out["config5_rank_share"] = other_config(pkg, synth, local_rank, dev, 5, args.window)
         except Exception as e:  # pragma: no cover
             out["config5_rank_share"] = {"error": str(e)}
-    if rank == 0 and world == 1 and not args.headline_only:
-        # aggregated (random-linear-combination) variant: reported beside, never instead of, `value`.  Its single-lane tail (one Miller
-        # loop + one final exponentiation per batch, ~11 ms) is not overlapped yet, so it only pays off on larger batches: measured on
-        # the resident batch and on the same records tiled x4 and x16 (262 144 / 1 048 576 items), each against the per-item kernel at
-        # the same size.
+    if rank == 0 and world == 1 and not args.headline_only and want("aggregated"):
         try:
-            seed_buf = np.frombuffer(bytes((7 * i + 1) & 0xFF for i in range(32)), dtype=np.uint8).copy()
-            res = {"note": "elp_verify_id_batch_aggregated_dev: per-item NIZK + one Miller loop, Pippenger MSM of the sig2's, one final "
-                           "exponentiation per batch; exact per-item fallback when the batch equation fails"}
-            for tiles in (1, 4, 16):
-                nb = B * tiles
-                recs_t = d_rec if tiles == 1 else d_rec.repeat(tiles)
-                fl_t = torch.zeros(nb, dtype=torch.uint8, device=dev)
-                cnt_t = torch.zeros(1, dtype=torch.int64, device=dev)
-                exp_t = np.tile(expect, tiles)
-
-                def run(agg):
-                    cnt_t.zero_()
-                    if agg:
-                        ctx._chk(ctx.lib.elp_verify_id_batch_aggregated_dev(ctx.h, stream, nb, recs_t.data_ptr(), mask, 1, d_ad.data_ptr(), None,
-                                                                            len(wl.ad), seed_buf.ctypes.data, fl_t.data_ptr(), cnt_t.data_ptr()))
-                    else:
-                        ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, nb, recs_t.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(wl.ad),
-                                                                 fl_t.data_ptr(), cnt_t.data_ptr()))
-                for agg in (True, False):
-                    run(agg)
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(2):
-                        run(agg)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms_b = e0.elapsed_time(e1) / 2
-                    ok = bool((fl_t.cpu().numpy() == exp_t).all()) and int(cnt_t.item()) == int(exp_t.sum())
-                    res["batch_%d_%s" % (nb, "aggregated" if agg else "per_item")] = {"value": nb / (ms_b * 1e-3), "ms_per_batch": ms_b, "parity_ok": ok}
-            out["aggregated"] = res
+            out["aggregated"] = aggregated_section(ctx, wl, synth, dev, mask, H, B)
         except Exception as e:  # pragma: no cover
             out["aggregated"] = {"error": str(e)}
-    if rank == 0 and world == 1 and args.curve == "bn254" and not args.no_second_curve:
+    if rank == 0 and world == 1 and args.curve == "bn254" and (not args.no_second_curve or "secondary" in args.only) and want("secondary"):
         try:
             out["secondary"] = secondary_workloads(pkg, synth, local_rank, dev, args.window)
         except Exception as e:  # pragma: no cover
             out["secondary"] = {"error": str(e)}
-    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only:
+    if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and want("host_api"):
         try:   # the reference-API path: std::vector<IdProof> / wire messages through the C++ PSVerifier (key set-up excluded and reported)
             out["host_api"] = host_api(pkg, wl, recs, B, A, H, first, expect, args.window, local_rank)
         except Exception as e:  # pragma: no cover
@@ -344,6 +315,103 @@ def main():
         dist.destroy_process_group()
     if not parity_ok:
         sys.exit(3)
+
+
+def aggregated_section(ctx, wl, synth, dev, mask, H, B):
+    """Aggregated (random-linear-combination) verification beside the per-item kernel -- reported, never `value`.  All measurements run on DISTINCT proofs (2^20 of
+    them, synthesised on the device by the batch prover from 65 536 credentials presented 16 times with fresh randomness: synth.distinct_proofs_dev), not on tiled
+    copies of one batch.  Single calls at 65 536 / 262 144 / 1 048 576 items, and the SUSTAINED rate of 65 536-item batches pipelined over two streams of the one
+    context (batch i on stream A, batch i + 1 on stream B; each stream has its own workspaces): the serial tail of a batch -- Fp12 product, Pippenger sum of the
+    sig2's, one Miller loop + final exponentiation, ~2.5 ms on a handful of workgroups -- runs beside the per-item kernel of the next batch."""
+    import numpy as np
+    import torch
+    main = torch.cuda.current_stream()
+    NT = 1 << 20
+    t0 = time.perf_counter()
+    d_all, amask, exp_all = wl.distinct_proofs_dev(NT, H, B, dev, main.cuda_stream)
+    assert amask == mask
+    t_gen = time.perf_counter() - t0
+    rsz = d_all.numel() // NT
+    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    seed_buf = np.frombuffer(bytes((7 * i + 1) & 0xFF for i in range(32)), dtype=np.uint8).copy()
+    fl = torch.zeros(NT, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    res = {"note": "elp_verify_id_batch_aggregated_dev: per-item NIZK + one Miller loop, Pippenger MSM of the sig2's, one final exponentiation per batch; exact "
+                   "per-item fallback when the batch equation fails.  Distinct proofs throughout (not tiled copies).",
+           "distinct_proofs": NT, "proof_synthesis_s": t_gen}
+
+    def call(agg, stream, first, n, cslot=0):
+        rp, fp, cp = d_all.data_ptr() + first * rsz, fl.data_ptr() + first, cnt.data_ptr() + 8 * cslot
+        if agg:
+            ctx._chk(ctx.lib.elp_verify_id_batch_aggregated_dev(ctx.h, stream, n, rp, mask, 1, d_ad.data_ptr(), None, len(wl.ad), seed_buf.ctypes.data, fp, cp))
+        else:
+            ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, n, rp, mask, 1, d_ad.data_ptr(), None, len(wl.ad), fp, cp))
+
+    for nb in (B, 4 * B, NT):
+        for agg in (True, False):
+            call(agg, main.cuda_stream, 0, nb)          # warm-up (workspaces)
+            torch.cuda.synchronize()
+            fl.zero_()
+            cnt.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2):
+                call(agg, main.cuda_stream, 0, nb)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_b = e0.elapsed_time(e1) / 2
+            ok = bool((fl[:nb].cpu().numpy() == exp_all[:nb]).all()) and int(cnt[0].item()) == 2 * int(exp_all[:nb].sum())
+            res["batch_%d_%s" % (nb, "aggregated" if agg else "per_item")] = {"value": nb / (ms_b * 1e-3), "ms_per_batch": ms_b, "parity_ok": ok}
+    # sustained: the 16 distinct batches of 65 536, twice over, alternating between two streams (aggregated) / back to back on one stream (per item)
+    sa, sb, sc, sd = (torch.cuda.Stream(device=dev) for _ in range(4))
+    nbat = NT // B
+    # With TWO streams nothing overlaps (measured: 17.72 against 17.75 ms per batch): while batch i + 1's per-item kernel holds every SIMD's registers the tail of batch i
+    # cannot start, and the kernel of batch i + 2 sits behind that tail in the same stream.  From three streams on a freed SIMD can go to either.
+    for label, agg, streams in (("aggregated_four_streams", True, (sa, sb, sc, sd)), ("aggregated_three_streams", True, (sa, sb, sc)), ("aggregated_two_streams", True, (sa, sb)),
+                                ("aggregated_one_stream", True, (sa,)), ("per_item_one_stream", False, (sa,)), ("per_item_two_streams", False, (sa, sb))):
+        for s_ in streams:
+            call(agg, s_.cuda_stream, 0, B)             # warm-up: this stream's workspaces
+        torch.cuda.synchronize()
+        fl.zero_()
+        cnt.zero_()
+        torch.cuda.synchronize()                         # the side streams do not wait for the default stream
+        t0 = time.perf_counter()
+        for rep in range(2):
+            for b in range(nbat):
+                s_ = streams[b % len(streams)]
+                call(agg, s_.cuda_stream, b * B, B, cslot=b % len(streams))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = bool((fl.cpu().numpy() == exp_all).all()) and int(cnt.sum().item()) == 2 * int(exp_all.sum())
+        res["sustained_%d_%s" % (B, label)] = {"value": 2 * NT / dt, "unit": "verifications/s", "ms_per_batch": dt / (2 * nbat) * 1e3, "batches": 2 * nbat,
+                                                "streams": len(streams), "parity_ok": ok}
+    # fallback in the middle of the pipeline: one batch carries a forged signature that passes its NIZK half (sig2 of another item) -- its batch equation fails,
+    # the per-item fallback of THAT batch decides; the batches around it stay on the fast path; every verdict stays exact
+    G1 = ctx.G1
+    d_bad = d_all[5 * B * rsz:6 * B * rsz].clone()
+    d_bad[7 * rsz + G1:7 * rsz + 2 * G1] = d_all[(5 * B + 8) * rsz + G1:(5 * B + 8) * rsz + 2 * G1]      # item 7 of the batch gets item 8's sig2
+    exp_bad = exp_all[5 * B:6 * B].copy()
+    exp_bad[7] = 0
+    fl.zero_()
+    cnt.zero_()
+    flb = torch.zeros(B, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(8):
+        s_ = (sa, sb)[b % 2]
+        if b == 3:
+            ctx._chk(ctx.lib.elp_verify_id_batch_aggregated_dev(ctx.h, s_.cuda_stream, B, d_bad.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(wl.ad),
+                                                                seed_buf.ctypes.data, flb.data_ptr(), cnt.data_ptr() + 16))
+        else:
+            call(True, s_.cuda_stream, b * B, B, cslot=b % 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    okf = bool((flb.cpu().numpy() == exp_bad).all()) and int(cnt[2].item()) == int(exp_bad.sum())
+    for b in range(8):
+        if b != 3:
+            okf = okf and bool((fl[b * B:(b + 1) * B].cpu().numpy() == exp_all[b * B:(b + 1) * B]).all())
+    res["fallback_mid_pipeline"] = {"parity_ok": okf, "ms_for_8_batches": dt * 1e3, "note": "batch 3 of 8 fails its batch equation (one swapped sig2) and is decided per item"}
+    return res
 
 
 def valu_bound(ctx, ops_key, window, B, kern_ms, macs_per_mul):

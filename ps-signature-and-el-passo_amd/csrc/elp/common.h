@@ -122,7 +122,10 @@ ELP_INL bool pair_or(bool b) {
 // or too small for the type.  4 resident waves x 64 lanes x 432 B = 108 KB of the CU's 160 KB.
 // Paired kernels run 8 waves per CU with half-size values: 54 words (216 B) per lane, 110 KB per CU.
 constexpr int ELP_HOT_WORDS = 108;
-constexpr int ELP_HOT_WORDS_PAIRED = 54;
+#ifndef ELP_HOT_WORDS_PAIRED_N
+#define ELP_HOT_WORDS_PAIRED_N 54      /* experiments: a translation unit may shrink its paired hot slot (hot_as<> falls back to private memory for values that no longer fit) */
+#endif
+constexpr int ELP_HOT_WORDS_PAIRED = ELP_HOT_WORDS_PAIRED_N;
 template <class C>
 ELP_HD constexpr int hot_words() { return is_paired<C>() ? ELP_HOT_WORDS_PAIRED : ELP_HOT_WORDS; }
 template <class T, class C>

@@ -324,7 +324,9 @@ ELP_HEAVY void fp12_exp_u64_gs(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = n
 template <class C>
 ELP_HEAVY void fp12_exp_u64(Fp12<C>& r, const Fp12<C>& a, u64 e, u32* hot = nullptr) {
 #if ELP_COMPRESSED_SQR
-  constexpr int MAXS = 8;
+  // snapshots per exponent: |z| of BN254 has 2 set bits below the top, the BLS12-381 |z| five (+ the top bit itself: one run ends there); an exponent with more
+  // set bits (the dense (z - 1) / 3 of the exact BLS12 chain) takes the plain loop below.  Sized per curve: the arrays are part of the hottest private frame.
+  constexpr int MAXS = C::IS_BN ? 2 : 6;
   int top = 63;
   while (!((e >> top) & 1)) top--;
   int nset = 0;

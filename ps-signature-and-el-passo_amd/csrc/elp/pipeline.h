@@ -1184,6 +1184,162 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
   return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// G1 JOBS AS A KERNEL OF THEIR OWN (round 4; ELP_OPT_SPLIT_PHASES = 3, the default on BLS12-381).
+//
+// In the paired layout the base-field work of a verification does not split over the lane pair: the three commitments V_phi, V_E1, V_E2 (one GLV
+// multiplication + fixed-base terms + an inversion each, src/ps-verifier.cc:91-108) and -- on a curve with a G1 cofactor -- the four subgroup tests (phi, E1,
+// E2, sig1) are whole jobs of ONE lane, seven jobs on two lanes = four job slots, a third of the paired kernel's time on BLS12-381, executed at the issue rate
+// of a kernel that holds 256 registers and an Fp12 frame per lane.  Here they are a kernel of their own in the plain layout: one lane per JOB, job-uniform waves
+// (workgroup b works on job b mod 4 of items [64 (b / 4), 64 (b / 4) + 64)), nothing but Jacobian G1 points in registers, several waves per SIMD.  The paired
+// kernel that follows (verify_id_item_paired_g1done) keeps everything over Fp2 -- [c]k, the fixed-base G2 sums, K, the transcript hash, Miller loop and final
+// exponentiation -- and reads the commitments' wire bytes and the jobs' verdicts from the launch workspace.
+//   job 0 / 1 / 2 : P = phi / E1 / E2:  on the curve, in G1;  V = [c]P + fixed-base terms, affine, serialised           -> row `job` of the workspace
+//   job 3         : sig1, sig2 on the curve; sig1 admissible under KEY_STRICT_SIG (sig1_admissible: != O and in G1)      -> verdict only
+// Workspace (32-bit words, word w of item i at ws[w * stride + i], coalesced across a wave): rows 0..2 of FBYTES / 4 words, then the four verdict words.
+template <class C>
+ELP_HD constexpr int g1jobs_ws_words() { return 3 * (C::FBYTES / 4) + 4; }
+template <class C>
+ELP_HEAVY void vid_g1_job(const KeyCtx<C>& key, int job, const u32* rec, u64 hidden_mask, bool retr, u32* vtab_slot, u32* ws, size_t stride, size_t i) {
+  static_assert(!is_paired<C>(), "plain layout: one lane per job");
+  constexpr int FBW = C::FBYTES / 4;
+  const int G1W = 2 * C::N;
+  u32* const okw = ws + (size_t)(3 * FBW + job) * stride + i;
+  if (job == 3) {
+    Aff<F1<C>> sig1, sig2;
+    bool ok = g1_load<C>(sig1, rec) && g1_load<C>(sig2, rec + G1W);
+    if (ok) ok = sig1_strict_ok<C>(key.flags, sig1);
+    *okw = ok ? 1u : 0u;
+    return;
+  }
+  if (job != 0 && !retr) {        // no E1 / E2 in the record (the condition is uniform over the launch)
+    *okw = 1u;
+    return;
+  }
+  Aff<F1<C>> P;
+  bool ok = g1_load<C>(P, rec + (2 + job) * G1W);
+  if constexpr (!C::IS_BN) {
+    if (ok && !(key.flags & KEY_NO_SUBGROUP_CHECK)) ok = g1_in_subgroup<C>(P);
+  }
+  u32 v[FBW];
+  for (int q = 0; q < FBW; q++) v[q] = 0;
+  if (ok) {
+    RecordSrc<C> src;
+    Scalar c;
+    src.open_lite(rec, hidden_mask, key.A, retr, c);
+    vid_job_g1_one<C, RecordSrc<C>>(key, src, job, P, c, v, vtab_slot);
+  }
+  for (int q = 0; q < FBW; q++) ws[(size_t)(job * FBW + q) * stride + i] = v[q];
+  *okw = ok ? 1u : 0u;
+}
+// what the paired kernel reads back
+struct G1JobsOut {
+  const u32* ws;
+  size_t stride, i;
+  ELP_HD bool ok() const {
+    u32 a = 1;
+    for (int j = 0; j < 4; j++) a &= ws[(size_t)(3 * FB4 + j) * stride + i];
+    return a != 0;
+  }
+  int FB4;      // FBYTES / 4 of the curve
+  ELP_HD void row(int t, uint8_t* out) const {        // wire bytes of commitment t
+    for (int q = 0; q < FB4; q++) {
+      const u32 x = ws[(size_t)(t * FB4 + q) * stride + i];
+      out[4 * q] = (uint8_t)x;
+      out[4 * q + 1] = (uint8_t)(x >> 8);
+      out[4 * q + 2] = (uint8_t)(x >> 16);
+      out[4 * q + 3] = (uint8_t)(x >> 24);
+    }
+  }
+};
+// NIZK half of the paired layout WITHOUT the G1 jobs: V_k and K by the pair, the commitments' bytes from the workspace.
+template <class C, class Src>
+ELP_HEAVY bool verify_id_paired_nizk_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F2<C>>& kk, const Scalar& c, const uint8_t* ad, size_t ad_len,
+                                        const G1JobsOut& pre, Aff<F2<C>>& aK) {
+  static_assert(is_paired<C>(), "paired layout only");
+  typedef F2<C> G2F;
+  const int A = key.A;
+  const int nrs = src.nrs();
+  const Scalar r_t = src.rs(retr ? nrs - 2 : nrs - 1);
+  const Scalar one_minus_c = scalar_one_minus<C>(c);
+  Aff<G2F> tabk[8];
+  {
+    Jac<G2F> jk[8];
+    jac_multiples8<G2F>(jk, kk);
+    Fp2<C> z2[7], zi2[7];
+    for (int i = 1; i < 8; i++) z2[i - 1] = jk[i].Z;
+    batch_zinv<C, 0, 7>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
+    tabk[0] = kk;
+    for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G2F>(tabk[i], jk[i], zi2[i - 1]);
+  }
+  // V_k = k^c prod_{hidden} YY_j^{r_j} gg^{r_t} XX^{1-c},  K = k prod_{revealed} YY_i^{m_i}     (src/ps-verifier.cc:72-88,214-229)
+  Jac<G2F> Vk, K;
+  u32* const wsk = key.vtab;
+  if (wsk) {
+    for (int i = 0; i < 8; i++) vtab_store<G2F>(wsk, i, tabk[i]);
+    g2_mul_gls_with<C, WsTab<G2F>>(Vk, WsTab<G2F>{wsk}, c);
+  } else {
+    g2_mul_gls_tab<C>(Vk, tabk, c);
+  }
+  jac_from_aff(K, kk);
+  {
+    int jh = 0;
+    for (int i = 0; i < A; i++) {
+      if (src.hidden(i)) {
+        acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, src.rs(jh));
+        jh++;
+      } else {
+        acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
+      }
+    }
+  }
+  acc_fixed_g2<C>(Vk, key, G2_BASE_GG, r_t);
+  acc_fixed_g2<C>(Vk, key, G2_BASE_XX, one_minus_c);
+  Fp2<C> z2[2], zi2[2];
+  z2[0] = Vk.Z;
+  z2[1] = K.Z;
+  batch_zinv<C, 0, 2>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
+  Aff<G2F> aVk;
+  jac_to_aff_with_zinv<G2F>(aVk, Vk, zi2[0]);
+  jac_to_aff_with_zinv<G2F>(aK, K, zi2[1]);
+  // c' = Hr(SHA256(hex k | hex phi | [hex E1 | hex E2] | hex V_k | hex V_phi | [hex V_E1 | hex V_E2] | ad))          (:111-122)
+  uint8_t buf[2 * C::FBYTES];
+  Transcript t;
+  transcript_init(t);
+  src.ser_k(buf);
+  sha256_update_hex(t.s, buf, 2 * C::FBYTES);
+  for (int q = 0; q < (retr ? 3 : 1); q++) {
+    src.ser_g1(q, buf);
+    sha256_update_hex(t.s, buf, C::FBYTES);
+  }
+  transcript_g2<C>(t, aVk);
+  for (int q = 0; q < (retr ? 3 : 1); q++) {
+    pre.row(q, buf);
+    sha256_update_hex(t.s, buf, C::FBYTES);
+  }
+  const Scalar c2 = transcript_challenge<C>(t, ad, ad_len);
+  return scalar_eq(c2, c);
+}
+template <class C>
+ELP_HEAVY bool verify_id_item_paired_g1done(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
+                                            const G1JobsOut& pre) {
+  static_assert(is_paired<C>(), "paired layout only");
+  const int G1W = 2 * C::N;
+  Aff<F1<C>> sig1, sig2;
+  Aff<F2<C>> kk, aK;
+  // both lanes need sig1 / sig2 (line evaluation); their validity, the strict-signature rule and everything about phi / E1 / E2 were decided by the G1 jobs
+  bool ok = g1_load<C>(sig1, rec);
+  ok &= g1_load<C>(sig2, rec + G1W);
+  ok &= pre.ok();
+  const bool okk = g2_load<C>(kk, rec + (retr ? 5 : 3) * G1W);
+  if (!ok || !okk) return false;
+  const Scalar c = scalar_load_w(rec + (retr ? 5 : 3) * G1W + 4 * C::N);
+  PairedRecordSrc<C> src;
+  src.init(rec, hidden_mask, key.A, retr);
+  if (!verify_id_paired_nizk_g2<C, PairedRecordSrc<C>>(key, src, retr, kk, c, ad, ad_len, pre, aK)) return false;
+  return ps_pairing_check<C>(key, sig1, sig2, aK);
+}
+
 // ---- wire ingest (SURVEY.md section 8f rank 1 + 2): T-L-V parsing, point decompression (one Fp / Fp2 square root each) and
 // Fr::setHashOf of the revealed attributes on the device.  Layout (src/ps-encoding.cc:451-467, Appendix C of SURVEY.md):
 //   01 L sig1 | 01 L sig2 | 02 2L k | 01 L phi | 03 20 c | 06 m (20 r)* | 07 A (len str)* [| 01 L E1 | 01 L E2],  L = FBYTES

@@ -1,0 +1,5 @@
+// G1 jobs of the EL PASSO verification on BN254 (k_vid_g1jobs, ELP_OPT_SPLIT_PHASES = 3): a translation unit of its own, compiled for several waves per SIMD.
+#define ELP_G1JOBS_TU 1
+#include "elpasso_impl.h"
+
+template void launch_vid_g1jobs<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<BN254>& key);

@@ -108,6 +108,10 @@ void elp_destroy(elp_ctx* c) {
   for (auto& w : c->vtab_ws)
     if (w.p) (void)hipFree(w.p);
   if (c->agg_ok) (void)hipFree(c->agg_ok);
+  for (auto& w : c->agg_parked) {
+    if (w.ws) (void)hipFree(w.ws);
+    if (w.ok) (void)hipFree(w.ok);
+  }
   if (c->coop_consts) (void)hipFree(c->coop_consts);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
   for (int i = 0; i < 4; i++)
@@ -135,7 +139,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_COALESCED_RECORDS: c->stage_records = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_STREAM_OVERLAP: c->overlap = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
-      if (value < 0 || value > 2) return ELP_ERR_ARG;
+      if (value < 0 || value > 3) return ELP_ERR_ARG;
       c->split = value;
       return ELP_OK;
     default: return ELP_ERR_ARG;

@@ -267,6 +267,24 @@ __global__ void __launch_bounds__(ELP_BLOCK, 4) k_vid_g1(KeyCtx<C> key, const u3
   for (int t = 0; t < (retr ? 3 : 1); t++)
     for (int q = 0; q < C::FBYTES / 4; q++) ws[(size_t)(2 * C::FBYTES / 4 + t * (C::FBYTES / 4) + q) * stride + i] = v1[t][q];
 }
+// ---- G1 jobs as a kernel of their own (elp/pipeline.h "G1 JOBS AS A KERNEL OF THEIR OWN"): one lane per job, job-uniform waves -- workgroup b runs job b & 3 of
+// items [64 (b >> 2), 64 (b >> 2) + 64) -- in the plain layout, Jacobian G1 points only: compiled for several waves per SIMD in a translation unit of its own.
+#ifndef ELP_G1JOBS_WAVES
+#define ELP_G1JOBS_WAVES 3
+#endif
+template <class C>
+__global__ void __launch_bounds__(ELP_BLOCK, ELP_G1JOBS_WAVES) k_vid_g1jobs(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, u32* ws, size_t stride, size_t n) {
+  constexpr int HOTW = (int)(sizeof(Jac<F1<C>>) / 4);
+  __shared__ __attribute__((aligned(16))) u32 hot_lds[ELP_BLOCK * HOTW];
+  key.hot = hot_lds + threadIdx.x * HOTW;
+  const int job = (int)(blockIdx.x & 3u);
+  const size_t i = (size_t)(blockIdx.x >> 2) * ELP_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  // this lane's 8-entry slice of the launch workspace for the table of multiples of its point (jobs 0..2); the workspace of n plain lanes is large enough
+  u32* slot = nullptr;
+  if (key.vtab && job < 3) slot = key.vtab + ((size_t)job * n + i) * (size_t)(8 * vtab_entry_words<F1<C>>());
+  vid_g1_job<C>(key, job, recs + i * (size_t)rec_words, mask, retr != 0, slot, ws, stride, i);
+}
 // Phase 2 behind the concurrent jobs: transcript hash (src/ps-verifier.cc:111-130), then the pairing check.
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_vid_pair2(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
@@ -521,6 +539,9 @@ __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, con
   __shared__ __attribute__((aligned(16))) u32 stage[L::STAGE_WORDS];
   pair_coop_body<C, NP>(key, consts, recs, rec_words, todo, kws, kstride, flags, done, accepted, n, blockIdx.x, Rall, stage);
 }
+#ifdef ELP_DBG_SMALL
+__device__ unsigned long long elp_dbg_small[32];
+#endif
 // Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them, 128
 // of their 256 lanes) of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
 // run them side by side without a second stream.
@@ -532,6 +553,24 @@ __global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* 
   constexpr size_t PAIR_BYTES = (size_t)(L::R_WORDS + L::STAGE_WORDS) * 4 + 16;
   constexpr size_t BYTES = PAIR_BYTES > Nizk4Lds<C>::BYTES ? PAIR_BYTES : Nizk4Lds<C>::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
+#ifdef ELP_DBG_SMALL      /* measurement builds only (tools/probes/lone_call_probe.py): per-wave wall-clock times and placement of the first two workgroups */
+  const unsigned long long dbg_t0 = wall_clock64();
+  struct DbgAtExit {
+    unsigned long long t0;
+    __device__ ~DbgAtExit() {
+      if ((threadIdx.x & 63) == 0 && blockIdx.x < 2) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = elp_dbg_small + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+        d[0] = t0;
+        d[1] = wall_clock64();
+        d[2] = hw;
+        d[3] = xcc;
+      }
+    }
+  } dbg_at_exit{dbg_t0};
+#endif
   if (blockIdx.x < nb_nizk) {
     vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
                       (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
@@ -774,9 +813,10 @@ template <class B>
 void launch_coop_consts(hipStream_t stream, void* d_consts) {
   hipLaunchKernelGGL((k_coop_consts<B>), dim3(1), dim3(ELP_BLOCK), 0, stream, (Fp2<B>*)d_consts);
 }
+#define ELP_REST_BY_CALLER ((hipStream_t)(intptr_t)-1)
 template <class B>
 void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
-                      uint8_t* d_flags, uint8_t* done, void* d_accepted) {
+                      uint8_t* d_flags, uint8_t* done, void* d_accepted, hipStream_t rest_stream) {      // rest_stream: where the per-lane kernel for the left-over items runs (null: `stream`)
   // up to 512 items (half the SIMDs: the other half is free for the kernel that runs beside this one): one item per wave, 32 lane pairs, 982 steps; above: two
   // items per wave, 16 lane pairs each, 1293 steps
   if (n <= 512)
@@ -785,6 +825,15 @@ void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_co
   else
     hipLaunchKernelGGL((k_pair_coop<B, 16>), dim3((unsigned)((n + 3) / 4)), dim3(ELP_COOP_BLOCK), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, todo, kws, kstride,
                        d_flags, done, (unsigned long long*)d_accepted, n);
+  // k_pair_rest carries the per-lane pairing's private frame (13.8 KB per lane): kernels with a large frame stay on ONE hardware queue per process -- scratch blocks
+  // are per queue, and a second queue that needs one makes the runtime reclaim the first queue's (seconds per event; DESIGN.md section 5, profiles/r04_scratch_stall.md)
+  if (rest_stream == ELP_REST_BY_CALLER) return;      // the caller queues launch_pair_rest itself (on its own stream, behind an event of `stream`)
+  hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, rest_stream ? rest_stream : stream, key, (const u32*)d_records, words, todo, (const uint8_t*)done, kws,
+                     kstride, d_flags, (unsigned long long*)d_accepted, n);
+}
+template <class B>
+void launch_pair_rest(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
+                      uint8_t* done, void* d_accepted) {
   hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, todo, (const uint8_t*)done, kws, kstride, d_flags,
                      (unsigned long long*)d_accepted, n);
 }
@@ -809,6 +858,21 @@ void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_co
   else
     hipLaunchKernelGGL((k_vid_small<B, 16>), dim3(nb_nizk + (unsigned)((n + 3) / 4)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
                        retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
+#ifdef ELP_DBG_SMALL
+  if (getenv("ELP_DBG_SMALL")) {
+    unsigned long long h[32];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(elp_dbg_small), sizeof h);
+    unsigned long long base = h[0];
+    fprintf(stderr, "k_vid_small n=%zu:", n);
+    for (int w = 0; w < 8; w++) {
+      const unsigned hw = (unsigned)h[w * 4 + 2];
+      fprintf(stderr, " %c%d[x%llu c%02u m%u] %+.2f..%.2f ms |", w < 4 ? 'N' : 'P', w & 3, h[w * 4 + 3] & 15, (hw >> 8) & 15, (hw >> 4) & 3, ((double)h[w * 4] - (double)base) / 1e5,
+              ((double)h[w * 4 + 1] - (double)base) / 1e5);
+    }
+    fprintf(stderr, "\n");
+  }
+#endif
   KeyCtx<B> k2 = key;
   k2.vtab = nullptr;
   hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, k2, (const u32*)d_records, words, kvalid, (const uint8_t*)done, kws, kstride, pair_ok,
@@ -831,7 +895,11 @@ template <class B>
 void launch_coop_consts(hipStream_t stream, void* d_consts);
 template <class B>
 void launch_pair_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride,
-                      uint8_t* d_flags, uint8_t* done, void* d_accepted);
+                      uint8_t* d_flags, uint8_t* done, void* d_accepted, hipStream_t rest_stream);
+#define ELP_REST_BY_CALLER ((hipStream_t)(intptr_t)-1)
+template <class B>
+void launch_pair_rest(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
+                      uint8_t* done, void* d_accepted);
 template <class B>
 void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
 template <class B>
@@ -859,7 +927,8 @@ struct CoopBuild<BN254> {
 };
 #ifndef ELP_COOP_TU
 extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_consts);
-extern template void launch_pair_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
+extern template void launch_pair_rest<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
+extern template void launch_pair_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted, hipStream_t rest_stream);
 extern template void launch_ps_k<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
 extern template void launch_agg_final_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
 extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
@@ -892,6 +961,24 @@ __global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_paired(KeyCtx<C> key, const u
     const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
     size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
     ok = verify_id_item_paired<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al);
+    if ((threadIdx.x & 1) == 0) flags[i] = ok ? 1 : 0;
+  }
+  count_accept_paired(ok, accepted);
+}
+// the paired kernel behind k_vid_g1jobs: everything over Fp2 of a verification; commitments and verdicts of the G1 jobs from the workspace
+template <class C>
+__global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_paired_g1(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
+                                                             const u32* ad_off, u32 ad_len, const u32* g1ws, size_t g1stride, uint8_t* flags,
+                                                             unsigned long long* accepted, size_t n) {
+  ELP_HOT_SETUP_PAIRED(key);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  bool ok = false;
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    G1JobsOut pre{g1ws, g1stride, i, C::FBYTES / 4};
+    ok = verify_id_item_paired_g1done<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al, pre);
     if ((threadIdx.x & 1) == 0) flags[i] = ok ? 1 : 0;
   }
   count_accept_paired(ok, accepted);
@@ -1524,6 +1611,17 @@ struct elp_ctx {
   void* agg_ws = nullptr;
   size_t agg_ws_bytes = 0;
   int* agg_ok = nullptr;      // device flag of the last aggregated batch
+  // The three fields above belong to ONE launch stream at a time (agg_stream).  A caller that pipelines aggregated batches over several streams of one context
+  // (batch i on stream A, batch i + 1 on stream B: the serial tail of one batch runs beside the per-item kernel of the next) gets a workspace per stream: the
+  // entry point parks the current set in agg_parked and takes out (or creates) the set of its stream.
+  struct AggWs {
+    hipStream_t stream;
+    void* ws;
+    size_t bytes;
+    int* ok;
+  };
+  hipStream_t agg_stream = nullptr;
+  std::vector<AggWs> agg_parked;
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
     hipStream_t stream;
@@ -2153,6 +2251,21 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   const size_t o_flags = 0, o_delta = al(n), o_sig2 = o_delta + al(n * 32), o_f1 = o_sig2 + al(n * Sizes<C>::G1),
                o_f2 = o_f1 + al(nw * sizeof(Fp12<C>)), o_f3 = o_f2 + al(nw2 * sizeof(Fp12<C>)), o_s2 = o_f3 + al(sizeof(Fp12<C>)),
                o_msm = o_s2 + al(Sizes<C>::G1), total = o_msm + msm_ws_bytes<C, 1>(n);
+  if (c->agg_stream != stream) {          // a workspace per launch stream (see elp_ctx::agg_parked)
+    if (c->agg_ws || c->agg_ok) c->agg_parked.push_back({c->agg_stream, c->agg_ws, c->agg_ws_bytes, c->agg_ok});
+    c->agg_ws = nullptr;
+    c->agg_ws_bytes = 0;
+    c->agg_ok = nullptr;
+    c->agg_stream = stream;
+    for (size_t q = 0; q < c->agg_parked.size(); q++)
+      if (c->agg_parked[q].stream == stream) {
+        c->agg_ws = c->agg_parked[q].ws;
+        c->agg_ws_bytes = c->agg_parked[q].bytes;
+        c->agg_ok = c->agg_parked[q].ok;
+        c->agg_parked.erase(c->agg_parked.begin() + (long)q);
+        break;
+      }
+  }
   if (c->agg_ws_bytes < total) {
     HIPCHK(c, hipStreamSynchronize(stream));
     if (c->agg_ws) (void)hipFree(c->agg_ws);
@@ -2256,6 +2369,18 @@ void launch_verify_id_paired(elp_ctx* c, hipStream_t stream, size_t n, const voi
                      (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
+// the two launches of ELP_OPT_SPLIT_PHASES = 3: G1 jobs (plain layout, own translation unit), then the paired kernel over their output
+template <class B>
+void launch_vid_g1jobs(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<B>& key) {
+  hipLaunchKernelGGL((k_vid_g1jobs<B>), dim3(4 * grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, ws, stride, n);
+}
+template <class B>
+void launch_verify_id_paired_g1(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                                const void* d_ad_off, size_t ad_len, const u32* g1ws, size_t g1stride, void* d_flags, void* d_accepted, const KeyCtx<Paired<B>>& key) {
+  (void)c;
+  hipLaunchKernelGGL((k_verify_id_paired_g1<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, g1ws, g1stride, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+}
 template <class B>
 void launch_verify_id_wire_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad,
                                   const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
@@ -2323,6 +2448,10 @@ extern template void launch_vid_g1<BN254>(hipStream_t stream, size_t n, const vo
 extern template void launch_vid_nizk4<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre, int k_done);
 extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre);
 #endif
+#ifndef ELP_G1JOBS_TU
+extern template void launch_vid_g1jobs<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<BN254>& key);
+extern template void launch_vid_g1jobs<BLS12_381>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, u32* ws, size_t stride, const KeyCtx<BLS12_381>& key);
+#endif
 #ifndef ELP_PAIR_TU
 extern template void launch_verify_id_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
@@ -2330,6 +2459,8 @@ extern template void launch_verify_id_wire_paired<BN254>(elp_ctx* c, hipStream_t
 extern template void launch_verify_id_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
 extern template void launch_ps_verify_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int nattr, void* d_flags, void* d_accepted);
 extern template void launch_verify_id_wire_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted);
+extern template void launch_verify_id_paired_g1<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, const u32* g1ws, size_t g1stride, void* d_flags, void* d_accepted, const KeyCtx<Paired<BN254>>& key);
+extern template void launch_verify_id_paired_g1<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, const u32* g1ws, size_t g1stride, void* d_flags, void* d_accepted, const KeyCtx<Paired<BLS12_381>>& key);
 extern template void launch_agg_final_paired<BN254>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
 extern template void launch_agg_final_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
 #endif
@@ -2394,9 +2525,10 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         if (c->overlap) {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
           key.vtab = nullptr;
-          launch_pair_coop<C>(js, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
+          launch_pair_coop<C>(js, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr, ELP_REST_BY_CALLER);
           HIPCHK(c, hipEventRecord(c->jev[1], js));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[1], 0));
+          launch_pair_rest<C>(st, key, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);      // large private frame: on the caller's queue (see launch_pair_coop)
         } else if (n <= 1024) {
           // default: NIZK half and pairing check as workgroup ranges of ONE launch (k_vid_small) -- side by side without a second stream.  (Its pairing
           // workgroups carry the NIZK half's register budget: where the pairing check alone fills the chip that halves their occupancy -- measured, 2048 items take
@@ -2405,7 +2537,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         } else {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
           key.vtab = nullptr;
-          launch_pair_coop<C>(st, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
+          launch_pair_coop<C>(st, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr, nullptr);
         }
         launch_vid_combine<C>(st, n, nizk_ok, pair_ok, d_flags, d_accepted);
         HIPCHK(c, hipGetLastError());
@@ -2418,6 +2550,26 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
     if (np < n) {
       const uint8_t* recs2 = (const uint8_t*)d_records + np * (size_t)words * 4;
       const u32* off2 = d_ad_off ? (const u32*)d_ad_off + np : nullptr;
+      bool launched = false;
+      if (c->split == 3) {
+        // G1 jobs (three commitments + the subgroup tests, one lane per job, plain layout) as a kernel of their own, then the paired kernel over Fp2
+        const size_t m = n - np;
+        const size_t stride = (size_t)grid_for(m) * ELP_BLOCK;
+        const size_t g1_bytes = (stride * (size_t)g1jobs_ws_words<C>() * 4 + 255) & ~(size_t)255;
+        void* extra = nullptr;
+        // one workspace serves both launches (they run one after the other on this stream): the paired kernel's lanes x its slice is the larger need
+        KeyCtx<Paired<C>> pkey = make_key_ws<Paired<C>>(c, (hipStream_t)stream, (size_t)grid_for_paired(m) * ELP_BLOCK, g1_bytes, &extra);
+        if (extra) {
+          KeyCtx<C> jkey = make_key<C>(c);
+          jkey.vtab = (u32*)pkey.vtab;       // 3 m slices of 8 G1 entries: smaller than the paired kernel's 2 m slices (pipeline.h vtab_words)
+          static_assert(3 * 8 * vtab_entry_words<F1<C>>() <= 2 * vtab_words<Paired<C>>(), "the job kernel's tables fit the paired kernel's workspace");
+          launch_vid_g1jobs<C>((hipStream_t)stream, m, recs2, words, mask, retr, (u32*)extra, stride, jkey);
+          launch_verify_id_paired_g1<C>(c, (hipStream_t)stream, m, recs2, words, mask, retr, d_ad, off2, ad_len, (const u32*)extra, stride, (uint8_t*)d_flags + np,
+                                        d_accepted, pkey);
+          launched = true;
+        }
+      }
+      if (!launched)
       launch_verify_id_paired<C>(c, (hipStream_t)stream, n - np, recs2, words, mask, retr, d_ad, off2, ad_len, (uint8_t*)d_flags + np, d_accepted);
       HIPCHK(c, hipGetLastError());
       if (np == 0) return ELP_OK;
@@ -2456,7 +2608,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       HIPCHK(c, hipGetLastError());
       return ELP_OK;
     }
-    if (c->split) {
+    if (c->split == 1) {
       // two phases: k_vid_nizk (two job waves per 64 items, two waves per SIMD) -> per-item verdict + K in the workspace -> k_vid_pair
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
@@ -2537,7 +2689,7 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
         const int words = 4 * C::N + 8 * nattr;
         launch_ps_k<C>((hipStream_t)stream, key, n, d_records, words, nattr, todo, kws, lanes);
-        launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, done, d_accepted);
+        launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, done, d_accepted, nullptr);
         HIPCHK(c, hipGetLastError());
         return ELP_OK;
       }

@@ -235,6 +235,43 @@ class Workload:
         G1 = ctx.G1
         return b"".join(sig[2 * i * G1:(2 * i + 2) * G1] + tails[i] for i in range(n_items)), (1 << H) - 1
 
+    def distinct_proofs_dev(self, n_items, nhidden, users, dev, stream, corrupt_every=97, corrupt_at=13, seed=7):
+        """n_items DISTINCT el_passo_verify_id records on the device, synthesised by the batch prover (elp_prove_id_batch_dev): `users` credentials (the
+        deterministic prove_id_batch inputs) presented n_items / users times each with fresh prover randomness per presentation -- every record differs in
+        sig1', sig2', k, E1, E2, c and the responses (a user's pseudonym phi and revealed attributes repeat, as they do when a user signs on again).  Every
+        corrupt_every-th item gets bit 0 of c flipped.  Returns (torch uint8 tensor of records, hidden_mask, expected flags np.uint8[n_items]).
+        Builds 2^20 proofs in seconds where the host-side generator of verify_id_batch needs a minute."""
+        import torch
+        ctx, A, H = self.ctx, self.A, nhidden
+        assert n_items % users == 0
+        base, mask = self.prove_id_batch(users, H, with_retrieval=True)
+        psz = len(base) // users
+        nrand = 2 + 1 + H + 1 + 1                                   # t, r, eps, rho[H], rho_t, rho_e
+        a = np.frombuffer(base, dtype=np.uint8).reshape(users, psz)
+        recs = np.tile(a, (n_items // users, 1))
+        rng = np.random.default_rng(seed)
+        fresh = rng.integers(0, 256, size=(n_items - users, nrand * 32), dtype=np.uint8)
+        fresh[:, 31::32] &= 0x1F                                    # below 2^253 < r on both curves
+        recs[users:, psz - nrand * 32:] = fresh
+        d_in = torch.from_numpy(recs.reshape(-1)).to(dev)
+        osz = ctx.lib.elp_verify_id_record_size(ctx.curve, A, H, 1)
+        d_out = torch.zeros(n_items * osz, dtype=torch.uint8, device=dev)
+        d_fl = torch.zeros(n_items, dtype=torch.uint8, device=dev)
+        d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_ad = torch.from_numpy(np.frombuffer(self.ad, dtype=np.uint8).copy()).to(dev)
+        ctx._chk(ctx.lib.elp_prove_id_batch_dev(ctx.h, stream, n_items, d_in.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(self.ad), d_out.data_ptr(),
+                                                d_fl.data_ptr(), d_cnt.data_ptr()))
+        torch.cuda.synchronize()
+        assert int(d_fl.sum().item()) == n_items, "the batch prover rejected an input"
+        expect = np.ones(n_items, dtype=np.uint8)
+        if corrupt_every:
+            bad = np.arange(corrupt_at, n_items, corrupt_every)
+            expect[bad] = 0
+            off_c = 5 * ctx.G1 + ctx.G2                             # sig1 | sig2 | phi | E1 | E2 | k | c ...
+            idx = torch.from_numpy(bad.astype(np.int64) * osz + off_c).to(dev)
+            d_out[idx] ^= 1
+        return d_out, mask, expect
+
     def request_id_batch(self, n_items, nhidden, first_item=0):
         """Input records of elp_request_id_batch: m[A] | t | rho_0 | rho[H].  Returns (records, hidden_mask)."""
         r = self.r

@@ -451,6 +451,27 @@ static KeyCtx<Paired<C>> paired_key(const TwinCtx<C>* c, u32* hot) {
   k.flags = c->key.flags;
   return k;
 }
+// ELP_OPT_SPLIT_PHASES = 3 on the host: the four G1 jobs of an item one after the other in the plain layout (stride-1 workspace), then the paired kernel's body
+// over their output -- the same two functions the kernels k_vid_g1jobs / k_verify_id_paired_g1 wrap.
+template <class B>
+static int twin_verify_id_g1split(const TwinCtx<B>* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
+  std::vector<u32> ws(g1jobs_ws_words<B>(), 0xdeadbeefu);
+  for (int job = 0; job < 4; job++) {
+    KeyCtx<B> k = c->key;
+    std::vector<u32> hot(ELP_HOT_WORDS, 0xdeadbeefu);
+    k.hot = hot.data();
+    std::vector<u32> slot(8 * vtab_entry_words<F1<B>>(), 0xdeadbeefu);
+    vid_g1_job<B>(k, job, rec, mask, retr != 0, getenv("ELP_TWIN_NO_VTAB") ? nullptr : slot.data(), ws.data(), 1, 0);
+  }
+  return run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<Paired<B>> k = paired_key<B>(c, hot.data());
+    std::vector<u32> vt(vtab_words<Paired<B>>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
+    G1JobsOut pre{ws.data(), 1, 0, B::FBYTES / 4};
+    return verify_id_item_paired_g1done<Paired<B>>(k, rec, mask, retr != 0, ad, adlen, pre) ? 1 : 0;
+  });
+}
 #if !defined(TWIN_PART) || TWIN_PART == 2
 typedef Paired<BLS12_381> BLSP;
 extern "C" {
@@ -463,6 +484,9 @@ int twin_blsp_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const
     k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return verify_id_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
   });
+}
+int twin_blsp_verify_id_g1split(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
+  return twin_verify_id_g1split<BLS12_381>((const TwinCtx<BLS12_381>*)cv, rec, mask, retr, ad, adlen);
 }
 int twin_blsp_ps_verify(void* cv, const u32* rec, int nattr) {
   const TwinCtx<BLS12_381>* c = (const TwinCtx<BLS12_381>*)cv;
@@ -587,6 +611,9 @@ int twin_bn254p_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, con
     k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
     return verify_id_item_paired<BN254P>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
   });
+}
+int twin_bn254p_verify_id_g1split(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
+  return twin_verify_id_g1split<BN254>((const TwinCtx<BN254>*)cv, rec, mask, retr, ad, adlen);
 }
 int twin_bn254p_verify_id_wire(void* cv, const uint8_t* msg, size_t len, int retr, const uint8_t* ad, size_t adlen) {
   const TwinCtx<BN254>* c = (const TwinCtx<BN254>*)cv;

@@ -319,6 +319,9 @@ def test_paired_layout_verify_id_golden(L):
                 ad = c["ad"].encode()
                 got = L.twin_bn254p_verify_id(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
                 assert bool(got) == c["expect"], (s["name"], c["label"])
+                # ELP_OPT_SPLIT_PHASES = 3: the G1 jobs as a kernel of their own (vid_g1_job), then the paired body over their output
+                got = L.twin_bn254p_verify_id_g1split(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
+                assert bool(got) == c["expect"], (s["name"], c["label"], "g1split")
                 n += 1
     assert n >= 40
     import copy
@@ -328,16 +331,17 @@ def test_paired_layout_verify_id_golden(L):
         P = CD.proof_decode(base64.b64decode(r["proof"]))
         ctx = _ctx(L, pk, svc=r["svc"].encode(), g_eg=g, apk=apk, h=h)
         mask = ctypes.c_uint64(hidden_mask(P.attributes))
-        assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, P), mask, 1, b"hello", 5) == 1
-        assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, P), mask, 1, b"hellO", 5) == 0
-        for fld in ("E1", "E2", "phi", "sig1", "sig2"):
+        for fn in (L.twin_bn254p_verify_id, L.twin_bn254p_verify_id_g1split):
+            assert fn(ctx, pack_verify_id(M, P), mask, 1, b"hello", 5) == 1
+            assert fn(ctx, pack_verify_id(M, P), mask, 1, b"hellO", 5) == 0
+            for fld in ("E1", "E2", "phi", "sig1", "sig2"):
+                Q = copy.copy(P)
+                setattr(Q, fld, G.g1_add(getattr(P, fld), pk.g))
+                assert fn(ctx, pack_verify_id(M, Q), mask, 1, b"hello", 5) == 0, fld
             Q = copy.copy(P)
-            setattr(Q, fld, G.g1_add(getattr(P, fld), pk.g))
-            assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, Q), mask, 1, b"hello", 5) == 0, fld
-        Q = copy.copy(P)
-        Q.rs = list(P.rs)
-        Q.rs[1] = (Q.rs[1] + 1) % M.r           # the response only the odd lane's job (V_E2) reads
-        assert L.twin_bn254p_verify_id(ctx, pack_verify_id(M, Q), mask, 1, b"hello", 5) == 0
+            Q.rs = list(P.rs)
+            Q.rs[1] = (Q.rs[1] + 1) % M.r           # the response only the odd lane's job (V_E2) reads
+            assert fn(ctx, pack_verify_id(M, Q), mask, 1, b"hello", 5) == 0
     s = d["scenarios"][0]
     pk = CD.pk_decode(base64.b64decode(s["pk"]))
     ctx = _ctx(L, pk)

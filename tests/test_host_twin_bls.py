@@ -108,10 +108,11 @@ def test_protocol_flows(L):
     assert PR.verify_id_noretr(pk, pr2, b"sess", b"service")
     assert L.twin_bls_verify_id(ctx, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
     # the same verdicts from the two-lanes-per-item layout (two threads here, every exchange a rendezvous)
-    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, pr), mask, 1, b"sess", 4) == 1
-    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, pr), mask, 1, b"sesS", 4) == 0
-    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, bad), mask, 1, b"sess", 4) == 0
-    assert L.twin_blsp_verify_id(ctx, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
+    for fn in (L.twin_blsp_verify_id, L.twin_blsp_verify_id_g1split):      # g1split: ELP_OPT_SPLIT_PHASES = 3, this curve's default (G1 jobs kernel + paired body)
+        assert fn(ctx, pack_verify_id(M, pr), mask, 1, b"sess", 4) == 1
+        assert fn(ctx, pack_verify_id(M, pr), mask, 1, b"sesS", 4) == 0
+        assert fn(ctx, pack_verify_id(M, bad), mask, 1, b"sess", 4) == 0
+        assert fn(ctx, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
     assert L.twin_blsp_ps_verify(ctx, pack_ps_verify(M, cred, vals), A) == 1
     assert L.twin_blsp_ps_verify(ctx, pack_ps_verify(M, want, vals), A) == 0
     P, Q = G.g1_mul(BLS_G1, 321), G.g2_mul(BLS_G2, 654)

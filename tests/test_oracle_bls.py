@@ -163,6 +163,7 @@ def test_off_subgroup_g1_inputs_are_rejected():
         assert L.elpo_verify_id(key, rb, mask, 1, b"sess", 4) == 0
         assert T.twin_bls_verify_id(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0
         assert T.twin_blsp_verify_id(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0          # the two-lanes-per-item layout
+        assert T.twin_blsp_verify_id_g1split(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0  # G1 jobs kernel + paired body (this curve's default)
     # a request whose commitment left the subgroup is not signed
     badrq = copy.copy(rq)
     badrq.A = G.g1_add(rq.A, t3)
@@ -213,6 +214,7 @@ def test_cofactor_sig1_forgery_is_rejected():
                 assert L.elpo_verify_id(key, rec, mask, 1, b"sess", 4) == want
                 assert T.twin_bls_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
                 assert T.twin_blsp_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
+                assert T.twin_blsp_verify_id_g1split(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
         # strict, but the caller vouches for subgroup membership (ELP_OPT_SUBGROUP_CHECK = 0): only the infinity test is left, as documented
         T.twin_bls_ctx_set_flags(tctx, 1 | 2)
         assert T.twin_blsp_verify_id(tctx, pack_verify_id(M, forged), ctypes.c_uint64(mask), 1, b"sess", 4) == 1
