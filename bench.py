@@ -115,7 +115,8 @@ def dry_run(args, rank, world):
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "u32", "data": "synthetic", "dry_run": True, "backend": "gloo" if world > 1 else "none",
                           "config": workload_config(args, world), "reduced_count": int(cnt.item()),
-                          "shard": {"first": first, "count": count}}))
+                          "shard": {"first": first, "count": count},
+                          "per_rank_memory_budget": shard.rank_memory_budget(args.curve, args.attrs, args.hidden, args.window, args.batch)}))
     if world > 1:
         dist.destroy_process_group()
     return 0 if int(cnt.item()) == world * args.batch and int(ranks.item()) == world else 4
@@ -363,12 +364,12 @@ def aggregated_section(ctx, wl, synth, dev, mask, H, B):
             ok = bool((fl[:nb].cpu().numpy() == exp_all[:nb]).all()) and int(cnt[0].item()) == 2 * int(exp_all[:nb].sum())
             res["batch_%d_%s" % (nb, "aggregated" if agg else "per_item")] = {"value": nb / (ms_b * 1e-3), "ms_per_batch": ms_b, "parity_ok": ok}
     # sustained: the 16 distinct batches of 65 536, twice over, alternating between two streams (aggregated) / back to back on one stream (per item)
-    sa, sb, sc, sd = (torch.cuda.Stream(device=dev) for _ in range(4))
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)      # the second one from the other priority pool: surely another hardware queue
     nbat = NT // B
-    # With TWO streams nothing overlaps (measured: 17.72 against 17.75 ms per batch): while batch i + 1's per-item kernel holds every SIMD's registers the tail of batch i
-    # cannot start, and the kernel of batch i + 2 sits behind that tail in the same stream.  From three streams on a freed SIMD can go to either.
-    for label, agg, streams in (("aggregated_four_streams", True, (sa, sb, sc, sd)), ("aggregated_three_streams", True, (sa, sb, sc)), ("aggregated_two_streams", True, (sa, sb)),
-                                ("aggregated_one_stream", True, (sa,)), ("per_item_one_stream", False, (sa,)), ("per_item_two_streams", False, (sa, sb))):
+    # Exactly two side streams.  What overlaps is the TAIL of one batch with the tail of the other (a per-item kernel holds every SIMD's registers, so a tail cannot run
+    # beside it: profiles/r04_agg_two_stream_timeline.txt), and only if the two streams sit on two hardware queues.  More streams do not help and run into the runtime's
+    # scratch reclaim between queues -- 80-295 ms per batch measured with three and four (profiles/r04_scratch_stall.md).
+    for label, agg, streams in (("aggregated_two_streams", True, (sa, sb)), ("aggregated_one_stream", True, (sa,)), ("per_item_one_stream", False, (sa,))):
         for s_ in streams:
             call(agg, s_.cuda_stream, 0, B)             # warm-up: this stream's workspaces
         torch.cuda.synchronize()
@@ -655,10 +656,10 @@ def host_api(pkg, wl, recs, B, A, H, first, expect, window, device):
     res = {"note": "C++ PSVerifier over the C-ABI (csrc/host): objects = std::vector<IdProof> -> el_passo_verify_id_batch; wire = std::vector<PSBuffer> "
                    "-> el_passo_verify_id_wire_batch; wire_packed = one contiguous buffer + offsets; host wall-clock per call, PCIe included, best / median of 5"}
     for tag, W, nctx in (("one_context", window, 1), ("two_contexts_one_gpu_w16", 16, 2)):
-        outv = (ctypes.c_double * 8)()
+        outv = (ctypes.c_double * 10)()
         acc = (ctypes.c_uint64 * 3)()
         flags = np.zeros(B, dtype=np.uint8)
-        rc = L.elph_bench_verify_id(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad,
+        rc = L.elph_bench_verify_id_pipelined(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad,
                                     recs, ctypes.c_size_t(B), ctypes.c_uint64(first), msgs, moff.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(W),
                                     ctypes.c_int(nctx), ctypes.c_int(device), ctypes.c_int(5), outv, acc, flags.ctypes.data_as(ctypes.c_void_p))
         if rc != 0:
@@ -668,7 +669,11 @@ def host_api(pkg, wl, recs, B, A, H, first, expect, window, device):
         res[tag] = {"window_bits": W, "contexts": nctx, "setup_s": outv[0], "build_objects_s": outv[1], "parity_ok": ok,
                     "objects": {"value": B / (outv[2] * 1e-3), "unit": "verifications/s", "best_ms": outv[2], "median_ms": outv[3]},
                     "wire": {"value": B / (outv[4] * 1e-3), "unit": "verifications/s", "best_ms": outv[4], "median_ms": outv[5], "bytes_per_message": len(msgs) / B},
-                    "wire_packed": {"value": B / (outv[6] * 1e-3), "unit": "verifications/s", "best_ms": outv[6], "median_ms": outv[7]}}
+                    "wire_packed": {"value": B / (outv[6] * 1e-3), "unit": "verifications/s", "best_ms": outv[6], "median_ms": outv[7]},
+                    "objects_pipelined": {"value": B / (outv[8] * 1e-3), "unit": "verifications/s", "ms_per_batch_sustained": outv[8], "ms_one_batch_alone": outv[9],
+                                          "note": "PSVerifier::el_passo_verify_id_submit / _collect, two batches in flight: the host packs batch i + 1 and its records cross "
+                                                  "PCIe while the GPU verifies batch i (elp_verify_id_batch_submit / _wait); with several contexts the calls fall back to "
+                                                  "the synchronous path"}}
     return res
 
 

@@ -39,6 +39,9 @@ enum {
 /* ---- context ------------------------------------------------------------------------------------------------ */
 /* replaces mcl::bls12::initPairing() (test/ps-tests.cc:142): selects the curve and the GPU. */
 int elp_init(int curve, int device, elp_ctx** out);
+/* GPUs visible to the process (hipGetDeviceCount; 0 without one): the ordinals elp_init accepts.  The host layer's PSVerifier(pk, devices, W) shards batches
+ * over one context per listed device. */
+int elp_device_count(void);
 void elp_destroy(elp_ctx* ctx);
 const char* elp_last_error(const elp_ctx* ctx);
 int elp_field_bytes(int curve);               /* F */
@@ -46,6 +49,9 @@ int elp_field_bytes(int curve);               /* F */
  * reference accepts sig1 = sig2 = infinity with a self-made NIZK (src/ps-verifier.cc:133-137 has no isZero test; golden case
  * "sig_both_zero"), which is a universal forgery since e(O,K) e(O,gg) = 1, although PSVerifier::verify rejects it
  * (src/ps-verifier.cc:16-18).  Set to 0 for bit-for-bit reference behaviour on that input.
+ * On a curve with a G1 cofactor (BLS12-381) "not the point at infinity" is asked of the ORDER-r COMPONENT: sig1 must also lie in G1 (unless
+ * ELP_OPT_SUBGROUP_CHECK = 0) -- a point whose order divides the cofactor pairs to 1 with everything, so (sig1, sig2) = (T, O) would satisfy the pairing
+ * equation for any K.  elp_ps_verify_batch applies the same rule whatever this option says (PSVerifier::verify always rejects sigma_1 = 1).
  * ELP_OPT_PAIRED_LAYOUT: which kernel layout verifies (results are identical).  0 = one lane per item; 1 = two lanes per item (the
  * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: the
  * two-lane kernel when the last round of 64 x SIMDs items would be at most half full (small batches, odd remainders) and always on
@@ -56,9 +62,12 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_SPLIT_PHASES (default 0; BN254 builds): 1 = the one-lane-per-item el_passo_verify_id runs as two kernels -- the NIZK half as independent jobs on two
  * job waves per workgroup, then the pairing check; 2 = the G2 job and the G1 jobs as concurrent kernels on two streams, then the pairing check.  Results are
  * identical; measured not faster than the fused kernel at full batches, faster at a light load.
+ * 3 (both curves; where the two-lanes-per-item kernel runs): the base-field jobs of a verification -- the three commitments V_phi, V_E1, V_E2 and, on
+ * BLS12-381, the four subgroup tests -- as a kernel of their own with one lane per job (k_vid_g1jobs), then the two-lane kernel over Fp2.  Results identical;
+ * measured on BLS12-381: 13.6 + 38.0 ms against 49.9 ms fused at 65 536 items: opt-in.
  * ELP_OPT_SUBGROUP_CHECK (default 1; BLS12-381 only, BN254 has G1 cofactor 1): the prover-supplied G1 points of a proof or request (phi, E1, E2;
- * the commitment A of el_passo_provide_id) must lie in the order-r subgroup, otherwise the item is rejected (one [z^2]P per point, ~9 % of a
- * verification).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
+ * the commitment A of el_passo_provide_id; sig1 under ELP_OPT_STRICT_SIGNATURE and in elp_ps_verify_batch) must lie in the order-r subgroup, otherwise the
+ * item is rejected (one [z^2]P per point, ~9 % of a verification; the sig1 test rides in a slot of the lane pair that was idle).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
  * pseudonyms or an undecryptable token.  The reference never meets the case (it runs on BN254); mcl's default does not check.  0 = no check.
  * ELP_OPT_COOP_PAIRING (default 1; BN254 builds): batches of at most 4096 items (value > 1: that many) and the closing step of aggregated verification run
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
@@ -72,8 +81,12 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_STREAM_OVERLAP (default 0): kernels of ONE call that do not depend on each other -- for small batches of el_passo_verify_id the pairing check beside the
  * NIZK half, for aggregated verification the Fp12 product beside the Pippenger sum -- run on a second stream owned by the context, joined by events before the
  * call's last kernel; the caller's stream semantics are unchanged.  Measured in a process of its own: 64 verifications 2.6 instead of 2.8 ms, 2048 of them
- * 5.0-5.5 instead of 5.7, aggregated 65 536 17.5 instead of 17.7-18.1 ms.  Off by default: inside a process that holds several other contexts and streams (bench.py) the
- * cross-stream waits were seen to stall for about a second per call on this ROCm release; enable it where the library owns the device. */
+ * 5.0-5.5 instead of 5.7, aggregated 65 536 17.5 instead of 17.7-18.1 ms.  Off by default (the default path gets the same overlap from one launch).
+ * The second stream only carries kernels with SMALL private frames: the second-long stalls seen in round 3 were the runtime reclaiming private-memory
+ * (scratch) blocks between hardware queues -- scratch is provisioned per queue, ~1 GB for a headline-sized launch of a kernel with a 14-16 KB frame -- and the
+ * rule since round 4 is that large-frame kernels of a call stay on the caller's stream (profiles/r04_scratch_stall.md).  The same rule for callers: launch
+ * verification batches of one process from ONE stream (two at most: aggregated batches pipelined over two streams overlap their serial tails); more
+ * processes or more GPUs scale, more streams run into the reclaim. */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
        ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
@@ -132,6 +145,15 @@ size_t elp_provide_id_record_size(int curve, int nattr, int nhidden);
  * flags[i] = 1 iff the reference would return true; *accepted = number of ones. */
 int elp_verify_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval,
                         const uint8_t* ad, const uint32_t* ad_off, size_t ad_len, uint8_t* flags, uint64_t* accepted);
+/* The same call in two halves for callers that PIPELINE batches (round 4): _submit queues the host-to-device copies (on the context's copy stream), the kernel and the
+ * copy of the verdicts back, and returns; _wait blocks until the batch of that slot is done and delivers its accepted count.  Two slots (0, 1), each with its own device
+ * buffers: while the kernel of slot 0 runs, the caller packs and submits slot 1, whose records travel over PCIe meanwhile -- a steady stream of batches then costs the kernel
+ * time alone (PSVerifier::el_passo_verify_id_submit / _collect; bench.py host_api.*.objects_pipelined).  records / ad / ad_off / flags must stay untouched until _wait returns and
+ * should be page-locked (elp_host_alloc), otherwise the copies are staged by the runtime and _submit blocks for their duration.  A slot must be waited for before it is
+ * submitted again; verdict semantics are those of elp_verify_id_batch. */
+int elp_verify_id_batch_submit(elp_ctx* ctx, int slot, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval, const uint8_t* ad,
+                               const uint32_t* ad_off, size_t ad_len, uint8_t* flags);
+int elp_verify_id_batch_wait(elp_ctx* ctx, int slot, uint64_t* accepted);
 /* The same verification straight from the reference's wire messages: msgs = concatenated IdProof::toBufferString() bytes
  * (src/ps-encoding.cc:451-467; base64 already removed), message i = msgs[msg_off[i] .. msg_off[i+1]).  T-L-V parsing, point
  * decompression (G?::deserialize, src/ps-encoding.cc:192,224) and Fr::setHashOf of the revealed attributes

@@ -61,6 +61,15 @@ const char* elp_version(void) { return "elpasso-hip 0.1 (gfx950)"; }
 
 int elp_field_bytes(int curve) { return curve == ELP_CURVE_BN254 ? 32 : curve == ELP_CURVE_BLS12_381 ? 48 : 0; }
 
+int elp_device_count(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return ndev;
+}
+
 int elp_init(int curve, int device, elp_ctx** out) {
   if (!out) return ELP_ERR_ARG;
   *out = nullptr;
@@ -111,6 +120,13 @@ void elp_destroy(elp_ctx* c) {
   for (auto& w : c->agg_parked) {
     if (w.ws) (void)hipFree(w.ws);
     if (w.ok) (void)hipFree(w.ok);
+  }
+  for (auto& a : c->aslot) {
+    for (void* q : {a.drec, a.dad, a.doff, a.dfl, a.dcnt})
+      if (q) (void)hipFree(q);
+    if (a.copied) (void)hipEventDestroy(a.copied);
+    if (a.done) (void)hipEventDestroy(a.done);
+    if (a.h_cnt) (void)hipHostFree(a.h_cnt);
   }
   if (c->coop_consts) (void)hipFree(c->coop_consts);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
@@ -290,6 +306,70 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   if (status == ELP_ERR_HIP && c->err.empty()) c->err = "HIP error in elp_verify_id_batch";
   if (status != ELP_OK) return status;
   if (accepted) *accepted = cntv;
+  return ELP_OK;
+}
+
+// ---- the pipelined form: submit / wait over two slots with persistent device buffers
+static int grow_dev(elp_ctx* c, void** p, size_t* cap, size_t need) {
+  if (*cap >= need && *p) return ELP_OK;
+  if (*p) HIPCHK(c, hipFree(*p));        // waits for work that may still use it (a slot is idle when it is resubmitted anyway)
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need + need / 8 + 256;
+  HIPCHK(c, hipMalloc(p, want));
+  *cap = want;
+  return ELP_OK;
+}
+int elp_verify_id_batch_submit(elp_ctx* c, int slot, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad, const uint32_t* ad_off,
+                               size_t ad_len, uint8_t* flags) {
+  int rc = check_fused(c, mask, need_rp(retr));
+  if (rc) return rc;
+  if (slot < 0 || slot > 1 || n == 0 || !records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  elp_ctx::AsyncSlot& s = c->aslot[slot];
+  if (s.busy) {
+    c->err = "elp_verify_id_batch_submit: the slot has a batch in flight (call elp_verify_id_batch_wait first)";
+    return ELP_ERR_STATE;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
+  if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
+  if (!s.copied) {
+    HIPCHK(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    HIPCHK(c, hipHostMalloc((void**)&s.h_cnt, 64, hipHostMallocDefault));
+    size_t dummy = 0;
+    if ((rc = grow_dev(c, &s.dcnt, &dummy, 8))) return rc;
+  }
+  const size_t ad_total = ad_off ? ad_off[n] : ad_len;
+  if ((rc = grow_dev(c, &s.drec, &s.rec_cap, n * rsz)) || (rc = grow_dev(c, &s.dfl, &s.fl_cap, n)) || (rc = grow_dev(c, &s.dad, &s.ad_cap, ad_total ? ad_total : 4)) ||
+      (ad_off && (rc = grow_dev(c, &s.doff, &s.off_cap, (n + 1) * 4))))
+    return rc;
+  // copies on the copy stream (they overlap the kernel of the other slot, which runs on the context's stream), then the kernel behind them
+  HIPCHK(c, hipMemcpyAsync(s.drec, records, n * rsz, hipMemcpyHostToDevice, c->pstream[0]));
+  if (ad_total) HIPCHK(c, hipMemcpyAsync(s.dad, ad, ad_total, hipMemcpyHostToDevice, c->pstream[0]));
+  if (ad_off) HIPCHK(c, hipMemcpyAsync(s.doff, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->pstream[0]));
+  HIPCHK(c, hipMemsetAsync(s.dcnt, 0, 8, c->pstream[0]));
+  HIPCHK(c, hipEventRecord(s.copied, c->pstream[0]));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, s.copied, 0));
+  rc = elp_verify_id_batch_dev(c, c->stream, n, s.drec, mask, retr, s.dad, ad_off ? s.doff : nullptr, ad_len, s.dfl, s.dcnt);
+  if (rc) return sync_fail(rc);
+  HIPCHK(c, hipMemcpyAsync(flags, s.dfl, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.h_cnt, s.dcnt, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(s.done, c->stream));
+  s.busy = true;
+  return ELP_OK;
+}
+int elp_verify_id_batch_wait(elp_ctx* c, int slot, uint64_t* accepted) {
+  if (!c || slot < 0 || slot > 1) return ELP_ERR_ARG;
+  elp_ctx::AsyncSlot& s = c->aslot[slot];
+  if (!s.busy) {
+    c->err = "elp_verify_id_batch_wait: nothing was submitted to the slot";
+    return ELP_ERR_STATE;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  s.busy = false;
+  HIPCHK(c, hipEventSynchronize(s.done));
+  if (accepted) *accepted = *s.h_cnt;
   return ELP_OK;
 }
 

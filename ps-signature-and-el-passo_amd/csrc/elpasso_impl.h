@@ -192,17 +192,24 @@ __device__ __forceinline__ void vid_nizk4_body(KeyCtx<C> key, const u32* recs, i
   constexpr int HOTW = Nizk4Lds<C>::HOTW;
   const int role = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   key.hot = role == 0 ? nullptr : hot_lds + (threadIdx.x - 64) * HOTW;
-  const size_t i = block * 64 + lane;
-  if (key.vtab) key.vtab += i * (size_t)vtab_words<C>();     // one slice per item: the G2 job uses its first part, each G1 job its own third of the rest
+  // A PARTIALLY FILLED WAVE RUNS ITS IDLE LANES ON A COPY OF THE LAST ITEM (round 4).  Private memory is interleaved by lane: one dword of all 64 lanes is one
+  // 256-byte row.  With a single active lane every spill / table store is a 4-byte write into a row nobody else touches -- a partial-line write that the memory
+  // side turns into read-modify-write -- and a lone el_passo_verify_id took 3.2-4.9 ms in this kernel, depending on which CU (which scratch addresses) it landed
+  // on, against 2.17 ms for the same wave with 64 items (profiles/r04_lone_call.md: per-wave times, same clocks).  Full rows cost nothing extra: the idle lanes
+  // share the wave's instruction stream anyway.  Copies use their own workspace slices and LDS rows and publish nothing.
+  const size_t slot = block * 64 + lane;
+  const bool real = slot < n;
+  const size_t i = real ? slot : n - 1;
+  if (key.vtab) key.vtab += slot * (size_t)vtab_words<C>();     // one slice per lane: the G2 job uses its first part, each G1 job its own third of the rest
   VidNizkState<C> st;
   st.ok = false;
-  if (i < n) {
+  {
     Aff<F2<C>> aK;
     vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i, k_done != 0, k_done == 1);
-    if (role == 1 && !k_done) vid_store_k<C>(kws, kstride, i, aK);
+    if (real && role == 1 && !k_done) vid_store_k<C>(kws, kstride, i, aK);
   }
   __syncthreads();
-  if (role == 0 && i < n) {
+  if (role == 0 && real) {
     const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
     const size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
     nizk_ok[i] = vid_nizk_finish<C>(sh[lane], st, retr != 0, a, al) ? 1 : 0;
@@ -676,12 +683,12 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
 // from the record's scalars alone (any 256-bit value is a valid scalar: nothing to validate here; k_vid_nizk validates the points and ignores the sums of an
 // invalid record).  Jacobian results: the NIZK jobs add them with complete additions.
 template <class C>
-__global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride,
-                                                   uint8_t* kvalid, size_t n) {
+__device__ __forceinline__ void vid_fixed_coop_body(const KeyCtx<C>& key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride,
+                                                    uint8_t* kvalid, size_t n, size_t block) {
   typedef F2<C> G;
   constexpr int J = ELP_PSK_LANES;
   const int sub = (int)(threadIdx.x & (J - 1)), which = (int)((threadIdx.x >> 3) & 1);
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / (2 * J);
+  const size_t i = (block * blockDim.x + threadIdx.x) / (2 * J);
   const bool live = i < n;
   PairedRecordSrc<C> src;
   src.init(recs + (live ? i : 0) * (size_t)rec_words, mask, key.A, retr != 0);
@@ -740,11 +747,19 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* rec
 // of k_vid_nizk4 reads it: one lane per item, beside k_vid_fixed_coop on the second stream.  A record whose k does not decode leaves its slice alone (the NIZK
 // kernel rejects the item before it would read it).
 template <class C>
-__global__ void ELP_LAUNCH_BOUNDS k_vid_ktab(KeyCtx<C> key, const u32* recs, int rec_words, int retr, size_t n) {
+__global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride,
+                                                   uint8_t* kvalid, size_t n) {
+  vid_fixed_coop_body<C>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
+}
+template <class C>
+__device__ __forceinline__ void vid_ktab_body(const KeyCtx<C>& key, const u32* recs, int rec_words, int retr, size_t n, size_t block) {
   typedef F2<C> G;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !key.vtab) return;
-  u32* const w = key.vtab + i * (size_t)vtab_words<C>();
+  // idle lanes of the last wave work on a copy of the last item and fill their OWN slices (full rows of private memory, and the table a copy lane of
+  // vid_nizk4_body reads): see the comment there
+  const size_t slot = block * blockDim.x + threadIdx.x;
+  if (n == 0 || !key.vtab) return;
+  const size_t i = slot < n ? slot : n - 1;
+  u32* const w = key.vtab + slot * (size_t)vtab_words<C>();
   Aff<G> kk;
   if (!g2_load<C>(kk, recs + i * (size_t)rec_words + (retr ? 5 : 3) * 2 * C::N)) return;
   if (aff_is_inf(kk)) {                     // k = O: every multiple is O (the multiplication then contributes nothing, as with a table built in place)
@@ -762,6 +777,20 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_ktab(KeyCtx<C> key, const u32* recs, int
     jac_to_aff_with_zinv<G>(a, jk[q], zi2[q - 1]);
     vtab_store<G>(w, q, a);
   }
+}
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_vid_ktab(KeyCtx<C> key, const u32* recs, int rec_words, int retr, size_t n) {
+  vid_ktab_body<C>(key, recs, rec_words, retr, n, blockIdx.x);
+}
+// The two of them as workgroup ranges of ONE launch (round 4: they are independent, and on a lone call each is a single workgroup on a chip of 256 CUs --
+// 0.33 ms and 0.21 ms one after the other, 0.33 ms side by side): workgroups [0, nb_fixed) sum, the rest build tables.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_vid_prep(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride, uint8_t* kvalid,
+                                             size_t n, unsigned nb_fixed) {
+  if (blockIdx.x < nb_fixed)
+    vid_fixed_coop_body<C>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
+  else
+    vid_ktab_body<C>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
 }
 // verdict of a small-batch el_passo_verify_id = its NIZK half (k_vid_nizk4) AND its pairing check (k_pair_coop / k_pair_rest), which ran side by side
 __global__ void ELP_LAUNCH_BOUNDS k_vid_combine(const uint8_t* nizk_ok, const uint8_t* pair_ok, uint8_t* flags, unsigned long long* accepted, size_t n) {
@@ -848,6 +877,13 @@ void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, c
                      (Jac<F2<B>>*)pre, kws, kstride, kvalid, n);
 }
 template <class B>
+void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
+                     uint8_t* kvalid) {
+  const unsigned nbf = grid_for(n * 2 * ELP_PSK_LANES);
+  hipLaunchKernelGGL((k_vid_prep<B>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws, kstride,
+                     kvalid, n, nbf);
+}
+template <class B>
 void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
                       const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
                       const void* pre) {
@@ -908,6 +944,9 @@ template <class B>
 void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
                            uint8_t* kvalid);
 template <class B>
+void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
+                     uint8_t* kvalid);
+template <class B>
 void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
 template <class B>
 void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int retr);
@@ -927,6 +966,7 @@ struct CoopBuild<BN254> {
 };
 #ifndef ELP_COOP_TU
 extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_consts);
+extern template void launch_vid_prep<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
 extern template void launch_pair_rest<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
 extern template void launch_pair_coop<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted, hipStream_t rest_stream);
 extern template void launch_ps_k<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
@@ -1622,6 +1662,16 @@ struct elp_ctx {
   };
   hipStream_t agg_stream = nullptr;
   std::vector<AggWs> agg_parked;
+  // slots of elp_verify_id_batch_submit / _wait: device buffers that live as long as the context (grown on demand), an event for "this slot's batch is done", the
+  // page-locked landing pad of its accepted count
+  struct AsyncSlot {
+    void *drec = nullptr, *dad = nullptr, *doff = nullptr, *dfl = nullptr, *dcnt = nullptr;
+    size_t rec_cap = 0, ad_cap = 0, off_cap = 0, fl_cap = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    uint64_t* h_cnt = nullptr;
+    bool busy = false;
+  };
+  AsyncSlot aslot[2];
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
     hipStream_t stream;
@@ -2514,9 +2564,13 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
           HIPCHK(c, hipEventRecord(c->jev[2], st));                        // what the caller queued before this call (the records) precedes the second stream's work
           HIPCHK(c, hipStreamWaitEvent(js, c->jev[2], 0));
         }
-        launch_vid_ktab<C>(js, key, n, d_records, words, retr);
-        if (c->overlap) HIPCHK(c, hipEventRecord(c->jev[3], js));
-        launch_vid_fixed_coop<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);
+        if (!c->overlap) {
+          launch_vid_prep<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);      // both as workgroup ranges of one launch
+        } else {
+          launch_vid_ktab<C>(js, key, n, d_records, words, retr);
+          HIPCHK(c, hipEventRecord(c->jev[3], js));
+          launch_vid_fixed_coop<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);
+        }
         if (c->overlap) {
           HIPCHK(c, hipEventRecord(c->jev[0], st));
           HIPCHK(c, hipStreamWaitEvent(js, c->jev[0], 0));

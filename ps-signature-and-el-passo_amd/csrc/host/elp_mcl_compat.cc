@@ -116,10 +116,12 @@ void Fr::setByCSPRNG() {
   st(b, v);
 }
 void Fr::setHashOf(const std::string& msg) {
-  cybozu::Sha256 h;
-  std::string d = h.digest(msg);
+  // one-shot SHA-256 without the streaming object (no per-byte feeding, no heap string for the digest): this runs once per revealed attribute of every proof
+  // that PSVerifier::el_passo_verify_id_batch packs (src/ps-verifier.cc:224) -- 262 144 times for the headline batch
+  uint8_t d[32];
+  cybozu::sha256OneShot((const uint8_t*)msg.data(), msg.size(), d);
   uint64_t v[4];
-  memcpy(v, d.data(), 32);
+  memcpy(v, d, 32);
   maskScalar(v);
   st(b, v);
 }
@@ -413,6 +415,89 @@ void Sha256::block(const uint8_t* p) {
   }
   h_[0] += a; h_[1] += b; h_[2] += c; h_[3] += d; h_[4] += e; h_[5] += f; h_[6] += g; h_[7] += h;
 }
+// ---- one-shot SHA-256 of a byte string: whole blocks straight from the message, the padded tail from a stack buffer; the compression function uses the x86 SHA
+// extensions where the CPU has them (checked once at run time), else the portable rounds above.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("sha,sse4.1,ssse3"))) static void compressShaNi(uint32_t state[8], const uint8_t* data, size_t nblocks) {
+  const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+  __m128i TMP = _mm_loadu_si128((const __m128i*)&state[0]);
+  __m128i STATE1 = _mm_loadu_si128((const __m128i*)&state[4]);
+  TMP = _mm_shuffle_epi32(TMP, 0xB1);             // CDAB
+  STATE1 = _mm_shuffle_epi32(STATE1, 0x1B);       // EFGH
+  __m128i STATE0 = _mm_alignr_epi8(TMP, STATE1, 8);   // ABEF
+  STATE1 = _mm_blend_epi16(STATE1, TMP, 0xF0);        // CDGH
+  while (nblocks--) {
+    const __m128i ABEF_SAVE = STATE0, CDGH_SAVE = STATE1;
+    __m128i M[4];
+    for (int i = 0; i < 4; i++) M[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(data + 16 * i)), MASK);
+    for (int r = 0; r < 16; r++) {                // 16 groups of four rounds; the message schedule advances one vector per group
+      __m128i MSG = _mm_add_epi32(M[r & 3], _mm_loadu_si128((const __m128i*)&K256[4 * r]));
+      STATE1 = _mm_sha256rnds2_epu32(STATE1, STATE0, MSG);
+      MSG = _mm_shuffle_epi32(MSG, 0x0E);
+      STATE0 = _mm_sha256rnds2_epu32(STATE0, STATE1, MSG);
+      if (r < 12) {                               // W[4(r+4) .. 4(r+4)+3] from the four vectors in flight
+        __m128i X = _mm_sha256msg1_epu32(M[r & 3], M[(r + 1) & 3]);
+        X = _mm_add_epi32(X, _mm_alignr_epi8(M[(r + 3) & 3], M[(r + 2) & 3], 4));
+        M[r & 3] = _mm_sha256msg2_epu32(X, M[(r + 3) & 3]);
+      }
+    }
+    STATE0 = _mm_add_epi32(STATE0, ABEF_SAVE);
+    STATE1 = _mm_add_epi32(STATE1, CDGH_SAVE);
+    data += 64;
+  }
+  TMP = _mm_shuffle_epi32(STATE0, 0x1B);          // FEBA
+  STATE1 = _mm_shuffle_epi32(STATE1, 0xB1);       // DCHG
+  STATE0 = _mm_blend_epi16(TMP, STATE1, 0xF0);    // DCBA
+  STATE1 = _mm_alignr_epi8(STATE1, TMP, 8);       // HGFE
+  _mm_storeu_si128((__m128i*)&state[0], STATE0);
+  _mm_storeu_si128((__m128i*)&state[4], STATE1);
+}
+static bool haveShaNi() {
+  static const bool v = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+  return v;
+}
+#else
+static bool haveShaNi() { return false; }
+static void compressShaNi(uint32_t*, const uint8_t*, size_t) {}
+#endif
+static void compressPortable(uint32_t st[8], const uint8_t* p, size_t nblocks) {
+  for (; nblocks--; p += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++)
+      w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = h + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+      uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+  }
+}
+void sha256OneShot(const uint8_t* msg, size_t n, uint8_t out[32], int force_portable) {
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  const bool ni = !force_portable && haveShaNi();
+  const size_t whole = n / 64;
+  if (whole) (ni ? compressShaNi : compressPortable)(st, msg, whole);
+  uint8_t tail[128];
+  const size_t rem = n - 64 * whole;
+  memset(tail, 0, sizeof tail);
+  if (rem) memcpy(tail, msg + 64 * whole, rem);
+  tail[rem] = 0x80;
+  const size_t tb = rem < 56 ? 1 : 2;
+  const uint64_t bits = (uint64_t)n * 8;
+  for (int i = 0; i < 8; i++) tail[64 * tb - 1 - i] = (uint8_t)(bits >> (8 * i));
+  (ni ? compressShaNi : compressPortable)(st, tail, tb);
+  for (int i = 0; i < 8; i++) {
+    out[4 * i] = (uint8_t)(st[i] >> 24);
+    out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(st[i] >> 8);
+    out[4 * i + 3] = (uint8_t)st[i];
+  }
+}
+bool sha256HasHardware() { return haveShaNi(); }
 void Sha256::feed(const uint8_t* p, size_t n) {
   for (size_t i = 0; i < n; i++) {
     buf_[len_++ & 63] = p[i];

@@ -115,6 +115,9 @@ std::string toHex(const uint8_t* p, size_t n);
 }  // namespace mcl
 
 namespace cybozu {
+// one-shot SHA-256 (x86 SHA extensions when the CPU has them; force_portable = 1 selects the portable rounds, for the test that compares the two)
+void sha256OneShot(const uint8_t* msg, size_t n, uint8_t out[32], int force_portable = 0);
+bool sha256HasHardware();
 // cybozu::Sha256 as the reference uses it: update(str)*, digest(str) -> 32 raw bytes (src/ps-verifier.cc:111-121)
 class Sha256 {
  public:

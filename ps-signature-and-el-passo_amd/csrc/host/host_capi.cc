@@ -168,14 +168,14 @@ int elph_unblind_randomize_b64(const char* pk_b64, const char* attrs_spec, const
 // of the reference's API starts: from std::vector<IdProof>.  out[0] = verifier set-up s (tables), out[1] = building the objects s,
 // out[2] / out[3] = object path best / median ms, out[4] / out[5] = wire-message path, out[6] / out[7] = packed wire path.
 // accepted[0..2] = accepted counts of the three paths; flags = verdicts of the object path.  `ncontexts` contexts on `device` (sharding test) .
-int elph_bench_verify_id(int A, int H, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi,
+static int benchVerifyId(int A, int H, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi,
                          const uint8_t* apk, const uint8_t* g_eg, const uint8_t* h, const char* service, const char* ad, const uint8_t* recs,
                          size_t n, uint64_t first_item, const uint8_t* msgs, const uint32_t* moff, int window_bits, int ncontexts, int device,
-                         int reps, double* out, uint64_t* accepted, uint8_t* flags) {
+                         int reps, double* out, uint64_t* accepted, uint8_t* flags, bool pipelined) {
   return guarded([&] {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    initPairing(BN254, device);
+    initPairing(BN254, device >= 0 ? device : 0);
     const size_t S1 = G1::size(), S2 = G2::size();
     PSPubKey pk;
     memcpy(pk.g.b, g, S1);
@@ -192,7 +192,17 @@ int elph_bench_verify_id(int A, int H, const uint8_t* g, const uint8_t* gg, cons
     memcpy(Gg.b, g_eg, S1);
     memcpy(Gh.b, h, S1);
     auto t0 = clk::now();
-    PSVerifier rp(pk, std::vector<int>((size_t)(ncontexts > 0 ? ncontexts : 1), device), window_bits);
+    // device == -2: one context per VISIBLE GPU (elp_device_count), `ncontexts` of them per GPU -- the multi-GPU dispatch as a node would run it
+    std::vector<int> devs;
+    if (device == -2) {
+      const int nd = elp_device_count();
+      if (nd <= 0) throw std::runtime_error("no GPU visible");
+      for (int d = 0; d < nd; d++)
+        for (int q = 0; q < (ncontexts > 0 ? ncontexts : 1); q++) devs.push_back(d);
+    } else {
+      devs.assign((size_t)(ncontexts > 0 ? ncontexts : 1), device);
+    }
+    PSVerifier rp(pk, devs, window_bits);
     // the first call installs the RP parameters (H1(service), authority_pk, g, h and their tables): part of the set-up
     (void)rp.el_passo_verify_id_batch({}, {}, service, Gapk, Gg, Gh);
     out[0] = secs(t0, clk::now());
@@ -241,6 +251,27 @@ int elph_bench_verify_id(int A, int H, const uint8_t* g, const uint8_t* gg, cons
       flags[j] = verdicts[j] ? 1 : 0;
       accepted[0] += flags[j];
     }
+    if (pipelined) {
+      // out[8] = ms per batch of a steady stream of such batches through el_passo_verify_id_submit / _collect (two in flight), out[9] = the same for ONE batch
+      // submitted and collected at once (the pipelined entry points without pipelining)
+      std::vector<bool> v;
+      auto stream_of = [&](int nb) {
+        auto a = clk::now();
+        size_t prev = rp.el_passo_verify_id_submit(proofs, ads, service, Gapk, Gg, Gh);
+        for (int it = 1; it < nb; it++) {
+          size_t t = rp.el_passo_verify_id_submit(proofs, ads, service, Gapk, Gg, Gh);
+          v = rp.el_passo_verify_id_collect(prev);
+          prev = t;
+        }
+        v = rp.el_passo_verify_id_collect(prev);
+        return secs(a, clk::now()) * 1e3 / nb;
+      };
+      (void)stream_of(2);                                   // warm-up: both slots' staging and device buffers
+      out[8] = stream_of(reps > 1 ? 2 * reps : 4);
+      out[9] = stream_of(1);
+      for (size_t j = 0; j < n; j++)
+        if (v[j] != verdicts[j]) throw std::runtime_error("pipelined path and batch path disagree on item " + std::to_string(j));
+    }
     accepted[1] = accepted[2] = 0;
     out[4] = out[5] = out[6] = out[7] = 0;
     if (msgs && moff) {
@@ -259,8 +290,25 @@ int elph_bench_verify_id(int A, int H, const uint8_t* g, const uint8_t* gg, cons
     return 0;
   });
 }
+int elph_bench_verify_id(int A, int H, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi,
+                         const uint8_t* apk, const uint8_t* g_eg, const uint8_t* h, const char* service, const char* ad, const uint8_t* recs,
+                         size_t n, uint64_t first_item, const uint8_t* msgs, const uint32_t* moff, int window_bits, int ncontexts, int device,
+                         int reps, double* out, uint64_t* accepted, uint8_t* flags) {
+  return benchVerifyId(A, H, g, gg, XX, Yi, YYi, apk, g_eg, h, service, ad, recs, n, first_item, msgs, moff, window_bits, ncontexts, device, reps, out, accepted, flags, false);
+}
+// the same + the pipelined object path: `out` has 10 entries (out[8], out[9]: see benchVerifyId)
+int elph_bench_verify_id_pipelined(int A, int H, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi,
+                                   const uint8_t* apk, const uint8_t* g_eg, const uint8_t* h, const char* service, const char* ad, const uint8_t* recs,
+                                   size_t n, uint64_t first_item, const uint8_t* msgs, const uint32_t* moff, int window_bits, int ncontexts, int device,
+                                   int reps, double* out, uint64_t* accepted, uint8_t* flags) {
+  return benchVerifyId(A, H, g, gg, XX, Yi, YYi, apk, g_eg, h, service, ad, recs, n, first_item, msgs, moff, window_bits, ncontexts, device, reps, out, accepted, flags, true);
+}
 
 // process defaults of the contexts the protocol classes create (elpSetDefaults)
 void elph_set_defaults(int device, int window_bits) { elpSetDefaults(device, window_bits); }
+// the host layer's one-shot SHA-256 (Fr::setHashOf of every revealed attribute goes through it): force_portable = 1 selects the portable rounds, 0 the x86 SHA
+// extensions where the CPU has them -- tests compare both with hashlib
+void elph_sha256(const uint8_t* msg, size_t n, uint8_t* out32, int force_portable) { cybozu::sha256OneShot(msg, n, out32, force_portable); }
+int elph_sha256_has_hardware() { return cybozu::sha256HasHardware() ? 1 : 0; }
 
 }  // extern "C"

@@ -4,8 +4,11 @@
 // pattern so that one launch covers every proof with the same pattern.
 #include "ps-verifier.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
 
 namespace {
@@ -70,6 +73,7 @@ std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, c
   for (auto& [mask, idx] : groups) {
     // fixed-stride records of the group, packed by several host threads (the record of item j starts at j * rsz; the revealed attributes
     // are hashed here, src/ps-verifier.cc:224); the per-item associated data goes into one blob with offsets
+    const auto t_group = std::chrono::steady_clock::now();
     const size_t n = idx.size();
     const size_t H = (size_t)__builtin_popcountll(mask);
     const size_t rsz = elp_verify_id_record_size(curveId(), (int)A, (int)H, retr ? 1 : 0);
@@ -106,6 +110,7 @@ std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, c
         if (!ad.empty()) memcpy(adbuf + adoff[j], ad.data(), ad.size());
       }
     });
+    const auto t_packed = std::chrono::steady_clock::now();
     // contiguous shards, one context (host thread + HIP stream, possibly another GPU) each; per-shard offsets are rebased to the shard
     m_set->forEachShard(n, [&](size_t r, size_t first, size_t count) {
       if (count == 0) return;
@@ -117,6 +122,11 @@ std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, c
                                         flags + first, &acc),
                "elp_verify_id_batch");
     });
+    if (getenv("ELP_HOST_TIMING")) {
+      const auto t_done = std::chrono::steady_clock::now();
+      fprintf(stderr, "PSVerifier: %zu proofs  pack+hash %.2f ms  verify (copies included) %.2f ms\n", n,
+              std::chrono::duration<double, std::milli>(t_packed - t_group).count(), std::chrono::duration<double, std::milli>(t_done - t_packed).count());
+    }
     for (size_t j = 0; j < n; j++) out[idx[j]] = flags[j] != 0;
   }
   return out;
@@ -130,6 +140,98 @@ std::vector<bool> PSVerifier::el_passo_verify_id_batch(const std::vector<IdProof
   useRpAll(service_name, &authority_pk, &g, &h);
   return verifyIdImpl(proofs, ads, true);
 }
+// ---- pipelined form (include/elpasso.h elp_verify_id_batch_submit / _wait)
+namespace {
+// one record (csrc/elp/pipeline.h verify_id record) from an IdProof; the revealed attributes are hashed here (src/ps-verifier.cc:224)
+inline void packRecord(uint8_t* w, const IdProof& p, bool retr, size_t S1, size_t S2) {
+  auto put = [&](const uint8_t* src, size_t len) {
+    memcpy(w, src, len);
+    w += len;
+  };
+  put(p.sig1.b, S1);
+  put(p.sig2.b, S1);
+  put(p.phi.b, S1);
+  if (retr) {
+    put(p.E1->b, S1);
+    put(p.E2->b, S1);
+  }
+  put(p.k.b, S2);
+  put(p.c.b, 32);
+  for (const Fr& r : p.rs) put(r.b, 32);
+  for (const std::string& a : p.attributes)
+    if (!a.empty()) {
+      Fr m;
+      m.setHashOf(a);
+      put(m.b, 32);
+    }
+}
+}  // namespace
+size_t PSVerifier::el_passo_verify_id_submit(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, const std::string& service_name,
+                                             const G1& authority_pk, const G1& g, const G1& h) const {
+  if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");
+  std::lock_guard<std::mutex> lock(m_stage->mu);
+  Stage& st = *m_stage;
+  int si = !st.slot[0].busy ? 0 : (!st.slot[1].busy ? 1 : -1);
+  if (si < 0) throw std::runtime_error("el_passo_verify_id_submit: two batches are in flight, collect one first");
+  Stage::Slot& sl = st.slot[si];
+  const std::string sig = service_name + "|" + authority_pk.serializeToHexStr() + g.serializeToHexStr() + h.serializeToHexStr();
+  const bool others = st.slot[1 - si].busy;
+  if (others && sig != st.rp_sig) throw std::runtime_error("el_passo_verify_id_submit: relying-party parameters differ from the batch in flight");
+  st.rp_sig = sig;
+  useRpAll(service_name, &authority_pk, &g, &h);        // a no-op when the parameters are the installed ones (ElpKey::useRp compares by value)
+  sl.ticket = st.next_ticket++;
+  sl.busy = true;
+  sl.sync_done = false;
+  sl.n = proofs.size();
+  // overlapped path: one context, every proof well-formed with one hidden pattern
+  const size_t A = m_key->attrs(), n = proofs.size();
+  bool uniform = m_set->size() == 1 && n > 0;
+  uint64_t mask = n ? elpHiddenMask(proofs[0].attributes) : 0;
+  const size_t H = (size_t)__builtin_popcountll(mask);
+  for (size_t i = 0; uniform && i < n; i++) {
+    const IdProof& p = proofs[i];
+    uniform = p.E1.has_value() && p.E2.has_value() && p.attributes.size() == A && p.rs.size() == H + 2 && H >= 2 && elpHiddenMask(p.attributes) == mask;
+  }
+  if (!uniform) {
+    sl.ready = verifyIdImpl(proofs, ads, true);
+    sl.sync_done = true;
+    return sl.ticket;
+  }
+  const size_t S1 = G1::size(), S2 = G2::size();
+  const size_t rsz = elp_verify_id_record_size(curveId(), (int)A, (int)H, 1);
+  elp_ctx* ctx = m_key->ctx();
+  uint8_t* const recs = sl.recs.get(ctx, n * rsz);
+  uint32_t* const adoff = (uint32_t*)sl.offs.get(ctx, (n + 1) * 4);
+  adoff[0] = 0;
+  for (size_t j = 0; j < n; j++) adoff[j + 1] = adoff[j] + (uint32_t)ads[j].size();
+  uint8_t* const adbuf = sl.ads.get(ctx, adoff[n] ? adoff[n] : 1);
+  uint8_t* const flags = sl.flags.get(ctx, n);
+  elpParallelFor(n, 512, [&](size_t lo, size_t hi) {
+    for (size_t j = lo; j < hi; j++) {
+      packRecord(recs + j * rsz, proofs[j], true, S1, S2);
+      if (!ads[j].empty()) memcpy(adbuf + adoff[j], ads[j].data(), ads[j].size());
+    }
+  });
+  elpCheck(ctx, elp_verify_id_batch_submit(ctx, si, n, recs, mask, 1, adbuf, adoff, 0, flags), "elp_verify_id_batch_submit");
+  return sl.ticket;
+}
+std::vector<bool> PSVerifier::el_passo_verify_id_collect(size_t ticket) const {
+  std::lock_guard<std::mutex> lock(m_stage->mu);
+  Stage& st = *m_stage;
+  int si = st.slot[0].busy && st.slot[0].ticket == ticket ? 0 : (st.slot[1].busy && st.slot[1].ticket == ticket ? 1 : -1);
+  if (si < 0) throw std::runtime_error("el_passo_verify_id_collect: unknown ticket");
+  Stage::Slot& sl = st.slot[si];
+  sl.busy = false;
+  if (sl.sync_done) return std::move(sl.ready);
+  elp_ctx* ctx = m_key->ctx();
+  uint64_t acc = 0;
+  elpCheck(ctx, elp_verify_id_batch_wait(ctx, si, &acc), "elp_verify_id_batch_wait");
+  const uint8_t* flags = sl.flags.get(ctx, sl.n);        // the same block: get() only grows
+  std::vector<bool> out(sl.n);
+  for (size_t j = 0; j < sl.n; j++) out[j] = flags[j] != 0;
+  return out;
+}
+
 std::vector<bool> PSVerifier::el_passo_verify_id_without_id_retrieval_batch(const std::vector<IdProof>& proofs,
                                                                             const std::vector<std::string>& ads,
                                                                             const std::string& service_name) const {

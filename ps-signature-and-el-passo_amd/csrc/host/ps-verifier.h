@@ -46,6 +46,15 @@ class PSVerifier {
                                           const G1* h = nullptr) const;
   std::vector<bool> verify_batch(const std::vector<PSCredential>& sigs, const std::vector<std::vector<std::string>>& all_attributes) const;
 
+  // ---- pipelined form of el_passo_verify_id_batch (round 4): submit() packs the batch into page-locked staging, queues copies + kernel and returns a ticket;
+  // collect(ticket) waits for it and returns the verdicts.  Up to TWO batches in flight: while the GPU verifies one, the host packs the next and its records
+  // travel over PCIe -- a steady stream of batches costs the kernel time alone (elp_verify_id_batch_submit / _wait).  Conditions for the overlapped path: one
+  // context, every proof of the batch well-formed with the same hidden pattern; anything else is verified synchronously inside submit() and merely handed
+  // out by collect().  The relying-party parameters must be the same for all batches in flight (a change throws).  Tickets are collected in submission order.
+  size_t el_passo_verify_id_submit(const std::vector<IdProof>& proofs, const std::vector<std::string>& associated_data, const std::string& service_name,
+                                   const G1& authority_pk, const G1& g, const G1& h) const;
+  std::vector<bool> el_passo_verify_id_collect(size_t ticket) const;
+
  private:
   std::vector<bool> verifyIdImpl(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retrieval) const;
   void useRpAll(const std::string& service, const G1* authority_pk, const G1* g, const G1* h) const;
@@ -56,6 +65,16 @@ class PSVerifier {
   struct Stage {
     std::mutex mu;
     ElpPinned recs, ads, flags;
+    // the two slots of the pipelined form
+    struct Slot {
+      ElpPinned recs, ads, offs, flags;
+      bool busy = false;
+      size_t ticket = 0, n = 0;
+      std::vector<bool> ready;         // verdicts of a batch that took the synchronous path
+      bool sync_done = false;
+    } slot[2];
+    size_t next_ticket = 1;
+    std::string rp_sig;                // relying-party parameters of the batches in flight
   };
   std::shared_ptr<Stage> m_stage;
 };

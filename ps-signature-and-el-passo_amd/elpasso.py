@@ -23,6 +23,9 @@ _c = ctypes
 _u8p = _c.c_void_p
 _SIGS = {
     "elp_init": (_c.c_int, [_c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "elp_device_count": (_c.c_int, []),
+    "elp_verify_id_batch_submit": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "elp_verify_id_batch_wait": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
     "elp_destroy": (None, [_c.c_void_p]),
     "elp_last_error": (_c.c_char_p, [_c.c_void_p]),
     "elp_field_bytes": (_c.c_int, [_c.c_int]),

@@ -48,3 +48,25 @@ def test_host_layer_builds():
     lib = ctypes.CDLL(b.build_host())
     for n in ("elph_init", "elph_verify_id_b64", "elph_prove_id_b64", "elph_request_id_b64", "elph_ps_verify_b64", "elph_user_name_b64"):
         assert hasattr(lib, n)
+
+
+def test_host_layer_sha256_one_shot_both_code_paths():
+    """csrc/host: Fr::setHashOf goes through a one-shot SHA-256 that uses the x86 SHA extensions where the CPU has them; both code paths against hashlib, every
+    length across the one- / two-block padding boundary and a few multi-block ones."""
+    import ctypes
+    import hashlib
+    import importlib
+    import os
+    b = importlib.import_module("ps-signature-and-el-passo_amd.build")
+    if not os.path.exists(b.HOST_LIB):
+        import pytest
+        pytest.skip("host library not built yet")
+    L = ctypes.CDLL(b.HOST_LIB)
+    L.elph_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int]
+    out = ctypes.create_string_buffer(32)
+    for n in list(range(0, 200)) + [255, 256, 1000, 4097]:
+        msg = bytes((7 * i + n) & 0xFF for i in range(n))
+        for force in (1, 0):
+            L.elph_sha256(msg, n, out, force)
+            assert out.raw == hashlib.sha256(msg).digest(), (n, force)
+    assert L.elph_sha256_has_hardware() in (0, 1)

@@ -104,3 +104,17 @@ def test_bench_without_gpu_fails_loudly_after_spawning():
     r, out = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0 and out is None
     assert "starting 2 ranks" in r.stderr
+
+
+def test_dry_run_prints_the_per_rank_memory_budget():
+    """`bench.py --gpus 8 --config 5 --dry-run` (what the driver can run before an 8-GPU node exists): every rank's budget -- 28.5 GB of W = 20 tables for the
+    16-attribute key + launch workspace + its 131 072-proof shard -- is computed from the table geometry and fits the 288 GB of one MI355X ten times over."""
+    import importlib
+    shard = importlib.import_module("ps-signature-and-el-passo_amd.shard")
+    b5 = shard.rank_memory_budget("bn254", 16, 4, 20, 131072)
+    assert b5["tables_bytes"] == 13 * (1 << 19) * (22 * 72 + 18 * 144) and 28.4e9 < b5["tables_bytes"] < 28.5e9 and b5["fits"] and b5["fraction_of_hbm"] < 0.11
+    b4 = shard.rank_memory_budget("bn254", 8, 4, 20, 65536)
+    assert abs(b4["tables_bytes"] / 2**30 - 15.54) < 0.01            # the 15.5 GiB bench.py reports from elp_key_table_bytes
+    assert b4["records_bytes"] == 65536 * 800
+    bls = shard.rank_memory_budget("bls12_381", 8, 4, 20, 65536)
+    assert abs(bls["tables_bytes"] / 2**30 - 24.17) < 0.01           # tools/probes/bls_probe.py: table_GiB=24.17

@@ -93,18 +93,45 @@ def test_cpp_verifier_shards_over_several_contexts(gpu_ctx):
     L.elph_last_error.restype = ctypes.c_char_p
     A, H = 8, 4
     wl = synth.Workload(gpu_ctx, A, seed=11, window_bits=8)
-    for n, nctx in ((301, 3), (64, 1), (5, 4)):
+    for n, nctx in ((301, 3), (64, 1), (5, 4), (1000, 1)):
         recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=2)
         msgs, moff = wl.wire_messages(recs, n, H, with_retrieval=True)
         moff = np.ascontiguousarray(moff, dtype=np.uint32)
-        outv = (ctypes.c_double * 8)()
+        outv = (ctypes.c_double * 10)()
         acc = (ctypes.c_uint64 * 3)()
         flags = np.zeros(n, dtype=np.uint8)
-        rc = L.elph_bench_verify_id(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad,
+        # _pipelined: the same three paths + el_passo_verify_id_submit / _collect with two batches in flight (one context: the overlapped path over
+        # elp_verify_id_batch_submit / _wait; several contexts: its synchronous fallback), verdicts compared with the batch call's inside
+        rc = L.elph_bench_verify_id_pipelined(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad,
                                     recs, ctypes.c_size_t(n), ctypes.c_uint64(0), msgs, moff.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(8),
                                     ctypes.c_int(nctx), ctypes.c_int(0), ctypes.c_int(1), outv, acc, flags.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0, L.elph_last_error()
         assert (flags == expect).all() and int(acc[0]) == int(acc[1]) == int(acc[2]) == int(expect.sum())
+
+
+def test_cpp_verifier_over_all_visible_devices(elp):
+    """Multi-GPU readiness: PSVerifier(pk, devices, W) built from the devices the process sees (elp_device_count), one context each, a batch sharded
+    over them by the C++ dispatcher -- real hipSetDevice switching.  Skips on a one-GPU box (where test_cpp_verifier_shards_over_several_contexts covers the
+    dispatcher with several contexts on device 0); the first run on a node exercises it."""
+    lib = elp.load_library()
+    nd = lib.elp_device_count()
+    if nd < 2:
+        pytest.skip("one GPU visible (%d): the several-contexts-on-one-device test covers the dispatcher here" % nd)
+    ctx = elp.Context(elp.CURVE_BN254, 0)
+    L = ctypes.CDLL(importlib.import_module("ps-signature-and-el-passo_amd.build").HOST_LIB)
+    L.elph_last_error.restype = ctypes.c_char_p
+    A, H, n = 8, 4, 4096 * nd
+    wl = synth.Workload(ctx, A, seed=777, window_bits=8)
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True)
+    msgs, moff = wl.wire_messages(recs, n, H, with_retrieval=True)
+    moff = np.ascontiguousarray(moff, dtype=np.uint32)
+    outv, acc, flags = (ctypes.c_double * 8)(), (ctypes.c_uint64 * 3)(), np.zeros(n, dtype=np.uint8)
+    rc = L.elph_bench_verify_id(ctypes.c_int(A), ctypes.c_int(H), wl.g, wl.gg, wl.XX, wl.Yi, wl.YYi, wl.apk, wl.g, wl.h, wl.service, wl.ad, recs,
+                                ctypes.c_size_t(n), ctypes.c_uint64(0), msgs, moff.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(8), ctypes.c_int(1),
+                                ctypes.c_int(-2), ctypes.c_int(1), outv, acc, flags.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, L.elph_last_error()
+    assert (flags == expect).all() and int(acc[0]) == int(acc[1]) == int(acc[2]) == int(expect.sum())
+    ctx.close()
 
 
 def test_headline_batch_full_size_w20_with_4096_oracle_samples(gpu_ctx):
