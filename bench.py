@@ -478,7 +478,7 @@ def valu_bound(ctx, ops_key, window, B, kern_ms, macs_per_mul):
                 vb.update({"fp_mul_equivalents_per_verification": per_item, "multiply_adds_per_verification": ops[key]["multiply_adds"],
                            "op_count_source": "profiles/op_counts.json[%s][%s]%s" % (ops_key, key, " (extrapolated)" if ops[key].get("extrapolated") else " (counted)"),
                            "achieved": ach, "frac": ach / peak})
-        pj = next((q for q in (os.path.join(ROOT, "profiles", t + "_summary.json") for t in ("r03", "r02")) if os.path.exists(q)), "")
+        pj = next((q for q in (os.path.join(ROOT, "profiles", t + "_summary.json") for t in ("r04", "r03", "r02")) if os.path.exists(q)), "")
         if ops_key == "verify_id" and pj:
             try:
                 pm = json.load(open(pj))

@@ -34,9 +34,9 @@ filt(f"{src}/pmc_b/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_b_k_verify_i
 if os.path.exists(f"{src}/pmc_c/{tag}_counter_collection.csv"):
     filt(f"{src}/pmc_c/{tag}_counter_collection.csv", f"{dst}/{tag}_pmc_c_k_verify_id.csv")
 s = json.load(open(f"{src}/summary.json"))
-h = {"kernel": "k_verify_id<BN254>", "items_per_launch": s["k_verify_id"]["grid"],
+h = {"kernel": "k_verify_id_staged<BN254>", "items_per_launch": s["k_verify_id"]["grid"],
      "tag": tag, "window": s.get("window"),
-     "build": "round-3 (29-bit limbs, single-reduction Fp2 products, lazy sums, LDS hot slot, fused loops; plain layout, signed-digit W = %s tables)" % s.get("window"),
+     "build": "round-%s build (29-bit limbs, single-reduction Fp2 products, lazy sums, LDS hot slot, fused loops; plain layout, coalesced record loads, signed-digit W = %s tables)" % (tag.lstrip("r0"), s.get("window")),
      "FETCH_SIZE_KiB": s["pmc_per_launch"]["FETCH_SIZE"], "WRITE_SIZE_KiB": s["pmc_per_launch"]["WRITE_SIZE"],
      "k_verify_id_bytes_per_launch": s["k_verify_id_bytes_per_launch"],
      "k_verify_id_bytes_per_launch_uncorrected": s["k_verify_id_bytes_per_launch_uncorrected"], "l2_hit_rate": s["l2_hit_rate"],
