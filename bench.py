@@ -696,7 +696,8 @@ def host_api(pkg, wl, recs, B, A, H, first, expect, window, device):
     moff = np.ascontiguousarray(moff, dtype=np.uint32)
     res = {"note": "C++ PSVerifier over the C-ABI (csrc/host): objects = std::vector<IdProof> -> el_passo_verify_id_batch; wire = std::vector<PSBuffer> "
                    "-> el_passo_verify_id_wire_batch; wire_packed = one contiguous buffer + offsets; host wall-clock per call, PCIe included, best / median of 5"}
-    for tag, W, nctx in (("one_context", window, 1), ("two_contexts_one_gpu_w16", 16, 2)):
+    # the same window width in both rows (round 3 compared W = 20 with W = 16): what differs is the dispatcher alone
+    for tag, W, nctx in (("one_context", window, 1), ("two_contexts_one_gpu", window, 2)):
         outv = (ctypes.c_double * 10)()
         acc = (ctypes.c_uint64 * 3)()
         flags = np.zeros(B, dtype=np.uint8)

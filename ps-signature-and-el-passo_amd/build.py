@@ -62,7 +62,8 @@ def _newest(paths):
 HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_pair.hip", ["-DELP_FP6_INLINE=1"]),
              ("elpasso_bn254_nizk.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_g2job.hip", ["-DELP_FP6_INLINE=1"]),
              ("elpasso_bn254_g1job.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_stage.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_coop.hip", []),
-             ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", []), ("elpasso_bls12_381_g1jobs.hip", []), ("elpasso_bn254_g1jobs.hip", [])]
+             ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", []), ("elpasso_bls12_381_g1jobs.hip", []), ("elpasso_bn254_g1jobs.hip", []),
+             ("elpasso_bls12_381_coop.hip", []), ("elpasso_bls12_381_nizk.hip", [])]
 
 
 def build_hip(force=False, verbose=False):

@@ -661,7 +661,7 @@ template <class C>
 struct VidShared {
   u32 vk[2 * C::FBYTES / 4];       // serialised V_k                  (G2 job)
   u32 v1[3][C::FBYTES / 4];        // serialised V_phi, V_E1, V_E2    (G1 job)
-  u32 ok_g1;                       // the G1 job's inputs were valid
+  u32 ok_role[4];                  // per job lane: the record decoded and this lane's own admission test (round 4: one subgroup test per lane on BLS12-381) passed
 };
 ELP_INL void bytes_to_words(u32* w, const uint8_t* b, int nbytes) {
   for (int i = 0; i < nbytes / 4; i++) w[i] = (u32)b[4 * i] | ((u32)b[4 * i + 1] << 8) | ((u32)b[4 * i + 2] << 16) | ((u32)b[4 * i + 3] << 24);
@@ -910,9 +910,10 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
   st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
   if (st.ok && !sig1_strict_ok<C>(key.flags, sig1)) st.ok = false;
   if (role == 0) {
+    sh.ok_role[0] = st.ok ? 1u : 0u;
     if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre);
   } else {
-    sh.ok_g1 = st.ok ? 1u : 0u;
+    sh.ok_role[1] = sh.ok_role[2] = sh.ok_role[3] = st.ok ? 1u : 0u;
     aff_set_inf(aK);
     if (st.ok) {
       vid_job_g1<C, RecordSrc<C>>(key, st.src, retr, phi, E1, E2, st.c, sh.v1);
@@ -927,14 +928,24 @@ ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u6
                               Aff<F2<C>>& aK, const Jac<F2<C>>* pre, bool k_done = false, bool table_ready = false) {      // k_done: K and the table of multiples of k were already made by the kernels that ran before (k_vid_fixed_coop, k_vid_ktab)
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
   Aff<F2<C>> kk;
-  st.src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
+  // every lane decodes the record (range and on-curve tests: cheap); the SUBGROUP tests of a curve with a G1 cofactor are dealt out, one per lane -- role 0:
+  // sig1 (under KEY_STRICT_SIG), 1: phi, 2: E1, 3: E2 -- and meet in sh.ok_role: four tests side by side instead of four in a row on every lane
+  st.src.sub_ = false;
   st.ok = st.src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, st.c);
-  if (st.ok && !sig1_strict_ok<C>(key.flags, sig1)) st.ok = false;
+  if (st.ok && (key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) st.ok = false;
+  if constexpr (!C::IS_BN) {
+    if (st.ok && !(key.flags & KEY_NO_SUBGROUP_CHECK)) {
+      if (role == 0)
+        st.ok = !(key.flags & KEY_STRICT_SIG) || g1_in_subgroup<C>(sig1);
+      else if (role == 1 || retr)
+        st.ok = g1_in_subgroup<C>(role == 1 ? phi : (role == 2 ? E1 : E2));
+    }
+  }
+  sh.ok_role[role] = st.ok ? 1u : 0u;
   u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
   if (role == 0) {
     if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre, table_ready);
   } else if (role == 1) {
-    sh.ok_g1 = st.ok ? 1u : 0u;
     aff_set_inf(aK);
     if (st.ok) {
       vid_job_g1_one<C, RecordSrc<C>>(key, st.src, 0, phi, st.c, sh.v1[0], ws1);
@@ -947,7 +958,7 @@ ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u6
 }
 template <class C>
 ELP_HEAVY bool vid_nizk_finish(const VidShared<C>& sh, const VidNizkState<C>& st, bool retr, const uint8_t* ad, size_t ad_len) {
-  if (!st.ok || !sh.ok_g1) return false;
+  if (!st.ok || !(sh.ok_role[0] & sh.ok_role[1] & sh.ok_role[2] & sh.ok_role[3])) return false;
   return vid_challenge_ok<C, RecordSrc<C>>(st.src, retr, sh.vk, sh.v1, st.c, ad, ad_len);
 }
 // Phase 2 of one item: the pairing check on the record's signature and the K of phase 1 (src/ps-verifier.cc:133-137).

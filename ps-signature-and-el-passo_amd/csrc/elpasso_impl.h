@@ -346,32 +346,40 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_pair(KeyCtx<C> key, const u32* recs, int
 #ifdef ELP_COOP_TU
 template <class C>
 struct CoopTables;
-template <>
-struct CoopTables<BN254> {
-  static __device__ __forceinline__ CoopProg check() {
-    using namespace elp::coop_bn254;
-    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}, CHECK_CHUNK_OFF};
-  }
-  static __device__ __forceinline__ CoopProg check32() {      // the same check scheduled for 32 lane pairs (one item per wave)
-    using namespace elp::coop_bn254;
-    return CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}, CHECK32_CHUNK_OFF};
-  }
-  static __device__ __forceinline__ CoopProg tail() {         // 32 lane pairs
-    using namespace elp::coop_bn254;
-    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}, TAIL_CHUNK_OFF};
-  }
-  static_assert(elp::coop_bn254::CHECK_NP == 16 && elp::coop_bn254::CHECK32_NP == 32 && elp::coop_bn254::TAIL_NP == 32, "lane pairs per item of the generated programs");
-  static constexpr int CHUNK = elp::coop_bn254::COOP_CHUNK;
-  template <int NP_>
-  static constexpr int max_chunk_terms() {
-    using namespace elp::coop_bn254;
-    return NP_ == 16 ? CHECK_MAX_CHUNK_TERMS : (CHECK32_MAX_CHUNK_TERMS > TAIL_MAX_CHUNK_TERMS ? CHECK32_MAX_CHUNK_TERMS : TAIL_MAX_CHUNK_TERMS);
-  }
-  static constexpr int NREG = elp::coop_bn254::COOP_NREG, NCONST = elp::coop_bn254::COOP_NCONST;
-  static constexpr int IN_P1 = elp::coop_bn254::IN_P1, IN_P2 = elp::coop_bn254::IN_P2, IN_QX = elp::coop_bn254::IN_QX, IN_QY = elp::coop_bn254::IN_QY,
-                       IN_ONE = elp::coop_bn254::IN_ONE, IN_F0 = elp::coop_bn254::IN_F0;
-  static __device__ __forceinline__ const uint8_t (*kinds())[3] { return elp::coop_bn254::CONST_KIND; }
+// one specialisation per curve whose generated programs the translation unit includes (elp/coop_prog_<curve>.h, namespace coop_<curve>)
+#define ELP_COOP_TABLES(CURVE, NS) \
+template <> \
+struct CoopTables<CURVE> { \
+  static __device__ __forceinline__ CoopProg check() { \
+    using namespace elp::NS; \
+    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}, CHECK_CHUNK_OFF}; \
+  } \
+  static __device__ __forceinline__ CoopProg check32() { \
+    using namespace elp::NS; \
+    return CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}, CHECK32_CHUNK_OFF}; \
+  } \
+  static __device__ __forceinline__ CoopProg tail() { \
+    using namespace elp::NS; \
+    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}, TAIL_CHUNK_OFF}; \
+  } \
+  static_assert(elp::NS::CHECK_NP == 16 && elp::NS::CHECK32_NP == 32 && elp::NS::TAIL_NP == 32, "lane pairs per item of the generated programs"); \
+  static constexpr int CHUNK = elp::NS::COOP_CHUNK; \
+  template <int NP_> \
+  static constexpr int max_chunk_terms() { \
+    using namespace elp::NS; \
+    return NP_ == 16 ? CHECK_MAX_CHUNK_TERMS : (CHECK32_MAX_CHUNK_TERMS > TAIL_MAX_CHUNK_TERMS ? CHECK32_MAX_CHUNK_TERMS : TAIL_MAX_CHUNK_TERMS); \
+  } \
+  static constexpr int NREG = elp::NS::COOP_NREG, NCONST = elp::NS::COOP_NCONST; \
+  static constexpr int IN_P1 = elp::NS::IN_P1, IN_P2 = elp::NS::IN_P2, IN_QX = elp::NS::IN_QX, IN_QY = elp::NS::IN_QY, \
+                       IN_ONE = elp::NS::IN_ONE, IN_F0 = elp::NS::IN_F0; \
+  static __device__ __forceinline__ const uint8_t (*kinds())[3] { return elp::NS::CONST_KIND; } \
 };
+#ifdef ELP_COOP_HAVE_BN254
+ELP_COOP_TABLES(BN254, coop_bn254)
+#endif
+#ifdef ELP_COOP_HAVE_BLS12_381
+ELP_COOP_TABLES(BLS12_381, coop_bls12_381)
+#endif
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_coop_consts(Fp2<C>* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,7 +668,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
   const u32* rec = recs + (i < n ? i : 0) * (size_t)rec_words;
   if (i < n) {
     Aff<F1<C>> s1, s2;
-    ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && !aff_is_inf(s1);       // every lane of the item decides the same
+    ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && sig1_admissible<C>(key.flags, s1);       // every lane of the item decides the same (src/ps-verifier.cc:16-18, in the order-r component)
     if (ok && sub == 0) jac_from_aff(K, aff_from_mem<G>(key.b2[G2_BASE_XX]));
   }
   coop_fixed_sum_g2<C>(K, key, sub, nattr, ok, [&](int a, int& base, Scalar& k) {
@@ -793,6 +801,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_prep(KeyCtx<C> key, const u32* recs, int
     vid_ktab_body<C>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
 }
 // verdict of a small-batch el_passo_verify_id = its NIZK half (k_vid_nizk4) AND its pairing check (k_pair_coop / k_pair_rest), which ran side by side
+template <class C>      // (a template only so that every translation unit that instantiates it gets its own copy)
 __global__ void ELP_LAUNCH_BOUNDS k_vid_combine(const uint8_t* nizk_ok, const uint8_t* pair_ok, uint8_t* flags, unsigned long long* accepted, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
@@ -920,7 +929,7 @@ void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const v
 }
 template <class B>
 void launch_vid_combine(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted) {
-  hipLaunchKernelGGL(k_vid_combine, dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, nizk_ok, pair_ok, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
+  hipLaunchKernelGGL((k_vid_combine<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, nizk_ok, pair_ok, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
 template <class B>
 void launch_agg_final_coop(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok) {
@@ -964,6 +973,23 @@ template <>
 struct CoopBuild<BN254> {
   static constexpr bool value = true;
 };
+// small batches of el_passo_verify_id (k_vid_prep -> k_vid_small / k_vid_nizk4 + k_pair_coop -> k_vid_combine): curves that have k_vid_nizk4 built for them too
+template <class B>
+struct SmallBuild {
+  static constexpr bool value = false;
+};
+template <>
+struct SmallBuild<BN254> {
+  static constexpr bool value = true;
+};
+template <>
+struct SmallBuild<BLS12_381> {
+  static constexpr bool value = true;
+};
+template <>
+struct CoopBuild<BLS12_381> {      // round 4: the pairing check (PS verification of small batches, the tail of aggregated verification); parity unpinned like everything on this curve
+  static constexpr bool value = true;
+};
 #ifndef ELP_COOP_TU
 extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_consts);
 extern template void launch_vid_prep<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
@@ -975,6 +1001,16 @@ extern template void launch_vid_fixed_coop<BN254>(hipStream_t stream, const KeyC
 extern template void launch_vid_combine<BN254>(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
 extern template void launch_vid_ktab<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, int retr);
 extern template void launch_vid_small<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done, const void* pre);
+extern template void launch_coop_consts<BLS12_381>(hipStream_t stream, void* d_consts);
+extern template void launch_pair_rest<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
+extern template void launch_pair_coop<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, const void* d_consts, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted, hipStream_t rest_stream);
+extern template void launch_ps_k<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride);
+extern template void launch_agg_final_coop<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, const void* d_consts, const void* F, const void* s2_std, int* agg_ok);
+extern template void launch_vid_prep<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
+extern template void launch_vid_fixed_coop<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
+extern template void launch_vid_combine<BLS12_381>(hipStream_t stream, size_t n, const uint8_t* nizk_ok, const uint8_t* pair_ok, void* d_flags, void* d_accepted);
+extern template void launch_vid_ktab<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, int retr);
+extern template void launch_vid_small<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done, const void* pre);
 #endif
 
 // ---- paired layout (elp/common.h "Lane pairs"): two lanes per item, 64-thread workgroups = 32 items, 256 registers per lane and two
@@ -2496,6 +2532,7 @@ extern template void launch_vid_g1<BN254>(hipStream_t stream, size_t n, const vo
 #endif
 #ifndef ELP_NIZK_TU
 extern template void launch_vid_nizk4<BN254>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre, int k_done);
+extern template void launch_vid_nizk4<BLS12_381>(hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BLS12_381>& key, const void* pre, int k_done);
 extern template void launch_vid_nizk<BN254>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, u32* kws, size_t kstride, const KeyCtx<BN254>& key, const void* pre);
 #endif
 #ifndef ELP_G1JOBS_TU
@@ -2524,9 +2561,9 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   const int H = popcount_mask(mask, c->A);
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
-  if constexpr (CoopBuild<C>::value && SplitBuild<C>::value) {
+  if constexpr (CoopBuild<C>::value && SmallBuild<C>::value) {
     if (c->coop && n <= c->coop_max) {
-      // small batch: NIZK half with two job lanes per item (k_vid_nizk), pairing check on 32 lanes per item (k_pair_coop)
+      // small batch: NIZK half with four job lanes per item (k_vid_nizk4), pairing check on 32 / 64 lanes per item (k_pair_coop)
       const void* consts = coop_consts_for<C>(c, (hipStream_t)stream);
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;

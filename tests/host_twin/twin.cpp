@@ -15,6 +15,9 @@
 #include "elp/params_bn254.h"
 #include "elp/coop.h"
 #include "elp/coop_prog_bn254.h"
+#if !defined(TWIN_PART) || TWIN_PART == 2
+#include "elp/coop_prog_bls12_381.h"
+#endif
 
 using namespace elp;
 
@@ -512,63 +515,65 @@ int twin_blsp_pairing(const u32* P, const u32* Q, u32* o) {
 }
 }
 #endif
-#if !defined(TWIN_PART) || TWIN_PART == 1
 // Cooperative pairing check (elp/coop.h): the level-scheduled program executed slot by slot on the host.  mode 0: [f_K(sig1) f_gg(-sig2)]^e by the 16-pair
 // program, mode 2: the same by the 32-pair program, mode 1 (the tail of aggregated verification, 32 pairs): [F f_gg(-sig2)]^e with F = f_K(sig1) computed here
 // by the ordinary Miller loop.  Writes the GT bytes; returns 1 iff the value is 1.
-extern "C" int twin_bn254_pair_coop(void* cv, const u32* sig1w, const u32* sig2w, const u32* Kw, int mode, u32* gt_out) {
-  typedef BN254 C;
-  using namespace elp::coop_bn254;
-  TwinCtx<C>* c = (TwinCtx<C>*)cv;
-  Aff<F1<C>> s1, s2;
-  Aff<F2<C>> K;
-  if (!g1_load<C>(s1, sig1w) || !g1_load<C>(s2, sig2w) || !g2_load<C>(K, Kw)) return -1;
-  std::vector<Fp2<C>> consts(COOP_NCONST);
-  for (int i = 0; i < COOP_NCONST; i++) {
-    consts[i].c0 = coop_const<C>(CONST_KIND, i, 0);
-    consts[i].c1 = coop_const<C>(CONST_KIND, i, 1);
-  }
-  std::vector<i32> R((size_t)COOP_NREG * coop_reg_words<C>(), 0x5a5a5a5);
-  coop_st<C>(R.data(), IN_P2, 0, s2.x);
-  coop_st<C>(R.data(), IN_P2, 1, fp_neg(s2.y));
-  coop_st<C>(R.data(), IN_ONE, 0, fp_one<C>());
-  coop_st<C>(R.data(), IN_ONE, 1, fp_zero<C>());
-  CoopProg P;
-  if (mode == 0 || mode == 2) {
-    coop_st<C>(R.data(), IN_P1, 0, s1.x);
-    coop_st<C>(R.data(), IN_P1, 1, s1.y);
-    coop_st<C>(R.data(), IN_QX, 0, K.x.c0);
-    coop_st<C>(R.data(), IN_QX, 1, K.x.c1);
-    coop_st<C>(R.data(), IN_QY, 0, K.y.c0);
-    coop_st<C>(R.data(), IN_QY, 1, K.y.c1);
-    if (mode == 0) {
-      P = CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}};
-      P.np = CHECK_NP;
-    } else {
-      P = CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}};
-      P.np = CHECK32_NP;
-    }
-  } else {
-    Fp12<C> F;
-    miller_loop<C, 1, 0>(F, &s1, &K, &s1, (const LineMem<C>* const*)0);
-    const Fp2<C>* e[6] = {&F.c0.c0, &F.c0.c1, &F.c0.c2, &F.c1.c0, &F.c1.c1, &F.c1.c2};
-    for (int j = 0; j < 6; j++) {
-      coop_st<C>(R.data(), IN_F0 + j, 0, e[j]->c0);
-      coop_st<C>(R.data(), IN_F0 + j, 1, e[j]->c1);
-    }
-    P = CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}};
-    P.np = TAIL_NP;
-  }
-  coop_run_host<C>(P, R.data(), consts.data(), (int)consts.size(), reinterpret_cast<const Fp2<C>*>(c->lines.data()));
-  Fp12<C> g;
-  Fp2<C>* o[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
-  for (int j = 0; j < 6; j++) {
-    o[j]->c0 = coop_ld<C>(R.data(), P.out[j], 0);
-    o[j]->c1 = coop_ld<C>(R.data(), P.out[j], 1);
-  }
-  gt_store<C>(gt_out, g);
-  return fp12_is_one(g) ? 1 : 0;
+#define TWIN_PAIR_COOP(FN, CURVE, NS) \
+extern "C" int FN(void* cv, const u32* sig1w, const u32* sig2w, const u32* Kw, int mode, u32* gt_out) { \
+  typedef CURVE C; \
+  using namespace elp::NS; \
+  TwinCtx<C>* c = (TwinCtx<C>*)cv; \
+  Aff<F1<C>> s1, s2; \
+  Aff<F2<C>> K; \
+  if (!g1_load<C>(s1, sig1w) || !g1_load<C>(s2, sig2w) || !g2_load<C>(K, Kw)) return -1; \
+  std::vector<Fp2<C>> consts(COOP_NCONST); \
+  for (int i = 0; i < COOP_NCONST; i++) { \
+    consts[i].c0 = coop_const<C>(CONST_KIND, i, 0); \
+    consts[i].c1 = coop_const<C>(CONST_KIND, i, 1); \
+  } \
+  std::vector<i32> R((size_t)COOP_NREG * coop_reg_words<C>(), 0x5a5a5a5); \
+  coop_st<C>(R.data(), IN_P2, 0, s2.x); \
+  coop_st<C>(R.data(), IN_P2, 1, fp_neg(s2.y)); \
+  coop_st<C>(R.data(), IN_ONE, 0, fp_one<C>()); \
+  coop_st<C>(R.data(), IN_ONE, 1, fp_zero<C>()); \
+  CoopProg P; \
+  if (mode == 0 || mode == 2) { \
+    coop_st<C>(R.data(), IN_P1, 0, s1.x); \
+    coop_st<C>(R.data(), IN_P1, 1, s1.y); \
+    coop_st<C>(R.data(), IN_QX, 0, K.x.c0); \
+    coop_st<C>(R.data(), IN_QX, 1, K.x.c1); \
+    coop_st<C>(R.data(), IN_QY, 0, K.y.c0); \
+    coop_st<C>(R.data(), IN_QY, 1, K.y.c1); \
+    if (mode == 0) { \
+      P = CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}}; \
+      P.np = CHECK_NP; \
+    } else { \
+      P = CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}}; \
+      P.np = CHECK32_NP; \
+    } \
+  } else { \
+    Fp12<C> F; \
+    miller_loop<C, 1, 0>(F, &s1, &K, &s1, (const LineMem<C>* const*)0); \
+    const Fp2<C>* e[6] = {&F.c0.c0, &F.c0.c1, &F.c0.c2, &F.c1.c0, &F.c1.c1, &F.c1.c2}; \
+    for (int j = 0; j < 6; j++) { \
+      coop_st<C>(R.data(), IN_F0 + j, 0, e[j]->c0); \
+      coop_st<C>(R.data(), IN_F0 + j, 1, e[j]->c1); \
+    } \
+    P = CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}}; \
+    P.np = TAIL_NP; \
+  } \
+  coop_run_host<C>(P, R.data(), consts.data(), (int)consts.size(), reinterpret_cast<const Fp2<C>*>(c->lines.data())); \
+  Fp12<C> g; \
+  Fp2<C>* o[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2}; \
+  for (int j = 0; j < 6; j++) { \
+    o[j]->c0 = coop_ld<C>(R.data(), P.out[j], 0); \
+    o[j]->c1 = coop_ld<C>(R.data(), P.out[j], 1); \
+  } \
+  gt_store<C>(gt_out, g); \
+  return fp12_is_one(g) ? 1 : 0; \
 }
+#if !defined(TWIN_PART) || TWIN_PART == 1
+TWIN_PAIR_COOP(twin_bn254_pair_coop, BN254, coop_bn254)
 // debug aid for tools/gen_coop.py: the register file (canonical values) after `nsteps` steps of the check program
 extern "C" int twin_bn254_coop_debug(void* cv, const u32* sig1w, const u32* sig2w, const u32* Kw, int nsteps, u32* regs_out) {
   typedef BN254 C;
@@ -670,6 +675,10 @@ int twin_bn254p_g2_decompress(const uint8_t* in, u32* o) {
 }
 #endif
 
+#if !defined(TWIN_PART) || TWIN_PART == 2
+// the same interpreter over the BLS12-381 programs (M-type twist, Hayashida-Hayasaka-Teruya chain taken to the third power: the value is the CUBE of the GT element)
+TWIN_PAIR_COOP(twin_bls_pair_coop, BLS12_381, coop_bls12_381)
+#endif
 // TWIN_PART selects one curve so the two halves can be compiled in parallel (tests/elp_testlib.py); default: both
 #if !defined(TWIN_PART) || TWIN_PART == 1
 TWIN(BN254, twin_bn254)

@@ -71,6 +71,49 @@ def test_committed_program_header_is_what_the_generator_emits(tmp_path):
     import sys
     from elp_testlib import ROOT
     out = tmp_path / "coop_prog_bn254.h"
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_coop.py"), str(out)])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_coop.py"), "bn254", str(out)])
     committed = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bn254.h")
     assert out.read_bytes() == open(committed, "rb").read()
+
+
+def test_bls12_381_programs_on_the_host_twin():
+    """The BLS12-381 programs (tools/gen_coop.py: M-type line placement, Hayashida-Hayasaka-Teruya chain taken to the third power) interpreted by the host twin: the
+    value equals the CUBE of the model's  e(sig1, K) e(-sig2, gg)  bit for bit for all three programs, and is 1 exactly for a valid PS signature.  PARITY UNPINNED like
+    everything on this curve (the model is this project's own)."""
+    from elp_testlib import BLS12_381, BLS_G2
+    Mb = Mcl(BLS12_381)
+    Gb, PRb = Mb.G, Protocol(Mb)
+    L = twin()
+    L.twin_bls_ctx_new.restype = ctypes.c_void_p
+    seed, A, N = 77, 3, 48
+    g = Mb.hash_to_g1("abc")
+    pk, skX = PRb.key_gen(g, BLS_G2, scalar_stream(seed, 0, Mb.r), [scalar_stream(seed, 1 + i, Mb.r) for i in range(A)])
+    ctx = ctypes.c_void_p(L.twin_bls_ctx_new(A, 4, g1_bases(Mb, pk, svc=b"svc"), g2_bases(Mb, pk)))
+    assert ctx.value
+    m = [scalar_stream(seed, 10 + i, Mb.r) for i in range(A)]
+    u = scalar_stream(seed, 20, Mb.r)
+    full = (scalar_stream(seed, 0, Mb.r) + sum(scalar_stream(seed, 1 + i, Mb.r) * m[i] for i in range(A))) % Mb.r
+    sig1, sig2 = Gb.g1_mul(g, u), Gb.g1_mul(g, u * full % Mb.r)
+    K = pk.XX
+    for i in range(A):
+        K = Gb.g2_add(K, Gb.g2_mul(pk.YYi[i], m[i]))
+    gt = ctypes.create_string_buffer(12 * N)
+    for s2, valid in ((sig2, True), (Gb.g1_add(sig2, g), False)):
+        e = Mb.G.F.f12_mul(Gb.pairing(sig1, K), Gb.pairing(Gb.g1_neg(s2), pk.gg))
+        e3 = Mb.G.F.f12_mul(Mb.G.F.f12_mul(e, e), e)
+        want = b"".join(fb(e3[k][0], N) + fb(e3[k][1], N) for k in [0, 2, 4, 1, 3, 5])
+        for mode in (0, 2, 1):
+            rc = L.twin_bls_pair_coop(ctx, g1b(sig1, N), g1b(s2, N), g2b(K, N), mode, gt)
+            assert rc == (1 if valid else 0), (mode, valid)
+            assert gt.raw == want, mode
+    L.twin_bls_ctx_free(ctx)
+
+
+def test_committed_bls12_381_program_header_is_what_the_generator_emits(tmp_path):
+    import os
+    import subprocess
+    import sys
+    from elp_testlib import ROOT
+    out = tmp_path / "coop_prog_bls12_381.h"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_coop.py"), "bls12_381", str(out)])
+    assert out.read_bytes() == open(os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bls12_381.h"), "rb").read()

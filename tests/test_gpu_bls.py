@@ -319,3 +319,66 @@ def test_headline_size_batch_w20_against_the_c_oracle(bls_ctx):
     L.elpo_key_free(key)
     # leave a small key behind for the tests that follow (22 GiB of W = 20 tables are released with it)
     synth.Workload(bls_ctx, 3, seed=1, window_bits=4)
+
+
+def test_small_batches_cooperative_on_bls(bls_ctx):
+    """Round 4: the cooperative small-batch path on BLS12-381 (programs generated by tools/gen_coop.py for the M-type twist and the Hayashida-Hayasaka-Teruya chain;
+    k_vid_prep -> k_vid_small / k_vid_nizk4 + k_pair_coop -> k_vid_combine, k_ps_k_coop + k_pair_coop for PS verification, k_agg_final_coop as the tail of aggregated
+    verification).  el_passo_verify_id and PS verification at n = 1, 63, 64, 65, 600 and 1100 (both program widths): verdicts equal the two-lanes-per-item kernels'
+    (ELP_OPT_COOP_PAIRING off), the generator's expectation and the C oracle's BLS12-381 build; tampered signatures, sig2 = infinity and the cofactor forgery included.
+    PARITY UNPINNED (no reference artefact exists for this curve)."""
+    import ctypes
+    import os
+    from test_oracle_bls import _small_order_point
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    L = oracle_bls()
+    L.elpo_set_strict.argtypes = [ctypes.c_int]
+    NT = max(1, min(16, len(os.sched_getaffinity(0))))
+    A, H = 8, 4
+    wl = synth.Workload(bls_ctx, A, seed=5, window_bits=8)
+    g1 = wl.g + wl.Yi + bls_ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+    key = ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
+    t3 = g1b(_small_order_point(3), N)
+    L.elpo_set_strict(1)                   # the context runs with the library's default ELP_OPT_STRICT_SIGNATURE
+    try:
+        for n in (1, 63, 64, 65, 600, 1100):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=3)
+            rsz = len(recs) // n
+            recs = bytearray(recs)
+            if n > 10:
+                recs[9 * rsz + 96:9 * rsz + 192] = recs[8 * rsz + 96:8 * rsz + 192]        # item 9 gets item 8's sig2: NIZK holds, pairing check fails
+                recs[4 * rsz + 96:4 * rsz + 192] = bytes(96)                                # item 4: sig2 = infinity (left to the per-lane kernel)
+                recs[5 * rsz:5 * rsz + 96] = t3                                             # item 5: the cofactor forgery (sig1 of order 3, sig2 = O)
+                recs[5 * rsz + 96:5 * rsz + 192] = bytes(96)
+            recs = bytes(recs)
+            bls_ctx.set_coop_pairing(0)
+            f0, c0 = bls_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            bls_ctx.set_coop_pairing(1)
+            f1, c1 = bls_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            assert (f0 == f1).all() and c0 == c1 == int(f1.sum()), n
+            if n > 10:
+                assert f1[9] == 0 and f1[4] == 0 and f1[5] == 0 and f1[8] == int(expect[8])
+            ofl = np.zeros(n, dtype=np.uint8)
+            L.elpo_verify_id_batch(key, n, recs, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+            assert (ofl == f1).all(), n
+            if n in (64, 600):          # the tail of aggregated verification on the cooperative program
+                fa, ca, held = bls_ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad, seed=bytes(range(32)))
+                assert (fa == f1).all() and ca == c1
+        wl3 = synth.Workload(bls_ctx, 3, seed=6, window_bits=8)
+        g13 = wl3.g + wl3.Yi + bls_ctx.hash_to_g1([wl3.service]) + wl3.g + wl3.apk + wl3.h + wl3.X
+        key3 = ctypes.c_void_p(L.elpo_key_new(3, g13, wl3.gg + wl3.XX + wl3.YYi))
+        for n in (1, 63, 64, 65, 600, 1100):
+            precs, pexpect = wl3.ps_verify_batch(n)
+            bls_ctx.set_coop_pairing(0)
+            p0, pc0 = bls_ctx.ps_verify_batch(precs, 3)
+            bls_ctx.set_coop_pairing(1)         # K on 8 lanes per item (k_ps_k_coop), pairing check on 32 / 64 lanes (k_pair_coop)
+            p1, pc1 = bls_ctx.ps_verify_batch(precs, 3)
+            assert (p0 == pexpect).all() and (p1 == pexpect).all() and pc0 == pc1 == int(pexpect.sum()), n
+            prsz = len(precs) // n
+            for i in range(0, n, 1 if n < 100 else 37):
+                assert L.elpo_ps_verify(key3, precs[i * prsz:(i + 1) * prsz], 3) == int(p1[i])
+        L.elpo_key_free(key3)
+    finally:
+        L.elpo_set_strict(0)
+        bls_ctx.set_coop_pairing(1)
+        L.elpo_key_free(key)

@@ -108,7 +108,7 @@ def test_protocol_flows(L):
     assert PR.verify_id_noretr(pk, pr2, b"sess", b"service")
     assert L.twin_bls_verify_id(ctx, pack_verify_id(M, pr2), mask, 0, b"sess", 4) == 1
     # the same verdicts from the two-lanes-per-item layout (two threads here, every exchange a rendezvous)
-    for fn in (L.twin_blsp_verify_id, L.twin_blsp_verify_id_g1split):      # g1split: ELP_OPT_SPLIT_PHASES = 3, this curve's default (G1 jobs kernel + paired body)
+    for fn in (L.twin_blsp_verify_id, L.twin_blsp_verify_id_g1split, L.twin_bls_verify_id_jobs4):      # g1split: ELP_OPT_SPLIT_PHASES = 3; jobs4: the small-batch form (k_vid_nizk4)
         assert fn(ctx, pack_verify_id(M, pr), mask, 1, b"sess", 4) == 1
         assert fn(ctx, pack_verify_id(M, pr), mask, 1, b"sesS", 4) == 0
         assert fn(ctx, pack_verify_id(M, bad), mask, 1, b"sess", 4) == 0

@@ -163,7 +163,8 @@ def test_off_subgroup_g1_inputs_are_rejected():
         assert L.elpo_verify_id(key, rb, mask, 1, b"sess", 4) == 0
         assert T.twin_bls_verify_id(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0
         assert T.twin_blsp_verify_id(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0          # the two-lanes-per-item layout
-        assert T.twin_blsp_verify_id_g1split(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0  # G1 jobs kernel + paired body (this curve's default)
+        assert T.twin_blsp_verify_id_g1split(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0  # G1 jobs kernel + paired body (ELP_OPT_SPLIT_PHASES = 3)
+        assert T.twin_bls_verify_id_jobs4(tctx, rb, ctypes.c_uint64(mask), 1, b"sess", 4) == 0     # small batches: four job lanes, one subgroup test each
     # a request whose commitment left the subgroup is not signed
     badrq = copy.copy(rq)
     badrq.A = G.g1_add(rq.A, t3)
@@ -215,6 +216,7 @@ def test_cofactor_sig1_forgery_is_rejected():
                 assert T.twin_bls_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
                 assert T.twin_blsp_verify_id(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
                 assert T.twin_blsp_verify_id_g1split(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want
+                assert T.twin_bls_verify_id_jobs4(tctx, rec, ctypes.c_uint64(mask), 1, b"sess", 4) == want      # small-batch form: the sig1 test is role 0's
         # strict, but the caller vouches for subgroup membership (ELP_OPT_SUBGROUP_CHECK = 0): only the infinity test is left, as documented
         T.twin_bls_ctx_set_flags(tctx, 1 | 2)
         assert T.twin_blsp_verify_id(tctx, pack_verify_id(M, forged), ctypes.c_uint64(mask), 1, b"sess", 4) == 1

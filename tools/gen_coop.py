@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
-from oracle.pymodel import BN254, Groups, Mcl  # noqa: E402
+from oracle.pymodel import BLS12_381, BN254, Groups, Mcl  # noqa: E402
 
 
 def naf(k):      # non-adjacent form, least significant digit first (as tools/gen_params.py, which generates C::ate_naf)
@@ -321,6 +321,49 @@ def f12_mul_line_d(f, l):
     return [f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(t2, t0), t1)]
 
 
+def f12_mul_two_lines_m(f, l1, l2):
+    """f * (a1 + b1 v + c1 v w) * (a2 + b2 v + c2 v w), M-type twist (csrc/elp/tower.h fp12_mul_by_two_lines_m_inl): the same six products as the D-type form,
+    L0 = (a1 a2 + xi c1 c2, a1 b2 + a2 b1, b1 b2), L1 = v (y_ac + y_bc v)."""
+    a1, b1, c1 = l1
+    a2, b2, c2 = l2
+    taa, tbb, tcc = a1 * a2, b1 * b2, c1 * c2
+    tbc = (b1 + c1) * (b2 + c2)
+    tab = (a1 + b1) * (a2 + b2)
+    tac = (a1 + c1) * (a2 + c2)
+    yab = (tab - taa) - tbb
+    yac = (tac - taa) - tcc
+    ybc = (tbc - tbb) - tcc
+    L0 = [taa + tcc.xi(), yab, tbb]
+    L1s = [L0[0], L0[1] + yac, L0[2] + ybc]
+    t0 = f6_mul(f[0], L0)
+    u = f6_mul_01(f[1], yac, ybc)               # t1 = f1 * L1 = v u
+    t1 = f6_mul_v(u)
+    t2 = f6_mul(f6_add(f[0], f[1]), L1s)
+    return [f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(t2, t0), t1)]
+
+
+def f12_mul_line_m(f, l):
+    """f * (a + b v + c v w), M-type twist (the else-branch of fp12_mul_by_line_inl)."""
+    a, b, c = l
+    t0 = f6_mul_01(f[0], a, b)
+    t1 = f6_mul_v(f6_mul_fp2(f[1], c))
+    t2 = f6_mul_01(f6_add(f[0], f[1]), a, b + c)
+    return [f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(t2, t0), t1)]
+
+
+def line_for_twist(cv, l):
+    """(a y_P, b x_P, c) of eval_line in the order the twist's sparse product takes its three coefficients: D-type (a, b, c) at 1, w, w^3; M-type (c, b, a) at 1, v, v w."""
+    return l if cv.twist == "D" else (l[2], l[1], l[0])
+
+
+def f12_mul_two_lines(cv, f, l1, l2):
+    return f12_mul_two_lines_d(f, l1, l2) if cv.twist == "D" else f12_mul_two_lines_m(f, line_for_twist(cv, l1), line_for_twist(cv, l2))
+
+
+def f12_mul_line(cv, f, l):
+    return f12_mul_line_d(f, l) if cv.twist == "D" else f12_mul_line_m(f, line_for_twist(cv, l))
+
+
 def ml_dbl_step(T):
     """Tangent at T (homogeneous projective) and T <- 2T; returns the un-evaluated line (a: times y_P, b: times x_P, c)."""
     X, Y, Z = T
@@ -403,6 +446,28 @@ def final_exp_bn(f, cv):
     return f12_mul(f12_cyc_sqr(T0), T1)
 
 
+def final_exp_bls_check(f, cv):
+    """BLS12 final exponentiation as the kernels use it where the result is only compared with 1 (csrc/elp/pairing.h final_exp<C, false>): easy part, then the hard part
+    taken to the third power, 3 (p^4 - p^2 + 1) / r = (z - 1)^2 (z + p) (z^2 + p^2 - 1) + 3 -- five sparse powers of z, no dense exponent.  GT has prime order r and
+    3 does not divide r: the value is 1 exactly when the pairing product is; validate() compares with the CUBE of the model's GT element."""
+    f = f12_hold(f)
+    t0 = f12_inv(f)
+    f = f12_mul(f12_conj(f), t0)
+    f = f12_hold(f12_mul(f12_frob(f, 2), f))
+    zabs, negz = abs(cv.z), cv.z < 0
+    a = f12_hold(f12_mul(f12_pow_z(f, zabs, negz), f12_conj(f)))            # f^(z-1)
+    a = f12_hold(f12_mul(f12_pow_z(a, zabs, negz), f12_conj(a)))            # ^(z-1)
+    b = f12_hold(f12_mul(f12_frob(a, 1), f12_pow_z(a, zabs, negz)))         # a^(z+p)
+    t = f12_hold(f12_pow_z(f12_hold(f12_pow_z(b, zabs, negz)), zabs, negz))
+    c = f12_mul(f12_mul(f12_frob(b, 2), t), f12_conj(b))                    # b^(z^2+p^2-1)
+    f3 = f12_mul(f12_cyc_sqr(f), f)
+    return f12_mul(c, f3)
+
+
+def final_exp(f, cv):
+    return final_exp_bn(f, cv) if cv.is_bn else final_exp_bls_check(f, cv)
+
+
 # input slots of the programs (the kernel fills these registers before running)
 IN_P1, IN_P2, IN_QX, IN_QY, IN_ONE = 0, 1, 2, 3, 4
 IN_F0 = 5                        # .. IN_F0 + 5: the Fp12 value F of the aggregated tail (c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2)
@@ -436,15 +501,19 @@ def trace_check(cv, variable_pair=True):
                 if f is None:
                     # f = 1: the product of the two lines itself (the same six products, no pass over f)
                     zero = one - one
-                    f = f12_mul_two_lines_d([[one, zero, zero], [zero, zero, zero]], lv, lf)
+                    f = f12_mul_two_lines(cv, [[one, zero, zero], [zero, zero, zero]], lv, lf)
                 else:
-                    f = f12_mul_two_lines_d(f, lv, lf)
+                    f = f12_mul_two_lines(cv, f, lv, lf)
             else:
                 if f is None:
                     zero = one - one
-                    f = [[lf[0], zero, zero], [lf[1], lf[2], zero]]
+                    if cv.twist == "D":
+                        f = [[lf[0], zero, zero], [lf[1], lf[2], zero]]
+                    else:
+                        lm = line_for_twist(cv, lf)
+                        f = [[lm[0], lm[1], zero], [zero, lm[2], zero]]
                 else:
-                    f = f12_mul_line_d(f, lf)
+                    f = f12_mul_line(cv, f, lf)
     if cv.z < 0:
         f = f12_conj(f)
     if cv.is_bn:
@@ -464,7 +533,7 @@ def trace_check(cv, variable_pair=True):
         Fin = [[p.input(IN_F0 + 0), p.input(IN_F0 + 1), p.input(IN_F0 + 2)], [p.input(IN_F0 + 3), p.input(IN_F0 + 4), p.input(IN_F0 + 5)]]
         f = f12_mul(f, Fin)
     p.fe_start = len(p.ops)          # everything traced from here on belongs to the final exponentiation (scheduled as late as possible)
-    r = final_exp_bn(f, cv)
+    r = final_exp(f, cv)
     return p, [x.mat() for x in (r[0][0], r[0][1], r[0][2], r[1][0], r[1][1], r[1][2])], n
 
 
@@ -731,16 +800,19 @@ def const_values(cv):
 
 def validate(cv):
     """The scheduled programs, executed numerically, against the model's pairing (value of e(P1, Q) e(P2, gg), bit for bit)."""
+    CONSTS.clear()                # constant ids are per curve (the BN254 header must come out byte-identical whatever was generated before)
     M = Mcl(cv)
     G = M.G
     F = G.F
     cvals = const_values(cv)
     g1 = M.hash_to_g1("abc")
-    gg = G.g2_mul(_bn_g2(cv), 7)
+    gg = G.g2_mul(_bn_g2(cv) if cv.is_bn else _BLS_G2, 7)
     Q = G.g2_mul(gg, 123456789)
     P1, P2 = G.g1_mul(g1, 424242), G.g1_mul(g1, 171717)
     lines = model_lines(cv, gg)
     want = F.f12_mul(G.pairing(P1, Q), G.pairing(P2, gg))
+    if not cv.is_bn:
+        want = F.f12_mul(F.f12_mul(want, want), want)         # the BLS12 programs end in the cubed hard part (final_exp_bls_check)
     res = {}
     # check: 16 lane pairs per item (two items per wave: batches); check32 / tail: 32 lane pairs (one item per wave: lone items, small batches, the one
     # closing pairing of aggregated verification) -- fewer, wider steps where the dependency depth allows
@@ -769,6 +841,13 @@ def validate(cv):
         print("%s: %d mul ops in %d mul steps, %d lin ops in %d lin steps, peak %d registers (+%d inputs), %d fixed lines" %
               (name, nmul, sum(1 for c, _ in steps if c == 1), nlin, sum(1 for c, _ in steps if c == 0), peak, IN_F0 + 6, nlines), file=sys.stderr)
     return res
+
+
+# the standard generator of the order-r subgroup of the BLS12-381 twist (as in tests/elp_testlib.py)
+_BLS_G2 = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+            0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+           (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+            0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
 
 
 def _bn_g2(cv):
@@ -867,8 +946,12 @@ def emit_header(res, path, cvname):
 
 if __name__ == "__main__":
     sys.setrecursionlimit(100000)
-    res = validate(BN254)
-    # optional argument: where to write (tests/test_coop.py regenerates into a temporary file and compares with the committed header byte for byte)
-    dest = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_bn254.h")
-    emit_header(res, dest, "bn254")
-    print("written", dest, file=sys.stderr)
+    # arguments: [bn254|bls12_381] [destination]; default: both curves into csrc/elp/ (tests/test_coop.py regenerates each into a temporary file and compares
+    # with the committed header byte for byte)
+    which = [sys.argv[1]] if len(sys.argv) > 1 and sys.argv[1] in ("bn254", "bls12_381") else ["bn254", "bls12_381"]
+    rest = [a for a in sys.argv[1:] if a not in ("bn254", "bls12_381")]
+    for name in which:
+        res = validate(BN254 if name == "bn254" else BLS12_381)
+        dest = rest[0] if rest else os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elp", "coop_prog_%s.h" % name)
+        emit_header(res, dest, name)
+        print("written", dest, file=sys.stderr)
