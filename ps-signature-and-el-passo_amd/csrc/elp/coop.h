@@ -7,7 +7,8 @@
 // needs ~8 ms whatever the batch size.  Inside every Fp12 operation 6 to 18 Fp2 products are independent: the program lists them level by
 // level, lane pair q executes slot q of a level, a barrier separates levels (all lanes of an item sit in one wave, so the barrier is the
 // in-order LDS pipeline).  Two classes of levels: products (one fp_mul_pair per lane: the lane of parity c computes component c) and linear
-// steps (Fp-linear combinations with small integer 2x2 matrices on (re, im), accumulated in 64-bit limbs and weakly reduced; loads of the
+// steps (Fp-linear combinations with small integer 2x2 matrices on (re, im), accumulated in 64-bit limbs and finished by ONE parallel carry pass where the
+// generator's magnitude analysis allows -- the products in between pull the values back towards p -- and by a reduction modulo p where not; loads of the
 // fixed lines; the one base-field inversion of the final exponentiation).  The value computed is the exact GT element (Devegili-Scott-Dahab
 // hard part): gen_coop.py validates the scheduled program against the big-int model bit for bit, tests/ compare the kernels with the oracle.
 #pragma once
@@ -21,11 +22,12 @@ namespace elp {
 struct CoopProg {        // one scheduled program (device pointers on the device, plain arrays on the host twin)
   const u32* prog;       // nsteps x NP descriptors of two words
   const uint8_t* cls;    // nsteps: 1 = product step
-  const u32* terms;      // term table of the LIN operations
+  const u32* terms;      // the 16-bit entries of the LIN operations, two per word; the entries of a chunk start at a word
   int nsteps;
   int out[6];            // registers of the result (c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2)
-  const u32* chunk_off = nullptr;   // first term of every chunk of COOP_CHUNK steps (+ end): the kernels stage descriptors and terms through LDS chunk by chunk
+  const u32* chunk_off = nullptr;   // first entry WORD of every chunk of COOP_CHUNK steps (+ end): the kernels stage descriptors and entries through LDS chunk by chunk
   int np = 16;                      // lane pairs per item the program was scheduled for (descriptors per step); the kernels know it at compile time
+  const u32* chunk_line = nullptr;  // per chunk: first | count << 16 of the line coefficients (Fp2 values of the fixed argument's lines) its LDL operations read
 };
 
 // The register file and the staged program live in LDS: on the device the interpreter takes LDS-address-space pointers, so that every access is a DS
@@ -33,12 +35,18 @@ struct CoopProg {        // one scheduled program (device pointers on the device
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) i32 coop_i32;
 typedef __attribute__((address_space(3))) u32 coop_u32;
+typedef __attribute__((address_space(3))) uint16_t coop_u16;
+typedef __attribute__((address_space(3))) unsigned long long coop_u64;
 #else
 typedef i32 coop_i32;
 typedef u32 coop_u32;
+typedef uint16_t coop_u16;
+typedef unsigned long long coop_u64;
 #endif
 
 enum { COOP_OP_MUL = 0, COOP_OP_MULC = 1, COOP_OP_MULS = 2, COOP_OP_LIN = 3, COOP_OP_LDL = 4, COOP_OP_INV = 5, COOP_OP_NOP = 15 };
+constexpr int COOP_IN_ONE = 4;             // register pinned to the constant (1, 0) in every program (tools/gen_coop.py IN_ONE; CoopTables<C>::IN_ONE is checked against it)
+constexpr u32 COOP_LIN_LIGHT = 1u << 19;   // LIN descriptor: the combination keeps the light finish (tools/gen_coop.py analyse)
 
 // register file of one item: R[reg][component][limb]
 template <class C>
@@ -59,7 +67,7 @@ ELP_INL void coop_st(coop_i32* R, int reg, int comp, const Fp<C>& a) {
 }
 
 // sum of 64-bit limb accumulators -> carried limbs of a value in (-1.5 p, 1.5 p): sequential carry, quotient by p estimated from the top limb
-// (the generator bounds the coefficient mass of a combination by 200, so the top limb stays below 2^31 and top * QK fits 64 bits), q p subtracted
+// (the generator bounds sum |coefficient| |value| of a combination by 600 p, so the top limb stays below 2^31 and top * QK fits 64 bits), q p subtracted
 template <class C>
 ELP_INL Fp<C> coop_lin_finish(const i64* acc) {
   constexpr int NL = C::NL;
@@ -88,6 +96,30 @@ ELP_INL Fp<C> coop_lin_finish(const i64* acc) {
   return r;
 }
 
+// the light finish: ONE parallel carry pass, the integer value untouched.  The generator proves |value| < 48 p for every register (top limb below 2^(LB-1),
+// what a product asks of its operands) and that the products in between pull the magnitudes back (tools/gen_coop.py analyse); the other limbs come out
+// carried (|limb| <= 2^(LB-1) + sum of |coefficients|).
+template <class C>
+ELP_INL Fp<C> coop_lin_carry(const i64* acc) {
+  constexpr int NL = C::NL;
+  Fp<C> r;
+  i32 cy[NL];
+  ELP_UNROLL
+  for (int i = 0; i < NL - 1; i++) {
+    const i32 lo = elp_balanced<C::LB>((u32)acc[i]);
+    cy[i] = (i32)((acc[i] - lo) >> C::LB);
+    r.v[i] = lo;
+  }
+  ELP_UNROLL
+  for (int i = 1; i < NL - 1; i++) r.v[i] += cy[i - 1];
+  const i64 top = acc[NL - 1] + cy[NL - 2];
+#if defined(ELP_BOUND_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+  assert(top > -((i64)1 << (C::LB - 1)) && top < ((i64)1 << (C::LB - 1)));
+#endif
+  r.v[NL - 1] = (i32)top;
+  return r;
+}
+
 // constant `id` of the MULC operations, component `comp` (Montgomery form), from the curve parameters
 template <class C>
 ELP_HEAVY Fp<C> coop_const(const uint8_t (*kind)[3], int id, int comp) {
@@ -106,75 +138,91 @@ ELP_HEAVY Fp<C> coop_const(const uint8_t (*kind)[3], int id, int comp) {
 }
 
 // One slot of one step for the lane of parity `comp`: computes the component `comp` of the slot's result.  Returns the destination register or -1
-// (empty slot).  `consts`: the COOP_NCONST Fp2 constants in the layout of the register file (the kernels keep them in LDS); `lines`: the precomputed
-// lines of the fixed argument as a flat array of Fp2 (a, b, c per line; stored un-carried by ml_precompute, carried here).
+// (empty slot).  `consts`: the COOP_NCONST Fp2 constants in the layout of the register file (the kernels keep them in LDS); `lines_w`: the precomputed
+// lines of the fixed argument as a flat array of Fp2 (a, b, c per line; stored un-carried by ml_precompute, carried here), seen as words, from coefficient
+// `line_base` on (the kernels stage the coefficients a chunk of steps reads through LDS together with the chunk: read in place, each costs the step that
+// needs it a global-memory round trip; the host twin passes the whole array and 0).
 // (inlined into the kernels' step loop: as a call, the result would travel through the lane's private memory -- a global-memory round trip per step)
 template <class C>
-ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const coop_i32* consts, const Fp2<C>* lines, Fp<C>& out);
+ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u16* terms, int comp, const coop_i32* R, const coop_i32* consts, const coop_i32* lines_w, int line_base, Fp<C>& out);
 #if !defined(__HIP_DEVICE_COMPILE__)
 template <class C>
 ELP_INL int coop_exec_slot(const CoopProg& P, int step, int slot, int comp, const i32* R, const i32* consts, const Fp2<C>* lines, Fp<C>& out) {
-  return coop_exec_desc<C>(P.prog[((size_t)step * P.np + slot) * 2], P.prog[((size_t)step * P.np + slot) * 2 + 1], P.terms, comp, R, consts, lines, out);
+  return coop_exec_desc<C>(P.prog[((size_t)step * P.np + slot) * 2], P.prog[((size_t)step * P.np + slot) * 2 + 1], reinterpret_cast<const uint16_t*>(P.terms), comp, R, consts,
+                           reinterpret_cast<const i32*>(lines), 0, out);
 }
 #endif
-// the same from the two descriptor words; `terms[d1 + t]` must be term t of a LIN descriptor (the kernels pass a pointer into their LDS copy of the chunk)
+// the same from the two descriptor words; `terms[d1 + t]` must be entry t of a LIN descriptor (the kernels pass a pointer into their LDS copy of the chunk)
 template <class C>
-ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u32* terms, int comp, const coop_i32* R, const coop_i32* consts, const Fp2<C>* lines, Fp<C>& out) {
+ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u16* terms, int comp, const coop_i32* R, const coop_i32* consts, const coop_i32* lines_w, int line_base, Fp<C>& out) {
   const int op = (int)(d0 >> 28);
   if (op == COOP_OP_NOP) return -1;
   const int dst = (int)((d0 >> 20) & 255);
   if (op <= COOP_OP_MULS) {
+    // component 0: a0 b0 - a1 b1;  component 1: a0 b1 + a1 b0  -- one two-term inner product  a0 y + a1 w  with a single reduction per lane.  The three kinds
+    // differ only in WHERE y and w are read (selected by address, one instruction stream: the lanes of a step mix them freely):
+    //   MUL  : b = register rb              y = b[comp], w = b[1 - comp]
+    //   MULC : b = constant (rb << 4) | x   the same, from the constants
+    //   MULS : b = (s, 0), s = component x of register rb:  y = comp ? 0 : s,  w = comp ? s : 0   (0 = the imaginary part of the pinned input ONE)
+    // and w is negated on the lane of component 0.
     const int ra = (int)((d0 >> 12) & 255), rb = (int)((d0 >> 4) & 255), x = (int)(d0 & 15);
+    const bool isc = op == COOP_OP_MULC, iss = op == COOP_OP_MULS;
+    const coop_i32* pb = isc ? consts : R;
+    const int regb = isc ? ((rb << 4) | x) : rb;
+    const int so = (rb * 2 + x) * C::NL, zo = (COOP_IN_ONE * 2 + 1) * C::NL;
+    const int oy = iss ? (comp ? zo : so) : (regb * 2 + comp) * C::NL;
+    const int ow = iss ? (comp ? so : zo) : (regb * 2 + (comp ^ 1)) * C::NL;
     const Fp<C> a0 = coop_ld<C>(R, ra, 0), a1 = coop_ld<C>(R, ra, 1);
-    Fp<C> b0, b1;
-    if (op == COOP_OP_MUL) {
-      b0 = coop_ld<C>(R, rb, 0);
-      b1 = coop_ld<C>(R, rb, 1);
-    } else if (op == COOP_OP_MULC) {
-      b0 = coop_ld<C>(consts, (rb << 4) | x, 0);
-      b1 = coop_ld<C>(consts, (rb << 4) | x, 1);
-    } else {                                     // a * (Fp scalar): b = (s, 0)
-      b0 = coop_ld<C>(R, rb, x);
-      b1 = fp_zero<C>();
-    }
-    // component 0: a0 b0 - a1 b1;  component 1: a0 b1 + a1 b0  -- one two-term inner product with a single reduction per lane
-    const Fp<C> y = comp ? b1 : b0;
-    const Fp<C> w = comp ? b0 : fp_neg(b1);
+    Fp<C> y, w;
+    ELP_UNROLL
+    for (int i = 0; i < C::NL; i++) y.v[i] = pb[oy + i];
+    ELP_UNROLL
+    for (int i = 0; i < C::NL; i++) w.v[i] = pb[ow + i];
+    const i32 sg = comp ? 0 : -1;                   // (v ^ sg) - sg = comp ? v : -v
+    ELP_UNROLL
+    for (int i = 0; i < C::NL; i++) w.v[i] = (w.v[i] ^ sg) - sg;
     out = fp_mul_pair<C>(a0, y, a1, w);
     return dst;
   }
   if (op == COOP_OP_LIN) {
-    const int nt = (int)(d0 & 0xFFFFF);
+    // this lane's entries: n0 of them for the real component, then n1 for the imaginary one; an entry names ONE source component (its word offset in the
+    // register file) and a coefficient -- a diagonal term costs a lane one load, a xi-multiple two
+    const int n0 = (int)(d0 & 127), n1 = (int)((d0 >> 7) & 127);
+    const int n = comp ? n1 : n0;
+    const coop_u16* ent = terms + d1 + (comp ? n0 : 0);
     i64 acc[C::NL];
     for (int i = 0; i < C::NL; i++) acc[i] = 0;
-    const int sh = comp ? 0 : 8;                  // row of the matrix that produces this lane's component: (m00 m01) or (m10 m11)
-    // four terms per round: the term words first, then all their operands (unconditionally: a zero coefficient costs nothing but the load), then the
-    // multiply-adds -- two LDS round trips per FOUR terms instead of two per term (a lone wave has nothing else to hide them behind)
+    // four entries per round (the lists are padded to multiples of four and start at multiples of 8 bytes): ONE 64-bit load of the entries, then all their
+    // operands, then the multiply-adds -- two LDS round trips per FOUR entries (a lone wave has nothing else to hide them behind)
+    const coop_u64* ent4 = reinterpret_cast<const coop_u64*>(ent);
     ELP_NOUNROLL
-    for (int t = 0; t < nt; t += 4) {
-      u32 tw[4];
+    for (int t = 0; t < n; t += 4) {
+      const unsigned long long ew = ent4[t >> 2];
+      u32 e[4];
       ELP_UNROLL
-      for (int q = 0; q < 4; q++) tw[q] = (t + q < nt) ? terms[d1 + t + q] : 0u;      // a zero word: register 0, coefficients 0
-      Fp<C> v0[4], v1[4];
+      for (int q = 0; q < 4; q++) e[q] = (u32)(ew >> (16 * q)) & 0xFFFFu;
+      Fp<C> v[4];
       ELP_UNROLL
       for (int q = 0; q < 4; q++) {
-        const int r = (int)((tw[q] >> 16) & 255);
-        v0[q] = coop_ld<C>(R, r, 0);
-        v1[q] = coop_ld<C>(R, r, 1);
+        const coop_i32* p = R + (e[q] >> 4);
+        ELP_UNROLL
+        for (int i = 0; i < C::NL; i++) v[q].v[i] = p[i];
       }
       ELP_UNROLL
       for (int q = 0; q < 4; q++) {
-        const i32 c0 = ((i32)((tw[q] >> (sh + 4)) << 28)) >> 28, c1 = ((i32)((tw[q] >> sh) << 28)) >> 28;
+        const i32 c = ((i32)(e[q] << 28)) >> 28;
         ELP_UNROLL
-        for (int i = 0; i < C::NL; i++) acc[i] += (i64)c0 * v0[q].v[i] + (i64)c1 * v1[q].v[i];
+        for (int i = 0; i < C::NL; i++) acc[i] += (i64)c * v[q].v[i];
       }
     }
-    out = coop_lin_finish<C>(acc);
+    out = (d0 & COOP_LIN_LIGHT) ? coop_lin_carry<C>(acc) : coop_lin_finish<C>(acc);
     return dst;
   }
   if (op == COOP_OP_LDL) {
-    const int k = (int)(d0 & 0xFFF);
-    out = comp ? lines[k].c1 : lines[k].c0;
+    const int k = (int)(d0 & 0xFFF) - line_base;
+    const coop_i32* p = lines_w + (k * 2 + comp) * C::NL;
+    ELP_UNROLL
+    for (int i = 0; i < C::NL; i++) out.v[i] = p[i];
     fp_carry(out);
     return dst;
   }

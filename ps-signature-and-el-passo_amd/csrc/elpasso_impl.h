@@ -352,15 +352,15 @@ template <> \
 struct CoopTables<CURVE> { \
   static __device__ __forceinline__ CoopProg check() { \
     using namespace elp::NS; \
-    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}, CHECK_CHUNK_OFF}; \
+    return CoopProg{CHECK_PROG, CHECK_CLASS, CHECK_TERMS, CHECK_NSTEPS, {CHECK_OUT[0], CHECK_OUT[1], CHECK_OUT[2], CHECK_OUT[3], CHECK_OUT[4], CHECK_OUT[5]}, CHECK_CHUNK_OFF, 16, CHECK_CHUNK_LINE}; \
   } \
   static __device__ __forceinline__ CoopProg check32() { \
     using namespace elp::NS; \
-    return CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}, CHECK32_CHUNK_OFF}; \
+    return CoopProg{CHECK32_PROG, CHECK32_CLASS, CHECK32_TERMS, CHECK32_NSTEPS, {CHECK32_OUT[0], CHECK32_OUT[1], CHECK32_OUT[2], CHECK32_OUT[3], CHECK32_OUT[4], CHECK32_OUT[5]}, CHECK32_CHUNK_OFF, 32, CHECK32_CHUNK_LINE}; \
   } \
   static __device__ __forceinline__ CoopProg tail() { \
     using namespace elp::NS; \
-    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}, TAIL_CHUNK_OFF}; \
+    return CoopProg{TAIL_PROG, TAIL_CLASS, TAIL_TERMS, TAIL_NSTEPS, {TAIL_OUT[0], TAIL_OUT[1], TAIL_OUT[2], TAIL_OUT[3], TAIL_OUT[4], TAIL_OUT[5]}, TAIL_CHUNK_OFF, 32, TAIL_CHUNK_LINE}; \
   } \
   static_assert(elp::NS::CHECK_NP == 16 && elp::NS::CHECK32_NP == 32 && elp::NS::TAIL_NP == 32, "lane pairs per item of the generated programs"); \
   static constexpr int CHUNK = elp::NS::COOP_CHUNK; \
@@ -369,6 +369,12 @@ struct CoopTables<CURVE> { \
     using namespace elp::NS; \
     return NP_ == 16 ? CHECK_MAX_CHUNK_TERMS : (CHECK32_MAX_CHUNK_TERMS > TAIL_MAX_CHUNK_TERMS ? CHECK32_MAX_CHUNK_TERMS : TAIL_MAX_CHUNK_TERMS); \
   } \
+  template <int NP_> \
+  static constexpr int max_chunk_lines() { \
+    using namespace elp::NS; \
+    return NP_ == 16 ? CHECK_MAX_CHUNK_LINES : (CHECK32_MAX_CHUNK_LINES > TAIL_MAX_CHUNK_LINES ? CHECK32_MAX_CHUNK_LINES : TAIL_MAX_CHUNK_LINES); \
+  } \
+  static_assert(elp::NS::IN_ONE == COOP_IN_ONE, "the interpreter reads its zero from the pinned input ONE"); \
   static constexpr int NREG = elp::NS::COOP_NREG, NCONST = elp::NS::COOP_NCONST; \
   static constexpr int IN_P1 = elp::NS::IN_P1, IN_P2 = elp::NS::IN_P2, IN_QX = elp::NS::IN_QX, IN_QY = elp::NS::IN_QY, \
                        IN_ONE = elp::NS::IN_ONE, IN_F0 = elp::NS::IN_F0; \
@@ -403,7 +409,8 @@ struct CoopLds {
   static constexpr int RPAD = 17;                     // the items of a wave run the same program in lockstep: without the offset item 1 would hit the banks of item 0 on every access
   static constexpr int R_WORDS = ITEMS * (RW + RPAD) + 2 * ITEMS;      // + two flag words per item
   static constexpr int MAXT = T::template max_chunk_terms<NP>();
-  static constexpr int STAGE_WORDS = T::CHUNK * NP * 2 + MAXT + T::NCONST * 2 * C::NL;
+  static constexpr int MAXLW = T::template max_chunk_lines<NP>() * 2 * C::NL;          // words of the line coefficients one chunk reads
+  static constexpr int STAGE_WORDS = T::CHUNK * NP * 2 + MAXT + T::NCONST * 2 * C::NL + MAXLW;
 };
 // orders the LDS traffic of one wave: the lanes of an item sit in one wave and the LDS pipeline serves a wave's accesses in order, so between two steps the
 // program needs no workgroup barrier, only that the compiler keeps the order
@@ -416,30 +423,35 @@ template <class C, int NP>
 __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines,
                                                 bool member = true) {      // member = false: a lane of a wider workgroup that only keeps the workgroup barriers company (k_vid_small)
   typedef CoopTables<C> T;
-  constexpr int MAXT = CoopLds<C, NP>::MAXT;
+  constexpr int MAXT = CoopLds<C, NP>::MAXT, MAXLW = CoopLds<C, NP>::MAXLW;
   constexpr int SW = NP * 2;                            // descriptor words per step (two per lane pair)
   constexpr int CH = T::CHUNK, DW = CH * SW;            // descriptor words per chunk
-  constexpr int ND = DW / ELP_COOP_BLOCK;               // descriptor words per lane and chunk
-  constexpr int NT = (MAXT + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;   // term words per lane and chunk
-  static_assert(DW % ELP_COOP_BLOCK == 0, "a chunk of descriptors is a whole number of words per lane");
+  constexpr int ND = (DW + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;     // descriptor words per lane and chunk
+  constexpr int NT = (MAXT + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;   // entry words per lane and chunk
+  constexpr int NLW = (MAXLW + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK; // line words per lane and chunk
+  static_assert(DW % 2 == 0 && MAXT % 2 == 0, "the entries of a chunk start at a multiple of 8 bytes");
   coop_u32* const sd = stage;
   coop_u32* const stt = stage + DW;
   coop_i32* const cw = (coop_i32*)(stage + DW + MAXT);     // the constants, in the layout of the register file
+  coop_i32* const lw = cw + T::NCONST * 2 * C::NL;         // the line coefficients of the current chunk
   {
     const i32* src = reinterpret_cast<const i32*>(consts);
     if (member)
       for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += ELP_COOP_BLOCK) cw[k] = src[k];
   }
   // chunk c+1 travels from global memory to registers WHILE chunk c executes (all loads of a chunk in flight together, fixed trip counts):
-  // fetched on demand, every chunk opened with a chain of dependent global round trips of ~1 us on waves that have nothing else to run
+  // fetched on demand, every chunk opened with a chain of dependent global round trips of ~1 us on waves that have nothing else to run -- and so did
+  // every step that reads a line of the fixed argument, until the lines travelled with the chunk
   u32 pd[ND];
   u32 pt[NT];
-  u32 t0n = 0, t1n = 0;
+  i32 pl[NLW > 0 ? NLW : 1];
+  u32 t0n = 0, t1n = 0, cln = 0;
   auto fetch = [&](int s0) {
     if (!member) return;
     const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
     t0n = P.chunk_off[s0 / CH];
     t1n = P.chunk_off[s0 / CH + 1];
+    cln = P.chunk_line[s0 / CH];
     const u32* src = P.prog + (size_t)s0 * SW;
     ELP_UNROLL
     for (int j = 0; j < ND; j++) {
@@ -451,29 +463,52 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
       const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
       pt[j] = k < t1n - t0n ? P.terms[t0n + k] : 0u;
     }
+    const i32* lsrc = reinterpret_cast<const i32*>(lines) + (size_t)(cln & 0xFFFFu) * (2 * C::NL);
+    const u32 lwords = (cln >> 16) * (u32)(2 * C::NL);
+    ELP_UNROLL
+    for (int j = 0; j < NLW; j++) {
+      const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+      pl[j] = k < lwords ? lsrc[k] : 0;
+    }
   };
   fetch(0);
   ELP_NOUNROLL
   for (int s0 = 0; s0 < P.nsteps; s0 += CH) {
     const int ns = P.nsteps - s0 < CH ? P.nsteps - s0 : CH;
     const u32 t0 = t0n;
+    const int lbase = (int)(cln & 0xFFFFu);
     __syncthreads();                                   // every wave is done with the previous chunk
     if (member) {
       ELP_UNROLL
-      for (int j = 0; j < ND; j++) sd[(int)threadIdx.x + j * ELP_COOP_BLOCK] = pd[j];
+      for (int j = 0; j < ND; j++) {
+        const int k = (int)threadIdx.x + j * ELP_COOP_BLOCK;
+        if (k < DW) sd[k] = pd[j];
+      }
       ELP_UNROLL
       for (int j = 0; j < NT; j++) {
         const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
         if (k < (u32)MAXT) stt[k] = pt[j];
       }
+      ELP_UNROLL
+      for (int j = 0; j < NLW; j++) {
+        const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+        if (k < (u32)MAXLW) lw[k] = pl[j];
+      }
     }
     __syncthreads();
     if (s0 + CH < P.nsteps) fetch(s0 + CH);
+    // the descriptor of step s + 1 is read while step s runs (it does not depend on the registers): one LDS round trip less on the path of every step
+    u32 nd0 = sd[pair * 2], nd1 = sd[pair * 2 + 1];
     ELP_NOUNROLL
     for (int s = 0; s < ns; s++) {
+      const u32 d0 = nd0, d1 = nd1;
+      if (s + 1 < ns) {
+        nd0 = sd[(s + 1) * SW + pair * 2];
+        nd1 = sd[(s + 1) * SW + pair * 2 + 1];
+      }
       if (active) {
         Fp<C> out;
-        const int dst = coop_exec_desc<C>(sd[s * SW + pair * 2], sd[s * SW + pair * 2 + 1], stt - t0, comp, R, cw, lines, out);
+        const int dst = coop_exec_desc<C>(d0, d1, (const coop_u16*)stt - 2 * (size_t)t0, comp, R, cw, lw, lbase, out);
         if (dst >= 0) coop_st<C>(R, dst, comp, out);     // the register allocation never lets a step write a register that the same step reads
       }
       coop_wave_sync();

@@ -12,15 +12,18 @@ M = Mcl(BN254)
 G, CD, PR = M.G, Codec(M), Protocol(M)
 
 
-@pytest.fixture(scope="module")
-def env():
-    L = twin()
+def make_env(L):
     d = load_golden("bn254_oracle_flows.json")
     pk = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
     L.twin_bn254_ctx_new.restype = ctypes.c_void_p
     h = L.twin_bn254_ctx_new(len(pk.Yi), 4, g1_bases(M, pk, svc=b"svc"), g2_bases(M, pk))
     assert h
     return L, ctypes.c_void_p(h), pk
+
+
+@pytest.fixture(scope="module")
+def env():
+    return make_env(twin())
 
 
 def _gt_bytes(e):

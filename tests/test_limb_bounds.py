@@ -17,6 +17,7 @@ def test_flows_stay_within_limb_bounds(tmp_path):
     L.twin_bls_ctx_new.restype = ctypes.c_void_p
     import test_host_twin as T
     import test_host_twin_bls as TB
+    import test_coop as TC
     saved = elp_testlib._twin
     elp_testlib._twin = L
     try:
@@ -31,5 +32,9 @@ def test_flows_stay_within_limb_bounds(tmp_path):
         TB.test_group_ops(L)
         TB.test_pairing_equals_model_and_is_bilinear(L)
         TB.test_protocol_flows(L)
+        # the cooperative programs: the light finish of a linear combination leaves magnitudes to the generator's analysis (tools/gen_coop.py analyse);
+        # here every product operand, every lazy sum and every top limb of those programs is checked on real values
+        TC.test_program_value_equals_model_pairing_product(TC.make_env(L))
+        TC.test_bls12_381_programs_on_the_host_twin()
     finally:
         elp_testlib._twin = saved

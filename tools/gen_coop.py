@@ -39,7 +39,7 @@ def naf(k):      # non-adjacent form, least significant digit first (as tools/ge
 
 
 NP = 16            # lane pairs per item
-CHUNK = 8          # steps per program chunk staged through LDS by the kernels
+CHUNK = 4          # steps per program chunk staged through LDS by the kernels
 NREG = 120         # Fp2 registers per item in LDS
 
 # ---- operations (SSA).  mul-class: MUL (a*b), MULC (a * constant[c]), MULS (a * Fp scalar = component `sel` of register b)
@@ -545,7 +545,7 @@ def srcs(op):
     return [x for x in (a, b) if x >= 0]
 
 
-def schedule(prog, outs, ninputs, np_=None):
+def schedule(prog, outs, ninputs, np_=None, cv=None):
     NP_ = np_ or NP
     ops = prog.ops
     live = [False] * len(ops)
@@ -556,6 +556,8 @@ def schedule(prog, outs, ninputs, np_=None):
             continue
         live[i] = True
         stack.extend(srcs(ops[i]))
+    vb, light = analyse(cv, ops, live)
+    prog.vb, prog.light = vb, light
     # ASAP levels; a level holds one class only: lin-class operations on even levels, products on odd ones
     level = [0] * len(ops)
     for i, op in enumerate(ops):
@@ -606,11 +608,25 @@ def schedule(prog, outs, ninputs, np_=None):
         if live[i] and ops[i][0] != INPUT:
             by_level[level[i]].append(i)
     # split levels wider than NP into rounds (each round is one barrier-separated step of the kernel)
+    # The lanes of a wave walk a step in lockstep: a round costs what its most expensive slot costs, and slots that take different paths (light / heavy
+    # finish of a combination) cost the sum.  Rounds are therefore cut from the level's operations SORTED by kind and length, in contiguous runs.
+    def weight(i):
+        if ops[i][0] != LIN:
+            return (0, 0)
+        return (0 if i in light else 1, max(sum(1 for _, m in ops[i][3] if m[0] or m[1]) + sum(1 for _, m in ops[i][3] if m[0] and m[1]),
+                                              sum(1 for _, m in ops[i][3] if m[2] or m[3]) + sum(1 for _, m in ops[i][3] if m[2] and m[3])))
     steps = []
     for lv, lst in enumerate(by_level):
         nr = (len(lst) + NP_ - 1) // NP_
+        if nr == 0:
+            continue
+        srt = sorted(lst, key=lambda i: (weight(i), i))
+        base, extra = divmod(len(srt), nr)
+        at = 0
         for k in range(nr):                              # balanced rounds
-            steps.append((lv & 1, lst[k::nr]))
+            n_ = base + (1 if k < extra else 0)
+            steps.append((lv & 1, srt[at:at + n_]))
+            at += n_
     step_of = {}
     for si, (_, lst) in enumerate(steps):
         for i in lst:
@@ -653,21 +669,93 @@ def schedule(prog, outs, ninputs, np_=None):
     return steps, reg, list(outs), peak
 
 
-def encode(ops, steps, reg, np_=None):
+# ---- magnitudes: which linear combinations may skip the modular reduction
+# The interpreter finishes a combination either HEAVY (sequential carry, quotient by p estimated from the top limb, q p subtracted: |value| < 1.5 p, ~150
+# instructions) or LIGHT (one parallel carry pass, the integer value untouched, ~55 instructions).  A product shrinks whatever it is given --
+# |a0 y + a1 w| / R + 0.51 p with R / p = 2^7.4 (BN254) or 2^11.3 (BLS12-381) -- so most combinations can stay light; what has to hold is that every
+# register stays below MAG p: the top limb of a product operand must stay below 2^(LB-1) (BN254: 84 p) and a heavy finish reads its quotient from a
+# top limb below 2^31 (BN254: 675 p).  `analyse` walks the operations in SSA order with a bound on |value| / p per operation.
+LIMBS = {"bn254": (9, 29), "bls12_381": (14, 28)}
+MAG = 48.0
+HEAVY_IN = 600.0
+HEAVY_OUT = 1.5
+LINE_MAG = 4.0            # the stored lines of the fixed argument are lazy sums of up to three products (csrc/elp/pairing.h ml_dbl_step_inl)
+
+
+def curve_name(cv):
+    return "bn254" if cv.is_bn else "bls12_381"
+
+
+def analyse(cv, ops, live=None):
+    """Returns (bound on |value| / p per operation, set of LIN operations that take the light finish)."""
+    nl, lb = LIMBS[curve_name(cv)]
+    rho = cv.p / float(1 << (nl * lb))
+    vb = [0.0] * len(ops)
+    light = set()
+    for i, (op, a, b, aux) in enumerate(ops):
+        if live is not None and not live[i]:
+            continue
+        if op == INPUT:
+            vb[i] = 1.5                       # canonical coordinates, or the Fp12 product of the aggregated tail
+        elif op == LDL:
+            vb[i] = LINE_MAG
+        elif op == MUL:
+            vb[i] = 2 * vb[a] * vb[b] * rho + 0.51
+        elif op == MULC:
+            vb[i] = 2 * vb[a] * 1.0 * rho + 0.51
+        elif op == MULS:
+            vb[i] = vb[a] * vb[b] * rho + 0.51
+        elif op == INV:
+            vb[i] = 1.1
+        elif op == LIN:
+            s0 = sum((abs(m[0]) + abs(m[1])) * vb[k] for k, m in aux)
+            s1 = sum((abs(m[2]) + abs(m[3])) * vb[k] for k, m in aux)
+            sm = max(s0, s1)
+            if sm <= MAG:
+                light.add(i)
+                vb[i] = sm
+            else:
+                assert sm <= HEAVY_IN, ("combination too large for the heavy finish", i, sm)
+                vb[i] = HEAVY_OUT
+        assert vb[i] <= MAG, (i, NAMES[op], vb[i])
+    return vb, light
+
+
+def lin_entries(m_terms, reg, nl):
+    """Per component the list of (word offset of the source component in the register file, coefficient) of a combination."""
+    out = ([], [])
+    for k, m in m_terms:
+        for comp in (0, 1):
+            for sel in (0, 1):
+                c = m[2 * comp + sel]
+                if c:
+                    out[comp].append(((reg[k] * 2 + sel) * nl, c))
+    return out
+
+
+def encode(ops, steps, reg, np_=None, light=(), nl=9):
     """Two 32-bit words per (step, slot):  word 0 = op:4 | dst:8 | a:8 | b:8 | aux:4  (LDL / MULC carry their index in b:aux, 12 bits); a LIN descriptor is
-    word 0 = op:4 | dst:8 | nterms:20, word 1 = offset into the term table, one word per term:  reg:8 | m00:4 | m01:4 | m10:4 | m11:4 (two's complement
-    nibbles);  NOP = 0xF."""
-    words, terms = [], []
-    for cls, lst in steps:
+    word 0 = op:4 | dst:8 | light:1 (bit 19) | n1:7 | n0:7, word 1 = index of its first entry in the table of 16-bit entries: n0 entries for the lane that
+    computes the real component, then n1 for the other;  entry = word offset of a source component in the register file:12 | coefficient:4 (two's
+    complement); every list is padded to a multiple of four entries (zero entries), so lists and chunks start at multiples of 8 bytes.  NOP = 0xF."""
+    words, ents = [], []
+    chunk_words = []
+    for si, (cls, lst) in enumerate(steps):
+        if si % CHUNK == 0:
+            chunk_words.append(len(ents) // 2)
         row = []
         for i in lst:
             op, a, b, aux = ops[i]
             if op == LIN:
-                off = len(terms)
-                assert off < (1 << 20) - 64
-                for k, m in aux:
-                    terms.append((reg[k] << 16) | ((m[0] & 15) << 12) | ((m[1] & 15) << 8) | ((m[2] & 15) << 4) | (m[3] & 15))
-                row += [(op << 28) | (reg[i] << 20) | len(aux), off]
+                e0, e1 = lin_entries(aux, reg, nl)
+                e0 += [(0, 0)] * (-len(e0) % 4)         # the interpreter reads four entries at a time (one 64-bit LDS load): lists are padded with
+                e1 += [(0, 0)] * (-len(e1) % 4)         # "0 x component 0 of register 0" and therefore start at multiples of 8 bytes
+                assert len(e0) < 128 and len(e1) < 128
+                off = len(ents)
+                for o_, c_ in e0 + e1:
+                    assert 0 <= o_ < 4096 and -8 <= c_ <= 7
+                    ents.append((o_ << 4) | (c_ & 15))
+                row += [(op << 28) | (reg[i] << 20) | ((1 << 19) if i in light else 0) | (len(e1) << 7) | len(e0), off]
                 continue
             ra = reg[a] if a >= 0 else 0
             rb = reg[b] if b >= 0 else 0
@@ -679,7 +767,10 @@ def encode(ops, steps, reg, np_=None):
             row += [(op << 28) | (reg[i] << 20) | (ra << 12) | (rb << 4) | x, 0]
         row += [0xF0000000, 0] * ((np_ or NP) - len(row) // 2)
         words.append(row)
-    return words, terms
+    assert len(ents) % 4 == 0
+    chunk_words.append(len(ents) // 2)
+    terms = [ents[2 * k] | (ents[2 * k + 1] << 16) for k in range(len(ents) // 2)]
+    return words, terms, chunk_words
 
 
 # ---- numeric execution of the SCHEDULED program in Python (validation of tracing + scheduling + register allocation against the model)
@@ -819,7 +910,7 @@ def validate(cv):
     for name, variable, np_ in (("check", True, 16), ("check32", True, 32), ("tail", False, 32)):
         prog, outs, nlines = trace_check(cv, variable)
         assert 3 * nlines == len(lines)
-        steps, reg, outs_c, peak = schedule(prog, outs, IN_F0 + 6, np_)
+        steps, reg, outs_c, peak = schedule(prog, outs, IN_F0 + 6, np_, cv)
         consts = [None] * len(CONSTS)
         for k, v in CONSTS.items():
             consts[v] = cvals[k]
@@ -879,8 +970,8 @@ def emit_header(res, path, cvname):
     out = []
     A = out.append
     A("// GENERATED by tools/gen_coop.py -- do not edit.  Level-scheduled Fp2 programs of the cooperative pairing kernels (csrc/elp/coop.h).")
-    A("// Each step holds <program>_NP descriptors of two words (one descriptor per lane pair of an item):  op:4 | dst:8 | a:8 | b:8 | aux:4 , 0   (LIN: op:4 | dst:8 | nterms:20 , term offset;")
-    A("// term = reg:8 | four signed nibbles of the 2x2 matrix acting on (re, im)).  *_CLASS: 1 = every slot of the step is an Fp2 product, 0 = linear class.")
+    A("// Each step holds <program>_NP descriptors of two words (one descriptor per lane pair of an item):  op:4 | dst:8 | a:8 | b:8 | aux:4 , 0   (LIN: op:4 | dst:8 | light:1 | n1:7 | n0:7 ,")
+    A("// index of the first 16-bit entry; entry = word offset of the source component in the register file:12 | coefficient:4).  *_CLASS: 1 = every slot of the step is an Fp2 product, 0 = linear class.")
     A("#pragma once")
     A("#include <stdint.h>")
     A("#ifndef ELP_COOP_TABLE")
@@ -909,10 +1000,12 @@ def emit_header(res, path, cvname):
             kinds.append((3, int(n_), 0 if w_ == "x" else 1))
     A("ELP_COOP_TABLE const uint8_t CONST_KIND[%d][3] = {%s};" % (len(kinds), ",".join("{%d,%d,%d}" % k for k in kinds)))
     for name, (prog, steps, reg, outs_c, peak, nmul, nlin, np_) in res.items():
-        words, terms = encode(prog.ops, steps, reg, np_)
+        words, terms, offs = encode(prog.ops, steps, reg, np_, prog.light, LIMBS[cvname][0])
         U = name.upper()
+        nlight = sum(1 for _, lst in steps for i in lst if prog.ops[i][0] == LIN and i in prog.light)
         A("constexpr int %s_NP = %d;" % (U, np_))
-        A("// %s: %d steps (%d products, %d linear-class operations, %d terms), peak %d registers" % (name, len(steps), nmul, nlin, len(terms), peak))
+        A("// %s: %d steps (%d products, %d linear-class operations of which %d keep the light finish, %d words of entries), peak %d registers" %
+          (name, len(steps), nmul, nlin, nlight, len(terms), peak))
         A("constexpr int %s_NSTEPS = %d;" % (U, len(steps)))
         A("constexpr int %s_NTERMS = %d;" % (U, len(terms)))
         A("constexpr int %s_OUT[6] = {%s};" % (U, ", ".join(str(reg[o]) for o in outs_c)))
@@ -921,15 +1014,15 @@ def emit_header(res, path, cvname):
         for row in words:
             A("  " + ",".join("0x%08xu" % w for w in row) + ",")
         A("};")
-        # the kernels stage the program through LDS in chunks of COOP_CHUNK steps: first term of every chunk (+ end)
-        offs, cnt = [], 0
-        for si, (cls, lst) in enumerate(steps):
-            if si % CHUNK == 0:
-                offs.append(cnt)
-            cnt += sum(len(prog.ops[i][3]) for i in lst if prog.ops[i][0] == LIN)
-        offs.append(cnt)
-        assert cnt == len(terms)
+        # the kernels stage the program through LDS in chunks of COOP_CHUNK steps: first word of the entries of every chunk (+ end)
         mx = max(b - a for a, b in zip(offs, offs[1:]))
+        # ... and with every chunk the coefficients of the fixed lines its LDL operations read (a contiguous range: first | count << 16)
+        cl = []
+        for c0 in range(0, len(steps), CHUNK):
+            ks = [prog.ops[i][3] for _, lst in steps[c0:c0 + CHUNK] for i in lst if prog.ops[i][0] == LDL]
+            cl.append((min(ks) | ((max(ks) - min(ks) + 1) << 16)) if ks else 0)
+        A("constexpr int %s_MAX_CHUNK_LINES = %d;" % (U, max(c >> 16 for c in cl)))
+        A("ELP_COOP_TABLE const uint32_t %s_CHUNK_LINE[%d] = {%s};" % (U, len(cl), ",".join(str(c) for c in cl)))
         A("constexpr int %s_MAX_CHUNK_TERMS = %d;" % (U, mx))
         A("ELP_COOP_TABLE const uint32_t %s_CHUNK_OFF[%d] = {%s};" % (U, len(offs), ",".join(str(o) for o in offs)))
         A("ELP_COOP_TABLE const uint32_t %s_TERMS[%d] = {" % (U, max(1, len(terms))))
