@@ -44,7 +44,7 @@ typedef uint16_t coop_u16;
 typedef unsigned long long coop_u64;
 #endif
 
-enum { COOP_OP_MUL = 0, COOP_OP_MULC = 1, COOP_OP_MULS = 2, COOP_OP_LIN = 3, COOP_OP_LDL = 4, COOP_OP_INV = 5, COOP_OP_NOP = 15 };
+enum { COOP_OP_MUL = 0, COOP_OP_MULC = 1, COOP_OP_MULS = 2, COOP_OP_LIN = 3, COOP_OP_LDL = 4, COOP_OP_INV = 5, COOP_OP_SQR = 6, COOP_OP_NOP = 15 };
 constexpr int COOP_IN_ONE = 4;             // register pinned to the constant (1, 0) in every program (tools/gen_coop.py IN_ONE; CoopTables<C>::IN_ONE is checked against it)
 constexpr u32 COOP_LIN_LIGHT = 1u << 19;   // LIN descriptor: the combination keeps the light finish (tools/gen_coop.py analyse)
 
@@ -67,7 +67,7 @@ ELP_INL void coop_st(coop_i32* R, int reg, int comp, const Fp<C>& a) {
 }
 
 // sum of 64-bit limb accumulators -> carried limbs of a value in (-1.5 p, 1.5 p): sequential carry, quotient by p estimated from the top limb
-// (the generator bounds sum |coefficient| |value| of a combination by 600 p, so the top limb stays below 2^31 and top * QK fits 64 bits), q p subtracted
+// (the generator bounds sum |coefficient| |value| of a combination by 600 p -- 8 000 p on BLS12-381 --, so the top limb stays below 2^31 and top * QK fits 64 bits), q p subtracted
 template <class C>
 ELP_INL Fp<C> coop_lin_finish(const i64* acc) {
   constexpr int NL = C::NL;
@@ -96,7 +96,7 @@ ELP_INL Fp<C> coop_lin_finish(const i64* acc) {
   return r;
 }
 
-// the light finish: ONE parallel carry pass, the integer value untouched.  The generator proves |value| < 48 p for every register (top limb below 2^(LB-1),
+// the light finish: ONE parallel carry pass, the integer value untouched.  The generator proves |value| < 48 p (BN254; 256 p on BLS12-381) for every register (top limb below 2^(LB-1),
 // what a product asks of its operands) and that the products in between pull the magnitudes back (tools/gen_coop.py analyse); the other limbs come out
 // carried (|limb| <= 2^(LB-1) + sum of |coefficients|).
 template <class C>
@@ -184,6 +184,20 @@ ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u16* terms, int comp, cons
     out = fp_mul_pair<C>(a0, y, a1, w);
     return dst;
   }
+  if (op == COOP_OP_SQR) {
+    // a step of squarings only (the generator never mixes them with other products: lanes on two paths would pay for both):
+    // component 0: (a0 + a1)(a0 - a1);  component 1: (2 a0) a1  -- ONE product of lazy sums per lane, a third fewer multiply-adds than the inner product
+    const int ra = (int)((d0 >> 12) & 255);
+    const Fp<C> a0 = coop_ld<C>(R, ra, 0), a1 = coop_ld<C>(R, ra, 1);
+    Fp<C> x, y;
+    ELP_UNROLL
+    for (int i = 0; i < C::NL; i++) {
+      x.v[i] = a0.v[i] + (comp ? a0.v[i] : a1.v[i]);
+      y.v[i] = comp ? a1.v[i] : a0.v[i] - a1.v[i];
+    }
+    out = fp_mul<C>(x, y);
+    return dst;
+  }
   if (op == COOP_OP_LIN) {
     // this lane's entries: n0 of them for the real component, then n1 for the imaginary one; an entry names ONE source component (its word offset in the
     // register file) and a coefficient -- a diagonal term costs a lane one load, a xi-multiple two
@@ -195,9 +209,11 @@ ELP_INL int coop_exec_desc(u32 d0, u32 d1, const coop_u16* terms, int comp, cons
     // four entries per round (the lists are padded to multiples of four and start at multiples of 8 bytes): ONE 64-bit load of the entries, then all their
     // operands, then the multiply-adds -- two LDS round trips per FOUR entries (a lone wave has nothing else to hide them behind)
     const coop_u64* ent4 = reinterpret_cast<const coop_u64*>(ent);
+    unsigned long long nw = ent4[0];               // the entries of round r + 1 are read while round r runs (past the last list: two words of padding)
     ELP_NOUNROLL
     for (int t = 0; t < n; t += 4) {
-      const unsigned long long ew = ent4[t >> 2];
+      const unsigned long long ew = nw;
+      nw = ent4[(t >> 2) + 1];
       u32 e[4];
       ELP_UNROLL
       for (int q = 0; q < 4; q++) e[q] = (u32)(ew >> (16 * q)) & 0xFFFFu;

@@ -612,7 +612,7 @@ def schedule(prog, outs, ninputs, np_=None, cv=None):
     # finish of a combination) cost the sum.  Rounds are therefore cut from the level's operations SORTED by kind and length, in contiguous runs.
     def weight(i):
         if ops[i][0] != LIN:
-            return (0, 0)
+            return (0, 0 if is_square(ops[i]) else 1)          # squarings together: a round of squarings only runs the cheaper SQR
         return (0 if i in light else 1, max(sum(1 for _, m in ops[i][3] if m[0] or m[1]) + sum(1 for _, m in ops[i][3] if m[0] and m[1]),
                                               sum(1 for _, m in ops[i][3] if m[2] or m[3]) + sum(1 for _, m in ops[i][3] if m[2] and m[3])))
     steps = []
@@ -627,6 +627,20 @@ def schedule(prog, outs, ninputs, np_=None, cv=None):
             n_ = base + (1 if k < extra else 0)
             steps.append((lv & 1, srt[at:at + n_]))
             at += n_
+    # a linear step that holds both kinds of finish pays for both: where one combination of a step needs the heavy finish, all of its combinations take it
+    force = set()
+    while True:
+        more = set()
+        for cls, lst in steps:
+            if cls == 0:
+                lins = [i for i in lst if ops[i][0] == LIN]
+                if any(i not in light for i in lins):
+                    more |= {i for i in lins if i in light}
+        if not more:
+            break
+        force |= more
+        vb, light = analyse(cv, ops, live, force)
+    prog.vb, prog.light = vb, light
     step_of = {}
     for si, (_, lst) in enumerate(steps):
         for i in lst:
@@ -674,11 +688,13 @@ def schedule(prog, outs, ninputs, np_=None, cv=None):
 # instructions) or LIGHT (one parallel carry pass, the integer value untouched, ~55 instructions).  A product shrinks whatever it is given --
 # |a0 y + a1 w| / R + 0.51 p with R / p = 2^7.4 (BN254) or 2^11.3 (BLS12-381) -- so most combinations can stay light; what has to hold is that every
 # register stays below MAG p: the top limb of a product operand must stay below 2^(LB-1) (BN254: 84 p) and a heavy finish reads its quotient from a
-# top limb below 2^31 (BN254: 675 p).  `analyse` walks the operations in SSA order with a bound on |value| / p per operation.
+# top limb below 2^31 (BN254: 675 p).  `analyse` walks the operations in SSA order with a bound on |value| / p per operation.  A squaring is bounded as the
+# single product of lazy sums it may become (SQR_CODE, operands below MAG / 2 only): |(a0 + a1)(a0 - a1)| <= 4 |a|^2.
 LIMBS = {"bn254": (9, 29), "bls12_381": (14, 28)}
-MAG = 48.0
-HEAVY_IN = 600.0
+# (MAG, largest sum |coefficient| |value| / p a heavy finish accepts): BN254 p >> 232 = 2^21.6, BLS12-381 p >> 364 = 2^16.7
+MAGS = {"bn254": (48.0, 600.0), "bls12_381": (256.0, 8000.0)}
 HEAVY_OUT = 1.5
+SQR_CODE = 6              # opcode of a squaring in a step made of squarings only (encode): one single-reduction product per lane, (a0 + a1)(a0 - a1) | (2 a0) a1
 LINE_MAG = 4.0            # the stored lines of the fixed argument are lazy sums of up to three products (csrc/elp/pairing.h ml_dbl_step_inl)
 
 
@@ -686,9 +702,10 @@ def curve_name(cv):
     return "bn254" if cv.is_bn else "bls12_381"
 
 
-def analyse(cv, ops, live=None):
+def analyse(cv, ops, live=None, force_heavy=()):
     """Returns (bound on |value| / p per operation, set of LIN operations that take the light finish)."""
     nl, lb = LIMBS[curve_name(cv)]
+    mag, heavy_in = MAGS[curve_name(cv)]
     rho = cv.p / float(1 << (nl * lb))
     vb = [0.0] * len(ops)
     light = set()
@@ -700,7 +717,7 @@ def analyse(cv, ops, live=None):
         elif op == LDL:
             vb[i] = LINE_MAG
         elif op == MUL:
-            vb[i] = 2 * vb[a] * vb[b] * rho + 0.51
+            vb[i] = (4 if a == b and vb[a] <= mag / 2 else 2) * vb[a] * vb[b] * rho + 0.51       # a squaring of a value below MAG / 2 may run as SQR
         elif op == MULC:
             vb[i] = 2 * vb[a] * 1.0 * rho + 0.51
         elif op == MULS:
@@ -711,14 +728,18 @@ def analyse(cv, ops, live=None):
             s0 = sum((abs(m[0]) + abs(m[1])) * vb[k] for k, m in aux)
             s1 = sum((abs(m[2]) + abs(m[3])) * vb[k] for k, m in aux)
             sm = max(s0, s1)
-            if sm <= MAG:
+            if sm <= mag and i not in force_heavy:
                 light.add(i)
                 vb[i] = sm
             else:
-                assert sm <= HEAVY_IN, ("combination too large for the heavy finish", i, sm)
+                assert sm <= heavy_in, ("combination too large for the heavy finish", i, sm)
                 vb[i] = HEAVY_OUT
-        assert vb[i] <= MAG, (i, NAMES[op], vb[i])
+        assert vb[i] <= mag, (i, NAMES[op], vb[i])
     return vb, light
+
+
+def is_square(op):
+    return op[0] == MUL and op[1] == op[2]
 
 
 def lin_entries(m_terms, reg, nl):
@@ -733,9 +754,9 @@ def lin_entries(m_terms, reg, nl):
     return out
 
 
-def encode(ops, steps, reg, np_=None, light=(), nl=9):
+def encode(ops, steps, reg, np_=None, light=(), nl=9, sqr_ok=None):
     """Two 32-bit words per (step, slot):  word 0 = op:4 | dst:8 | a:8 | b:8 | aux:4  (LDL / MULC carry their index in b:aux, 12 bits); a LIN descriptor is
-    word 0 = op:4 | dst:8 | light:1 (bit 19) | n1:7 | n0:7, word 1 = index of its first entry in the table of 16-bit entries: n0 entries for the lane that
+    word 0 = op:4 | dst:8 | light:1 (bit 19) | n1:7 | n0:7 (a step whose products are all squarings of values below MAG / 2 is encoded with SQR_CODE: op:4 | dst:8 | a:8), word 1 = index of its first entry in the table of 16-bit entries: n0 entries for the lane that
     computes the real component, then n1 for the other;  entry = word offset of a source component in the register file:12 | coefficient:4 (two's
     complement); every list is padded to a multiple of four entries (zero entries), so lists and chunks start at multiples of 8 bytes.  NOP = 0xF."""
     words, ents = [], []
@@ -744,8 +765,12 @@ def encode(ops, steps, reg, np_=None, light=(), nl=9):
         if si % CHUNK == 0:
             chunk_words.append(len(ents) // 2)
         row = []
+        sq_step = cls == 1 and sqr_ok is not None and all(i in sqr_ok for i in lst)
         for i in lst:
             op, a, b, aux = ops[i]
+            if sq_step:
+                row += [(SQR_CODE << 28) | (reg[i] << 20) | (reg[a] << 12), 0]
+                continue
             if op == LIN:
                 e0, e1 = lin_entries(aux, reg, nl)
                 e0 += [(0, 0)] * (-len(e0) % 4)         # the interpreter reads four entries at a time (one 64-bit LDS load): lists are padded with
@@ -770,6 +795,7 @@ def encode(ops, steps, reg, np_=None, light=(), nl=9):
     assert len(ents) % 4 == 0
     chunk_words.append(len(ents) // 2)
     terms = [ents[2 * k] | (ents[2 * k + 1] << 16) for k in range(len(ents) // 2)]
+    terms += [0, 0]          # the interpreter reads the entries of the NEXT round of four while it works on the current one: one 64-bit word past the last list
     return words, terms, chunk_words
 
 
@@ -982,7 +1008,7 @@ def emit_header(res, path, cvname):
     A("constexpr int COOP_NP = %d;   // lane pairs per item of the batch program (CHECK); CHECK32 / TAIL: their own *_NP" % NP)
     A("constexpr int COOP_NREG = %d;" % NREG)
     A("constexpr int COOP_CHUNK = %d;" % CHUNK)
-    A("enum { OP_MUL = %d, OP_MULC = %d, OP_MULS = %d, OP_LIN = %d, OP_LDL = %d, OP_INV = %d, OP_NOP = 15 };" % (MUL, MULC, MULS, LIN, LDL, INV))
+    A("enum { OP_MUL = %d, OP_MULC = %d, OP_MULS = %d, OP_LIN = %d, OP_LDL = %d, OP_INV = %d, OP_SQR = %d, OP_NOP = 15 };" % (MUL, MULC, MULS, LIN, LDL, INV, SQR_CODE))
     A("enum { IN_P1 = %d, IN_P2 = %d, IN_QX = %d, IN_QY = %d, IN_ONE = %d, IN_F0 = %d };" % (IN_P1, IN_P2, IN_QX, IN_QY, IN_ONE, IN_F0))
     A("constexpr int COOP_NCONST = %d;" % len(CONSTS))
     A("// constants of the MULC operations: kind 0 = 1/2, 1 = 3 b' (twist), 2 = Frobenius coefficient gamma_{n,k} of Fp12, 3 = coefficient of psi^n on G2 (k = 0: x, 1: y)")
@@ -1000,12 +1026,14 @@ def emit_header(res, path, cvname):
             kinds.append((3, int(n_), 0 if w_ == "x" else 1))
     A("ELP_COOP_TABLE const uint8_t CONST_KIND[%d][3] = {%s};" % (len(kinds), ",".join("{%d,%d,%d}" % k for k in kinds)))
     for name, (prog, steps, reg, outs_c, peak, nmul, nlin, np_) in res.items():
-        words, terms, offs = encode(prog.ops, steps, reg, np_, prog.light, LIMBS[cvname][0])
+        sqr_ok = {i for i, o in enumerate(prog.ops) if is_square(o) and prog.vb[o[1]] <= MAGS[cvname][0] / 2}
+        words, terms, offs = encode(prog.ops, steps, reg, np_, prog.light, LIMBS[cvname][0], sqr_ok)
+        nsq = sum(1 for c, lst in steps if c == 1 and all(i in sqr_ok for i in lst))
         U = name.upper()
         nlight = sum(1 for _, lst in steps for i in lst if prog.ops[i][0] == LIN and i in prog.light)
         A("constexpr int %s_NP = %d;" % (U, np_))
-        A("// %s: %d steps (%d products, %d linear-class operations of which %d keep the light finish, %d words of entries), peak %d registers" %
-          (name, len(steps), nmul, nlin, nlight, len(terms), peak))
+        A("// %s: %d steps (%d products -- %d steps of squarings only --, %d linear-class operations of which %d keep the light finish, %d words of entries), peak %d registers" %
+          (name, len(steps), nmul, nsq, nlin, nlight, len(terms), peak))
         A("constexpr int %s_NSTEPS = %d;" % (U, len(steps)))
         A("constexpr int %s_NTERMS = %d;" % (U, len(terms)))
         A("constexpr int %s_OUT[6] = {%s};" % (U, ", ".join(str(reg[o]) for o in outs_c)))
