@@ -400,11 +400,11 @@ __global__ void ELP_LAUNCH_BOUNDS k_coop_consts(Fp2<C>* out) {
 // 4.9 KB of program = 39.5 KB per workgroup, four workgroups -- 16 items, two waves per SIMD -- per CU) or 2 items x 32 lane pairs (one item per wave: lone items,
 // batches that leave SIMDs idle anyway, the one closing pairing of aggregated verification: a quarter fewer steps).
 #define ELP_COOP_BLOCK 128
-template <class C, int NP>
+template <class C, int NP, int BLOCK = ELP_COOP_BLOCK>      // BLOCK: lanes of the workgroup that interpret (k_vid_small: all 256, twice the items per workgroup)
 struct CoopLds {
   typedef CoopTables<C> T;
   static constexpr int LANES = 2 * NP;                // lanes of one item
-  static constexpr int ITEMS = ELP_COOP_BLOCK / LANES;
+  static constexpr int ITEMS = BLOCK / LANES;
   static constexpr int RW = T::NREG * 2 * C::NL;      // words of one item's register file
   static constexpr int RPAD = 17;                     // the items of a wave run the same program in lockstep: without the offset item 1 would hit the banks of item 0 on every access
   static constexpr int R_WORDS = ITEMS * (RW + RPAD) + 2 * ITEMS;      // + two flag words per item
@@ -419,16 +419,16 @@ __device__ __forceinline__ void coop_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <class C, int NP>
+template <class C, int NP, int BLOCK = ELP_COOP_BLOCK>
 __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, coop_u32* stage, bool active, int pair, int comp, const Fp2<C>* consts, const Fp2<C>* lines,
                                                 bool member = true) {      // member = false: a lane of a wider workgroup that only keeps the workgroup barriers company (k_vid_small)
   typedef CoopTables<C> T;
-  constexpr int MAXT = CoopLds<C, NP>::MAXT, MAXLW = CoopLds<C, NP>::MAXLW;
+  constexpr int MAXT = CoopLds<C, NP, BLOCK>::MAXT, MAXLW = CoopLds<C, NP, BLOCK>::MAXLW;
   constexpr int SW = NP * 2;                            // descriptor words per step (two per lane pair)
   constexpr int CH = T::CHUNK, DW = CH * SW;            // descriptor words per chunk
-  constexpr int ND = (DW + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;     // descriptor words per lane and chunk
-  constexpr int NT = (MAXT + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK;   // entry words per lane and chunk
-  constexpr int NLW = (MAXLW + ELP_COOP_BLOCK - 1) / ELP_COOP_BLOCK; // line words per lane and chunk
+  constexpr int ND = (DW + BLOCK - 1) / BLOCK;     // descriptor words per lane and chunk
+  constexpr int NT = (MAXT + BLOCK - 1) / BLOCK;   // entry words per lane and chunk
+  constexpr int NLW = (MAXLW + BLOCK - 1) / BLOCK; // line words per lane and chunk
   static_assert(DW % 2 == 0 && MAXT % 2 == 0, "the entries of a chunk start at a multiple of 8 bytes");
   coop_u32* const sd = stage;
   coop_u32* const stt = stage + DW;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
   {
     const i32* src = reinterpret_cast<const i32*>(consts);
     if (member)
-      for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += ELP_COOP_BLOCK) cw[k] = src[k];
+      for (int k = (int)threadIdx.x; k < T::NCONST * 2 * C::NL; k += BLOCK) cw[k] = src[k];
   }
   // chunk c+1 travels from global memory to registers WHILE chunk c executes (all loads of a chunk in flight together, fixed trip counts):
   // fetched on demand, every chunk opened with a chain of dependent global round trips of ~1 us on waves that have nothing else to run -- and so did
@@ -455,19 +455,19 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
     const u32* src = P.prog + (size_t)s0 * SW;
     ELP_UNROLL
     for (int j = 0; j < ND; j++) {
-      const int k = (int)threadIdx.x + j * ELP_COOP_BLOCK;
+      const int k = (int)threadIdx.x + j * BLOCK;
       pd[j] = k < ns * SW ? src[k] : ((k & 1) ? 0u : 0xF0000000u);     // past the end: empty slots
     }
     ELP_UNROLL
     for (int j = 0; j < NT; j++) {
-      const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+      const u32 k = threadIdx.x + (u32)j * BLOCK;
       pt[j] = k < t1n - t0n ? P.terms[t0n + k] : 0u;
     }
     const i32* lsrc = reinterpret_cast<const i32*>(lines) + (size_t)(cln & 0xFFFFu) * (2 * C::NL);
     const u32 lwords = (cln >> 16) * (u32)(2 * C::NL);
     ELP_UNROLL
     for (int j = 0; j < NLW; j++) {
-      const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+      const u32 k = threadIdx.x + (u32)j * BLOCK;
       pl[j] = k < lwords ? lsrc[k] : 0;
     }
   };
@@ -481,17 +481,17 @@ __device__ __forceinline__ void coop_run_device(const CoopProg& P, coop_i32* R, 
     if (member) {
       ELP_UNROLL
       for (int j = 0; j < ND; j++) {
-        const int k = (int)threadIdx.x + j * ELP_COOP_BLOCK;
+        const int k = (int)threadIdx.x + j * BLOCK;
         if (k < DW) sd[k] = pd[j];
       }
       ELP_UNROLL
       for (int j = 0; j < NT; j++) {
-        const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+        const u32 k = threadIdx.x + (u32)j * BLOCK;
         if (k < (u32)MAXT) stt[k] = pt[j];
       }
       ELP_UNROLL
       for (int j = 0; j < NLW; j++) {
-        const u32 k = threadIdx.x + (u32)j * ELP_COOP_BLOCK;
+        const u32 k = threadIdx.x + (u32)j * BLOCK;
         if (k < (u32)MAXLW) lw[k] = pl[j];
       }
     }
@@ -531,16 +531,16 @@ __device__ __forceinline__ bool coop_is_one(const CoopProg& P, coop_i32* R, bool
 }
 // items [0, n): sig1 | sig2 at the head of the record, K in the workspace (vid_store_k layout); todo[i] != 0 selects the items to check.  An item whose sig1,
 // sig2 or K is the point at infinity (or fails validation) is left to the per-lane kernel: done[i] stays 0.  Otherwise flags[i] = verdict, done[i] = 1.
-template <class C, int NP>
+template <class C, int NP, int BLOCK = ELP_COOP_BLOCK>
 __device__ __forceinline__ void pair_coop_body(const KeyCtx<C>& key, const Fp2<C>* consts, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws,
                                                size_t kstride, uint8_t* flags, uint8_t* done, unsigned long long* accepted, size_t n, size_t block, i32* Rall,
                                                u32* stage) {      // Rall / stage: CoopLds<C, NP>::R_WORDS / STAGE_WORDS words of LDS; lanes 0..127 of the workgroup
   typedef CoopTables<C> T;
-  typedef CoopLds<C, NP> L;
-  // The interpreter is laid out for ELP_COOP_BLOCK lanes.  In a wider workgroup (k_vid_small: 256) the lanes above take part in every workgroup barrier and in
+  typedef CoopLds<C, NP, BLOCK> L;
+  // The interpreter is laid out for BLOCK lanes.  In a wider workgroup the lanes above take part in every workgroup barrier and in
   // nothing else -- `member` false, no LDS / global access: leaving early instead would rely on the barrier not counting terminated waves, which the HIP
   // programming model does not promise.
-  const bool member = threadIdx.x < ELP_COOP_BLOCK;
+  const bool member = threadIdx.x < BLOCK;
   const int slot = member ? (int)(threadIdx.x / L::LANES) : 0, pair = (int)((threadIdx.x % L::LANES) >> 1), comp = (int)(threadIdx.x & 1);
   coop_i32* R = (coop_i32*)Rall + slot * (L::RW + L::RPAD);
   coop_i32* flagw = (coop_i32*)Rall + L::ITEMS * (L::RW + L::RPAD) + slot;     // [slot]: is-one flag, [ITEMS + slot]: "inputs usable"
@@ -573,7 +573,7 @@ __device__ __forceinline__ void pair_coop_body(const KeyCtx<C>& key, const Fp2<C
   __syncthreads();
   const bool active = member && flagw[L::ITEMS] != 0;
   const CoopProg P = NP == 16 ? T::check() : T::check32();
-  coop_run_device<C, NP>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines), member);
+  coop_run_device<C, NP, BLOCK>(P, R, (coop_u32*)stage, active, pair, comp, consts, reinterpret_cast<const Fp2<C>*>(key.gg_lines), member);
   const bool one = coop_is_one<C>(P, R, active, pair, comp, flagw, member);
   if (pair == 0 && comp == 0 && active) {
     flags[i] = one ? 1 : 0;
@@ -592,14 +592,14 @@ __global__ void __launch_bounds__(ELP_COOP_BLOCK) k_pair_coop(KeyCtx<C> key, con
 #ifdef ELP_DBG_SMALL
 __device__ unsigned long long elp_dbg_small[32];
 #endif
-// Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them, 128
-// of their 256 lanes) of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
+// Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them)
+// of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
 // run them side by side without a second stream.
 template <class C, int NP>
 __global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
                                                   const u32* ad_off, u32 ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride,
                                                   uint8_t* pair_ok, uint8_t* done, size_t n, const Jac<F2<C>>* pre, unsigned nb_nizk) {
-  typedef CoopLds<C, NP> L;
+  typedef CoopLds<C, NP, 256> L;              // all four waves of a pairing workgroup interpret: 8 (4) items per workgroup
   constexpr size_t PAIR_BYTES = (size_t)(L::R_WORDS + L::STAGE_WORDS) * 4 + 16;
   constexpr size_t BYTES = PAIR_BYTES > Nizk4Lds<C>::BYTES ? PAIR_BYTES : Nizk4Lds<C>::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
@@ -625,10 +625,11 @@ __global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* 
     vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
                       (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
   } else {
-    // the pairing interpreter is laid out for 128 lanes; the other two waves of the workgroup stay for its barriers only (pair_coop_body, `member`)
+    // the workgroup carries the NIZK half's register budget -- one wave per SIMD --, so all four waves interpret: a compute unit then holds half the items of
+    // k_pair_coop's sixteen on half its waves, each wave alone on its SIMD (round 4; before, two of the four waves only kept the barriers company)
     KeyCtx<C> k2 = key;
     k2.vtab = nullptr;
-    pair_coop_body<C, NP>(k2, consts, recs, rec_words, kvalid, kws, kstride, pair_ok, done, nullptr, n, blockIdx.x - nb_nizk, (i32*)smem,
+    pair_coop_body<C, NP, 256>(k2, consts, recs, rec_words, kvalid, kws, kstride, pair_ok, done, nullptr, n, blockIdx.x - nb_nizk, (i32*)smem,
                           (u32*)(smem + (((size_t)L::R_WORDS * 4 + 15) & ~(size_t)15)));
   }
 }
@@ -933,10 +934,10 @@ void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_co
                       const void* pre) {
   const unsigned nb_nizk = grid_for(n);
   if (n <= 512)
-    hipLaunchKernelGGL((k_vid_small<B, 32>), dim3(nb_nizk + (unsigned)((n + 1) / 2)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
+    hipLaunchKernelGGL((k_vid_small<B, 32>), dim3(nb_nizk + (unsigned)((n + 3) / 4)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
                        retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
   else
-    hipLaunchKernelGGL((k_vid_small<B, 16>), dim3(nb_nizk + (unsigned)((n + 3) / 4)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
+    hipLaunchKernelGGL((k_vid_small<B, 16>), dim3(nb_nizk + (unsigned)((n + 7) / 8)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
                        retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
 #ifdef ELP_DBG_SMALL
   if (getenv("ELP_DBG_SMALL")) {
@@ -1756,6 +1757,8 @@ struct elp_ctx {
   int overlap = 0;            // ELP_OPT_STREAM_OVERLAP: independent kernels of one call on the context's second stream (small-batch verify_id, aggregated tail)
   int stage_records = 1;      // ELP_OPT_COALESCED_RECORDS: k_verify_id_staged (records through LDS into a private copy) instead of k_verify_id; measured equal in time
   int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
+  size_t small_one_max = 0;      // el_passo_verify_id batches up to this many items run k_vid_small (one launch); above, k_vid_nizk4 then k_pair_coop.  0 = the measured
+                                 // cross-over of the curve: 3 072 (BN254: 2 048 items 4.4 vs 5.1 ms, 4 096 items 6.3 vs 5.6 ms), 4 096 (BLS12-381: 11.9 vs 14.2 ms)
   size_t coop_max = 4096;     // 16 items per CU x 256 CUs: one round of the cooperative kernel; measured cross-over against the per-lane kernels between 4096 and 8192 items
   void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
   hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
@@ -2655,10 +2658,10 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
           HIPCHK(c, hipEventRecord(c->jev[1], js));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[1], 0));
           launch_pair_rest<C>(st, key, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);      // large private frame: on the caller's queue (see launch_pair_coop)
-        } else if (n <= 1024) {
-          // default: NIZK half and pairing check as workgroup ranges of ONE launch (k_vid_small) -- side by side without a second stream.  (Its pairing
-          // workgroups carry the NIZK half's register budget: where the pairing check alone fills the chip that halves their occupancy -- measured, 2048 items take
-          // 7.0 ms in one launch against 5.5 in two.)
+        } else if (n <= (c->small_one_max ? c->small_one_max : (size_t)(C::IS_BN ? 3072 : 4096))) {
+          // default: NIZK half and pairing check as workgroup ranges of ONE launch (k_vid_small) -- side by side without a second stream.  Its pairing
+          // workgroups carry the NIZK half's register budget (one wave per SIMD); with all four of their waves interpreting they process items at the rate of
+          // k_pair_coop's two waves per SIMD, so the one launch serves every batch of the cooperative path (ELP_SMALL_ONE_MAX: A/B against two launches).
           launch_vid_small<C>(st, key, consts, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kvalid, kws, lanes, pair_ok, done, pre);
         } else {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
