@@ -101,70 +101,79 @@ def _g2_decode(bs):
     return odd and y[0] != 0
 
 
-def wire_open_model(msg, A, retr):
-    """(accepted, digest) exactly as tests/host_twin/fuzz_wire.cpp reports them"""
+def wire_parse(msg, A, retr):
+    """None if the documented format rejects the message, else its fields (sig1, sig2, k, phi, c, rs, attributes, E1, E2, canonical flag of k) as raw bytes / integers"""
     b = bytes(msg)
     off = 0
     parts = []
     for typ, want in ((1, L), (1, L), (2, 2 * L), (1, L), (3, 32)):
         e = _elem(b, off, typ, want)
         if e is None:
-            return False, None
+            return None
         parts.append(e[0])
         off = e[1]
     s1, s2, kk, phi, cc = parts
     if off >= len(b) or b[off] != 6:
-        return False, None
+        return None
     v = _var(b, off + 1)
     if v is None or v[0] > 64:
-        return False, None
+        return None
     nrs, off = v
     rs = []
     for _ in range(nrs):
         v = _var(b, off)
         if v is None or v[0] != 32 or v[1] + 32 > len(b):
-            return False, None
+            return None
         r = int.from_bytes(b[v[1]:v[1] + 32], "little")
         if r >= M.r:
-            return False, None
+            return None
         rs.append(r)
         off = v[1] + 32
     if off >= len(b) or b[off] != 7:
-        return False, None
+        return None
     v = _var(b, off + 1)
     if v is None or v[0] != A:
-        return False, None
+        return None
     off = v[1]
     attrs = []
     for _ in range(A):
         v = _var(b, off)
         if v is None or v[1] + v[0] > len(b):
-            return False, None
+            return None
         attrs.append(b[v[1]:v[1] + v[0]])
         off = v[1] + v[0]
     H = sum(1 for a in attrs if len(a) == 0)
     if nrs != H + (2 if retr else 1) or H < (2 if retr else 1):
-        return False, None
+        return None
     e1 = e2 = None
     if retr:
         e = _elem(b, off, 1, L)
         if e is None:
-            return False, None
+            return None
         e1, off = e
         e = _elem(b, off, 1, L)
         if e is None:
-            return False, None
+            return None
         e2, off = e
     c = int.from_bytes(cc, "little")
     if c >= M.r:
-        return False, None
+        return None
     if retr and not (_g1_ok(e1) and _g1_ok(e2)):
-        return False, None
+        return None
     if not (_g1_ok(s1) and _g1_ok(s2) and _g1_ok(phi)):
-        return False, None
+        return None
     kflag = _g2_decode(kk)
     if kflag is None:
+        return None
+    return s1, s2, kk, phi, c, rs, attrs, e1, e2, kflag
+
+
+def wire_open_model(msg, A, retr):
+    """(accepted, digest) exactly as tests/host_twin/fuzz_wire.cpp reports them"""
+    f = wire_parse(msg, A, retr)
+    if f is None:
         return False, None
+    s1, s2, kk, phi, c, rs, attrs, e1, e2, kflag = f
     d = bytearray(32)
 
     def fold(bs):
