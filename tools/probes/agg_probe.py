@@ -1,4 +1,5 @@
-"""Aggregated verification at the headline size, a few calls (run under rocprofv3 --kernel-trace --stats to see its kernels)."""
+"""Aggregated verification at the headline size, a few calls (run under rocprofv3 --kernel-trace --stats to see its kernels).
+Usage: [CURVE=bls] python tools/probes/agg_probe.py [batch] [window] [ELP_COOP value]"""
 import importlib
 import os
 import sys
@@ -11,8 +12,8 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("ps-signature-and-el-passo_amd")
 synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
 dev = torch.device("cuda", 0)
-ctx = pkg.Context(pkg.CURVE_BN254, 0)
-wl = synth.Workload(ctx, 8, seed=20211, window_bits=16)
+ctx = pkg.Context(pkg.CURVE_BLS12_381 if os.environ.get("CURVE", "bn254").startswith("bls") else pkg.CURVE_BN254, 0)
+wl = synth.Workload(ctx, 8, seed=20211, window_bits=int(sys.argv[2]) if len(sys.argv) > 2 else 16)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 if len(sys.argv) > 3:
     os.environ["ELP_COOP"] = sys.argv[3]
