@@ -595,14 +595,33 @@ __device__ unsigned long long elp_dbg_small[32];
 // Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them)
 // of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
 // run them side by side without a second stream.
+#define ELP_VID_SMALL_PARAMS                                                                                                                                     \
+  KeyCtx<C> key, const Fp2<C>*consts, const u32 *recs, int rec_words, u64 mask, int retr, const uint8_t *ad, const u32 *ad_off, u32 ad_len, uint8_t *nizk_ok,          \
+      const uint8_t *kvalid, const u32 *kws, size_t kstride, uint8_t *pair_ok, uint8_t *done, size_t n, const Jac<F2<C>>*pre, unsigned nb_nizk
 template <class C, int NP>
-__global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* consts, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad,
-                                                  const u32* ad_off, u32 ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride,
-                                                  uint8_t* pair_ok, uint8_t* done, size_t n, const Jac<F2<C>>* pre, unsigned nb_nizk) {
+__device__ __forceinline__ void vid_small_body(ELP_VID_SMALL_PARAMS, unsigned char* smem) {
   typedef CoopLds<C, NP, 256> L;              // all four waves of a pairing workgroup interpret: 8 (4) items per workgroup
-  constexpr size_t PAIR_BYTES = (size_t)(L::R_WORDS + L::STAGE_WORDS) * 4 + 16;
-  constexpr size_t BYTES = PAIR_BYTES > Nizk4Lds<C>::BYTES ? PAIR_BYTES : Nizk4Lds<C>::BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
+  if (blockIdx.x < nb_nizk) {
+    vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
+                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
+  } else {
+    // the workgroup carries the NIZK half's register budget, so all four waves interpret: a compute unit then holds half the items of
+    // k_pair_coop's sixteen on half its waves, each wave alone on its SIMD (round 4; before, two of the four waves only kept the barriers company)
+    KeyCtx<C> k2 = key;
+    k2.vtab = nullptr;
+    pair_coop_body<C, NP, 256>(k2, consts, recs, rec_words, kvalid, kws, kstride, pair_ok, done, nullptr, n, blockIdx.x - nb_nizk, (i32*)smem,
+                               (u32*)(smem + (((size_t)L::R_WORDS * 4 + 15) & ~(size_t)15)));
+  }
+}
+template <class C, int NP>
+struct VidSmallLds {
+  typedef CoopLds<C, NP, 256> L;
+  static constexpr size_t PAIR_BYTES = (size_t)(L::R_WORDS + L::STAGE_WORDS) * 4 + 16;
+  static constexpr size_t BYTES = PAIR_BYTES > Nizk4Lds<C>::BYTES ? PAIR_BYTES : Nizk4Lds<C>::BYTES;
+};
+template <class C, int NP>
+__global__ void __launch_bounds__(256) k_vid_small(ELP_VID_SMALL_PARAMS) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[VidSmallLds<C, NP>::BYTES];
 #ifdef ELP_DBG_SMALL      /* measurement builds only (tools/probes/lone_call_probe.py): per-wave wall-clock times and placement of the first two workgroups */
   const unsigned long long dbg_t0 = wall_clock64();
   struct DbgAtExit {
@@ -621,17 +640,15 @@ __global__ void __launch_bounds__(256) k_vid_small(KeyCtx<C> key, const Fp2<C>* 
     }
   } dbg_at_exit{dbg_t0};
 #endif
-  if (blockIdx.x < nb_nizk) {
-    vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
-                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
-  } else {
-    // the workgroup carries the NIZK half's register budget -- one wave per SIMD --, so all four waves interpret: a compute unit then holds half the items of
-    // k_pair_coop's sixteen on half its waves, each wave alone on its SIMD (round 4; before, two of the four waves only kept the barriers company)
-    KeyCtx<C> k2 = key;
-    k2.vtab = nullptr;
-    pair_coop_body<C, NP, 256>(k2, consts, recs, rec_words, kvalid, kws, kstride, pair_ok, done, nullptr, n, blockIdx.x - nb_nizk, (i32*)smem,
-                          (u32*)(smem + (((size_t)L::R_WORDS * 4 + 15) & ~(size_t)15)));
-  }
+  vid_small_body<C, NP>(key, consts, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, pre, nb_nizk, smem);
+}
+// The same launch for batches that need more than one round of pairing workgroups: built for TWO waves per SIMD (256 registers: the NIZK half spills more and
+// takes longer, which a batch of thousands hides), so that a compute unit holds two pairing workgroups -- the sixteen items of k_pair_coop -- beside the NIZK
+// workgroups instead of after them.
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vid_small2(ELP_VID_SMALL_PARAMS) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[VidSmallLds<C, 16>::BYTES];
+  vid_small_body<C, 16>(key, consts, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, pre, nb_nizk, smem);
 }
 // the items k_pair_coop left alone (points at infinity): the ordinary per-lane check
 template <class C>
@@ -959,6 +976,15 @@ void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_co
   hipLaunchKernelGGL((k_pair_rest<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, k2, (const u32*)d_records, words, kvalid, (const uint8_t*)done, kws, kstride, pair_ok,
                      (unsigned long long*)nullptr, n);
 }
+// k_vid_small2 only (the caller queues k_pair_rest through launch_pair_rest): instantiated in elpasso_<curve>_small2.hip, the translation unit built for two waves per SIMD
+template <class B>
+void launch_vid_small2(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                       const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
+                       const void* pre) {
+  const unsigned nb_nizk = grid_for(n);
+  hipLaunchKernelGGL((k_vid_small2<B>), dim3(nb_nizk + (unsigned)((n + 7) / 8)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
+                     retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
+}
 template <class B>
 void launch_vid_ktab(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int retr) {
   hipLaunchKernelGGL((k_vid_ktab<B>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, retr, n);
@@ -999,6 +1025,10 @@ template <class B>
 void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
                       const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
                       const void* pre);
+template <class B>
+void launch_vid_small2(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                       const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
+                       const void* pre);
 #endif
 // which curves have the cooperative kernels (their own translation unit, elpasso_<curve>_coop.hip)
 template <class B>
@@ -1026,7 +1056,17 @@ template <>
 struct CoopBuild<BLS12_381> {      // round 4: the pairing check (PS verification of small batches, the tail of aggregated verification); parity unpinned like everything on this curve
   static constexpr bool value = true;
 };
+// k_vid_small2 (one-launch small batches at two waves per SIMD): where two pairing workgroups fit a compute unit's LDS
+template <class B>
+struct Small2Build {
+  static constexpr bool value = false;
+};
+template <>
+struct Small2Build<BN254> {
+  static constexpr bool value = true;
+};
 #ifndef ELP_COOP_TU
+extern template void launch_vid_small2<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done, const void* pre);
 extern template void launch_coop_consts<BN254>(hipStream_t stream, void* d_consts);
 extern template void launch_vid_prep<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride, uint8_t* kvalid);
 extern template void launch_pair_rest<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, uint8_t* done, void* d_accepted);
@@ -1757,8 +1797,10 @@ struct elp_ctx {
   int overlap = 0;            // ELP_OPT_STREAM_OVERLAP: independent kernels of one call on the context's second stream (small-batch verify_id, aggregated tail)
   int stage_records = 1;      // ELP_OPT_COALESCED_RECORDS: k_verify_id_staged (records through LDS into a private copy) instead of k_verify_id; measured equal in time
   int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
-  size_t small_one_max = 0;      // el_passo_verify_id batches up to this many items run k_vid_small (one launch); above, k_vid_nizk4 then k_pair_coop.  0 = the measured
-                                 // cross-over of the curve: 3 072 (BN254: 2 048 items 4.4 vs 5.1 ms, 4 096 items 6.3 vs 5.6 ms), 4 096 (BLS12-381: 11.9 vs 14.2 ms)
+  size_t small_dense_from = 1792;   // one-launch batches above this many items run k_vid_small2 (built for two waves per SIMD): up to here the pairing and NIZK workgroups
+                                    // of k_vid_small fit the chip in one round (n / 8 + n / 64 <= 256); measured 2 048 items 3.80 vs 4.38 ms, 3 072: 3.84 vs 4.28, 4 096: 4.69 vs 5.56 (two launches)
+  size_t small_one_max = 4096;   // el_passo_verify_id batches up to this many items run k_vid_small / k_vid_small2 (one launch); above, k_vid_nizk4 then k_pair_coop
+                                 // (4 096 items: BN254 4.69 vs 5.56 ms, BLS12-381 11.9 vs 14.2 ms)
   size_t coop_max = 4096;     // 16 items per CU x 256 CUs: one round of the cooperative kernel; measured cross-over against the per-lane kernels between 4096 and 8192 items
   void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
   hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
@@ -2658,11 +2700,22 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
           HIPCHK(c, hipEventRecord(c->jev[1], js));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[1], 0));
           launch_pair_rest<C>(st, key, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);      // large private frame: on the caller's queue (see launch_pair_coop)
-        } else if (n <= (c->small_one_max ? c->small_one_max : (size_t)(C::IS_BN ? 3072 : 4096))) {
+        } else if (n <= c->small_one_max) {
           // default: NIZK half and pairing check as workgroup ranges of ONE launch (k_vid_small) -- side by side without a second stream.  Its pairing
           // workgroups carry the NIZK half's register budget (one wave per SIMD); with all four of their waves interpreting they process items at the rate of
           // k_pair_coop's two waves per SIMD, so the one launch serves every batch of the cooperative path (ELP_SMALL_ONE_MAX: A/B against two launches).
-          launch_vid_small<C>(st, key, consts, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kvalid, kws, lanes, pair_ok, done, pre);
+          bool dense = false;
+          if constexpr (Small2Build<C>::value) dense = n > c->small_dense_from;
+          if (dense) {
+            if constexpr (Small2Build<C>::value) {
+              launch_vid_small2<C>(st, key, consts, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kvalid, kws, lanes, pair_ok, done, pre);
+              KeyCtx<C> k2 = key;
+              k2.vtab = nullptr;
+              launch_pair_rest<C>(st, k2, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr);
+            }
+          } else {
+            launch_vid_small<C>(st, key, consts, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kvalid, kws, lanes, pair_ok, done, pre);
+          }
         } else {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
           key.vtab = nullptr;

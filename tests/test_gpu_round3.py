@@ -195,7 +195,7 @@ def test_config5_end_to_end_eight_virtual_ranks(gpu_ctx):
 
 def test_cooperative_pairing_small_batches(gpu_ctx):
     """ELP_OPT_COOP_PAIRING: batches of <= 8192 items run the pairing check on 32 lanes per item (k_pair_coop, level-scheduled program).  Plain PS verification and
-    el_passo_verify_id at n = 1 ... 4096 (every switch of the small-batch path: 512 / 513, 3 072 / 3 073): verdicts equal the per-lane kernels' (option off), the generator's expectation and the C oracle's; items with
+    el_passo_verify_id at n = 1 ... 4096 (every switch of the small-batch path: 512 / 513, 1 792 / 1 793): verdicts equal the per-lane kernels' (option off), the generator's expectation and the C oracle's; items with
     sig2 = infinity / tampered signatures / corrupted NIZK take the same verdicts in both modes."""
     L = oracle()
     A, H = 8, 4
@@ -203,8 +203,9 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
     key = _oracle_key(L, wl, gpu_ctx, A)
     try:
         # sizes on both sides of every switch of the path: k_vid_small on 32 lane pairs per item (4 items per pairing workgroup: 3, 5 leave one partly filled) up to 512,
-        # on 16 lane pairs (8 items per workgroup, all four waves interpreting) up to 3 072, two launches (k_vid_nizk4, k_pair_coop) above
-        for n in (1, 3, 5, 63, 64, 65, 511, 513, 1027, 3072, 3073, 4096):
+        # on 16 lane pairs (8 items per workgroup, all four waves interpreting) up to 1 792, its two-waves-per-SIMD build k_vid_small2 up to 4 096; the two-launch
+        # form (k_vid_nizk4, k_pair_coop) runs under ELP_OPT_STREAM_OVERLAP below
+        for n in (1, 3, 5, 63, 64, 65, 511, 513, 1027, 1792, 1793, 3073, 4096):
             recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=3)
             rsz = len(recs) // n
             recs = bytearray(recs)
