@@ -615,13 +615,14 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     ctx.close()
     ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
     wl = synth.Workload(ctx, 8, seed=20211, window_bits=window)
-    nl = 4096
+    nl = 8192
     vrecs, vmask, vexpect = wl.verify_id_batch(nl, 4, with_retrieval=True)
     d_vrec = torch.from_numpy(np.frombuffer(vrecs, dtype=np.uint8).copy()).to(dev)
     d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    d_fl = torch.zeros(nl, dtype=torch.uint8, device=dev)
     for coop in (1, 0):
         ctx.set_coop_pairing(coop)
-        for m in (4096, 1, 64, 1024, 4096):
+        for m in (8192, 1, 64, 1024, 4096, 8192):
             ms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_vrec.data_ptr(), vmask, 1, d_ad.data_ptr(), None, len(wl.ad),
                                                                          d_fl.data_ptr(), d_cnt.data_ptr())))
             lat["verify_id_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms

@@ -69,11 +69,12 @@ int elp_field_bytes(int curve);               /* F */
  * the commitment A of el_passo_provide_id; sig1 under ELP_OPT_STRICT_SIGNATURE and in elp_ps_verify_batch) must lie in the order-r subgroup, otherwise the
  * item is rejected (one [z^2]P per point, ~9 % of a verification; the sig1 test rides in a slot of the lane pair that was idle).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
  * pseudonyms or an undecryptable token.  The reference never meets the case (it runs on BN254); mcl's default does not check.  0 = no check.
- * ELP_OPT_COOP_PAIRING (default 1; both curves since round 4 -- on BLS12-381 a lone el_passo_verify_id takes 6.3 instead of 23.7 ms): batches of at most 4096 items (value > 1: that many) and the closing step of aggregated verification run
+ * ELP_OPT_COOP_PAIRING (default 1; both curves since round 4 -- on BLS12-381 a lone el_passo_verify_id takes 6.3 instead of 23.7 ms): small batches -- PS verifications of at most 4096
+ * items, el_passo_verify_id of at most 9216 (BLS12-381: 8192); value > 1: that many for both -- and the closing step of aggregated verification run
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
- * (pair) per item, and the NIZK half of el_passo_verify_id spreads its jobs over four waves per 64 items with the fixed-base G2 sums on 8 lanes each: measured, a
- * lone PS verification takes 1.8 ms instead of 5.1, 4096 of them 3.3 ms instead of 4.6, 64 el_passo_verify_id 2.8 ms and 1024 of them 4.9 ms instead of 8.8 (NIZK half and pairing check in one launch), 4096 of them 6.2 ms.
- * Results are identical.  0 = off.
+ * (pair) per item, and the NIZK half of el_passo_verify_id spreads its jobs over four waves per 64 items with the fixed-base G2 sums on 8 lanes each, in the same launch
+ * as the pairing check: measured (round 4), a lone PS verification takes 1.5 ms instead of 5.1, 4096 of them 2.9 ms instead of 4.6; el_passo_verify_id: 1 item 2.5 ms, 64 items 2.6,
+ * 1024 items 2.7, 4096 items 4.8, 8192 items 7.3 ms instead of 8.8-9.2 at any of these sizes.  Results are identical.  0 = off.
  * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
  * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.
  * Needs records of a multiple of 16 bytes, at most 1152, at a 16-byte aligned address; otherwise the in-place kernel runs.  Results are identical and so is the

@@ -151,7 +151,8 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_COOP_PAIRING:
       if (value < 0) return ELP_ERR_ARG;
       c->coop = value ? 1 : 0;
-      c->coop_max = value > 1 ? (size_t)value : 4096;     // 1 = the documented default limit again (also after an earlier larger value)
+      c->coop_max = value > 1 ? (size_t)value : 4096;     // 1 = the documented default limits again (also after an earlier larger value)
+      c->vid_coop_max = value > 1 ? (size_t)value : 0;
       return ELP_OK;
     case ELP_OPT_SUBGROUP_CHECK: c->subgroup_check = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_COALESCED_RECORDS: c->stage_records = value ? 1 : 0; return ELP_OK;

@@ -1799,8 +1799,10 @@ struct elp_ctx {
   int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
   size_t small_dense_from = 1792;   // one-launch batches above this many items run k_vid_small2 (built for two waves per SIMD): up to here the pairing and NIZK workgroups
                                     // of k_vid_small fit the chip in one round (n / 8 + n / 64 <= 256); measured 2 048 items 3.80 vs 4.38 ms, 3 072: 3.84 vs 4.28, 4 096: 4.69 vs 5.56 (two launches)
-  size_t small_one_max = 4096;   // el_passo_verify_id batches up to this many items run k_vid_small / k_vid_small2 (one launch); above, k_vid_nizk4 then k_pair_coop
-                                 // (4 096 items: BN254 4.69 vs 5.56 ms, BLS12-381 11.9 vs 14.2 ms)
+  size_t small_one_max = ~(size_t)0;   // el_passo_verify_id batches up to this many items run k_vid_small / k_vid_small2 (one launch); above, k_vid_nizk4 then k_pair_coop
+                                       // (4 096 items: BN254 4.69 vs 5.56 ms, BLS12-381 11.9 vs 14.2 ms): the whole cooperative range by default (ELP_SMALL_ONE_MAX: A/B)
+  size_t vid_coop_max = 0;       // upper limit of the cooperative path for el_passo_verify_id; 0 = the measured cross-over against the two-lane kernels' 9.1-9.4 ms round:
+                                 // 9 216 items (BN254: 8 192 items 7.3 ms, 9 216: 8.5, 10 240: 9.3), 8 192 (BLS12-381)
   size_t coop_max = 4096;     // 16 items per CU x 256 CUs: one round of the cooperative kernel; measured cross-over against the per-lane kernels between 4096 and 8192 items
   void* coop_consts = nullptr;     // constants table of the cooperative programs (built on first use)
   hipStream_t jstream = nullptr;   // second stream of split = 2 (the G1 job)
@@ -2642,7 +2644,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
   if constexpr (CoopBuild<C>::value && SmallBuild<C>::value) {
-    if (c->coop && n <= c->coop_max) {
+    if (c->coop && n <= (c->vid_coop_max ? c->vid_coop_max : (size_t)(C::IS_BN ? 9216 : 8192))) {
       // small batch: NIZK half with four job lanes per item (k_vid_nizk4), pairing check on 32 / 64 lanes per item (k_pair_coop)
       const void* consts = coop_consts_for<C>(c, (hipStream_t)stream);
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;

@@ -205,7 +205,7 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
         # sizes on both sides of every switch of the path: k_vid_small on 32 lane pairs per item (4 items per pairing workgroup: 3, 5 leave one partly filled) up to 512,
         # on 16 lane pairs (8 items per workgroup, all four waves interpreting) up to 1 792, its two-waves-per-SIMD build k_vid_small2 up to 4 096; the two-launch
         # form (k_vid_nizk4, k_pair_coop) runs under ELP_OPT_STREAM_OVERLAP below
-        for n in (1, 3, 5, 63, 64, 65, 511, 513, 1027, 1792, 1793, 3073, 4096):
+        for n in (1, 3, 5, 63, 64, 65, 511, 513, 1027, 1792, 1793, 4096, 9216, 9217):      # 9 216 / 9 217: last cooperative batch / first two-lane one at the default limit
             recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=3)
             rsz = len(recs) // n
             recs = bytearray(recs)

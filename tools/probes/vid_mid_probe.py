@@ -1,5 +1,5 @@
 """el_passo_verify_id at a few mid-size batch lengths through the default path, a few calls each (kernel-trace / counter passes run over this).
-Usage: python tools/probes/vid_mid_probe.py [window] [n ...]"""
+Usage: [CURVE=bls] [COOP_MAX=..] [ELP_SMALL_ONE_MAX=..] [ELP_SMALL_DENSE_FROM=..] python tools/probes/vid_mid_probe.py [window] [n ...]"""
 import importlib
 import os
 import sys
@@ -14,7 +14,9 @@ synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 NS = [int(a) for a in sys.argv[2:]] or [4096, 1024]
 dev = torch.device("cuda", 0)
-ctx = pkg.Context(pkg.CURVE_BN254, 0)
+ctx = pkg.Context(pkg.CURVE_BLS12_381 if os.environ.get("CURVE", "bn254").startswith("bls") else pkg.CURVE_BN254, 0)
+if os.environ.get("COOP_MAX"):          # A/B: 0 = per-lane kernels, > 1 = upper limit of the cooperative path
+    ctx.set_coop_pairing(int(os.environ["COOP_MAX"]))
 stream = torch.cuda.current_stream().cuda_stream
 wl = synth.Workload(ctx, 8, seed=20211, window_bits=W)
 B = max(NS)
