@@ -671,7 +671,9 @@ __global__ void ELP_LAUNCH_BOUNDS k_pair_rest(KeyCtx<C> key, const u32* recs, in
 // Fixed-base sums on ELP_PSK_LANES lanes: the nterms x nwin table entries of  sum_t k_t B_t  are dealt round-robin to the lanes (each recomputes the signed digit
 // of its window from the scalar: the carry chain is a few integer operations per window), partial sums are folded through lane shuffles with complete Jacobian
 // additions.  `term(t, base, k)` names term t.  All 64 lanes of the wave must call (the shuffles); lane 0 of every group of 8 returns the sum.
-#define ELP_PSK_LANES 8
+#ifndef ELP_PSK_LANES
+#define ELP_PSK_LANES 8       /* 16 was measured in round 4: a lone el_passo_verify_id 2.41 instead of 2.49 ms, but 4 096 of them 4.93 instead of 4.76 and config 2 unchanged (2.96 ms) */
+#endif
 template <class C, class TermFn>
 __device__ __forceinline__ void coop_fixed_sum_g2(Jac<F2<C>>& K, const KeyCtx<C>& key, int sub, int nterms, bool live, TermFn term) {
   typedef F2<C> G;
@@ -707,8 +709,8 @@ __device__ __forceinline__ void coop_fixed_sum_g2(Jac<F2<C>>& K, const KeyCtx<C>
     if (live && (sub & (2 * m - 1)) == 0) jac_add<G>(K, K, o);
   }
 }
-// K of a plain PS verification on 8 lanes per item: 48 sequential mixed additions (A = 3, W = 16) become 6 + 3 full ones; the one inversion of the affine
-// result stays.
+// K of a plain PS verification on ELP_PSK_LANES lanes per item: 48 sequential mixed additions (A = 3, W = 16) become 6 + 3 full ones;
+// the one inversion of the affine result stays.
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
   typedef F2<C> G;
@@ -737,9 +739,9 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
     }
   }
 }
-// The fixed-base halves of el_passo_verify_id's G2 work for small batches, 16 lanes per item (src/ps-verifier.cc:76-88,220-227): lanes 0-7 compute
+// The fixed-base halves of el_passo_verify_id's G2 work for small batches, 2 x ELP_PSK_LANES lanes per item (src/ps-verifier.cc:76-88,220-227): the lower half computes
 //     out[2 i]     = sum_{hidden} rs_j YY_i + r_t gg + (1 - c) XX          (V_k without its [c]k term)
-// and lanes 8-15
+// and the upper half
 //     out[2 i + 1] = sum_{revealed} m_i YY_i                               (K without k)
 // from the record's scalars alone (any 256-bit value is a valid scalar: nothing to validate here; k_vid_nizk validates the points and ignores the sums of an
 // invalid record).  Jacobian results: the NIZK jobs add them with complete additions.
@@ -748,7 +750,7 @@ __device__ __forceinline__ void vid_fixed_coop_body(const KeyCtx<C>& key, const 
                                                     uint8_t* kvalid, size_t n, size_t block) {
   typedef F2<C> G;
   constexpr int J = ELP_PSK_LANES;
-  const int sub = (int)(threadIdx.x & (J - 1)), which = (int)((threadIdx.x >> 3) & 1);
+  const int sub = (int)(threadIdx.x & (J - 1)), which = (int)((threadIdx.x / J) & 1);
   const size_t i = (block * blockDim.x + threadIdx.x) / (2 * J);
   const bool live = i < n;
   PairedRecordSrc<C> src;
