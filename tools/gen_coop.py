@@ -1053,7 +1053,7 @@ def emit_header(res, path, cvname):
         A("ELP_COOP_TABLE const uint32_t %s_CHUNK_LINE[%d] = {%s};" % (U, len(cl), ",".join(str(c) for c in cl)))
         A("constexpr int %s_MAX_CHUNK_TERMS = %d;" % (U, mx))
         A("ELP_COOP_TABLE const uint32_t %s_CHUNK_OFF[%d] = {%s};" % (U, len(offs), ",".join(str(o) for o in offs)))
-        A("ELP_COOP_TABLE const uint32_t %s_TERMS[%d] = {" % (U, max(1, len(terms))))
+        A("alignas(16) ELP_COOP_TABLE const uint32_t %s_TERMS[%d] = {" % (U, max(1, len(terms))))       # the host twin reads four entries as one 64-bit word
         for k in range(0, len(terms), 16):
             A("  " + ",".join("0x%08xu" % w for w in terms[k:k + 16]) + ",")
         if not terms:
