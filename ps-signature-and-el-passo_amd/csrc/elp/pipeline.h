@@ -46,7 +46,8 @@ struct KeyCtx {
 // The reference's el_passo_verify_id accepts sig1 = sig2 = infinity with a self-made NIZK (e(O,K) e(O,gg) = 1: a universal forgery;
 // golden case "sig_both_zero", src/ps-verifier.cc:133-137 has no isZero test although PSVerifier::verify :16-18 has one).  The library
 // rejects it by default (elp_set_option(ELP_OPT_STRICT_SIGNATURE)); reference-compatible behaviour is opt-in.
-enum { KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2 };   // KEY_NO_SUBGROUP_CHECK: skip g1_in_subgroup on prover-supplied points (ELP_OPT_SUBGROUP_CHECK = 0)
+enum { KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2, KEY_PHASE_MIX = 4 };   // KEY_PHASE_MIX: the second half of a two-lane launch's workgroups runs the pairing check BEFORE the NIZK half (verify_id_item_paired)
+//   // KEY_NO_SUBGROUP_CHECK: skip g1_in_subgroup on prover-supplied points (ELP_OPT_SUBGROUP_CHECK = 0)
 // words of workspace per lane: 1P .. 8P of k and of up to three G1 points
 template <class C>
 ELP_HD constexpr int vtab_words() { return 8 * vtab_entry_words<F2<C>>() + 3 * 8 * vtab_entry_words<F1<C>>(); }
@@ -1011,7 +1012,7 @@ struct PairedRecordSrc {
 template <class C, class Src>
 ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F1<C>>& P0,
                                      const Aff<F1<C>>& P1, const Aff<F2<C>>& kk, const Scalar& c, const uint8_t* ad, size_t ad_len,
-                                     Aff<F2<C>>& aK) {
+                                     Aff<F2<C>>& aK, bool with_k = true) {      // with_k = false: K was computed before (verify_id_paired_k); aK comes back as k
   static_assert(is_paired<C>(), "paired layout only");
   typedef F1<C> G1F;
   typedef F2<C> G2F;
@@ -1077,7 +1078,7 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, Src& src, bool retr, 
       if (src.hidden(i)) {
         acc_fixed_g2<C>(Vk, key, G2_BASE_YY0 + i, src.rs(jh));
         jh++;
-      } else {
+      } else if (with_k) {
         acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
       }
     }
@@ -1155,8 +1156,25 @@ ELP_HEAVY bool verify_id_paired_nizk(const KeyCtx<C>& key, Src& src, bool retr, 
   return scalar_eq(c2, c);
 }
 
+// K = k prod_{revealed} YY_i^{m_i} alone (src/ps-verifier.cc:72-88), affine: what the pairing check needs of the NIZK half
+template <class C, class Src>
+ELP_HEAVY void verify_id_paired_k(const KeyCtx<C>& key, Src& src, const Aff<F2<C>>& kk, Aff<F2<C>>& aK) {
+  typedef F2<C> G2F;
+  Jac<G2F> K;
+  jac_from_aff(K, kk);
+  for (int i = 0; i < key.A; i++)
+    if (!src.hidden(i)) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, src.next_revealed_hash(i));
+  Fp2<C> z2[1], zi2[1];
+  z2[0] = K.Z;
+  batch_zinv<C, 0, 1>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
+  jac_to_aff_with_zinv<G2F>(aK, K, zi2[0]);
+}
+// pair_first (wave-uniform; k_verify_id_paired under KEY_PHASE_MIX): the pairing check runs BEFORE the NIZK half.  The two halves are independent once K exists
+// (the verdict is their AND), and a launch whose waves all walk them in the same order has every wave in the same phase at the same time -- the private-memory
+// working sets of the Fp12 arithmetic of all waves compete for L2 together.  With half of the workgroups in the other order a SIMD's two waves are in different
+// phases for most of the launch.
 template <class C>
-ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len) {
+ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len, bool pair_first = false) {
   static_assert(is_paired<C>(), "paired layout only");
   const bool odd = pair_odd();
   const int G1W = 2 * C::N;
@@ -1191,6 +1209,14 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
   const Scalar c = scalar_load_w(rec + (retr ? 5 : 3) * G1W + 4 * C::N);
   PairedRecordSrc<C> src;
   src.init(rec, hidden_mask, key.A, retr);
+  if (pair_first) {
+    verify_id_paired_k<C, PairedRecordSrc<C>>(key, src, kk, aK);
+    const bool pok = ps_pairing_check<C>(key, sig1, sig2, aK);
+    Aff<F2<C>> unused;
+    src.init(rec, hidden_mask, key.A, retr);
+    const bool nok = verify_id_paired_nizk<C, PairedRecordSrc<C>>(key, src, retr, P0, P1, kk, c, ad, ad_len, unused, false);
+    return pok && nok;
+  }
   if (!verify_id_paired_nizk<C, PairedRecordSrc<C>>(key, src, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
   return ps_pairing_check<C>(key, sig1, sig2, aK);
 }

@@ -1114,7 +1114,7 @@ __global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_paired(KeyCtx<C> key, const u
   if (i < n) {
     const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
     size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
-    ok = verify_id_item_paired<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al);
+    ok = verify_id_item_paired<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al, (key.flags & KEY_PHASE_MIX) && blockIdx.x >= gridDim.x / 2);
     if ((threadIdx.x & 1) == 0) flags[i] = ok ? 1 : 0;
   }
   count_accept_paired(ok, accepted);
@@ -1799,6 +1799,7 @@ struct elp_ctx {
   int overlap = 0;            // ELP_OPT_STREAM_OVERLAP: independent kernels of one call on the context's second stream (small-batch verify_id, aggregated tail)
   int stage_records = 1;      // ELP_OPT_COALESCED_RECORDS: k_verify_id_staged (records through LDS into a private copy) instead of k_verify_id; measured equal in time
   int coop = 1;               // ELP_OPT_COOP_PAIRING: small batches (<= coop_max items) and the aggregated tail run the pairing check on 32 lanes per item (elp/coop.h)
+  int phase_mix = 0;             // KEY_PHASE_MIX (experiment, ELP_PHASE_MIX): half of the two-lane verify launch's workgroups check the pairing before the NIZK half
   size_t small_dense_from = 1792;   // one-launch batches above this many items run k_vid_small2 (built for two waves per SIMD): up to here the pairing and NIZK workgroups
                                     // of k_vid_small fit the chip in one round (n / 8 + n / 64 <= 256); measured 2 048 items 3.80 vs 4.38 ms, 3 072: 3.84 vs 4.28, 4 096: 4.69 vs 5.56 (two launches)
   size_t small_one_max = ~(size_t)0;   // el_passo_verify_id batches up to this many items run k_vid_small / k_vid_small2 (one launch); above, k_vid_nizk4 then k_pair_coop
@@ -1834,7 +1835,7 @@ static KeyCtx<C> make_key(const elp_ctx* c) {   // C may be Paired<B>: the key m
   k.b1 = (const Aff<typename F1<C>::MemF>*)c->b1;
   k.b2 = (const Aff<typename F2<C>::MemF>*)c->b2;
   k.gg_lines = (const LineMem<C>*)c->lines;
-  k.flags = (c->strict_sig ? KEY_STRICT_SIG : 0) | (c->subgroup_check ? 0 : KEY_NO_SUBGROUP_CHECK);
+  k.flags = (c->strict_sig ? KEY_STRICT_SIG : 0) | (c->subgroup_check ? 0 : KEY_NO_SUBGROUP_CHECK) | (c->phase_mix ? KEY_PHASE_MIX : 0);
   return k;
 }
 

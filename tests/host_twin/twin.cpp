@@ -485,7 +485,7 @@ int twin_blsp_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const
     KeyCtx<BLSP> k = paired_key<BLS12_381>(c, hot.data());
     std::vector<u32> vt(vtab_words<BLSP>(), 0xdeadbeefu);
     k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
-    return verify_id_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
+    return verify_id_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen, (k.flags & KEY_PHASE_MIX) != 0) ? 1 : 0;      /* flags 4: the pairing check first */
   });
 }
 int twin_blsp_verify_id_g1split(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
@@ -614,7 +614,7 @@ int twin_bn254p_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, con
     KeyCtx<BN254P> k = paired_key<BN254>(c, getenv("ELP_TWIN_NO_HOT") ? nullptr : hot.data());
     std::vector<u32> vt(vtab_words<BN254P>(), 0xdeadbeefu);
     k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
-    return verify_id_item_paired<BN254P>(k, rec, mask, retr != 0, ad, adlen) ? 1 : 0;
+    return verify_id_item_paired<BN254P>(k, rec, mask, retr != 0, ad, adlen, (k.flags & KEY_PHASE_MIX) != 0) ? 1 : 0;    /* flags 4: the pairing check first */
   });
 }
 int twin_bn254p_verify_id_g1split(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {

@@ -319,6 +319,11 @@ def test_paired_layout_verify_id_golden(L):
                 ad = c["ad"].encode()
                 got = L.twin_bn254p_verify_id(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
                 assert bool(got) == c["expect"], (s["name"], c["label"])
+                if n % 3 == 0:      # KEY_PHASE_MIX: the pairing check before the NIZK half (the order half of a launch's workgroups take under ELP_PHASE_MIX)
+                    L.twin_bn254_ctx_set_flags(ctxs[c["svc"]], 4)
+                    got = L.twin_bn254p_verify_id(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
+                    L.twin_bn254_ctx_set_flags(ctxs[c["svc"]], 0)
+                    assert bool(got) == c["expect"], (s["name"], c["label"], "pairing first")
                 # ELP_OPT_SPLIT_PHASES = 3: the G1 jobs as a kernel of their own (vid_g1_job), then the paired body over their output
                 got = L.twin_bn254p_verify_id_g1split(ctxs[c["svc"]], pack_verify_id(M, P), ctypes.c_uint64(hidden_mask(P.attributes)), 0, ad, len(ad))
                 assert bool(got) == c["expect"], (s["name"], c["label"], "g1split")
@@ -331,7 +336,10 @@ def test_paired_layout_verify_id_golden(L):
         P = CD.proof_decode(base64.b64decode(r["proof"]))
         ctx = _ctx(L, pk, svc=r["svc"].encode(), g_eg=g, apk=apk, h=h)
         mask = ctypes.c_uint64(hidden_mask(P.attributes))
-        for fn in (L.twin_bn254p_verify_id, L.twin_bn254p_verify_id_g1split):
+        for fn in (L.twin_bn254p_verify_id, L.twin_bn254p_verify_id_g1split, "pairing first"):
+            if fn == "pairing first":
+                L.twin_bn254_ctx_set_flags(ctx, 4)
+                fn = L.twin_bn254p_verify_id
             assert fn(ctx, pack_verify_id(M, P), mask, 1, b"hello", 5) == 1
             assert fn(ctx, pack_verify_id(M, P), mask, 1, b"hellO", 5) == 0
             for fld in ("E1", "E2", "phi", "sig1", "sig2"):
