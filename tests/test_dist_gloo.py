@@ -117,4 +117,4 @@ def test_dry_run_prints_the_per_rank_memory_budget():
     assert abs(b4["tables_bytes"] / 2**30 - 15.54) < 0.01            # the 15.5 GiB bench.py reports from elp_key_table_bytes
     assert b4["records_bytes"] == 65536 * 800
     bls = shard.rank_memory_budget("bls12_381", 8, 4, 20, 65536)
-    assert abs(bls["tables_bytes"] / 2**30 - 24.17) < 0.01           # tools/probes/bls_probe.py: table_GiB=24.17
+    assert abs(bls["tables_bytes"] / 2**30 - 24.17) < 0.01           # tools/probes/verify_probe.py: table_GiB=24.17

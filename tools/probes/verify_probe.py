@@ -1,4 +1,4 @@
-"""Headline-shaped batch alone on either curve (CURVE=bn254|bls; ELP_LAYOUT, ELP_SPLIT, ELP_STAGE select the kernel variant); BLS12-381 by default (for rocprofv3 passes and A/B of ELP_OPT_SUBGROUP_CHECK): python tools/probes/bls_probe.py [window] [batch] [reps]"""
+"""Headline-shaped batch alone on either curve (CURVE=bn254|bls; ELP_LAYOUT, ELP_SPLIT, ELP_STAGE select the kernel variant); BLS12-381 by default (for rocprofv3 passes and A/B of ELP_OPT_SUBGROUP_CHECK): python tools/probes/verify_probe.py [window] [batch] [reps]"""
 import ctypes
 import importlib
 import os
