@@ -382,3 +382,40 @@ def test_small_batches_cooperative_on_bls(bls_ctx):
         L.elpo_set_strict(0)
         bls_ctx.set_coop_pairing(1)
         L.elpo_key_free(key)
+
+
+def test_phase_mix_experiment_keeps_the_verdicts(elp, bls_ctx):
+    """ELP_PHASE_MIX (experiment, off by default; profiles/r04_bls_ceiling.md): the second half of a two-lane launch's workgroups checks the pairing BEFORE the NIZK half.
+    Same verdicts as the default order on a batch with corrupted NIZK responses, a swapped sig2, sig2 = infinity and the cofactor forgery -- items of both halves of the
+    launch.  PARITY UNPINNED like everything on this curve."""
+    import os
+    from test_oracle_bls import _small_order_point
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    A, H, n = 8, 4, 520
+    wl = synth.Workload(bls_ctx, A, seed=11, window_bits=8)
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=5, corrupt_at=2)
+    rsz = len(recs) // n
+    recs = bytearray(recs)
+    t3 = g1b(_small_order_point(3), N)
+    for base in (8, 400):                                                                   # one group of special items in each half of the launch
+        recs[(base + 1) * rsz + 96:(base + 1) * rsz + 192] = recs[base * rsz + 96:base * rsz + 192]          # foreign sig2: NIZK holds, pairing check fails
+        recs[(base + 3) * rsz + 96:(base + 3) * rsz + 192] = bytes(96)                                         # sig2 = infinity
+        recs[(base + 5) * rsz:(base + 5) * rsz + 96] = t3                                                      # the cofactor forgery
+        recs[(base + 5) * rsz + 96:(base + 5) * rsz + 192] = bytes(96)
+    recs = bytes(recs)
+    bls_ctx.set_coop_pairing(0)                       # the two-lane kernel, not the cooperative path
+    f0, c0 = bls_ctx.verify_id_batch(recs, mask, True, wl.ad)
+    bls_ctx.set_coop_pairing(1)
+    os.environ["ELP_PHASE_MIX"] = "1"
+    try:
+        ctx = elp.Context(elp.CURVE_BLS12_381, 0)
+    finally:
+        del os.environ["ELP_PHASE_MIX"]
+    try:
+        wl2 = synth.Workload(ctx, A, seed=11, window_bits=8)           # the same seed: the same key and proofs
+        ctx.set_coop_pairing(0)
+        f1, c1 = ctx.verify_id_batch(recs, mask, True, wl2.ad)
+    finally:
+        ctx.close()
+    assert (f0 == f1).all() and c0 == c1
+    assert f0[9] == 0 and f0[11] == 0 and f0[13] == 0 and f0[401] == 0 and f0[405] == 0 and int(f0.sum()) > n // 2
