@@ -672,12 +672,11 @@ __global__ void ELP_LAUNCH_BOUNDS k_pair_rest(KeyCtx<C> key, const u32* recs, in
 // of its window from the scalar: the carry chain is a few integer operations per window), partial sums are folded through lane shuffles with complete Jacobian
 // additions.  `term(t, base, k)` names term t.  All 64 lanes of the wave must call (the shuffles); lane 0 of every group of 8 returns the sum.
 #ifndef ELP_PSK_LANES
-#define ELP_PSK_LANES 8       /* 16 was measured in round 4: a lone el_passo_verify_id 2.41 instead of 2.49 ms, but 4 096 of them 4.93 instead of 4.76 and config 2 unchanged (2.96 ms) */
+#define ELP_PSK_LANES 8       /* 16 everywhere was measured in round 4: a lone el_passo_verify_id 2.41 instead of 2.49 ms, but 4 096 of them 4.93 instead of 4.76 and config 2 unchanged (2.96 ms): launch_vid_prep takes 16 for the smallest batches only */
 #endif
-template <class C, class TermFn>
+template <class C, int J = ELP_PSK_LANES, class TermFn>
 __device__ __forceinline__ void coop_fixed_sum_g2(Jac<F2<C>>& K, const KeyCtx<C>& key, int sub, int nterms, bool live, TermFn term) {
   typedef F2<C> G;
-  constexpr int J = ELP_PSK_LANES;
   if (live) {
     const int W = key.W, nwin = key.nwin, total = nterms * nwin;
     ELP_NOUNROLL
@@ -745,11 +744,10 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
 //     out[2 i + 1] = sum_{revealed} m_i YY_i                               (K without k)
 // from the record's scalars alone (any 256-bit value is a valid scalar: nothing to validate here; k_vid_nizk validates the points and ignores the sums of an
 // invalid record).  Jacobian results: the NIZK jobs add them with complete additions.
-template <class C>
+template <class C, int J = ELP_PSK_LANES>      // J lanes per sum: 8 for batches, 16 for the smallest (launch_vid_prep)
 __device__ __forceinline__ void vid_fixed_coop_body(const KeyCtx<C>& key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride,
                                                     uint8_t* kvalid, size_t n, size_t block) {
   typedef F2<C> G;
-  constexpr int J = ELP_PSK_LANES;
   const int sub = (int)(threadIdx.x & (J - 1)), which = (int)((threadIdx.x / J) & 1);
   const size_t i = (block * blockDim.x + threadIdx.x) / (2 * J);
   const bool live = i < n;
@@ -760,7 +758,7 @@ __device__ __forceinline__ void vid_fixed_coop_body(const KeyCtx<C>& key, const 
   const int nterms = which == 0 ? H + 2 : key.A - H;
   Jac<G> S;
   jac_set_inf(S);
-  coop_fixed_sum_g2<C>(S, key, sub, nterms, live, [&](int t, int& base, Scalar& k) {
+  coop_fixed_sum_g2<C, J>(S, key, sub, nterms, live, [&](int t, int& base, Scalar& k) {
     if (which == 0) {
       if (t < H) {                                  // t-th hidden attribute: response rs_t on YY_a
         int a = 0, seen = 0;
@@ -847,11 +845,11 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_ktab(KeyCtx<C> key, const u32* recs, int
 }
 // The two of them as workgroup ranges of ONE launch (round 4: they are independent, and on a lone call each is a single workgroup on a chip of 256 CUs --
 // 0.33 ms and 0.21 ms one after the other, 0.33 ms side by side): workgroups [0, nb_fixed) sum, the rest build tables.
-template <class C>
+template <class C, int J>
 __global__ void ELP_LAUNCH_BOUNDS k_vid_prep(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride, uint8_t* kvalid,
                                              size_t n, unsigned nb_fixed) {
   if (blockIdx.x < nb_fixed)
-    vid_fixed_coop_body<C>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
+    vid_fixed_coop_body<C, J>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
   else
     vid_ktab_body<C>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
 }
@@ -943,9 +941,16 @@ void launch_vid_fixed_coop(hipStream_t stream, const KeyCtx<B>& key, size_t n, c
 template <class B>
 void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
                      uint8_t* kvalid) {
+  // 16 lanes per fixed-base sum where the call is latency (a lone call 2.41 instead of 2.49 ms, 64 items 2.54 / 2.61), 8 where it is work (4 096 items: 4.76 / 4.93)
+  if (n <= 512) {
+    const unsigned nbf = grid_for(n * 2 * 16);
+    hipLaunchKernelGGL((k_vid_prep<B, 16>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
+                       kstride, kvalid, n, nbf);
+    return;
+  }
   const unsigned nbf = grid_for(n * 2 * ELP_PSK_LANES);
-  hipLaunchKernelGGL((k_vid_prep<B>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws, kstride,
-                     kvalid, n, nbf);
+  hipLaunchKernelGGL((k_vid_prep<B, ELP_PSK_LANES>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre,
+                     kws, kstride, kvalid, n, nbf);
 }
 template <class B>
 void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
