@@ -1222,7 +1222,7 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// G1 JOBS AS A KERNEL OF THEIR OWN (round 4; ELP_OPT_SPLIT_PHASES = 3, the default on BLS12-381).
+// G1 JOBS AS A KERNEL OF THEIR OWN (round 4; ELP_OPT_SPLIT_PHASES = 3, opt-in on both curves: measured no faster than the fused kernels).
 //
 // In the paired layout the base-field work of a verification does not split over the lane pair: the three commitments V_phi, V_E1, V_E2 (one GLV
 // multiplication + fixed-base terms + an inversion each, src/ps-verifier.cc:91-108) and -- on a curve with a G1 cofactor -- the four subgroup tests (phi, E1,

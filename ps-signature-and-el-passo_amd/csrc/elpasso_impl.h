@@ -948,6 +948,12 @@ void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const v
                        kstride, kvalid, n, nbf);
     return;
   }
+  if (n > 4096) {      // beyond one wave per SIMD of eight-lane sums the lane count is work: four lanes per sum (20 mixed + 2 complete additions per lane instead of 10 + 3)
+    const unsigned nbf4 = grid_for(n * 2 * 4);
+    hipLaunchKernelGGL((k_vid_prep<B, 4>), dim3(nbf4 + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
+                       kstride, kvalid, n, nbf4);
+    return;
+  }
   const unsigned nbf = grid_for(n * 2 * ELP_PSK_LANES);
   hipLaunchKernelGGL((k_vid_prep<B, ELP_PSK_LANES>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre,
                      kws, kstride, kvalid, n, nbf);
