@@ -644,7 +644,36 @@ template <class C>
 ELP_INL void g1_mul_glv_tab(Jac<F1<C>>& r, const Aff<F1<C>>* tab, const Scalar& k_in) {
   g1_mul_glv_with<C, PrivTab<F1<C>>>(r, PrivTab<F1<C>>{tab}, k_in);
 }
-template <class C, class Tab>
+// the table of g2_mul_gls_with in two pieces: d k (8 entries) and psi^j (d k), j = 1, 2, 3 (24 entries, entry (j - 1) * 8 + d - 1)
+template <class F>
+struct WsTabPsi {
+  const u32* base;
+  const u32* psi;
+  ELP_INL Aff<F> operator()(int j, int i) const { return j == 0 ? WsTab<F>{base}(i) : WsTab<F>{psi}((j - 1) * 8 + i); }
+};
+// psi^j on an affine point of the twist: (conj^j x * gx_j, conj^j y * gy_j), j = 1, 2, 3
+template <class C>
+ELP_INL void g2_psi_aff(Aff<F2<C>>& t, int j) {
+  Fp2<C> gx, gy;
+  if (j == 1) {
+    ELP_LOAD_FP2(gx, C::g2frob(1, 0, c_, i_));
+    ELP_LOAD_FP2(gy, C::g2frob(1, 1, c_, i_));
+  } else if (j == 2) {
+    ELP_LOAD_FP2(gx, C::g2frob(2, 0, c_, i_));
+    ELP_LOAD_FP2(gy, C::g2frob(2, 1, c_, i_));
+  } else {
+    ELP_LOAD_FP2(gx, C::g2frob(3, 0, c_, i_));
+    ELP_LOAD_FP2(gy, C::g2frob(3, 1, c_, i_));
+  }
+  if (j & 1) {
+    t.x = fp2_conj(t.x);
+    t.y = fp2_conj(t.y);
+  }
+  fp2_mul<C>(t.x, t.x, gx);
+  fp2_mul<C>(t.y, t.y, gy);
+}
+// PSI: `tab(j, i)` delivers psi^j ((i + 1) P) (WsTabPsi); otherwise `tab(i)` delivers (i + 1) P and psi^j is applied at every addition that needs it
+template <class C, class Tab, bool PSI = false>
 ELP_HEAVY void g2_mul_gls_with(Jac<F2<C>>& r, const Tab& tab, const Scalar& k_in) {
   typedef F2<C> F;
   u32 m[4][3];
@@ -653,8 +682,13 @@ ELP_HEAVY void g2_mul_gls_with(Jac<F2<C>>& r, const Tab& tab, const Scalar& k_in
   for (int j = 0; j < 4; j++) limbs_add_eights<3, 17>(m[j]);
   Jac<F> acc;
   jac_set_inf(acc);
+  auto fetch = [&](int jj, int d) -> Aff<F> {
+    const int e = d == 0 ? 0 : (d < 0 ? -d : d) - 1;
+    if constexpr (PSI) return tab(jj, e);
+    else return tab(e);
+  };
   int dg = limbs_window<3>(m[0], 4 * 16, 4) - 8;
-  Aff<F> t = tab(dg == 0 ? 0 : (dg < 0 ? -dg : dg) - 1);
+  Aff<F> t = fetch(0, dg);
   ELP_NOUNROLL
   for (int step = 0; step < 68; step++) {
     const int w = 16 - (step >> 2), j = step & 3;
@@ -667,27 +701,11 @@ ELP_HEAVY void g2_mul_gls_with(Jac<F2<C>>& r, const Tab& tab, const Scalar& k_in
     if (step + 1 < 68) {
       const int wn = 16 - ((step + 1) >> 2), jn = (step + 1) & 3;
       dgn = limbs_window<3>(m[jn], 4 * wn, 4) - 8;
-      tn = tab(dgn == 0 ? 0 : (dgn < 0 ? -dgn : dgn) - 1);
+      tn = fetch(jn, dgn);
     }
     if (dg != 0 && !aff_is_inf(t)) {
-      if (j != 0) {                        // psi^j on an affine point: (conj^j x * gx_j, conj^j y * gy_j)
-        Fp2<C> gx, gy;
-        if (j == 1) {
-          ELP_LOAD_FP2(gx, C::g2frob(1, 0, c_, i_));
-          ELP_LOAD_FP2(gy, C::g2frob(1, 1, c_, i_));
-        } else if (j == 2) {
-          ELP_LOAD_FP2(gx, C::g2frob(2, 0, c_, i_));
-          ELP_LOAD_FP2(gy, C::g2frob(2, 1, c_, i_));
-        } else {
-          ELP_LOAD_FP2(gx, C::g2frob(3, 0, c_, i_));
-          ELP_LOAD_FP2(gy, C::g2frob(3, 1, c_, i_));
-        }
-        if (j & 1) {
-          t.x = fp2_conj(t.x);
-          t.y = fp2_conj(t.y);
-        }
-        fp2_mul<C>(t.x, t.x, gx);
-        fp2_mul<C>(t.y, t.y, gy);
+      if constexpr (!PSI) {
+        if (j != 0) g2_psi_aff<C>(t, j);
       }
       if (neg[j] != (dg < 0)) t.y = fp2_neg(t.y);
       jac_madd_inl<F>(acc, acc, t);

@@ -42,6 +42,8 @@ struct KeyCtx {
   u32* vtab = nullptr;            // this lane's slice of the launch workspace for the tables of small multiples (vtab_words<C>() words, 16-byte aligned) or null:
                                   // the host hands the base of the workspace in, the kernel advances it to its lane (curve.h, WsTab)
   int flags = 0;                  // KEY_STRICT_SIG: proofs with sig1 == infinity are rejected (PS / EL PASSO require sigma_1 != 1)
+  u32* vpsi = nullptr;            // small batches only: this item's psi^j images (j = 1, 2, 3) of the multiples 1k .. 8k, 24 entries of vtab_entry_words<F2<C>>() words beside
+                                  // the table in vtab (k_vid_ktab writes them, the G2 job of k_vid_small reads them: curve.h WsTabPsi), or null
 };
 // The reference's el_passo_verify_id accepts sig1 = sig2 = infinity with a self-made NIZK (e(O,K) e(O,gg) = 1: a universal forgery;
 // golden case "sig_both_zero", src/ps-verifier.cc:133-137 has no isZero test although PSVerifier::verify :16-18 has one).  The library
@@ -700,7 +702,9 @@ ELP_HEAVY void vid_job_g2(const KeyCtx<C>& key, Src& src, bool retr, const Aff<F
   const int nrs = src.nrs();
   const Scalar r_t = src.rs(retr ? nrs - 2 : nrs - 1);
   Jac<G2F> Vk;
-  if (table_ready && key.vtab) {
+  if (table_ready && key.vtab && key.vpsi) {
+    g2_mul_gls_with<C, WsTabPsi<G2F>, true>(Vk, WsTabPsi<G2F>{key.vtab, key.vpsi}, c);      // psi^j (d k) read, not recomputed at each of the 51 additions that need one
+  } else if (table_ready && key.vtab) {
     g2_mul_gls_with<C, WsTab<G2F>>(Vk, WsTab<G2F>{key.vtab}, c);
   } else {
     // 1k .. 8k: Jacobian multiples, one inversion (of the product of the norms) for the seven that need it

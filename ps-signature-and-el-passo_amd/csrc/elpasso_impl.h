@@ -201,6 +201,7 @@ __device__ __forceinline__ void vid_nizk4_body(KeyCtx<C> key, const u32* recs, i
   const bool real = slot < n;
   const size_t i = real ? slot : n - 1;
   if (key.vtab) key.vtab += slot * (size_t)vtab_words<C>();     // one slice per lane: the G2 job uses its first part, each G1 job its own third of the rest
+  if (key.vpsi) key.vpsi += slot * (size_t)(24 * vtab_entry_words<F2<C>>());
   VidNizkState<C> st;
   st.ok = false;
   {
@@ -825,6 +826,8 @@ __device__ __forceinline__ void vid_ktab_body(const KeyCtx<C>& key, const u32* r
   if (!g2_load<C>(kk, recs + i * (size_t)rec_words + (retr ? 5 : 3) * 2 * C::N)) return;
   if (aff_is_inf(kk)) {                     // k = O: every multiple is O (the multiplication then contributes nothing, as with a table built in place)
     for (int q = 0; q < 8; q++) vtab_store<G>(w, q, kk);
+    if (key.vpsi)
+      for (int q = 0; q < 24; q++) vtab_store<G>(key.vpsi + slot * (size_t)(24 * vtab_entry_words<G>()), q, kk);
     return;
   }
   Jac<G> jk[8];
@@ -832,11 +835,18 @@ __device__ __forceinline__ void vid_ktab_body(const KeyCtx<C>& key, const u32* r
   Fp2<C> z2[7], zi2[7];
   for (int q = 1; q < 8; q++) z2[q - 1] = jk[q].Z;
   batch_zinv<C, 0, 7>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
-  vtab_store<G>(w, 0, kk);
-  for (int q = 1; q < 8; q++) {
-    Aff<G> a;
-    jac_to_aff_with_zinv<G>(a, jk[q], zi2[q - 1]);
+  u32* const wp = key.vpsi ? key.vpsi + slot * (size_t)(24 * vtab_entry_words<G>()) : nullptr;     // psi^j of every multiple beside the table (WsTabPsi)
+  for (int q = 0; q < 8; q++) {
+    Aff<G> a = kk;
+    if (q) jac_to_aff_with_zinv<G>(a, jk[q], zi2[q - 1]);
     vtab_store<G>(w, q, a);
+    if (wp) {
+      for (int j = 1; j < 4; j++) {
+        Aff<G> t = a;
+        g2_psi_aff<C>(t, j);
+        vtab_store<G>(wp, (j - 1) * 8 + q, t);
+      }
+    }
   }
 }
 template <class C>
@@ -2665,8 +2675,12 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
       void* extra = nullptr;
       const size_t pre_bytes = (lanes * 2 * sizeof(Jac<F2<C>>) + 255) & ~(size_t)255;      // fixed-base parts of V_k and K per item (k_vid_fixed_coop)
-      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + pre_bytes + 4 * lanes, &extra);
+      const size_t psi_bytes = lanes * (size_t)(24 * vtab_entry_words<F2<C>>()) * 4;        // psi^j images of the multiples of k (k_vid_ktab -> the G2 job): a multiple of 16 per lane
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + pre_bytes + ((4 * lanes + 255) & ~(size_t)255) + psi_bytes, &extra);
       if (consts && extra) {
+        // ... where the NIZK workgroup is the critical path of the call (one round of pairing workgroups: a lone call 2.36 -> 2.23 ms, 64 items 2.48 -> 2.31, 1 024 items
+        // 2.69 -> 2.42); above, the 24 extra entries per item only cost k_vid_prep time (4 096 items: 4.96 against 4.62 ms)
+        if (n <= c->small_dense_from) key.vpsi = (u32*)((uint8_t*)extra + k_bytes + pre_bytes + ((4 * lanes + 255) & ~(size_t)255));
         // k_vid_fixed_coop (fixed-base sums, K) and k_vid_ktab (multiples of k) -> k_vid_nizk4 and k_pair_coop -> k_vid_combine.  The pairing check only
         // needs K, the NIZK half only the sums and the table: with ELP_OPT_STREAM_OVERLAP the two pairs of kernels run side by side on two streams
         //   caller's stream:  memset, k_vid_fixed_coop ------------------(e0)  wait(e3) k_vid_nizk4 ............ wait(e1) k_vid_combine
