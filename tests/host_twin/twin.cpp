@@ -132,6 +132,31 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     g2_store<C>(o, r);                                                                                                 \
     return 1;                                                                                                          \
   }                                                                                                                    \
+  /* the form the G2 job of small batches runs: multiples 1P .. 8P and their psi^j images laid out as k_vid_ktab writes them (WsTabPsi), psi read not recomputed */ \
+  int pfx##_g2_mul_gls_psi(const u32* P, const u32* k, u32* o) {                                                       \
+    typedef F2<C> G;                                                                                                   \
+    Aff<G> p, r;                                                                                                       \
+    if (!g2_load<C>(p, P)) return 0;                                                                                   \
+    constexpr int EW = vtab_entry_words<G>();                                                                          \
+    alignas(16) static thread_local u32 tab[8 * EW], psi[24 * EW];                                                     \
+    Jac<G> jk[8];                                                                                                      \
+    jac_multiples8<G>(jk, p);                                                                                          \
+    for (int q = 0; q < 8; q++) {                                                                                      \
+      Aff<G> a = p;                                                                                                    \
+      if (q) jac_to_aff<G>(a, jk[q]);                                                                                  \
+      vtab_store<G>(tab, q, a);                                                                                        \
+      for (int j = 1; j < 4; j++) {                                                                                    \
+        Aff<G> t = a;                                                                                                  \
+        g2_psi_aff<C>(t, j);                                                                                           \
+        vtab_store<G>(psi, (j - 1) * 8 + q, t);                                                                        \
+      }                                                                                                                \
+    }                                                                                                                  \
+    Jac<G> j;                                                                                                          \
+    g2_mul_gls_with<C, WsTabPsi<G>, true>(j, WsTabPsi<G>{tab, psi}, scalar_load_w(k));                                 \
+    jac_to_aff<G>(r, j);                                                                                               \
+    g2_store<C>(o, r);                                                                                                 \
+    return 1;                                                                                                          \
+  }                                                                                                                    \
   int pfx##_g1_add(const u32* P, const u32* Q, u32* o) {                                                               \
     Aff<F1<C>> p, q, r;                                                                                                \
     if (!g1_load<C>(p, P) || !g1_load<C>(q, Q)) return 0;                                                              \
