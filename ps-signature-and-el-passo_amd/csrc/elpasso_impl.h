@@ -813,21 +813,27 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_fixed_coop(KeyCtx<C> key, const u32* rec
                                                    uint8_t* kvalid, size_t n) {
   vid_fixed_coop_body<C>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
 }
-template <class C>
+template <class C, bool QUAD = false>      // QUAD: four lanes per item -- all four build the multiples, lane 0 stores them, lane j = 1, 2, 3 makes and stores their psi^j images
 __device__ __forceinline__ void vid_ktab_body(const KeyCtx<C>& key, const u32* recs, int rec_words, int retr, size_t n, size_t block) {
   typedef F2<C> G;
   // idle lanes of the last wave work on a copy of the last item and fill their OWN slices (full rows of private memory, and the table a copy lane of
   // vid_nizk4_body reads): see the comment there
-  const size_t slot = block * blockDim.x + threadIdx.x;
+  const size_t lin = block * blockDim.x + threadIdx.x;
+  const size_t slot = QUAD ? lin >> 2 : lin;
+  const int sub = QUAD ? (int)(lin & 3) : 0;
   if (n == 0 || !key.vtab) return;
   const size_t i = slot < n ? slot : n - 1;
   u32* const w = key.vtab + slot * (size_t)vtab_words<C>();
+  u32* const wp = key.vpsi ? key.vpsi + slot * (size_t)(24 * vtab_entry_words<G>()) : nullptr;     // psi^j of every multiple beside the table (WsTabPsi)
   Aff<G> kk;
   if (!g2_load<C>(kk, recs + i * (size_t)rec_words + (retr ? 5 : 3) * 2 * C::N)) return;
   if (aff_is_inf(kk)) {                     // k = O: every multiple is O (the multiplication then contributes nothing, as with a table built in place)
-    for (int q = 0; q < 8; q++) vtab_store<G>(w, q, kk);
-    if (key.vpsi)
-      for (int q = 0; q < 24; q++) vtab_store<G>(key.vpsi + slot * (size_t)(24 * vtab_entry_words<G>()), q, kk);
+    if (sub == 0)
+      for (int q = 0; q < 8; q++) vtab_store<G>(w, q, kk);
+    if (wp)
+      for (int jj = 1; jj < 4; jj++)
+        if (!QUAD || sub == jj)
+          for (int q = 0; q < 8; q++) vtab_store<G>(wp, (jj - 1) * 8 + q, kk);
     return;
   }
   Jac<G> jk[8];
@@ -835,16 +841,22 @@ __device__ __forceinline__ void vid_ktab_body(const KeyCtx<C>& key, const u32* r
   Fp2<C> z2[7], zi2[7];
   for (int q = 1; q < 8; q++) z2[q - 1] = jk[q].Z;
   batch_zinv<C, 0, 7>((Fp<C>*)0, (const Fp<C>*)0, zi2, z2);
-  u32* const wp = key.vpsi ? key.vpsi + slot * (size_t)(24 * vtab_entry_words<G>()) : nullptr;     // psi^j of every multiple beside the table (WsTabPsi)
   for (int q = 0; q < 8; q++) {
     Aff<G> a = kk;
     if (q) jac_to_aff_with_zinv<G>(a, jk[q], zi2[q - 1]);
-    vtab_store<G>(w, q, a);
+    if (sub == 0) vtab_store<G>(w, q, a);
     if (wp) {
-      for (int j = 1; j < 4; j++) {
-        Aff<G> t = a;
-        g2_psi_aff<C>(t, j);
-        vtab_store<G>(wp, (j - 1) * 8 + q, t);
+      if (QUAD) {
+        if (sub != 0) {
+          g2_psi_aff<C>(a, sub);
+          vtab_store<G>(wp, (sub - 1) * 8 + q, a);
+        }
+      } else {
+        for (int jj = 1; jj < 4; jj++) {
+          Aff<G> t = a;
+          g2_psi_aff<C>(t, jj);
+          vtab_store<G>(wp, (jj - 1) * 8 + q, t);
+        }
       }
     }
   }
@@ -855,13 +867,13 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_ktab(KeyCtx<C> key, const u32* recs, int
 }
 // The two of them as workgroup ranges of ONE launch (round 4: they are independent, and on a lone call each is a single workgroup on a chip of 256 CUs --
 // 0.33 ms and 0.21 ms one after the other, 0.33 ms side by side): workgroups [0, nb_fixed) sum, the rest build tables.
-template <class C, int J>
+template <class C, int J, bool QUAD = false>
 __global__ void ELP_LAUNCH_BOUNDS k_vid_prep(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride, uint8_t* kvalid,
                                              size_t n, unsigned nb_fixed) {
   if (blockIdx.x < nb_fixed)
     vid_fixed_coop_body<C, J>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
   else
-    vid_ktab_body<C>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
+    vid_ktab_body<C, QUAD>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
 }
 // verdict of a small-batch el_passo_verify_id = its NIZK half (k_vid_nizk4) AND its pairing check (k_pair_coop / k_pair_rest), which ran side by side
 template <class C>      // (a template only so that every translation unit that instantiates it gets its own copy)
@@ -952,10 +964,21 @@ template <class B>
 void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
                      uint8_t* kvalid) {
   // 16 lanes per fixed-base sum where the call is latency (a lone call 2.41 instead of 2.49 ms, 64 items 2.54 / 2.61), 8 where it is work (4 096 items: 4.76 / 4.93)
+  // with the psi-images wanted (key.vpsi: batches whose NIZK workgroup is the critical path) the table of an item is built on four lanes: a lone call's k_vid_prep 0.36 -> 0.30 ms
   if (n <= 512) {
     const unsigned nbf = grid_for(n * 2 * 16);
-    hipLaunchKernelGGL((k_vid_prep<B, 16>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
-                       kstride, kvalid, n, nbf);
+    if (key.vpsi)
+      hipLaunchKernelGGL((k_vid_prep<B, 16, true>), dim3(nbf + grid_for(n * 4)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre,
+                         kws, kstride, kvalid, n, nbf);
+    else
+      hipLaunchKernelGGL((k_vid_prep<B, 16>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
+                         kstride, kvalid, n, nbf);
+    return;
+  }
+  if (key.vpsi) {
+    const unsigned nbf8 = grid_for(n * 2 * ELP_PSK_LANES);
+    hipLaunchKernelGGL((k_vid_prep<B, ELP_PSK_LANES, true>), dim3(nbf8 + grid_for(n * 4)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                       (Jac<F2<B>>*)pre, kws, kstride, kvalid, n, nbf8);
     return;
   }
   if (n > 4096) {      // beyond one wave per SIMD of eight-lane sums the lane count is work: four lanes per sum (20 mixed + 2 complete additions per lane instead of 10 + 3)
