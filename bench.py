@@ -322,6 +322,12 @@ def run_child_section(args, name):
     every further queue makes the runtime reclaim blocks between queues -- seconds per event (profiles/r04_scratch_stall.md).  The child builds its own context and
     workload (same seed, same window width) and prints the section's JSON."""
     cmd = [sys.executable, os.path.abspath(__file__), "--child-section", name, "--config", str(args.config), "--window", str(args.window), "--curve", args.curve]
+    # Under a profiler (rocprofv3 preloads its tool library into every child) the child's 2^20-item dispatches of OTHER kernels would land in the same counter
+    # directory, distort the per-kernel averages and -- serialised under --pmc -- run into the time-out: profile the headline with --headline-only, and skip the
+    # child sections when a profiler preload is detected anyway (round-4 advisor finding).
+    if any(os.environ.get(k) for k in ("ROCPROFILER_LIBRARY_PATH", "ROCPROF_OUTPUT_PATH", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
+            "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return {"skipped": "profiler environment detected: child sections are not run under rocprofv3 (use --headline-only / --only for profiling passes)"}
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]

@@ -51,7 +51,10 @@ int elp_field_bytes(int curve);               /* F */
  * (src/ps-verifier.cc:16-18).  Set to 0 for bit-for-bit reference behaviour on that input.
  * On a curve with a G1 cofactor (BLS12-381) "not the point at infinity" is asked of the ORDER-r COMPONENT: sig1 must also lie in G1 (unless
  * ELP_OPT_SUBGROUP_CHECK = 0) -- a point whose order divides the cofactor pairs to 1 with everything, so (sig1, sig2) = (T, O) would satisfy the pairing
- * equation for any K.  elp_ps_verify_batch applies the same rule whatever this option says (PSVerifier::verify always rejects sigma_1 = 1).
+ * equation for any K.  elp_ps_verify_batch applies the same rule whatever ELP_OPT_STRICT_SIGNATURE says (PSVerifier::verify always rejects sigma_1 = 1).
+ * NOTE: the order-r half of the rule is the ELP_OPT_SUBGROUP_CHECK test of sig1.  With ELP_OPT_SUBGROUP_CHECK = 0 it is off on EVERY path (record, wire,
+ * aggregated, cooperative, elp_ps_verify_batch), and on BLS12-381 (sig1 of order 3, sig2 = O) is a universal forgery again: turn the check off only for
+ * inputs whose sig1 (and phi, E1, E2) the caller has already validated to lie in G1.
  * ELP_OPT_PAIRED_LAYOUT: which kernel layout verifies (results are identical).  0 = one lane per item; 1 = two lanes per item (the
  * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: the
  * two-lane kernel when the last round of 64 x SIMDs items would be at most half full (small batches, odd remainders) and always on
@@ -87,9 +90,12 @@ int elp_field_bytes(int curve);               /* F */
  * (scratch) blocks between hardware queues -- scratch is provisioned per queue, ~1 GB for a headline-sized launch of a kernel with a 14-16 KB frame -- and the
  * rule since round 4 is that large-frame kernels of a call stay on the caller's stream (profiles/r04_scratch_stall.md).  The same rule for callers: launch
  * verification batches of one process from ONE stream (two at most: aggregated batches pipelined over two streams overlap their serial tails); more
- * processes or more GPUs scale, more streams run into the reclaim. */
+ * processes or more GPUs scale, more streams run into the reclaim.
+ * ELP_OPT_FAULT_INJECT (default 0; a test hook for the error paths of callers): the next `value` calls of elp_verify_id_batch_submit on this context fail with
+ * ELP_ERR_STATE before anything is queued; nothing else is affected.
+ */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
-       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8 };
+       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

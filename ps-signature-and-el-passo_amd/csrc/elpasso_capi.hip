@@ -158,6 +158,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_SUBGROUP_CHECK: c->subgroup_check = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_COALESCED_RECORDS: c->stage_records = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_STREAM_OVERLAP: c->overlap = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_FAULT_INJECT: c->fail_submits = value > 0 ? value : 0; return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
       if (value < 0 || value > 3) return ELP_ERR_ARG;
       c->split = value;
@@ -269,6 +270,11 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
   if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  if (c->fail_submits > 0) {                     // ELP_OPT_FAULT_INJECT
+    c->fail_submits--;
+    c->err = "elp_verify_id_batch_submit: injected failure (ELP_OPT_FAULT_INJECT)";
+    return ELP_ERR_STATE;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
   if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
@@ -334,13 +340,19 @@ int elp_verify_id_batch_submit(elp_ctx* c, int slot, size_t n, const uint8_t* re
     c->err = "elp_verify_id_batch_submit: the slot has a batch in flight (call elp_verify_id_batch_wait first)";
     return ELP_ERR_STATE;
   }
+  if (c->fail_submits > 0) {                     // ELP_OPT_FAULT_INJECT
+    c->fail_submits--;
+    c->err = "elp_verify_id_batch_submit: injected failure (ELP_OPT_FAULT_INJECT)";
+    return ELP_ERR_STATE;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
   if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
-  if (!s.copied) {
-    HIPCHK(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    HIPCHK(c, hipHostMalloc((void**)&s.h_cnt, 64, hipHostMallocDefault));
+  // one-time resources of the slot, each guarded on its own: a failure half-way leaves the others to be created by the next submit
+  if (!s.copied) HIPCHK(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+  if (!s.done) HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (!s.h_cnt) HIPCHK(c, hipHostMalloc((void**)&s.h_cnt, 64, hipHostMallocDefault));
+  if (!s.dcnt) {
     size_t dummy = 0;
     if ((rc = grow_dev(c, &s.dcnt, &dummy, 8))) return rc;
   }

@@ -964,11 +964,13 @@ template <class B>
 void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, void* pre, u32* kws, size_t kstride,
                      uint8_t* kvalid) {
   // 16 lanes per fixed-base sum where the call is latency (a lone call 2.41 instead of 2.49 ms, 64 items 2.54 / 2.61), 8 where it is work (4 096 items: 4.76 / 4.93)
-  // with the psi-images wanted (key.vpsi: batches whose NIZK workgroup is the critical path) the table of an item is built on four lanes: a lone call's k_vid_prep 0.36 -> 0.30 ms
+  // with the psi-images wanted (key.vpsi: batches whose NIZK workgroup is the critical path) the table of an item is built on four lanes: a lone call's k_vid_prep 0.36 -> 0.30 ms;
+  // 4 * grid_for(n) table workgroups, so that the slots up to the end of the last 64-item wave are filled like in the one-lane form (the copy lanes of
+  // vid_nizk4_body read their own slices: round-4 advisor finding -- with grid_for(4 n) they read workspace this call had not written)
   if (n <= 512) {
     const unsigned nbf = grid_for(n * 2 * 16);
     if (key.vpsi)
-      hipLaunchKernelGGL((k_vid_prep<B, 16, true>), dim3(nbf + grid_for(n * 4)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre,
+      hipLaunchKernelGGL((k_vid_prep<B, 16, true>), dim3(nbf + 4 * grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre,
                          kws, kstride, kvalid, n, nbf);
     else
       hipLaunchKernelGGL((k_vid_prep<B, 16>), dim3(nbf + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
@@ -977,7 +979,7 @@ void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const v
   }
   if (key.vpsi) {
     const unsigned nbf8 = grid_for(n * 2 * ELP_PSK_LANES);
-    hipLaunchKernelGGL((k_vid_prep<B, ELP_PSK_LANES, true>), dim3(nbf8 + grid_for(n * 4)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+    hipLaunchKernelGGL((k_vid_prep<B, ELP_PSK_LANES, true>), dim3(nbf8 + 4 * grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                        (Jac<F2<B>>*)pre, kws, kstride, kvalid, n, nbf8);
     return;
   }
@@ -1830,6 +1832,7 @@ struct elp_ctx {
     bool busy = false;
   };
   AsyncSlot aslot[2];
+  int fail_submits = 0;          // ELP_OPT_FAULT_INJECT
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
     hipStream_t stream;

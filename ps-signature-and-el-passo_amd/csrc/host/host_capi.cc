@@ -267,6 +267,25 @@ static int benchVerifyId(int A, int H, const uint8_t* g, const uint8_t* gg, cons
         return secs(a, clk::now()) * 1e3 / nb;
       };
       (void)stream_of(2);                                   // warm-up: both slots' staging and device buffers
+      // a submit that fails half-way (the LAST context refuses its shard after the others were queued) must leave the verifier usable: no ticket, the slot
+      // free, the shards that were queued drained -- then two batches in flight work as before (round-4 advisor finding)
+      for (int round = 0; round < 2; round++) {
+        rp.set_option(ELP_OPT_FAULT_INJECT, 1, (int)rp.contexts() - 1);
+        bool threw = false;
+        try {
+          (void)rp.el_passo_verify_id_submit(proofs, ads, service, Gapk, Gg, Gh);
+        } catch (const std::exception&) {
+          threw = true;
+        }
+        if (!threw) throw std::runtime_error("the injected submit failure did not surface");
+      }
+      {
+        const size_t t1 = rp.el_passo_verify_id_submit(proofs, ads, service, Gapk, Gg, Gh);
+        const size_t t2 = rp.el_passo_verify_id_submit(proofs, ads, service, Gapk, Gg, Gh);
+        const std::vector<bool> v1 = rp.el_passo_verify_id_collect(t1), v2 = rp.el_passo_verify_id_collect(t2);
+        for (size_t j = 0; j < n; j++)
+          if (v1[j] != verdicts[j] || v2[j] != verdicts[j]) throw std::runtime_error("verdicts after a failed submit differ on item " + std::to_string(j));
+      }
       out[8] = stream_of(reps > 1 ? 2 * reps : 4);
       out[9] = stream_of(1);
       for (size_t j = 0; j < n; j++)

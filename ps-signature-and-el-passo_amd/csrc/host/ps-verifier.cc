@@ -20,6 +20,11 @@ PSVerifier::PSVerifier(const PSPubKey& pk, const std::vector<int>& devices, int 
     : m_pk(pk), m_set(std::make_shared<ElpShardSet>(pk, devices, window_bits)), m_stage(std::make_shared<Stage>()) {
   m_key = std::shared_ptr<ElpKey>(m_set, &m_set->key(0));
 }
+void PSVerifier::set_option(int option, int value, int shard) const {
+  std::lock_guard<std::mutex> lock(m_stage->mu);
+  for (size_t r = 0; r < m_set->size(); r++)
+    if (shard < 0 || (size_t)shard == r) elpCheck(m_set->key(r).ctx(), elp_set_option(m_set->key(r).ctx(), option, value), "elp_set_option");
+}
 void PSVerifier::useRpAll(const std::string& service, const G1* apk, const G1* g, const G1* h) const {
   m_set->forEachShard(m_set->size(), [&](size_t r, size_t, size_t) { m_set->key(r).useRp(service, apk, g, h); });
 }
@@ -177,42 +182,76 @@ size_t PSVerifier::el_passo_verify_id_submit(const std::vector<IdProof>& proofs,
   const std::string sig = service_name + "|" + authority_pk.serializeToHexStr() + g.serializeToHexStr() + h.serializeToHexStr();
   const bool others = st.slot[1 - si].busy;
   if (others && sig != st.rp_sig) throw std::runtime_error("el_passo_verify_id_submit: relying-party parameters differ from the batch in flight");
-  st.rp_sig = sig;
+  // Nothing of the slot or of the stage is committed before the batch is queued (or verified) successfully: a submit that throws -- a transient HIP
+  // error, staging that cannot grow -- hands out no ticket, so it must leave the slot free and the signature of the batches in flight as it was
+  // (round-4 advisor finding: two failed submits used to block the verifier for good).
   useRpAll(service_name, &authority_pk, &g, &h);        // a no-op when the parameters are the installed ones (ElpKey::useRp compares by value)
-  sl.ticket = st.next_ticket++;
-  sl.busy = true;
-  sl.sync_done = false;
-  sl.n = proofs.size();
-  // overlapped path: one context, every proof well-formed with one hidden pattern
-  const size_t A = m_key->attrs(), n = proofs.size();
-  bool uniform = m_set->size() == 1 && n > 0;
+  // overlapped path: every proof well-formed with one hidden pattern; the batch is cut into one contiguous shard per context
+  const size_t A = m_key->attrs(), n = proofs.size(), N = m_set->size();
+  bool uniform = n > 0;
   uint64_t mask = n ? elpHiddenMask(proofs[0].attributes) : 0;
   const size_t H = (size_t)__builtin_popcountll(mask);
   for (size_t i = 0; uniform && i < n; i++) {
     const IdProof& p = proofs[i];
     uniform = p.E1.has_value() && p.E2.has_value() && p.attributes.size() == A && p.rs.size() == H + 2 && H >= 2 && elpHiddenMask(p.attributes) == mask;
   }
+  std::vector<bool> ready;
+  bool sync_done = false;
   if (!uniform) {
-    sl.ready = verifyIdImpl(proofs, ads, true);
-    sl.sync_done = true;
-    return sl.ticket;
-  }
-  const size_t S1 = G1::size(), S2 = G2::size();
-  const size_t rsz = elp_verify_id_record_size(curveId(), (int)A, (int)H, 1);
-  elp_ctx* ctx = m_key->ctx();
-  uint8_t* const recs = sl.recs.get(ctx, n * rsz);
-  uint32_t* const adoff = (uint32_t*)sl.offs.get(ctx, (n + 1) * 4);
-  adoff[0] = 0;
-  for (size_t j = 0; j < n; j++) adoff[j + 1] = adoff[j] + (uint32_t)ads[j].size();
-  uint8_t* const adbuf = sl.ads.get(ctx, adoff[n] ? adoff[n] : 1);
-  uint8_t* const flags = sl.flags.get(ctx, n);
-  elpParallelFor(n, 512, [&](size_t lo, size_t hi) {
-    for (size_t j = lo; j < hi; j++) {
-      packRecord(recs + j * rsz, proofs[j], true, S1, S2);
-      if (!ads[j].empty()) memcpy(adbuf + adoff[j], ads[j].data(), ads[j].size());
+    ready = verifyIdImpl(proofs, ads, true);
+    sync_done = true;
+  } else {
+    const size_t S1 = G1::size(), S2 = G2::size();
+    const size_t rsz = elp_verify_id_record_size(curveId(), (int)A, (int)H, 1);
+    if (sl.shard.size() != N) sl.shard = std::vector<Stage::ShardBuf>(N);
+    // page-locked staging of every shard from its own context (grown before anything is queued)
+    std::vector<uint8_t*> recs(N), adbuf(N), flags(N);
+    std::vector<uint32_t*> adoff(N);
+    std::vector<size_t> first(N), count(N);
+    for (size_t r = 0; r < N; r++) {
+      ElpShardSet::range(n, r, N, first[r], count[r]);
+      elp_ctx* ctx = m_set->key(r).ctx();
+      const size_t c = count[r];
+      size_t adbytes = 0;
+      for (size_t j = 0; j < c; j++) adbytes += ads[first[r] + j].size();
+      recs[r] = sl.shard[r].recs.get(ctx, (c ? c : 1) * rsz);
+      adoff[r] = (uint32_t*)sl.shard[r].offs.get(ctx, (c + 1) * 4);
+      adbuf[r] = sl.shard[r].ads.get(ctx, adbytes ? adbytes : 1);
+      flags[r] = sl.shard[r].flags.get(ctx, c ? c : 1);
+      adoff[r][0] = 0;
+      for (size_t j = 0; j < c; j++) adoff[r][j + 1] = adoff[r][j] + (uint32_t)ads[first[r] + j].size();
     }
-  });
-  elpCheck(ctx, elp_verify_id_batch_submit(ctx, si, n, recs, mask, 1, adbuf, adoff, 0, flags), "elp_verify_id_batch_submit");
+    // shard by shard: pack on all host threads, queue copies + kernel on the shard's context (asynchronous), go on packing the next shard while the
+    // first ones already verify
+    std::vector<char> queued(N, 0);
+    try {
+      for (size_t r = 0; r < N; r++) {
+        if (count[r] == 0) continue;
+        elpParallelFor(count[r], 512, [&](size_t lo, size_t hi) {
+          for (size_t j = lo; j < hi; j++) {
+            packRecord(recs[r] + j * rsz, proofs[first[r] + j], true, S1, S2);
+            const std::string& ad = ads[first[r] + j];
+            if (!ad.empty()) memcpy(adbuf[r] + adoff[r][j], ad.data(), ad.size());
+          }
+        });
+        elp_ctx* ctx = m_set->key(r).ctx();
+        elpCheck(ctx, elp_verify_id_batch_submit(ctx, si, count[r], recs[r], mask, 1, adbuf[r], adoff[r], 0, flags[r]), "elp_verify_id_batch_submit");
+        queued[r] = 1;
+      }
+    } catch (...) {
+      for (size_t r = 0; r < N; r++)          // drain what was queued: the slot of those contexts must be idle again
+        if (queued[r]) (void)elp_verify_id_batch_wait(m_set->key(r).ctx(), si, nullptr);
+      throw;
+    }
+    sl.first = first;
+    sl.count = count;
+  }
+  st.rp_sig = sig;
+  sl.ready = std::move(ready);
+  sl.sync_done = sync_done;
+  sl.n = n;
+  sl.ticket = st.next_ticket++;
+  sl.busy = true;
   return sl.ticket;
 }
 std::vector<bool> PSVerifier::el_passo_verify_id_collect(size_t ticket) const {
@@ -223,12 +262,22 @@ std::vector<bool> PSVerifier::el_passo_verify_id_collect(size_t ticket) const {
   Stage::Slot& sl = st.slot[si];
   sl.busy = false;
   if (sl.sync_done) return std::move(sl.ready);
-  elp_ctx* ctx = m_key->ctx();
-  uint64_t acc = 0;
-  elpCheck(ctx, elp_verify_id_batch_wait(ctx, si, &acc), "elp_verify_id_batch_wait");
-  const uint8_t* flags = sl.flags.get(ctx, sl.n);        // the same block: get() only grows
   std::vector<bool> out(sl.n);
-  for (size_t j = 0; j < sl.n; j++) out[j] = flags[j] != 0;
+  std::exception_ptr err;
+  for (size_t r = 0; r < sl.shard.size(); r++) {          // every shard is waited for, whatever the others returned: the slot is idle afterwards
+    if (sl.count[r] == 0) continue;
+    elp_ctx* ctx = m_set->key(r).ctx();
+    uint64_t acc = 0;
+    try {
+      elpCheck(ctx, elp_verify_id_batch_wait(ctx, si, &acc), "elp_verify_id_batch_wait");
+    } catch (...) {
+      if (!err) err = std::current_exception();
+      continue;
+    }
+    const uint8_t* flags = sl.shard[r].flags.get(ctx, sl.count[r]);        // the same block: get() only grows
+    for (size_t j = 0; j < sl.count[r]; j++) out[sl.first[r] + j] = flags[j] != 0;
+  }
+  if (err) std::rethrow_exception(err);
   return out;
 }
 

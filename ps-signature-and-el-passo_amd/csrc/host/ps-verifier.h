@@ -16,6 +16,8 @@ class PSVerifier {
   // (SURVEY.md section 8e); window_bits < 0 = the process default
   PSVerifier(const PSPubKey& pk, const std::vector<int>& devices, int window_bits = -1);
   size_t contexts() const { return m_set->size(); }
+  // elp_set_option (include/elpasso.h) on context `shard`, or on every context of this verifier (shard < 0)
+  void set_option(int option, int value, int shard = -1) const;
 
   bool verify(const PSCredential& sig, const std::vector<std::string>& all_attributes) const;
 
@@ -46,11 +48,14 @@ class PSVerifier {
                                           const G1* h = nullptr) const;
   std::vector<bool> verify_batch(const std::vector<PSCredential>& sigs, const std::vector<std::vector<std::string>>& all_attributes) const;
 
-  // ---- pipelined form of el_passo_verify_id_batch (round 4): submit() packs the batch into page-locked staging, queues copies + kernel and returns a ticket;
-  // collect(ticket) waits for it and returns the verdicts.  Up to TWO batches in flight: while the GPU verifies one, the host packs the next and its records
-  // travel over PCIe -- a steady stream of batches costs the kernel time alone (elp_verify_id_batch_submit / _wait).  Conditions for the overlapped path: one
-  // context, every proof of the batch well-formed with the same hidden pattern; anything else is verified synchronously inside submit() and merely handed
-  // out by collect().  The relying-party parameters must be the same for all batches in flight (a change throws).  Tickets are collected in submission order.
+  // ---- pipelined form of el_passo_verify_id_batch (round 4; several contexts since round 5): submit() packs the batch into page-locked staging, queues
+  // copies + kernel and returns a ticket; collect(ticket) waits for it and returns the verdicts.  Up to TWO batches in flight: while the GPUs verify one,
+  // the host packs the next and its records travel over PCIe -- a steady stream of batches costs the kernel time alone (elp_verify_id_batch_submit / _wait).
+  // A verifier with several contexts (PSVerifier(pk, devices, W): the one-process form of the multi-GPU split) cuts every batch into one contiguous shard
+  // per context, each with its own staging, copy stream and slot pair; shard r is queued as soon as it is packed.  Condition for the overlapped path:
+  // every proof of the batch well-formed with the same hidden pattern; anything else is verified synchronously inside submit() and merely handed out by
+  // collect().  The relying-party parameters must be the same for all batches in flight (a change throws).  A submit() that throws leaves no trace: no
+  // ticket, the slot free.  Tickets are collected in submission order.
   size_t el_passo_verify_id_submit(const std::vector<IdProof>& proofs, const std::vector<std::string>& associated_data, const std::string& service_name,
                                    const G1& authority_pk, const G1& g, const G1& h) const;
   std::vector<bool> el_passo_verify_id_collect(size_t ticket) const;
@@ -66,8 +71,12 @@ class PSVerifier {
     std::mutex mu;
     ElpPinned recs, ads, flags;
     // the two slots of the pipelined form
+    struct ShardBuf {
+      ElpPinned recs, ads, offs, flags;   // staging of one shard, page-locked through the shard's own context
+    };
     struct Slot {
-      ElpPinned recs, ads, offs, flags;
+      std::vector<ShardBuf> shard;       // one per context
+      std::vector<size_t> first, count;  // the shards of the batch in flight
       bool busy = false;
       size_t ticket = 0, n = 0;
       std::vector<bool> ready;         // verdicts of a batch that took the synchronous path

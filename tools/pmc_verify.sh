@@ -1,6 +1,6 @@
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VMEM SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmcA -o r -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmcB -o r -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VMEM SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmcA -o r -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --headline-only > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmcB -o r -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --headline-only > /dev/null 2>&1
 cd $R; python3 - <<PY
 import csv,collections
 for name in ("pmcA","pmcB"):
