@@ -91,11 +91,16 @@ int elp_field_bytes(int curve);               /* F */
  * rule since round 4 is that large-frame kernels of a call stay on the caller's stream (profiles/r04_scratch_stall.md).  The same rule for callers: launch
  * verification batches of one process from ONE stream (two at most: aggregated batches pipelined over two streams overlap their serial tails); more
  * processes or more GPUs scale, more streams run into the reclaim.
+ * ELP_OPT_PAIR4 (default 1; round 5): the pairing check e(sig1, K) e(-sig2, gg) == 1 on FOUR lanes per item (a DPP quad: the Fp12 value of the Miller loop and of the
+ * final exponentiation spread over four lanes, 27 / 42 registers per lane, no private memory in the loops; csrc/elp/quad.h, pair4.h) for batches between the range of the
+ * cooperative interpreter and the batches that fill the chip at one or two lanes per item: el_passo_verify_id of 9 217 ... 32 768 items (BLS12-381: from 8 193) --
+ * NIZK half in the job kernels of the small-batch path, then k_pair4 -- and PS verifications of 4 097 ... 32 768 items.  0 = off (the two-lane kernels take these
+ * sizes), 2 = wherever the path exists (any batch up to 131 072 items; for A/B measurements).  Verdicts are identical.
  * ELP_OPT_FAULT_INJECT (default 0; a test hook for the error paths of callers): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  * ELP_ERR_STATE before anything is queued; nothing else is affected.
  */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
-       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9 };
+       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

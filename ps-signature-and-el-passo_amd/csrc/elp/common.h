@@ -63,6 +63,14 @@
 #define ELP_FP6 ELP_INL
 #endif
 
+// -DELP_BISECT=k (experiments only: tools/probes/bls_fault_repro.sh): the PS-verification path of a translation unit returns early after step k, so that a run-time
+// fault of a non-default build can be pinned to the first step whose code it needs.  Undefined in every product build.
+#if defined(ELP_BISECT) && defined(__HIP_DEVICE_COMPILE__)
+#define ELP_BISECT_AT(k) (ELP_BISECT == (k))
+#else
+#define ELP_BISECT_AT(k) false
+#endif
+
 namespace elp {
 typedef uint32_t u32;
 typedef uint64_t u64;

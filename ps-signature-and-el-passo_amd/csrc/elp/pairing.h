@@ -411,6 +411,10 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
   fp12_mul<C>(f, t1, t0);      // f^(p^6 - 1)
   fp12_frob<C>(t0, f, 2);
   fp12_mul<C>(f, t0, f);       // ^(p^2 + 1)
+  if (ELP_BISECT_AT(3)) {
+    r = f;
+    return;
+  }
   if constexpr (C::IS_BN && !EXACT) {
     // Fuentes-Castaneda, Knapp, Rodriguez-Henriquez: the multiple 2z(6z^2+3z+1) of the hard part (a non-zero integer below r, hence prime to it),
     //     l0 + l1 p + l2 p^2 + l3 p^3,   l2 = 6z + 6z^2 + 12z^3,  l1 = l2 - 2z,  l0 = l2 + 6z^2 + 1,  l3 = l1 - 1:
@@ -482,6 +486,10 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
       if (C::Z_NEG) fp12_conj(a, a);        // z - 1 < 0 as well
     } else {
       fp12_exp_z<C>(t, f, hot);
+      if (ELP_BISECT_AT(4)) {
+        r = t;
+        return;
+      }
       fp12_conj(b, f);
       fp12_mul<C>(a, t, b);                 // f^(z-1)
     }
@@ -491,6 +499,10 @@ ELP_HEAVY void final_exp(Fp12<C>& r, const Fp12<C>& f_in, u32* hot = nullptr) {
     fp12_exp_z<C>(t, a, hot);
     fp12_frob<C>(b, a, 1);
     fp12_mul<C>(b, b, t);                   // a^(z+p)
+    if (ELP_BISECT_AT(5)) {
+      r = b;
+      return;
+    }
     fp12_exp_z<C>(t, b, hot);
     fp12_exp_z<C>(t, t, hot);
     fp12_frob<C>(c, b, 2);

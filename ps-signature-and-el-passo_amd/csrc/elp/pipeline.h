@@ -1592,6 +1592,7 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   for (int i = 0; i < nattr; i++) acc_fixed_g2<C>(K, key, G2_BASE_YY0 + i, scalar_load_w(ms + 8 * i));
   Aff<G2F> aK;
   jac_to_aff<G2F>(aK, K);
+  if (ELP_BISECT_AT(1)) return !aff_is_inf(aK);
   Aff<G1F> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);
@@ -1600,6 +1601,7 @@ ELP_HEAVY bool ps_verify_item(const KeyCtx<C>& key, const u32* rec, int nattr) {
   Fp12<C>& f = fh ? *fh : f_priv;
   const LineMem<C>* lines[1] = {key.gg_lines};
   miller_loop<C, 1, 1>(f, &sig1, &aK, &nsig2, lines);
+  if (ELP_BISECT_AT(2)) return fp2_is_zero<C>(f.c0.c0);
   return final_exp_is_one<C>(f, key.hot);
 }
 

@@ -232,9 +232,27 @@ ELP_INL void fp12q_mul(Fp12Q<C>& r, const Fp12Q<C>& a, const Fp12Q<C>& b) {
   fp6_mul2<C>(t, a.h, Y, Z, W);
   r.h = t;
 }
+// r = a^2 by complex squaring: t = a0 a1, u = (a0 + a1)(a0 + v a1), c0 = u - t - v t, c1 = 2 t.  The low pair computes u, the high pair t -- ONE Fp6 product
+// (six fp_mul_pair per lane) instead of the fused pair of the general product -- and t crosses to the low pair once.
 template <class C>
-ELP_INL void fp12q_sqr(Fp12Q<C>& r, const Fp12Q<C>& a) {   // general squaring (Miller loop): the schoolbook form costs the pair the same either way
-  fp12q_mul<C>(r, a, a);
+ELP_INL void fp12q_sqr(Fp12Q<C>& r, const Fp12Q<C>& a) {
+  const bool hi = quad_hi();
+  const Fp6<C> p = fp6_quad_swap(a.h);
+  Fp6<C> X, Y, vo;                                  // X = a0 + a1 (the same on both pairs); low: Y = a0 + v a1 = own + v p
+  fp6_add(X, a.h, p);
+  fp6_mul_by_v(vo, p);
+  fp6_add(Y, a.h, vo);
+  const Fp6<C> U = fp6_select(hi, a.h, X), V = fp6_select(hi, p, Y);
+  Fp6<C> m;
+  fp6_mul<C>(m, U, V);                              // low: u, high: t
+  const Fp6<C> t = fp6_quad_swap(m);               // low: t
+  Fp6<C> lo;
+  lo.c0 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(m.c0, t.c0), fp2_mul_xi_lazy(t.c2)));      // u - t - v t: 1 + 1 + 2
+  lo.c1 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(m.c1, t.c1), t.c0));
+  lo.c2 = fp2_carry_fast(fp2_sub_lazy(fp2_sub_lazy(m.c2, t.c2), t.c1));
+  r.h.c0 = fp2_select(hi, fp2_dbl(m.c0), lo.c0);
+  r.h.c1 = fp2_select(hi, fp2_dbl(m.c1), lo.c1);
+  r.h.c2 = fp2_select(hi, fp2_dbl(m.c2), lo.c2);
 }
 
 // ---- Fp4 = Fp2[s]/(s^2 - xi) on a quad.  An element X = x0 + x1 s has the components (x0.re, x0.im, x1.re, x1.im) = X[0..3]; component c lives on
@@ -297,39 +315,54 @@ ELP_INL void fp12q_cyc_sqr(Fp12Q<C>& r, const Fp12Q<C>& a) {
   r.h = t;
 }
 
-// Karabina compressed squaring (tower.h: cyc_comp_sqr_inl): only (z2, z3, z4, z5) are carried -- on the quad: low pair (c1, c2) = (z4, z3), high pair
-// (c0, c2) = (z2, z5); two fp4q_mul per step.
+// Karabina compressed squaring (tower.h: cyc_comp_sqr_inl): only b = z2 + z3 s and c = z4 + z5 s are carried.  The two Fp4 squarings of a step are
+// INDEPENDENT, so here each lane pair owns one of them whole -- the low pair b, the high pair c, as two-lane squarings (fp4_sqr: three fp2_sqr, one
+// base-field product per lane each) -- and only the results cross:   b' = 3 s C + 2 conj(b),   c' = 3 B - 2 conj(c)   (s C = xi C1 + C0 s).
 template <class C>
 struct CycCompQ {
-  Fp2<C> u, w;     // low pair: (u, w) = (z4, z3); high pair: (u, w) = (z2, z5)
+  Fp2<C> x0, x1;     // low pair: (z2, z3); high pair: (z4, z5)
 };
 template <class C>
 ELP_INL void fp12q_to_comp(CycCompQ<C>& r, const Fp12Q<C>& a) {
+  // Fp12Q: low pair (c0, c1, c2) = (z0, z4, z3), high pair (c0, c1, c2) = (z2, z1, z5).  low wants (z2, z3): z2 from the high pair's c0; high wants (z4, z5): z4 from the low pair's c1
   const bool hi = quad_hi();
-  r.u = fp2_select(hi, a.h.c0, a.h.c1);
-  r.w = a.h.c2;
+  const Fp2<C> give = fp2_select(hi, a.h.c0, a.h.c1);          // low gives z4, high gives z2
+  r.x0 = fp2_quad_swap(give);
+  r.x1 = a.h.c2;
 }
 template <class C>
 ELP_INL void cyc_compq_sqr(CycCompQ<C>& r, const CycCompQ<C>& a) {
   const bool hi = quad_hi();
-  // block B = (z2 | z3): x0 = z2 = high u, x1 = z3 = low w;   block C = (z4 | z5): x0 = z4 = low u, x1 = z5 = high w
-  const Fp<C> xb = fp_select(hi, a.u.c, a.w.c), xc = fp_select(hi, a.w.c, a.u.c);
-  Fp2<C> oB, oC;
-  oB.c = fp4q_mul<C, 1, 1, 0>(xb, xb);                          // (B0 | B1)
-  oC.c = fp4q_mul<C, 0, 0, 0>(xc, xc);                          // (C0 | C1)
-  // low:  u = z4' = 3 B0 - 2 z4,  w = z3' = 3 C0 - 2 z3        high: u = z2' = 3 xi C1 + 2 z2,  w = z5' = 3 B1 + 2 z5
-  const Fp2<C> xC = fp2_carry_fast(fp2_mul_xi_lazy(oC));
-  const Fp2<C> Tu = fp2_select(hi, xC, oB), Tw = fp2_select(hi, oB, oC);
-  auto upd = [&](const Fp2<C>& T, const Fp2<C>& z) {
-    Fp2<C> o = fp2_add_lazy(fp2_add_lazy(fp2_add_lazy(T, T), T), fp2_add_lazy(z, z));
-    Fp2<C> l = fp2_sub_lazy(fp2_add_lazy(fp2_add_lazy(T, T), T), fp2_add_lazy(z, z));
-    Fp2<C> s = fp2_select(hi, o, l);
+  Fp2<C> S0, S1;
+  fp4_sqr<C>(S0, S1, a.x0, a.x1);                               // low: B, high: C
+  const Fp2<C> P0 = fp2_quad_swap(S0), P1 = fp2_quad_swap(S1);  // low: C, high: B
+  // low:  x0' = z2' = 3 xi C1 + 2 z2,  x1' = z3' = 3 C0 - 2 z3        high: x0' = z4' = 3 B0 - 2 z4,  x1' = z5' = 3 B1 + 2 z5
+  const Fp2<C> xP1 = fp2_carry_fast(fp2_mul_xi_lazy(P1));
+  const Fp2<C> T0 = fp2_select(hi, P0, xP1), T1 = fp2_select(hi, P1, P0);
+  auto upd = [&](const Fp2<C>& T, const Fp2<C>& z, bool plus) {
+    const Fp2<C> t3 = fp2_add_lazy(fp2_add_lazy(T, T), T), z2 = fp2_add_lazy(z, z);
+    Fp2<C> s = fp2_select(plus, fp2_add_lazy(t3, z2), fp2_sub_lazy(t3, z2));
     fp2_reduce_weak(s);
     return s;
   };
-  const Fp2<C> nu = upd(Tu, a.u), nw = upd(Tw, a.w);
-  r.u = nu;
-  r.w = nw;
+  const Fp2<C> n0 = upd(T0, a.x0, !hi), n1 = upd(T1, a.x1, hi);
+  r.x0 = n0;
+  r.x1 = n1;
+}
+// the whole (z2, z3, z4, z5) on every lane pair, in the two-lane form of tower.h (for norms and decompression, which run on both pairs alike)
+template <class C>
+ELP_INL void compq_to_paired(CycComp<C>& r, const CycCompQ<C>& a) {
+  const bool hi = quad_hi();
+  const Fp2<C> p0 = fp2_quad_swap(a.x0), p1 = fp2_quad_swap(a.x1);
+  r.z2 = fp2_select(hi, p0, a.x0);
+  r.z3 = fp2_select(hi, p1, a.x1);
+  r.z4 = fp2_select(hi, a.x0, p0);
+  r.z5 = fp2_select(hi, a.x1, p1);
+}
+// this lane pair's half of a value both pairs hold in full
+template <class C>
+ELP_INL void fp12q_from_paired(Fp12Q<C>& r, const Fp12<C>& a) {
+  r.h = fp6_select(quad_hi(), a.c1, a.c0);
 }
 
 // f <- f * l for a D-type line l = a + b w + c w^3 = (a, 0, 0) + (b, c, 0) w  (a, b, c carried Fp2 values, the same on both pairs):

@@ -1,0 +1,5 @@
+// Four-lanes-per-item pairing check for BLS12-381 (elp/pair4.h, elpasso_pair4.h; parity unpinned like everything on this curve): a translation unit of its own.
+#define ELP_PAIR4_TU 1
+#include "elpasso_pair4.h"
+
+template void launch_pair4<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);

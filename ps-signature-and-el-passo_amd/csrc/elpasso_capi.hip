@@ -159,6 +159,10 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_COALESCED_RECORDS: c->stage_records = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_STREAM_OVERLAP: c->overlap = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_FAULT_INJECT: c->fail_submits = value > 0 ? value : 0; return ELP_OK;
+    case ELP_OPT_PAIR4:
+      if (value < 0 || value > 2) return ELP_ERR_ARG;
+      c->pair4 = value;
+      return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
       if (value < 0 || value > 3) return ELP_ERR_ARG;
       c->split = value;

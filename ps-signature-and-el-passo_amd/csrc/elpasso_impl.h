@@ -1833,6 +1833,7 @@ struct elp_ctx {
   };
   AsyncSlot aslot[2];
   int fail_submits = 0;          // ELP_OPT_FAULT_INJECT
+  int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
     hipStream_t stream;
@@ -2684,6 +2685,19 @@ extern template void launch_agg_final_paired<BN254>(elp_ctx* c, hipStream_t stre
 extern template void launch_agg_final_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
 #endif
 
+// the pairing check on FOUR lanes per item (elp/pair4.h, elpasso_pair4.h; translation units elpasso_<curve>_pair4.hip): reads K and `todo` like k_pair_rest
+#ifndef ELP_PAIR4_TU
+template <class B>
+void launch_pair4(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
+                  void* d_accepted);
+extern template void launch_pair4<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
+extern template void launch_pair4<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
+#endif
+// batch sizes served by the four-lane pairing check (ELP_OPT_PAIR4 = 1): above the cooperative interpreter's range, up to two waves per SIMD of quads
+#ifndef ELP_PAIR4_MAX
+#define ELP_PAIR4_MAX 32768
+#endif
+
 template <class C>
 int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,
                             const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
@@ -2694,9 +2708,13 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
   if constexpr (CoopBuild<C>::value && SmallBuild<C>::value) {
-    if (c->coop && n <= (c->vid_coop_max ? c->vid_coop_max : (size_t)(C::IS_BN ? 9216 : 8192))) {
+    const bool small = c->coop && n <= (c->vid_coop_max ? c->vid_coop_max : (size_t)(C::IS_BN ? 9216 : 8192));
+    // mid-size batches (round 5): the same job kernels for the NIZK half, the pairing check on FOUR lanes per item (k_pair4) -- between the interpreter's range and
+    // the batches that fill the chip at one or two lanes per item
+    const bool mid = c->pair4 == 2 ? n <= (size_t)(4 * ELP_PAIR4_MAX) : (c->pair4 == 1 && !small && n <= (size_t)ELP_PAIR4_MAX);
+    if (small || mid) {
       // small batch: NIZK half with four job lanes per item (k_vid_nizk4), pairing check on 32 / 64 lanes per item (k_pair_coop)
-      const void* consts = coop_consts_for<C>(c, (hipStream_t)stream);
+      const void* consts = mid ? (const void*)c : coop_consts_for<C>(c, (hipStream_t)stream);      // the interpreter's constants: not needed by the four-lane check
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
       void* extra = nullptr;
@@ -2706,7 +2724,7 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       if (consts && extra) {
         // ... where the NIZK workgroup is the critical path of the call (one round of pairing workgroups: a lone call 2.36 -> 2.23 ms, 64 items 2.48 -> 2.31, 1 024 items
         // 2.69 -> 2.42); above, the 24 extra entries per item only cost k_vid_prep time (4 096 items: 4.96 against 4.62 ms)
-        if (n <= c->small_dense_from) key.vpsi = (u32*)((uint8_t*)extra + k_bytes + pre_bytes + ((4 * lanes + 255) & ~(size_t)255));
+        if (n <= c->small_dense_from && !mid) key.vpsi = (u32*)((uint8_t*)extra + k_bytes + pre_bytes + ((4 * lanes + 255) & ~(size_t)255));
         // k_vid_fixed_coop (fixed-base sums, K) and k_vid_ktab (multiples of k) -> k_vid_nizk4 and k_pair_coop -> k_vid_combine.  The pairing check only
         // needs K, the NIZK half only the sums and the table: with ELP_OPT_STREAM_OVERLAP the two pairs of kernels run side by side on two streams
         //   caller's stream:  memset, k_vid_fixed_coop ------------------(e0)  wait(e3) k_vid_nizk4 ............ wait(e1) k_vid_combine
@@ -2720,7 +2738,8 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         uint8_t* kvalid = done + lanes;
         uint8_t* pair_ok = kvalid + lanes;
         hipStream_t js = st;
-        if (c->overlap) {
+        const bool overlap = c->overlap && !mid;
+        if (overlap) {
           if (!c->jstream) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->jstream, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->jev[0], hipEventDisableTiming));
@@ -2733,23 +2752,26 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
           js = c->jstream;
         }
         HIPCHK(c, hipMemsetAsync(done, 0, lanes, st));
-        if (c->overlap) {
+        if (overlap) {
           HIPCHK(c, hipEventRecord(c->jev[2], st));                        // what the caller queued before this call (the records) precedes the second stream's work
           HIPCHK(c, hipStreamWaitEvent(js, c->jev[2], 0));
         }
-        if (!c->overlap) {
+        if (!overlap) {
           launch_vid_prep<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);      // both as workgroup ranges of one launch
         } else {
           launch_vid_ktab<C>(js, key, n, d_records, words, retr);
           HIPCHK(c, hipEventRecord(c->jev[3], js));
           launch_vid_fixed_coop<C>(st, key, n, d_records, words, mask, retr, pre, kws, lanes, kvalid);
         }
-        if (c->overlap) {
+        if (overlap) {
           HIPCHK(c, hipEventRecord(c->jev[0], st));
           HIPCHK(c, hipStreamWaitEvent(js, c->jev[0], 0));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[3], 0));
         }
-        if (c->overlap) {
+        if (mid) {
+          launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
+          launch_pair4<C>(st, key.gg_lines, n, d_records, words, kvalid, kws, lanes, pair_ok, nullptr);
+        } else if (overlap) {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
           key.vtab = nullptr;
           launch_pair_coop<C>(js, key, consts, n, d_records, words, kvalid, kws, lanes, pair_ok, done, nullptr, ELP_REST_BY_CALLER);
@@ -2910,9 +2932,11 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   if constexpr (CoopBuild<C>::value) {
-    if (c->coop && n <= c->coop_max) {
-      // small batch: K per item on one lane each (three table sums), then the pairing check on 32 lanes per item
-      const void* consts = coop_consts_for<C>(c, (hipStream_t)stream);
+    const bool small = c->coop && n <= c->coop_max;
+    const bool mid = c->pair4 == 2 ? n <= (size_t)(4 * ELP_PAIR4_MAX) : (c->pair4 == 1 && !small && n <= (size_t)ELP_PAIR4_MAX);      // four lanes per item above the interpreter's range
+    if (small || mid) {
+      // small batch: K per item on eight lanes (three table sums), then the pairing check on 32 lanes per item (interpreter) or on four (k_pair4)
+      const void* consts = mid ? (const void*)c : coop_consts_for<C>(c, (hipStream_t)stream);
       const size_t lanes = (size_t)grid_for(n) * ELP_BLOCK;
       const size_t k_bytes = (lanes * (size_t)vid_k_words<C>() * 4 + 255) & ~(size_t)255;
       void* extra = nullptr;
@@ -2927,7 +2951,10 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
         const int words = 4 * C::N + 8 * nattr;
         launch_ps_k<C>((hipStream_t)stream, key, n, d_records, words, nattr, todo, kws, lanes);
-        launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, done, d_accepted, nullptr);
+        if (mid)
+          launch_pair4<C>((hipStream_t)stream, key.gg_lines, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, d_accepted);
+        else
+          launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, done, d_accepted, nullptr);
         HIPCHK(c, hipGetLastError());
         return ELP_OK;
       }

@@ -18,6 +18,8 @@ OPT_SUBGROUP_CHECK = 5
 OPT_COOP_PAIRING = 6
 OPT_COALESCED_RECORDS = 7
 OPT_STREAM_OVERLAP = 8
+OPT_FAULT_INJECT = 9
+OPT_PAIR4 = 10
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -185,6 +187,10 @@ class Context:
     def set_stream_overlap(self, on):
         """ELP_OPT_STREAM_OVERLAP (default off): independent kernels of one call on the context's second stream (small-batch verify_id, aggregated tail)."""
         self._chk(self.lib.elp_set_option(self.h, OPT_STREAM_OVERLAP, int(bool(on))))
+
+    def set_pair4(self, mode):
+        """ELP_OPT_PAIR4: 0 = off, 1 = the four-lanes-per-item pairing check for mid-size batches (default), 2 = wherever the path exists."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_PAIR4, int(mode)))
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default 0): 1 / 2 = one-lane-per-item verify_id as phase-split kernels (NIZK jobs, then the pairing); identical results."""

@@ -73,3 +73,76 @@ def test_config4_wire_path_full_size_vs_oracle(gpu_ctx):
     L.elpo_verify_id_batch(key, len(idx), samp, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
     assert (ofl == wflags[idx]).all() and int((ofl == 0).sum()) == len(bad)
     L.elpo_key_free(key)
+
+
+@pytest.mark.parametrize("n", [9217, 12288, 16384, 32768])
+def test_four_lane_pairing_mid_batches_vs_oracle(gpu_ctx, n):
+    """VERDICT r4 #1b: el_passo_verify_id at the sizes between the cooperative interpreter and the full-chip kernels -- NIZK half in the job kernels, the pairing check
+    e(sig1, K) e(-sig2, gg) == 1 (src/ps-verifier.cc:132-137) on FOUR lanes per item (k_pair4, ELP_OPT_PAIR4 default): every verdict against the generator's expectation
+    and the two-lane kernels' (option off), 600+ of them -- a stride plus EVERY corrupted item -- against the C oracle; corrupted signatures, items whose group law meets
+    P + P, ragged last workgroups."""
+    L = oracle()
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=515, window_bits=8)
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=53, corrupt_at=7, degenerate_items=(5, 4097), window_bits=8)
+    gpu_ctx.set_pair4(1)
+    f4, c4 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+    gpu_ctx.set_pair4(0)
+    f2, c2 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+    gpu_ctx.set_pair4(1)
+    assert (f4 == expect).all() and c4 == int(expect.sum())
+    assert (f2 == f4).all() and c2 == c4
+    bad = [i for i in range(n) if not expect[i]]
+    idx = sorted(set(list(range(0, n, max(1, n // 600))) + bad))
+    key = _oracle_key(L, wl, gpu_ctx, A)
+    rsz = len(recs) // n
+    samp = b"".join(recs[i * rsz:(i + 1) * rsz] for i in idx)
+    ofl = np.zeros(len(idx), dtype=np.uint8)
+    L.elpo_verify_id_batch(key, len(idx), samp, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+    assert (ofl == f4[idx]).all() and int((ofl == 0).sum()) == len(bad)
+    L.elpo_key_free(key)
+
+
+def test_four_lane_pairing_forced_small_and_ps_verify(gpu_ctx):
+    """The same kernel forced onto sizes it does not serve by default (ELP_OPT_PAIR4 = 2): a lone item, partly filled quads / waves, PS verification (src/ps-verifier.cc:13-35)
+    with tampered signatures, sig2 = infinity, sig1 = infinity; verdicts equal the default paths' and the C oracle's."""
+    L = oracle()
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=99, window_bits=8)
+    key = _oracle_key(L, wl, gpu_ctx, A)
+    try:
+        for n in (1, 3, 15, 16, 17, 63, 65, 1000):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=5, corrupt_at=1)
+            gpu_ctx.set_pair4(2)
+            f4, c4 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            gpu_ctx.set_pair4(1)
+            f1, c1 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            assert (f4 == expect).all() and (f1 == expect).all() and c4 == c1 == int(expect.sum())
+            rsz = len(recs) // n
+            ofl = np.zeros(n, dtype=np.uint8)
+            L.elpo_verify_id_batch(key, n, recs, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+            assert (ofl == f4).all()
+        wl3 = synth.Workload(gpu_ctx, 3, seed=100, window_bits=8)
+        key3 = _oracle_key(L, wl3, gpu_ctx, 3)
+        for n in (1, 17, 4096, 5000, 20000):
+            recs, expect = wl3.ps_verify_batch(n, corrupt_every=11, corrupt_at=3)
+            recs = bytearray(recs)
+            rsz = len(recs) // n
+            if n >= 17:
+                recs[5 * rsz + 64:5 * rsz + 128] = bytes(64)            # item 5: sig2 = infinity -> reject
+                recs[6 * rsz:6 * rsz + 64] = bytes(64)                  # item 6: sig1 = infinity -> reject (src/ps-verifier.cc:16-18)
+                expect = expect.copy()
+                expect[5] = expect[6] = 0
+            recs = bytes(recs)
+            gpu_ctx.set_pair4(2)
+            f4, c4 = gpu_ctx.ps_verify_batch(recs, 3)
+            gpu_ctx.set_pair4(0)
+            f0, c0 = gpu_ctx.ps_verify_batch(recs, 3)
+            gpu_ctx.set_pair4(1)
+            assert (f4 == expect).all() and (f0 == expect).all() and c4 == c0 == int(expect.sum())
+            for i in list(range(0, n, max(1, n // 40))) + ([5, 6] if n >= 17 else []):
+                assert L.elpo_ps_verify(key3, recs[i * rsz:(i + 1) * rsz], 3) == int(f4[i]), (n, i)
+        L.elpo_key_free(key3)
+    finally:
+        gpu_ctx.set_pair4(1)
+        L.elpo_key_free(key)

@@ -151,6 +151,45 @@ def main():
                 res[name]["W%d" % W]["counted"] = "sparse tables: only the entries this item reads are present"
             elif W != 20:
                 res[name]["W%d" % W] = entry(*extrapolate(i, W), extrapolated=True)
+    # ---- the other BASELINE configurations (round 5): PS verification with 3 attributes (config 2, src/ps-verifier.cc:13-35) and issuance with 8 attributes,
+    # 4 hidden (config 3, src/ps-signer.cc:63-146), counted the same way -- sparse tables holding the entries the item reads, the item must still verify / be issued
+    def entry9(m, s, pr, qd):
+        return {"fp_mul": m, "fp_sqr": s, "fp_mul_pair": pr, "fp_mul_quad": qd, "multiply_adds": 162 * m + 126 * s + 243 * pr + 405 * qd,
+                "fp_mul_equivalents": round(m + 126 / 162 * s + 1.5 * pr + 2.5 * qd), "counted": "sparse tables: only the entries this item reads are present"}
+    try:
+        ob3 = OracleBackedCtx()
+        wl3 = synth.Workload(ob3, 3)
+        prec, pexp = wl3.ps_verify_batch(1, corrupt_every=0)
+        b13 = b"".join(ob3.b1.get(i, bytes(64)) for i in range(3 + 6))
+        b23 = b"".join(ob3.b2[i] for i in range(3 + 2))
+        pm = [int.from_bytes(prec[128 + 32 * i:128 + 32 * i + 32], "little") for i in range(3)]
+        res["ps_verify"] = {"config": "BN254, PS verification, 3 attributes (BASELINE config 2)"}
+        for W in (8, 16, 20):
+            ctx = ctypes.c_void_p(L.twin_bn254_ctx_new_sparse(3, W, b13, b23))
+            for i in range(3):
+                L.twin_bn254_table_touch(ctx, 2, 2 + i, int(pm[i]).to_bytes(32, "little"))
+            counts(L)
+            assert L.twin_bn254_ps_verify(ctx, prec, 3) == 1, "a table entry was missing at W=%d" % W
+            res["ps_verify"]["W%d" % W] = entry9(*counts(L))
+            L.twin_bn254_ctx_free(ctx)
+        irec, imask, iexp = wl.provide_id_batch(1, H, corrupt_every=0)
+        isc = [int.from_bytes(irec[64 + 32 * i:64 + 32 * i + 32], "little") for i in range(1 + (H + 1) + (A - H) + 1)]
+        irs, ims, iu = isc[1:1 + H + 1], isc[1 + H + 1:1 + H + 1 + (A - H)], isc[-1]
+        hidden = [i for i in range(A) if (imask >> i) & 1]
+        revealed = [i for i in range(A) if not (imask >> i) & 1]
+        touches = [(0, irs[0]), (0, iu)] + [(1 + i, irs[1 + j]) for j, i in enumerate(hidden)] + [(1 + i, ims[j]) for j, i in enumerate(revealed)]
+        res["provide_id"] = {"config": "BN254, el_passo_provide_id, 8 attributes, 4 hidden (BASELINE config 3)"}
+        for W in (8, 16, 20):
+            ctx = ctypes.c_void_p(L.twin_bn254_ctx_new_sparse(A, W, b1, b2))
+            for base, k in touches:
+                L.twin_bn254_table_touch(ctx, 1, base, int(k).to_bytes(32, "little"))
+            counts(L)
+            out = ctypes.create_string_buffer(128)
+            assert L.twin_bn254_provide_id(ctx, irec, ctypes.c_uint64(imask), b"hello", 5, out) == 1, "a table entry was missing at W=%d" % W
+            res["provide_id"]["W%d" % W] = entry9(*counts(L))
+            L.twin_bn254_ctx_free(ctx)
+    except Exception as e:  # pragma: no cover
+        res["other_configs_error"] = str(e)
     # ---- BLS12-381 (14 limbs of 28 bits: product 196 + reduction 196 multiply-adds; square 105 + 196; pair 2 x 196 + 196; quad 4 x 196 + 196)
     try:
         res["verify_id_bls12_381"] = bls_counts(L)

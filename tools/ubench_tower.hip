@@ -133,11 +133,12 @@ struct Ops<4> {
   static ELP_INL void expz(V& r, const V& a) { fp12q_exp_u64_gs<C>(r, a, C::ZABS); }
   static ELP_INL void to_comp(K& k, const V& a) { fp12q_to_comp<C>(k, a); }
   static ELP_INL void comp_sqr(K& k) { cyc_compq_sqr<C>(k, k); }
-  static ELP_INL void comp_into(V& a, const K& k) {
+  static ELP_INL void comp_into(V& a, const K& k) {      // back into the Fp12Q slots: low (c1, c2) = (z4, z3), high (c0, c2) = (z2, z5)
     const bool hi = quad_hi();
-    a.h.c0 = fp2_select(hi, k.u, a.h.c0);
-    a.h.c1 = fp2_select(hi, a.h.c1, k.u);
-    a.h.c2 = k.w;
+    const Fp2<C> other = fp2_quad_swap(k.x0);             // low receives z4, high receives z2
+    a.h.c0 = fp2_select(hi, other, a.h.c0);
+    a.h.c1 = fp2_select(hi, a.h.c1, other);
+    a.h.c2 = k.x1;
   }
 };
 
