@@ -68,10 +68,11 @@ HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=
 
 
 def build_hip(force=False, verbose=False):
-    deps = [os.path.join(CSRC, u) for u, _ in HIP_UNITS] + [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elp"),
+    deps = [os.path.join(CSRC, u) for u, _ in HIP_UNITS] + [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elpasso_pair4.h"), os.path.join(CSRC, "elp"),
                                                            os.path.join(HERE, "..", "include")]
     # rebuild key = hash of the sources and flags (per unit: the shared headers + that unit's own file), not modification times
     shared = [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elp"), os.path.join(HERE, "..", "include")]
+    unit_headers = {"elpasso_bn254_pair4.hip": ["elpasso_pair4.h"], "elpasso_bls12_381_pair4.hip": ["elpasso_pair4.h"]}      # headers only these units include
     unit_extra = {u: os.environ.get("ELP_EXTRA_FLAGS_" + u.split(".")[0].upper(), "").split() for u, _ in HIP_UNITS}     # experiments only
     lib_digest = _digest(deps, [(u, f, unit_extra[u]) for u, f in HIP_UNITS])
     if not force and _stamp_ok(LIB, lib_digest):
@@ -86,7 +87,7 @@ def build_hip(force=False, verbose=False):
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
         objs.append(obj)
         extra = unit_extra[unit]
-        udig = _digest(shared + [os.path.join(CSRC, unit)], [flags, extra])
+        udig = _digest(shared + [os.path.join(CSRC, unit)] + [os.path.join(CSRC, h) for h in unit_headers.get(unit, [])], [flags, extra])
         if not force and _stamp_ok(obj, udig):
             continue                                   # this unit's sources and flags are unchanged: keep its object
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags + extra + ["-c", "-o", obj, os.path.join(CSRC, unit)]

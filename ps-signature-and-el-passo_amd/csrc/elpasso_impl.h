@@ -1833,6 +1833,7 @@ struct elp_ctx {
   };
   AsyncSlot aslot[2];
   int fail_submits = 0;          // ELP_OPT_FAULT_INJECT
+  int mid_two_launches = 0;      // experiments (ELP_PAIR4_TWO_LAUNCHES=1): the mid-size path as k_vid_nizk4 then k_pair4 instead of the one launch k_vid_mid
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
@@ -2686,10 +2687,15 @@ extern template void launch_agg_final_paired<BLS12_381>(elp_ctx* c, hipStream_t 
 #endif
 
 // the pairing check on FOUR lanes per item (elp/pair4.h, elpasso_pair4.h; translation units elpasso_<curve>_pair4.hip): reads K and `todo` like k_pair_rest
-#ifndef ELP_PAIR4_TU
 template <class B>
 void launch_pair4(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
                   void* d_accepted);
+template <class B>
+void launch_vid_mid(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off,
+                    size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, const void* pre);
+#ifndef ELP_PAIR4_TU
+extern template void launch_vid_mid<BN254>(hipStream_t stream, const KeyCtx<BN254>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, const void* pre);
+extern template void launch_vid_mid<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, const void* pre);
 extern template void launch_pair4<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 extern template void launch_pair4<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 #endif
@@ -2768,9 +2774,11 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
           HIPCHK(c, hipStreamWaitEvent(js, c->jev[0], 0));
           HIPCHK(c, hipStreamWaitEvent(st, c->jev[3], 0));
         }
-        if (mid) {
+        if (mid && c->mid_two_launches) {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
           launch_pair4<C>(st, key.gg_lines, n, d_records, words, kvalid, kws, lanes, pair_ok, nullptr);
+        } else if (mid) {
+          launch_vid_mid<C>(st, key, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kvalid, kws, lanes, pair_ok, pre);      // both halves as workgroup ranges of one launch
         } else if (overlap) {
           launch_vid_nizk4<C>(st, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, nizk_ok, kws, lanes, key, pre, 1);
           key.vtab = nullptr;

@@ -18,7 +18,7 @@ for r in rows:
     n = r["Kernel_Name"]
     if "at::native" in n or "elementwise" in n:
         continue
-    key = (n.split("(")[0].replace("void ", "")[:70], r.get("Grid_Size", "?"), r.get("Scratch_Size", r.get("Private_Segment_Size", "?")), r.get("VGPR_Count", "?"))
+    key = (n.split("(")[0].replace("void ", "")[:70], r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Scratch_Size", r.get("Private_Segment_Size", "?")), r.get("VGPR_Count", "?"))
     if key not in agg:
         order.append(key)
     agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
