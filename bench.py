@@ -41,7 +41,7 @@ def parse_args(argv=None):
     ap.add_argument("--attrs", type=int, default=0)
     ap.add_argument("--hidden", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launch, shard, count-reduce and report path; no kernel, value = null")
-    ap.add_argument("--window", type=int, default=20, help="fixed-base window bits of the key tables (library default 8; 20 = 16 GiB of signed-digit tables "
+    ap.add_argument("--window", type=int, default=-1, help="fixed-base window bits of the key tables (library default 8; 20 = 16 GiB of signed-digit tables "
                     "for the 8-attribute key, 13 table additions per scalar instead of 16 at W = 16: profiles/r02_window_sweep.json); reported in `config` and `key_tables`")
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"], help="curve of the headline run")
     ap.add_argument("--no-second-curve", action="store_true", help="skip the secondary BLS12-381 measurement at N=1")
@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs: every k_verify_id launch has the headline size)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="items timed on the CPU oracle (0 disables, -1 = max(4096, 256 x cores))")
     args = ap.parse_args(argv)
+    if args.window < 0:      # default table width: 20 bits (15.5 GiB) for the configuration the metric is quoted on, 16 bits (2.5 GiB at 16 attributes) for config 5:
+        args.window = 16 if args.config == 5 else 20      # an RP with several IdP keys cannot afford 28.5 GB per key and rank; --window 20 opts in
     cfg = CONFIGS[args.config]
     args.batch = args.batch or cfg["batch"]
     args.attrs = args.attrs or cfg["attrs"]
@@ -290,11 +292,13 @@ def main():
     if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and (args.window or 8) != 16 and want("w16"):
         try:   # the same workload on the 16-bit tables (1/16 of the memory): what the wide tables buy
             out["w16"] = other_config(pkg, synth, local_rank, dev, 4, 16)
+            out["value_w16"] = out["w16"]["value"]              # the same workload on 1.2 GiB of tables (1/13 of the headline's): what a key-per-IdP deployment can afford
+            out["ms_per_step_w16"] = out["w16"]["kernel_ms"]
         except Exception as e:  # pragma: no cover
             out["w16"] = {"error": str(e)}
     if rank == 0 and world == 1 and args.curve == "bn254" and args.config == 4 and not args.headline_only and want("config5"):
         try:   # BASELINE.json config 5 at N = 1: one rank's share (131 072 proofs, 16 attributes) on this GPU
-            out["config5_rank_share"] = other_config(pkg, synth, local_rank, dev, 5, args.window)
+            out["config5_rank_share"] = other_config(pkg, synth, local_rank, dev, 5, 16)        # W = 16: 2.5 GiB per rank (W = 20: 28.5 GB, opt-in via --config 5 --window 20)
         except Exception as e:  # pragma: no cover
             out["config5_rank_share"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.headline_only and want("aggregated"):
@@ -462,6 +466,26 @@ def aggregated_section(ctx, wl, synth, dev, mask, H, B):
     return res
 
 
+def valu_frac(ctx, ops_key, window, items, kern_ms):
+    """valu_bound of a secondary workload: counted Montgomery-product equivalents per item (profiles/op_counts.json[ops_key]) x items / kernel time against the
+    fp_mul micro-benchmark peak of this lease (BN254 limbs)."""
+    try:
+        ops = json.load(open(os.path.join(ROOT, "profiles", "op_counts.json"))).get(ops_key, {})
+        key = "W%d" % (window or 8)
+        if key not in ops:
+            return {"note": "no op count for %s at %s" % (ops_key, key)}
+        fm = ctypes.c_float()
+        lanes, iters = 256 * 4 * 64 * 8, 1000
+        ctx._chk(ctx.lib.elp_bench_fp_mul(ctx.h, lanes, iters, ctypes.byref(fm)))
+        peak = lanes * iters * 2 / (fm.value * 1e-3)
+        per_item = ops[key]["fp_mul_equivalents"]
+        ach = per_item * items / (kern_ms * 1e-3)
+        return {"fp_mul_equivalents_per_item": per_item, "achieved": ach, "fp_mul_peak_per_s": peak, "frac": ach / peak, "unit": "modmul/s",
+                "op_count_source": "profiles/op_counts.json[%s][%s] (counted)" % (ops_key, key)}
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)}
+
+
 def valu_bound(ctx, ops_key, window, B, kern_ms, macs_per_mul):
     """Secondary ceiling (the binding one: the path is integer-VALU bound, not HBM bound): Montgomery products/s of the kernel against the
     fp_mul micro-benchmark of the same limb code at full occupancy, + the instruction-issue reading of the round's PMC pass."""
@@ -609,9 +633,26 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
     res["ps_verify_4096x3attrs"] = {"value": n / (ms * 1e-3), "unit": "verifications/s", "kernel_ms": ms,
                                     "parity_ok": bool((d_fl.cpu().numpy() == expect).all()),
-                                    "path": "cooperative kernels (k_ps_k_coop: K on 8 lanes per item; k_pair_coop: pairing check on 32 lanes per item)"}
+                                    "path": "cooperative kernels (k_ps_k_coop: K on 8 lanes per item; k_pair_coop: pairing check on 32 lanes per item)",
+                                    "valu_bound": valu_frac(ctx, "ps_verify", window, n, ms),
+                                    "roofline": {"bound": "hbm", "achieved": n * 228 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": n * 228 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_item": 228}}
+    # PS verification between the interpreter's range and the full-chip kernels: the four-lanes-per-item pairing check (ELP_OPT_PAIR4, round 5) on / off
+    nm = 16384
+    mrecs, mexpect = wl.ps_verify_batch(nm)
+    d_mrec = torch.from_numpy(np.frombuffer(mrecs, dtype=np.uint8).copy()).to(dev)
+    d_mfl = torch.zeros(nm, dtype=torch.uint8, device=dev)
+    mid = {}
+    for mode in (0, 1):
+        ctx.set_pair4(mode)
+        for m in (8192, 12288, 16384):
+            mms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, m, d_mrec.data_ptr(), 3, d_mfl.data_ptr(), d_cnt.data_ptr())))
+            mid["ps_verify_n%d_%s_ms" % (m, "four_lanes" if mode else "two_lanes")] = mms
+    mid["parity_ok"] = bool((d_mfl.cpu().numpy() == mexpect).all())
+    res["mid_batches_ps_verify"] = mid
     # small batches and lone items, cooperative kernels on / off (ELP_OPT_COOP_PAIRING): latency, not throughput
     lat = {}
+    ctx.set_pair4(0)          # this section compares the interpreter with the per-lane kernels; the four-lane path has the sections mid_batches_*
     for coop in (1, 0):
         ctx.set_coop_pairing(coop)
         for m in (4096, 1, 1024, 4096):       # the first entry warms tables and TLBs for this mode (its time is overwritten by the last)
@@ -620,6 +661,7 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     ctx.set_coop_pairing(1)
     ctx.close()
     ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
+    ctx.set_pair4(0)
     wl = synth.Workload(ctx, 8, seed=20211, window_bits=window)
     nl = 8192
     vrecs, vmask, vexpect = wl.verify_id_batch(nl, 4, with_retrieval=True)
@@ -633,6 +675,22 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
                                                                          d_fl.data_ptr(), d_cnt.data_ptr())))
             lat["verify_id_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms
     lat["parity_ok"] = bool((d_fl.cpu().numpy()[:nl] == vexpect).all())
+    ctx.set_coop_pairing(1)
+    # mid-size batches (round 5; VERDICT r4 "what's missing" #2): NIZK half in the job kernels + the pairing check on four lanes per item (k_vid_mid, ELP_OPT_PAIR4)
+    # against the two-lane kernels' flat round
+    nmid = 16384
+    mvrecs, mvmask, mvexpect = wl.verify_id_batch(nmid, 4, with_retrieval=True)
+    d_mvrec = torch.from_numpy(np.frombuffer(mvrecs, dtype=np.uint8).copy()).to(dev)
+    d_mvfl = torch.zeros(nmid, dtype=torch.uint8, device=dev)
+    midv = {}
+    for mode in (0, 1):
+        ctx.set_pair4(mode)
+        for m in (9217, 12288, 16384):
+            mms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_mvrec.data_ptr(), mvmask, 1, d_ad.data_ptr(), None, len(wl.ad),
+                                                                          d_mvfl.data_ptr(), d_cnt.data_ptr())))
+            midv["verify_id_n%d_%s_ms" % (m, "four_lanes" if mode else "two_lanes")] = mms
+    midv["parity_ok"] = bool((d_mvfl.cpu().numpy() == mvexpect).all())
+    res["mid_batches_verify_id"] = midv
     if os.environ.get("ELP_BENCH_SMALL_OVERLAP"):      # experiment: the two-stream form of the same calls (ELP_OPT_STREAM_OVERLAP) inside this process
         ctx.set_coop_pairing(1)
         ctx.set_stream_overlap(1)
@@ -657,7 +715,10 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     ms = timed(lambda: ctx._chk(ctx.lib.elp_provide_id_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), mask, d_ad.data_ptr(), None,
                                                                   len(wl.ad), d_sig.data_ptr(), d_fl.data_ptr(), d_cnt.data_ptr())))
     res["provide_id_65536x8attrs"] = {"value": n / (ms * 1e-3), "unit": "issuances/s", "kernel_ms": ms,
-                                      "parity_ok": bool((d_fl.cpu().numpy() == expect).all())}
+                                      "parity_ok": bool((d_fl.cpu().numpy() == expect).all()),
+                                      "valu_bound": valu_frac(ctx, "provide_id", window, n, ms),
+                                      "roofline": {"bound": "hbm", "achieved": n * 548 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": n * 548 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_item": 548}}
     # wire ingest: the same kind of proofs as undecoded IdProof messages -- T-L-V parse, point decompression
     # and attribute hashing run inside the kernel
     nw = 65536

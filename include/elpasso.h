@@ -93,9 +93,11 @@ int elp_field_bytes(int curve);               /* F */
  * processes or more GPUs scale, more streams run into the reclaim.
  * ELP_OPT_PAIR4 (default 1; round 5): the pairing check e(sig1, K) e(-sig2, gg) == 1 on FOUR lanes per item (a DPP quad: the Fp12 value of the Miller loop and of the
  * final exponentiation spread over four lanes, 27 / 42 registers per lane, no private memory in the loops; csrc/elp/quad.h, pair4.h) for batches between the range of the
- * cooperative interpreter and the batches that fill the chip at one or two lanes per item: el_passo_verify_id of 9 217 ... 32 768 items (BLS12-381: from 8 193) --
- * NIZK half in the job kernels of the small-batch path, then k_pair4 -- and PS verifications of 4 097 ... 32 768 items.  0 = off (the two-lane kernels take these
- * sizes), 2 = wherever the path exists (any batch up to 131 072 items; for A/B measurements).  Verdicts are identical.
+ * cooperative interpreter and the batches that fill the chip at one or two lanes per item: el_passo_verify_id of 3 073 ... 16 384 items -- NIZK half in the
+ * job kernels of the small-batch path and the four-lane check as workgroup ranges of ONE launch (k_vid_mid) -- and PS verifications of 4 097 ... 16 384 items
+ * (k_ps_k_coop, then k_pair4); up to 16 384 items the quads run one wave per SIMD.  Measured on BN254: 8 192 proofs 7.08 -> 4.38 ms, 16 384 proofs 9.45 -> 6.9 ms;
+ * BLS12-381: 8 192 proofs 19.4 -> 11.6 ms.  0 = off (the interpreter / the two-lane kernels take these sizes), 2 = wherever the path exists (any batch up to
+ * 131 072 items; for A/B measurements).  Verdicts are identical.
  * ELP_OPT_FAULT_INJECT (default 0; a test hook for the error paths of callers): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  * ELP_ERR_STATE before anything is queued; nothing else is affected.
  */

@@ -2699,9 +2699,14 @@ extern template void launch_vid_mid<BLS12_381>(hipStream_t stream, const KeyCtx<
 extern template void launch_pair4<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 extern template void launch_pair4<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 #endif
-// batch sizes served by the four-lane pairing check (ELP_OPT_PAIR4 = 1): above the cooperative interpreter's range, up to two waves per SIMD of quads
+// batch sizes served by the four-lane pairing check by default (ELP_OPT_PAIR4 = 1), from the A/B sweeps of profiles/r05_four_lane.md: up to 16 384 items the quads
+// of a batch run ONE wave per SIMD (256 workgroups of 64 items); el_passo_verify_id from 3 073 items (below, the interpreter's one launch is as fast or faster:
+// 2 048 items 3.64 vs 3.75 ms, 4 096 items 3.87 vs 4.65), PS verification above the interpreter's 4 096 (4 096 items: 2.90 vs 3.47 ms; 5 120: 4.73 vs 3.52)
 #ifndef ELP_PAIR4_MAX
-#define ELP_PAIR4_MAX 32768
+#define ELP_PAIR4_MAX 16384
+#endif
+#ifndef ELP_PAIR4_VID_FROM
+#define ELP_PAIR4_VID_FROM 3072
 #endif
 
 template <class C>
@@ -2714,10 +2719,10 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;  // rs[0] (and rs[1]) are the responses of attributes 0 (and 1), src/ps-verifier.cc:95,107
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
   if constexpr (CoopBuild<C>::value && SmallBuild<C>::value) {
-    const bool small = c->coop && n <= (c->vid_coop_max ? c->vid_coop_max : (size_t)(C::IS_BN ? 9216 : 8192));
-    // mid-size batches (round 5): the same job kernels for the NIZK half, the pairing check on FOUR lanes per item (k_pair4) -- between the interpreter's range and
-    // the batches that fill the chip at one or two lanes per item
-    const bool mid = c->pair4 == 2 ? n <= (size_t)(4 * ELP_PAIR4_MAX) : (c->pair4 == 1 && !small && n <= (size_t)ELP_PAIR4_MAX);
+    // mid-size batches (round 5): the same job kernels for the NIZK half, the pairing check on FOUR lanes per item (k_vid_mid / k_pair4) -- between the batches the
+    // interpreter serves best and the batches that fill the chip at one or two lanes per item
+    const bool mid = c->pair4 == 2 ? n <= (size_t)(8 * ELP_PAIR4_MAX) : (c->pair4 == 1 && n > (size_t)ELP_PAIR4_VID_FROM && n <= (size_t)ELP_PAIR4_MAX);
+    const bool small = !mid && c->coop && n <= (c->vid_coop_max ? c->vid_coop_max : (size_t)(C::IS_BN ? 9216 : 8192));
     if (small || mid) {
       // small batch: NIZK half with four job lanes per item (k_vid_nizk4), pairing check on 32 / 64 lanes per item (k_pair_coop)
       const void* consts = mid ? (const void*)c : coop_consts_for<C>(c, (hipStream_t)stream);      // the interpreter's constants: not needed by the four-lane check
@@ -2940,8 +2945,8 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if (nattr < 0 || nattr > c->A) return ELP_ERR_ARG;
   if (n == 0) return ELP_OK;
   if constexpr (CoopBuild<C>::value) {
-    const bool small = c->coop && n <= c->coop_max;
-    const bool mid = c->pair4 == 2 ? n <= (size_t)(4 * ELP_PAIR4_MAX) : (c->pair4 == 1 && !small && n <= (size_t)ELP_PAIR4_MAX);      // four lanes per item above the interpreter's range
+    const bool small = c->coop && n <= c->coop_max && c->pair4 != 2;
+    const bool mid = c->pair4 == 2 ? n <= (size_t)(8 * ELP_PAIR4_MAX) : (c->pair4 == 1 && !small && n <= (size_t)ELP_PAIR4_MAX);      // four lanes per item above the interpreter's range
     if (small || mid) {
       // small batch: K per item on eight lanes (three table sums), then the pairing check on 32 lanes per item (interpreter) or on four (k_pair4)
       const void* consts = mid ? (const void*)c : coop_consts_for<C>(c, (hipStream_t)stream);

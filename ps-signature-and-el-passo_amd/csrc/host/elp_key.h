@@ -48,8 +48,9 @@ class ElpKey {
 };
 
 // Process-wide defaults for the contexts that PSSigner / PSRequester / PSVerifier create from now on: GPU ordinal and width of the fixed-base
-// window tables (0 = the library default, 8; 16 = 2.5 GiB and 20 = 32 GiB for an 8-attribute BN254 key, ~17 % / ~20 % fewer products per verification).
-// The reference's constructors (src/ps-verifier.h:18) carry no such parameters, so a drop-in caller chooses them here once.
+// window tables.  Default since round 5: 16 bits -- 1.2 GiB of signed-digit tables for an 8-attribute BN254 key (0.3 s to build), 17.3 ms per 65 536 verifications;
+// 20 bits buys 2.6 % (16.9 ms) for 15.5 GiB per key and is an explicit opt-in (a relying party with several IdP keys cannot afford it per key); 0 = the C-ABI's
+// own default (8 bits, 80 MB).  The reference's constructors (src/ps-verifier.h:18) carry no such parameters, so a drop-in caller chooses them here once.
 void elpSetDefaults(int device, int window_bits);
 int elpDefaultDevice();
 int elpDefaultWindowBits();

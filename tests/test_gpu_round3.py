@@ -201,6 +201,7 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
     A, H = 8, 4
     wl = synth.Workload(gpu_ctx, A, seed=5, window_bits=8)
     key = _oracle_key(L, wl, gpu_ctx, A)
+    gpu_ctx.set_pair4(0)        # the four-lane path of round 5 (default from 3 073 items) off: this test is about the interpreter at every size it can serve
     try:
         # sizes on both sides of every switch of the path: k_vid_small on 32 lane pairs per item (4 items per pairing workgroup: 3, 5 leave one partly filled) up to 512,
         # on 16 lane pairs (8 items per workgroup, all four waves interpreting) up to 1 792, its two-waves-per-SIMD build k_vid_small2 up to 4 096; the two-launch
@@ -260,6 +261,7 @@ def test_cooperative_pairing_small_batches(gpu_ctx):
         exp2[9] = 0
         assert not held2 and (fl2 == exp2).all()
     finally:
+        gpu_ctx.set_pair4(1)
         gpu_ctx.set_coop_pairing(1)
 
 

@@ -75,7 +75,7 @@ def test_config4_wire_path_full_size_vs_oracle(gpu_ctx):
     L.elpo_key_free(key)
 
 
-@pytest.mark.parametrize("n", [9217, 12288, 16384, 32768])
+@pytest.mark.parametrize("n", [3073, 9217, 12288, 16384, 32768])
 def test_four_lane_pairing_mid_batches_vs_oracle(gpu_ctx, n):
     """VERDICT r4 #1b: el_passo_verify_id at the sizes between the cooperative interpreter and the full-chip kernels -- NIZK half in the job kernels, the pairing check
     e(sig1, K) e(-sig2, gg) == 1 (src/ps-verifier.cc:132-137) on FOUR lanes per item (k_pair4, ELP_OPT_PAIR4 default): every verdict against the generator's expectation
@@ -85,7 +85,7 @@ def test_four_lane_pairing_mid_batches_vs_oracle(gpu_ctx, n):
     A, H = 8, 4
     wl = synth.Workload(gpu_ctx, A, seed=515, window_bits=8)
     recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=53, corrupt_at=7, degenerate_items=(5, 4097), window_bits=8)
-    gpu_ctx.set_pair4(1)
+    gpu_ctx.set_pair4(1 if n <= 16384 else 2)          # default range of the path: 3 073 ... 16 384 items; forced above
     f4, c4 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
     gpu_ctx.set_pair4(0)
     f2, c2 = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
