@@ -16,7 +16,13 @@
 #define ELP_HD
 #endif
 
+// -DELP_NO_FORCE_INLINE (host builds of the test twins under sanitizers only): the routines stay ordinary inline functions, so that the instrumented build is made of
+// many small functions instead of a few with 10^5 instructions (which neither g++ nor clang finish instrumenting in half an hour)
+#if defined(ELP_NO_FORCE_INLINE) && !defined(__HIPCC__)
+#define ELP_INL inline
+#else
 #define ELP_INL ELP_HD inline __attribute__((always_inline))
+#endif
 
 // "Heavy" routines are real (non-inlined) functions on the device: a pairing inlined into one kernel would be
 // several MB of straight-line code; a call hierarchy (fp_mul <- fp2_mul <- fp6_mul <- fp12_mul ...) keeps the

@@ -139,6 +139,10 @@ def build_twin(so, flags):
 def twin():
     """Host (g++) build of the device headers — test-only library, built on demand."""
     global _twin
+    if _twin is None and os.environ.get("ELP_TWIN_LIB"):       # a pre-built variant of the twin (tests/test_sanitized_arithmetic.py: the ASan / UBSan build)
+        _twin = ctypes.CDLL(os.environ["ELP_TWIN_LIB"])
+        for n in ("twin_bn254_ctx_new", "twin_bls_ctx_new"):
+            getattr(_twin, n).restype = ctypes.c_void_p
     if _twin is None:
         so = os.path.join(ROOT, "tests", "host_twin", "libtwin.so")
         src = os.path.join(ROOT, "tests", "host_twin", "twin.cpp")

@@ -17,6 +17,8 @@ _lib = None
 
 def quad_twin(flags=("-O2",), name="libtwin_quad.so"):
     global _lib
+    if os.environ.get("ELP_TWINQ_LIB"):          # a pre-built variant (tests/test_sanitized_arithmetic.py: the ASan / UBSan build)
+        return ctypes.CDLL(os.environ["ELP_TWINQ_LIB"])
     so = os.path.join(ROOT, "tests", "host_twin", name)
     src = os.path.join(ROOT, "tests", "host_twin", "twin_quad.cpp")
     inc = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc")
