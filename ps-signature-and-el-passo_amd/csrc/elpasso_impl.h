@@ -2721,7 +2721,8 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   if constexpr (CoopBuild<C>::value && SmallBuild<C>::value) {
     // mid-size batches (round 5): the same job kernels for the NIZK half, the pairing check on FOUR lanes per item (k_vid_mid / k_pair4) -- between the batches the
     // interpreter serves best and the batches that fill the chip at one or two lanes per item
-    const bool mid = c->pair4 == 2 ? n <= (size_t)(8 * ELP_PAIR4_MAX) : (c->pair4 == 1 && n > (size_t)ELP_PAIR4_VID_FROM && n <= (size_t)ELP_PAIR4_MAX);
+    const bool mid = c->pair4 == 2 ? n <= (size_t)(8 * ELP_PAIR4_MAX)
+                                   : (c->pair4 == 1 && n <= (size_t)ELP_PAIR4_MAX && (n > (size_t)ELP_PAIR4_VID_FROM || !c->coop));      // interpreter off: four lanes beat two at every size of the range
     const bool small = !mid && c->coop && n <= (c->vid_coop_max ? c->vid_coop_max : (size_t)(C::IS_BN ? 9216 : 8192));
     if (small || mid) {
       // small batch: NIZK half with four job lanes per item (k_vid_nizk4), pairing check on 32 / 64 lanes per item (k_pair_coop)

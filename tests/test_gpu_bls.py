@@ -419,3 +419,69 @@ def test_phase_mix_experiment_keeps_the_verdicts(elp, bls_ctx):
         ctx.close()
     assert (f0 == f1).all() and c0 == c1
     assert f0[9] == 0 and f0[11] == 0 and f0[13] == 0 and f0[401] == 0 and f0[405] == 0 and int(f0.sum()) > n // 2
+
+
+def test_four_lane_path_on_bls12_381(bls_ctx):
+    """Round 5: el_passo_verify_id of 3 073 ... 16 384 items and PS verifications of 4 097 ... 16 384 run the pairing check on FOUR lanes per item (k_vid_mid / k_pair4,
+    ELP_OPT_PAIR4; elp/quad.h, pair4.h with the M-type line product and the Hayashida-Hayasaka-Teruya chain cubed).  n = 3 100 and 8 200: verdicts equal the option-off
+    paths', the generator's expectation and -- on a stride plus every corrupted / crafted item -- the C oracle's BLS12-381 build; tampered signature, sig2 = infinity and
+    the cofactor forgery (sig1 of order 3, sig2 = O) included.  PARITY UNPINNED (no reference artefact exists for this curve)."""
+    import ctypes
+    import os
+    from test_oracle_bls import _small_order_point
+    synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+    L = oracle_bls()
+    L.elpo_set_strict.argtypes = [ctypes.c_int]
+    NT = max(1, min(16, len(os.sched_getaffinity(0))))
+    A, H = 8, 4
+    wl = synth.Workload(bls_ctx, A, seed=55, window_bits=8)
+    g1 = wl.g + wl.Yi + bls_ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+    key = ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
+    t3 = g1b(_small_order_point(3), N)
+    L.elpo_set_strict(1)
+    try:
+        for n in (3100, 8200):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=41, corrupt_at=3)
+            rsz = len(recs) // n
+            recs = bytearray(recs)
+            recs[9 * rsz + 96:9 * rsz + 192] = recs[8 * rsz + 96:8 * rsz + 192]        # item 9 gets item 8's sig2: NIZK holds, pairing check fails
+            recs[4 * rsz + 96:4 * rsz + 192] = bytes(96)                                # item 4: sig2 = infinity
+            recs[5 * rsz:5 * rsz + 96] = t3                                             # item 5: the cofactor forgery
+            recs[5 * rsz + 96:5 * rsz + 192] = bytes(96)
+            recs = bytes(recs)
+            bls_ctx.set_pair4(1)
+            f4, c4 = bls_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            bls_ctx.set_pair4(0)
+            f0, c0 = bls_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            bls_ctx.set_pair4(1)
+            assert (f4 == f0).all() and c4 == c0 == int(f4.sum()), n
+            assert f4[9] == 0 and f4[4] == 0 and f4[5] == 0 and f4[8] == int(expect[8])
+            idx = sorted(set(list(range(0, n, n // 300)) + [i for i in range(n) if not expect[i]] + [4, 5, 8, 9]))
+            samp = b"".join(recs[i * rsz:(i + 1) * rsz] for i in idx)
+            ofl = np.zeros(len(idx), dtype=np.uint8)
+            L.elpo_verify_id_batch(key, len(idx), samp, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+            assert (ofl == f4[idx]).all(), n
+        wl3 = synth.Workload(bls_ctx, 3, seed=56, window_bits=8)
+        g13 = wl3.g + wl3.Yi + bls_ctx.hash_to_g1([wl3.service]) + wl3.g + wl3.apk + wl3.h + wl3.X
+        key3 = ctypes.c_void_p(L.elpo_key_new(3, g13, wl3.gg + wl3.XX + wl3.YYi))
+        n = 5000
+        precs, pexpect = wl3.ps_verify_batch(n, corrupt_every=13, corrupt_at=2)
+        prsz = len(precs) // n
+        precs = bytearray(precs)
+        precs[5 * prsz:5 * prsz + 96] = t3                                              # the forgery against PSVerifier::verify
+        precs[5 * prsz + 96:5 * prsz + 192] = bytes(96)
+        precs = bytes(precs)
+        pexpect = pexpect.copy()
+        pexpect[5] = 0
+        p4, pc4 = bls_ctx.ps_verify_batch(precs, 3)
+        bls_ctx.set_pair4(0)
+        p0, pc0 = bls_ctx.ps_verify_batch(precs, 3)
+        bls_ctx.set_pair4(1)
+        assert (p4 == pexpect).all() and (p0 == pexpect).all() and pc4 == pc0 == int(pexpect.sum())
+        for i in list(range(0, n, 50)) + [5]:
+            assert L.elpo_ps_verify(key3, precs[i * prsz:(i + 1) * prsz], 3) == int(p4[i]), i
+        L.elpo_key_free(key3)
+    finally:
+        L.elpo_set_strict(0)
+        bls_ctx.set_pair4(1)
+        L.elpo_key_free(key)
