@@ -98,11 +98,15 @@ int elp_field_bytes(int curve);               /* F */
  * (k_ps_k_coop, then k_pair4); up to 16 384 items the quads run one wave per SIMD.  Measured on BN254: 8 192 proofs 7.08 -> 4.38 ms, 16 384 proofs 9.45 -> 6.9 ms;
  * BLS12-381: 8 192 proofs 19.4 -> 11.6 ms.  0 = off (the interpreter / the two-lane kernels take these sizes), 2 = wherever the path exists (any batch up to
  * 131 072 items; for A/B measurements).  Verdicts are identical.
+ * ELP_OPT_WIRE_DECODE (default 1; round 5): elp_verify_id_wire_batch[_dev] with at most 16 384 messages decodes them into records first (T-L-V parse, point
+ * decompression and attribute hashing as a kernel of job-uniform waves) and verifies the records on the small / mid-size paths above -- a lone wire message ~3 ms
+ * instead of ~9 -- when all messages of the batch hide the same attributes (one 16-byte read-back, i.e. one stream synchronisation inside the call); mixed patterns and
+ * larger batches take the fused wire kernels.  0 = always the fused kernels.  Verdicts are identical.
  * ELP_OPT_FAULT_INJECT (default 0; a test hook for the error paths of callers): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  * ELP_ERR_STATE before anything is queued; nothing else is affected.
  */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
-       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10 };
+       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10, ELP_OPT_WIRE_DECODE = 11 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

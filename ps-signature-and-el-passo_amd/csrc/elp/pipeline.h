@@ -1534,6 +1534,55 @@ ELP_HEAVY bool verify_id_wire_item(const KeyCtx<C>& key, const uint8_t* msg, siz
   return verify_id_core<C, WireSrc<C>>(key, src, retr, sig1, sig2, phi, E1, E2, kk, c, ad, ad_len);
 }
 
+// ---- wire message -> verify_id record, job by job (round 5: wire batches on the small / mid-size paths).  The record paths (interpreter, four lanes per item)
+// take fixed-stride records; a relying party receives IdProof::toBufferString() messages (src/ps-encoding.cc:451-467).  k_wire_decode turns one into the other with
+// job-uniform waves: job 0..4 decompress sig1, sig2, phi, E1, E2 (one Fp square root each), job 5 decompresses k (Fp2 square root), job 6 validates the structure,
+// copies c and the responses, hashes the revealed attributes (Fr::setHashOf, src/ps-verifier.cc:224) and reports the hidden mask.  Every job parses the T-L-V
+// structure itself (a few hundred instructions) and writes its own words of the record; ok[job] = 0 marks the item invalid.  The record's size does not depend on the
+// number of hidden attributes (1 + (H + 2 | H + 1) + (A - H) scalars), only its interpretation does: the record kernels take ONE mask per launch, so the caller runs
+// them only when every message of the batch has the same pattern.  Subgroup tests (BLS12-381) are left to the record path, which repeats them on the decoded points.
+constexpr int WIRE_DECODE_JOBS = 7;
+template <class C>
+ELP_HEAVY bool wire_decode_job(int job, int A, const uint8_t* msg, size_t len, bool retr, u32* rec, u64* mask_out) {
+  WireSrc<C> src;
+  Scalar c;
+  if (!src.parse(msg, len, A, retr, c)) return false;
+  const int G1W = 2 * C::N;
+  if (job < 5) {
+    if (job >= 3 && !retr) return true;
+    const uint8_t* body = job == 0 ? src.p1_ : job == 1 ? src.p2_ : job == 2 ? src.pphi_ : job == 3 ? src.pe1_ : src.pe2_;
+    Aff<F1<C>> P;
+    if (!g1_deserialize<C>(P, body)) return false;
+    g1_store<C>(rec + job * G1W, P);
+    return true;
+  }
+  u32* const wk = rec + (retr ? 5 : 3) * G1W;
+  if (job == 5) {
+    Aff<F2<C>> kk;
+    bool kflag = false;
+    if (!g2_deserialize<C>(kk, src.pk_, &kflag)) return false;
+    g2_store<C>(wk, kk);
+    return true;
+  }
+  // job 6: scalars
+  u32* w = wk + 4 * C::N;
+  for (int i = 0; i < 8; i++) w[i] = c.v[i];
+  w += 8;
+  for (int j = 0; j < src.nrs(); j++) {
+    const Scalar r = src.rs(j);
+    for (int i = 0; i < 8; i++) w[i] = r.v[i];
+    w += 8;
+  }
+  for (int i = 0; i < A; i++)
+    if (!src.hidden(i)) {
+      const Scalar m = src.next_revealed_hash(i);
+      for (int q = 0; q < 8; q++) w[q] = m.v[q];
+      w += 8;
+    }
+  *mask_out = src.mask_;
+  return true;
+}
+
 // The same in the paired layout: both lanes parse the message; the five G1 decompressions (one Fp square root each) are split between the
 // lanes (even: sig1, phi, E1; odd: sig2, E2), sig1 / sig2 are then swapped so both lanes hold both, k is decompressed by the pair together.
 template <class C>

@@ -133,6 +133,7 @@ void elp_destroy(elp_ctx* c) {
     if (a.h_cnt) (void)hipHostFree(a.h_cnt);
   }
   if (c->coop_consts) (void)hipFree(c->coop_consts);
+  if (c->wire_ws) (void)hipFree(c->wire_ws);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
   for (int i = 0; i < 4; i++)
     if (c->jev[i]) (void)hipEventDestroy(c->jev[i]);
@@ -160,6 +161,7 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_COALESCED_RECORDS: c->stage_records = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_STREAM_OVERLAP: c->overlap = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_FAULT_INJECT: c->fail_submits = value > 0 ? value : 0; return ELP_OK;
+    case ELP_OPT_WIRE_DECODE: c->wire_decode = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_PAIR4:
       if (value < 0 || value > 2) return ELP_ERR_ARG;
       c->pair4 = value;

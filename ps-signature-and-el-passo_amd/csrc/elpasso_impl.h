@@ -679,21 +679,39 @@ template <class C, int J = ELP_PSK_LANES, class TermFn>
 __device__ __forceinline__ void coop_fixed_sum_g2(Jac<F2<C>>& K, const KeyCtx<C>& key, int sub, int nterms, bool live, TermFn term) {
   typedef F2<C> G;
   if (live) {
+    // the mixed addition inlined once (the running sum stays in registers: as a call it moved 216 bytes per lane through private memory on every step -- the
+    // kernel ran at 8 cycles per instruction with under one wave resident per SIMD, profiles/r05_four_lane.md) and the table entry of the NEXT step fetched before
+    // the current addition is computed: its address depends on the scalars only
     const int W = key.W, nwin = key.nwin, total = nterms * nwin;
+    auto entry_of = [&](int t, bool& have) {
+      Aff<G> e;
+      aff_set_inf(e);
+      have = false;
+      if (t < total) {
+        const int a = t / nwin, j = t - a * nwin;
+        int base;
+        Scalar kraw;
+        term(a, base, kraw);
+        const Scalar k = scalar_mod_r<C>(kraw);
+        int carry = 0, d = 0;
+        for (int jj = 0; jj <= j; jj++) d = fixed_base_digit(k, jj, W, carry);
+        if (d != 0) {
+          e = aff_from_mem<G>(key.t2[((size_t)base * nwin + j) * key.per + ((d < 0 ? -d : d) - 1)]);
+          if (d < 0) e.y = G::neg(e.y);
+          have = true;
+        }
+      }
+      return e;
+    };
+    bool have = false;
+    Aff<G> e = entry_of(sub, have);
     ELP_NOUNROLL
     for (int t = sub; t < total; t += J) {
-      const int a = t / nwin, j = t - a * nwin;
-      int base;
-      Scalar kraw;
-      term(a, base, kraw);
-      const Scalar k = scalar_mod_r<C>(kraw);
-      int carry = 0, d = 0;
-      for (int jj = 0; jj <= j; jj++) d = fixed_base_digit(k, jj, W, carry);
-      if (d != 0) {
-        Aff<G> e = aff_from_mem<G>(key.t2[((size_t)base * nwin + j) * key.per + ((d < 0 ? -d : d) - 1)]);
-        if (d < 0) e.y = G::neg(e.y);
-        jac_madd<G>(K, K, e);
-      }
+      bool have_next = false;
+      const Aff<G> en = entry_of(t + J, have_next);
+      if (have) jac_madd_inl<G>(K, K, e);
+      e = en;
+      have = have_next;
     }
   }
   ELP_NOUNROLL
@@ -711,10 +729,9 @@ __device__ __forceinline__ void coop_fixed_sum_g2(Jac<F2<C>>& K, const KeyCtx<C>
 }
 // K of a plain PS verification on ELP_PSK_LANES lanes per item: 48 sequential mixed additions (A = 3, W = 16) become 6 + 3 full ones;
 // the one inversion of the affine result stays.
-template <class C>
-__global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+template <class C, int J>
+__device__ __forceinline__ void ps_k_coop_body(const KeyCtx<C>& key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
   typedef F2<C> G;
-  constexpr int J = ELP_PSK_LANES;
   const int sub = (int)(threadIdx.x & (J - 1));
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / J;
   bool ok = false;
@@ -726,7 +743,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
     ok = g1_load<C>(s1, rec) && g1_load<C>(s2, rec + 2 * C::N) && sig1_admissible<C>(key.flags, s1);       // every lane of the item decides the same (src/ps-verifier.cc:16-18, in the order-r component)
     if (ok && sub == 0) jac_from_aff(K, aff_from_mem<G>(key.b2[G2_BASE_XX]));
   }
-  coop_fixed_sum_g2<C>(K, key, sub, nattr, ok, [&](int a, int& base, Scalar& k) {
+  coop_fixed_sum_g2<C, J>(K, key, sub, nattr, ok, [&](int a, int& base, Scalar& k) {
     base = G2_BASE_YY0 + a;
     k = scalar_load_w(rec + 4 * C::N + 8 * a);
   });
@@ -738,6 +755,18 @@ __global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, in
       vid_store_k<C>(kws, kstride, i, aK);
     }
   }
+}
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_ps_k_coop(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+  ps_k_coop_body<C, ELP_PSK_LANES>(key, recs, rec_words, nattr, todo, kws, kstride, n);
+}
+// The same for batches that are work, not latency (above 4 096 items): four lanes per sum and 256-thread workgroups (the four waves of a workgroup go to the four SIMDs
+// of one compute unit; one-wave workgroups were seen to double up on SIMDs in k_pair4, profiles/r05_four_lane.md -- for these kernels the measured gain came from
+// the inlined mixed addition of coop_fixed_sum_g2, not from the workgroup shape: 1.83 -> 1.79 -> 1.51 ms for the sums and tables of 16 384 items).
+#define ELP_WIDE_BLOCK 256
+template <class C>
+__global__ void __launch_bounds__(ELP_WIDE_BLOCK) k_ps_k_coop_wide(KeyCtx<C> key, const u32* recs, int rec_words, int nattr, uint8_t* todo, u32* kws, size_t kstride, size_t n) {
+  ps_k_coop_body<C, 4>(key, recs, rec_words, nattr, todo, kws, kstride, n);
 }
 // The fixed-base halves of el_passo_verify_id's G2 work for small batches, 2 x ELP_PSK_LANES lanes per item (src/ps-verifier.cc:76-88,220-227): the lower half computes
 //     out[2 i]     = sum_{hidden} rs_j YY_i + r_t gg + (1 - c) XX          (V_k without its [c]k term)
@@ -822,6 +851,7 @@ __device__ __forceinline__ void vid_ktab_body(const KeyCtx<C>& key, const u32* r
   const size_t slot = QUAD ? lin >> 2 : lin;
   const int sub = QUAD ? (int)(lin & 3) : 0;
   if (n == 0 || !key.vtab) return;
+  if (slot >= ((n + ELP_BLOCK - 1) / ELP_BLOCK) * (size_t)ELP_BLOCK) return;      // the workspace has one slice per lane of the 64-item waves: workgroups wider than a wave (k_vid_prep_wide) end beyond it
   const size_t i = slot < n ? slot : n - 1;
   u32* const w = key.vtab + slot * (size_t)vtab_words<C>();
   u32* const wp = key.vpsi ? key.vpsi + slot * (size_t)(24 * vtab_entry_words<G>()) : nullptr;     // psi^j of every multiple beside the table (WsTabPsi)
@@ -874,6 +904,14 @@ __global__ void ELP_LAUNCH_BOUNDS k_vid_prep(KeyCtx<C> key, const u32* recs, int
     vid_fixed_coop_body<C, J>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
   else
     vid_ktab_body<C, QUAD>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
+}
+template <class C, int J>
+__global__ void __launch_bounds__(ELP_WIDE_BLOCK) k_vid_prep_wide(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, Jac<F2<C>>* out, u32* kws, size_t kstride,
+                                                                  uint8_t* kvalid, size_t n, unsigned nb_fixed) {
+  if (blockIdx.x < nb_fixed)
+    vid_fixed_coop_body<C, J>(key, recs, rec_words, mask, retr, out, kws, kstride, kvalid, n, blockIdx.x);
+  else
+    vid_ktab_body<C, false>(key, recs, rec_words, retr, n, blockIdx.x - nb_fixed);
 }
 // verdict of a small-batch el_passo_verify_id = its NIZK half (k_vid_nizk4) AND its pairing check (k_pair_coop / k_pair_rest), which ran side by side
 template <class C>      // (a template only so that every translation unit that instantiates it gets its own copy)
@@ -952,6 +990,11 @@ void launch_pair_rest(hipStream_t stream, const KeyCtx<B>& key, size_t n, const 
 }
 template <class B>
 void launch_ps_k(hipStream_t stream, const KeyCtx<B>& key, size_t n, const void* d_records, int words, int nattr, uint8_t* todo, u32* kws, size_t kstride) {
+  if (n > 4096) {      // four lanes per sum, 256-thread workgroups (k_ps_k_coop_wide)
+    hipLaunchKernelGGL((k_ps_k_coop_wide<B>), dim3((unsigned)((n * 4 + ELP_WIDE_BLOCK - 1) / ELP_WIDE_BLOCK)), dim3(ELP_WIDE_BLOCK), 0, stream, key, (const u32*)d_records, words,
+                       nattr, todo, kws, kstride, n);
+    return;
+  }
   hipLaunchKernelGGL((k_ps_k_coop<B>), dim3(grid_for(n * ELP_PSK_LANES)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, nattr, todo, kws, kstride, n);
 }
 template <class B>
@@ -984,9 +1027,18 @@ void launch_vid_prep(hipStream_t stream, const KeyCtx<B>& key, size_t n, const v
     return;
   }
   if (n > 4096) {      // beyond one wave per SIMD of eight-lane sums the lane count is work: four lanes per sum (20 mixed + 2 complete additions per lane instead of 10 + 3)
-    const unsigned nbf4 = grid_for(n * 2 * 4);
-    hipLaunchKernelGGL((k_vid_prep<B, 4>), dim3(nbf4 + grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
+    // ... in 256-thread workgroups (k_vid_prep_wide; 16 384 items: 1.83 -> see profiles/r05_four_lane.md): one-wave workgroups leave SIMDs idle at these launch sizes
+    const unsigned nbf4 = (unsigned)((n * 2 * 4 + ELP_WIDE_BLOCK - 1) / ELP_WIDE_BLOCK);
+    const unsigned nbt = (unsigned)(((size_t)grid_for(n) * ELP_BLOCK + ELP_WIDE_BLOCK - 1) / ELP_WIDE_BLOCK);      // table slots up to the end of the last 64-item wave
+    hipLaunchKernelGGL((k_vid_prep_wide<B, 4>), dim3(nbf4 + nbt), dim3(ELP_WIDE_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr, (Jac<F2<B>>*)pre, kws,
                        kstride, kvalid, n, nbf4);
+    return;
+  }
+  if (n > 2048) {      // eight lanes per sum, but in 256-thread workgroups: 3 072 items are 816 one-wave workgroups, more than the dispatcher spreads evenly
+    const unsigned nbf8 = (unsigned)((n * 2 * ELP_PSK_LANES + ELP_WIDE_BLOCK - 1) / ELP_WIDE_BLOCK);
+    const unsigned nbt = (unsigned)(((size_t)grid_for(n) * ELP_BLOCK + ELP_WIDE_BLOCK - 1) / ELP_WIDE_BLOCK);
+    hipLaunchKernelGGL((k_vid_prep_wide<B, ELP_PSK_LANES>), dim3(nbf8 + nbt), dim3(ELP_WIDE_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                       (Jac<F2<B>>*)pre, kws, kstride, kvalid, n, nbf8);
     return;
   }
   const unsigned nbf = grid_for(n * 2 * ELP_PSK_LANES);
@@ -1834,6 +1886,9 @@ struct elp_ctx {
   AsyncSlot aslot[2];
   int fail_submits = 0;          // ELP_OPT_FAULT_INJECT
   int mid_two_launches = 0;      // experiments (ELP_PAIR4_TWO_LAUNCHES=1): the mid-size path as k_vid_nizk4 then k_pair4 instead of the one launch k_vid_mid
+  int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
+  void* wire_ws = nullptr;       // records + verdicts of that path (grown on demand)
+  size_t wire_ws_bytes = 0;
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
@@ -2916,12 +2971,77 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
   HIPCHK(c, hipGetLastError());
   return ELP_OK;
 }
+// Wire messages on the small / mid-size paths (round 5): decode into records with job-uniform waves (pipeline.h wire_decode_job: workgroup b runs job b % 7 of the
+// items [64 (b / 7), 64 (b / 7) + 64)), then the record path, then the AND with the decoder's verdicts.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_wire_decode(int A, const uint8_t* msgs, const u32* msg_off, int retr, u32* recs, int rec_words, uint8_t* okj, unsigned long long* mask_agg,
+                                                size_t n) {
+  const int job = (int)(blockIdx.x % WIRE_DECODE_JOBS);
+  const size_t i = (size_t)(blockIdx.x / WIRE_DECODE_JOBS) * ELP_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  u64 mask = 0;
+  const bool ok = wire_decode_job<C>(job, A, msgs + msg_off[i], (size_t)(msg_off[i + 1] - msg_off[i]), retr != 0, recs + i * (size_t)rec_words, &mask);
+  okj[(size_t)job * n + i] = ok ? 1 : 0;
+  if (job == WIRE_DECODE_JOBS - 1 && ok) {
+    atomicAnd(&mask_agg[0], (unsigned long long)mask);
+    atomicOr(&mask_agg[1], (unsigned long long)mask);
+  }
+}
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_wire_combine(const uint8_t* verdict, const uint8_t* okj, uint8_t* flags, unsigned long long* accepted, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    ok = verdict[i] != 0;
+    for (int j = 0; j < WIRE_DECODE_JOBS; j++) ok = ok && okj[(size_t)j * n + i] != 0;
+    flags[i] = ok ? 1 : 0;
+  }
+  count_accept(ok, accepted);
+}
 template <class C>
 int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_msgs, const void* d_msg_off, int retr,
                                           const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags, void* d_accepted) {
   int rc = check_fused(c, 0, need_rp(retr));
   if (rc) return rc;
   if (n == 0) return ELP_OK;
+  if constexpr (CoopBuild<C>::value && SmallBuild<C>::value) {
+    // Batches of the sizes the record paths serve better than a round of the fused wire kernels (a lone message: ~3 ms instead of ~9): decode, check that all
+    // messages hide the same attributes (the record kernels take one mask per launch; one 16-byte read-back), verify as records, AND with the decoder's verdicts.
+    // Mixed patterns, and batches in which no message parses, take the fused kernels below.
+    if (c->wire_decode && (c->coop || c->pair4) && n <= (size_t)ELP_PAIR4_MAX) {
+      const int words = verify_id_record_words<C>(c->A, retr ? 2 : 1, retr != 0);      // the record's size does not depend on the number of hidden attributes
+      const size_t rec_bytes = (n * (size_t)words * 4 + 255) & ~(size_t)255, ok_bytes = (((size_t)WIRE_DECODE_JOBS + 1) * n + 255) & ~(size_t)255;
+      const size_t need = rec_bytes + ok_bytes + 256;
+      if (c->wire_ws_bytes < need) {
+        if (c->wire_ws) HIPCHK(c, hipFree(c->wire_ws));
+        c->wire_ws = nullptr;
+        c->wire_ws_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->wire_ws, need + need / 4));
+        c->wire_ws_bytes = need + need / 4;
+      }
+      hipStream_t st = (hipStream_t)stream;
+      u32* recs = (u32*)c->wire_ws;
+      uint8_t* okj = (uint8_t*)c->wire_ws + rec_bytes;
+      uint8_t* verdict = okj + (size_t)WIRE_DECODE_JOBS * n;
+      unsigned long long* agg = (unsigned long long*)((uint8_t*)c->wire_ws + rec_bytes + ok_bytes);
+      HIPCHK(c, hipMemsetAsync(recs, 0, rec_bytes, st));       // a message that does not decode leaves an all-zero (rejected) record, not stale memory
+      HIPCHK(c, hipMemsetAsync(agg, 0xff, 8, st));
+      HIPCHK(c, hipMemsetAsync(agg + 1, 0, 8, st));
+      hipLaunchKernelGGL((k_wire_decode<C>), dim3(grid_for(n) * WIRE_DECODE_JOBS), dim3(ELP_BLOCK), 0, st, c->A, (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, recs, words,
+                         okj, agg, n);
+      unsigned long long h[2] = {0, 1};
+      HIPCHK(c, hipMemcpyAsync(h, agg, 16, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+      if (h[0] == h[1]) {          // one hidden pattern (a batch without a single well-formed message leaves ~0 != 0)
+        rc = elp_verify_id_batch_dev_t<C>(c, stream, n, recs, (uint64_t)h[0], retr, d_ad, d_ad_off, ad_len, verdict, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_wire_combine<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, st, (const uint8_t*)verdict, (const uint8_t*)okj, (uint8_t*)d_flags,
+                           (unsigned long long*)d_accepted, n);
+        HIPCHK(c, hipGetLastError());
+        return ELP_OK;
+      }
+    }
+  }
   if constexpr (PairedBuild<C>::value) {
     const size_t np = layout_split(c, n);       // messages [0, np): plain kernel; [np, n): paired kernel
     if (np < n) {

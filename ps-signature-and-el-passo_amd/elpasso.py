@@ -20,6 +20,7 @@ OPT_COALESCED_RECORDS = 7
 OPT_STREAM_OVERLAP = 8
 OPT_FAULT_INJECT = 9
 OPT_PAIR4 = 10
+OPT_WIRE_DECODE = 11
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -191,6 +192,10 @@ class Context:
     def set_pair4(self, mode):
         """ELP_OPT_PAIR4: 0 = off, 1 = the four-lanes-per-item pairing check for mid-size batches (default), 2 = wherever the path exists."""
         self._chk(self.lib.elp_set_option(self.h, OPT_PAIR4, int(mode)))
+
+    def set_wire_decode(self, on):
+        """ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages through a decode kernel + the record paths (default) or always through the fused wire kernels."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_WIRE_DECODE, int(bool(on))))
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default 0): 1 / 2 = one-lane-per-item verify_id as phase-split kernels (NIZK jobs, then the pairing); identical results."""

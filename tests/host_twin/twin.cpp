@@ -388,6 +388,13 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
   int pfx##_verify_id_wire(void* c, const uint8_t* msg, size_t len, int retr, const uint8_t* ad, size_t adlen) {          \
     return verify_id_wire_item<C>(((TwinCtx<C>*)c)->key, msg, len, retr != 0, ad, adlen) ? 1 : 0;                      \
   }                                                                                                                    \
+  int pfx##_wire_decode(const uint8_t* msg, size_t len, int A, int retr, u32* rec, uint64_t* mask) {                      \
+    int ok = 1;                                                                                                         \
+    u64 m = 0;                                                                                                          \
+    for (int job = 0; job < WIRE_DECODE_JOBS; job++) ok &= wire_decode_job<C>(job, A, msg, len, retr != 0, rec, &m) ? 1 : 0; \
+    *mask = m;                                                                                                          \
+    return ok;                                                                                                          \
+  }                                                                                                                    \
   int pfx##_prove_id(void* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen, u32* out) {      \
     return prove_id_item<C>(((TwinCtx<C>*)c)->key, rec, mask, retr != 0, ad, adlen, out) ? 1 : 0;                      \
   }                                                                                                                    \

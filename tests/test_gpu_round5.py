@@ -146,3 +146,54 @@ def test_four_lane_pairing_forced_small_and_ps_verify(gpu_ctx):
     finally:
         gpu_ctx.set_pair4(1)
         L.elpo_key_free(key)
+
+
+def test_wire_batches_take_the_record_paths_after_decoding(gpu_ctx):
+    """Round 5: elp_verify_id_wire_batch with <= 16 384 messages decodes them into records (k_wire_decode: seven job-uniform waves per 64 messages) and verifies those on
+    the small / mid-size paths (ELP_OPT_WIRE_DECODE).  n = 1 ... 4 100 of the reference's wire format (src/ps-encoding.cc:451-467): verdicts equal the fused wire kernels'
+    (option off), the record path's on the generator's records and the generator's expectation; truncated / garbage messages reject without disturbing their neighbours;
+    a batch with two different hidden patterns falls back to the fused kernels and still gives every verdict."""
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=321, window_bits=8)
+    try:
+        for n in (1, 65, 1000, 4100):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=9, corrupt_at=4)
+            msgs, moff = wl.wire_messages(recs, n, H, with_retrieval=True)
+            moff = np.asarray(moff, dtype=np.int64)
+            mlist = [bytes(msgs[int(moff[i]):int(moff[i + 1])]) for i in range(n)]
+            want = expect.copy()
+            if n >= 65:
+                mlist[3] = mlist[3][:len(mlist[3]) // 2]              # truncated
+                mlist[7] = b"\x01\x20" + bytes(30)                    # garbage
+                mlist[11] = mlist[11] + b"\x00"                       # trailing byte: whatever the fused kernel says
+                want[3] = want[7] = 0
+            gpu_ctx.set_wire_decode(1)
+            f1, c1 = gpu_ctx.verify_id_wire_batch(mlist, True, wl.ad)
+            gpu_ctx.set_wire_decode(0)
+            f0, c0 = gpu_ctx.verify_id_wire_batch(mlist, True, wl.ad)
+            assert (f1 == f0).all() and c1 == c0 == int(f1.sum()), n
+            keep = np.ones(n, dtype=bool)
+            if n >= 65:
+                keep[11] = False
+            assert (f1[keep] == want[keep]).all(), n
+            rf, rc = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            same = keep.copy()
+            if n >= 65:
+                same[[3, 7]] = False
+            assert (rf[same] == f1[same]).all()
+        # two hidden patterns in one batch: no common mask -> the fused kernels
+        n = 130
+        recs_a, mask_a, exp_a = wl.verify_id_batch(n, 4, with_retrieval=True, corrupt_every=7, corrupt_at=1)
+        recs_b, mask_b, exp_b = wl.verify_id_batch(n, 3, with_retrieval=True, corrupt_every=5, corrupt_at=2)
+        ma, oa = wl.wire_messages(recs_a, n, 4, with_retrieval=True)
+        mb, ob = wl.wire_messages(recs_b, n, 3, with_retrieval=True)
+        oa, ob = np.asarray(oa, dtype=np.int64), np.asarray(ob, dtype=np.int64)
+        mixed, want = [], []
+        for i in range(n):
+            mixed += [bytes(ma[int(oa[i]):int(oa[i + 1])]), bytes(mb[int(ob[i]):int(ob[i + 1])])]
+            want += [int(exp_a[i]), int(exp_b[i])]
+        gpu_ctx.set_wire_decode(1)
+        fm, cm = gpu_ctx.verify_id_wire_batch(mixed, True, wl.ad)
+        assert list(fm) == want and cm == sum(want)
+    finally:
+        gpu_ctx.set_wire_decode(1)

@@ -418,3 +418,48 @@ def test_aggregation_multiplier_in_glv_form(L):
             else:
                 assert got in want
         assert which is not None
+
+
+def test_wire_messages_decode_into_the_records_of_the_record_path(L):
+    """Round 5: k_wire_decode turns IdProof::toBufferString() messages (src/ps-encoding.cc:451-467) into verify_id records so that wire batches can take the small /
+    mid-size record paths.  Every job of wire_decode_job on the reference's own messages (golden proofs incl. the tampered ones that still parse): the record equals the
+    one packed from the decoded message by the model, the mask equals the hidden pattern; truncated messages decode to "invalid"."""
+    d = load_golden("bn254_oracle_flows.json")
+    n = 0
+    for s in d["scenarios"]:
+        pk = CD.pk_decode(base64.b64decode(s["pk"]))
+        A = len(pk.Yi)
+        for p in s["proofs"][:2]:
+            for c in p["cases"][:6]:
+                raw = base64.b64decode(c["proof"])
+                try:
+                    pr = CD.proof_decode(raw)
+                except Exception:
+                    continue
+                want = pack_verify_id(M, pr)
+                rec = ctypes.create_string_buffer(len(want) + 64)
+                mask = ctypes.c_uint64(0)
+                ok = L.twin_bn254_wire_decode(raw, len(raw), A, 0, rec, ctypes.byref(mask))
+                if len(pr.attributes) != A:
+                    assert ok == 0
+                    continue
+                assert ok == 1, (s["name"], c["label"])
+                assert rec.raw[:len(want)] == want, (s["name"], c["label"])
+                assert mask.value == hidden_mask(pr.attributes)
+                n += 1
+        raw = base64.b64decode(s["proofs"][0]["cases"][0]["proof"])
+        rec = ctypes.create_string_buffer(4096)
+        mask = ctypes.c_uint64(0)
+        for cut in (0, 1, 33, len(raw) // 2, len(raw) - 1):
+            assert L.twin_bn254_wire_decode(raw[:cut], cut, A, 0, rec, ctypes.byref(mask)) == 0
+    assert n > 40
+    w = load_golden("bn254_oracle_with_retrieval.json")
+    for r in w["runs"]:
+        pk = CD.pk_decode(base64.b64decode(r["pk"]))
+        raw = base64.b64decode(r["proof"])
+        pr = CD.proof_decode(raw)
+        want = pack_verify_id(M, pr)
+        rec = ctypes.create_string_buffer(len(want) + 64)
+        mask = ctypes.c_uint64(0)
+        assert L.twin_bn254_wire_decode(raw, len(raw), len(pk.Yi), 1, rec, ctypes.byref(mask)) == 1
+        assert rec.raw[:len(want)] == want and mask.value == hidden_mask(pr.attributes)
