@@ -58,6 +58,20 @@
 #define ELP_FP2 ELP_INL
 #endif
 
+// A device function that is not a kernel and makes no call is a LEAF: it never saves its return address s[30:31], and the branch-relaxation pass of ROCm 7.2's LLVM expands
+// the far branches of a leaf longer than 128 KB through exactly that register pair (profiles/r05_bls_fault.md).  ELP_NONLEAF() at the top of a routine that may grow past
+// 128 KB in some build (-DELP_NONLEAF_GUARD=1) makes it a caller -- one empty call -- so that the prologue saves the pair.
+#ifndef ELP_NONLEAF_GUARD
+#define ELP_NONLEAF_GUARD 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && ELP_NONLEAF_GUARD
+namespace elp {
+static __device__ __attribute__((noinline)) void elp_nonleaf_anchor() { asm volatile("" ::: "memory"); }
+}
+#define ELP_NONLEAF() ::elp::elp_nonleaf_anchor()
+#else
+#define ELP_NONLEAF() ((void)0)
+#endif
 // ELP_FP6: linkage of the Fp6-level routines (fp6_mul, fp6_sqr, fp6_mul_by_01, fp6_mul_by_fp2).  -DELP_FP6_INLINE=1 makes the
 // Fp12-level routines (fp12_mul, fp12_sqr, sparse line product) single leaf functions.
 #ifndef ELP_FP6_INLINE

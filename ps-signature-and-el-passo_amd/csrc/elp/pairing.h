@@ -205,6 +205,7 @@ ELP_HEAVY void ml_precompute(LineCoef<C>* out, const Aff<F2<C>>& q) {
 template <class C, int NV, int NF>
 ELP_HEAVY void miller_loop(Fp12<C>& f, const Aff<F1<C>>* pv, const Aff<F2<C>>* qv, const Aff<F1<C>>* pf,
                            const LineMem<C>* const* lines) {
+  ELP_NONLEAF();
   G2Proj<C> T[NV > 0 ? NV : 1];
   Fp2<C> nqy[NV > 0 ? NV : 1];
   bool live_v[NV > 0 ? NV : 1];

@@ -423,33 +423,30 @@ ELP_INL Fp2<C> fp2_scatter(const Fp<C>& c0, const Fp<C>& c1) {
   }
   return r;
 }
-// Square root in Fp2 for p = 3 (mod 4) ("complex method").  Returns false when a is not a square.  Paired layout: both lanes run the
-// whole computation on gathered components (decompression only; not on the verification path proper).
+// Square root in Fp2 for p = 3 (mod 4) ("complex method"), two Fp exponentiations and no inversion (round 5; three to four before).  With n = sqrt(a0^2 + a1^2),
+// alpha = (a0 + n) / 2, t = alpha^((p - 3) / 4) and x = t alpha:  x t = alpha^((p - 1) / 2) is the Legendre symbol of alpha.  +1: x^2 = alpha, 1 / x = t and the
+// root is x + (a1 t / 2) i.  -1: x^2 = -alpha, 1 / x = -t and the root is (-a1 t / 2) + x i (then u^2 - v^2 = (a0 - n) / 2 + (a0 + n) / 2 = a0, 2 u v = a1).
+// Returns false when a is not a square (its norm is not one in Fp).  Which of the two roots comes out is not specified: the one caller (g2_deserialize) picks by the
+// encoding's parity flag.  Paired layout: both lanes run the whole computation on gathered components (decompression only; not on the verification path proper).
 template <class C>
 ELP_HEAVY bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a_in) {
   const Fp2Full<C> a = fp2_gather<C>(a_in);
-  if (fp_is_zero<C>(a.c1)) {
-    Fp<C> s;
-    if (fp_sqrt<C>(s, a.c0)) {
-      r = fp2_scatter<C>(s, fp_zero<C>());
-      return true;
-    }
-    bool ok = fp_sqrt<C>(s, fp_neg(a.c0));
-    r = fp2_scatter<C>(fp_zero<C>(), s);
-    return ok;
+  if (fp_is_zero<C>(a.c1)) {           // a in Fp: sqrt(a0), or i sqrt(-a0) (one of a0, -a0 is a square)
+    const Fp<C> s = fp_pow_const<C>(a.c0, ExpPp1d4<C>());
+    const bool real = fp_eq(fp_sqr<C>(s), a.c0);
+    r = real ? fp2_scatter<C>(s, fp_zero<C>()) : fp2_scatter<C>(fp_zero<C>(), s);
+    return true;
   }
   Fp<C> n;
   if (!fp_sqrt<C>(n, fp_add(fp_sqr<C>(a.c0), fp_sqr<C>(a.c1)))) return false;
   Fp<C> inv2;
   ELP_LOAD_FP(inv2, C::inv2(i_));
-  Fp<C> t = fp_mul<C>(fp_add(a.c0, n), inv2);
-  Fp<C> x;
-  if (!fp_sqrt<C>(x, t)) {
-    t = fp_mul<C>(fp_sub(a.c0, n), inv2);
-    if (!fp_sqrt<C>(x, t)) return false;
-  }
-  Fp<C> y = fp_mul<C>(a.c1, fp_inv<C>(fp_dbl(x)));
-  r = fp2_scatter<C>(x, y);
+  const Fp<C> alpha = fp_mul<C>(fp_add(a.c0, n), inv2);        // != 0: alpha = 0 would mean n = -a0, a1 = 0
+  const Fp<C> t = fp_pow_const<C>(alpha, ExpPm3d4<C>());
+  const Fp<C> x = fp_mul<C>(t, alpha);
+  const bool qr = fp_eq(fp_mul<C>(x, t), fp_one<C>());
+  const Fp<C> y = fp_mul<C>(fp_mul<C>(a.c1, t), inv2);
+  r = qr ? fp2_scatter<C>(x, y) : fp2_scatter<C>(fp_neg(y), x);
   return true;
 }
 template <class C>

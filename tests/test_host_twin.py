@@ -49,6 +49,21 @@ def test_fp_arith(L):
         assert L.twin_bn254_fp2_sqrt(fb(sq[0]) + fb(sq[1]), o2)
         r = (ib(o2.raw[:32]), ib(o2.raw[32:]))
         assert F.f2_sqr(r) == sq
+    # elements of Fp (a square of Fp: a real root; a non-square: a purely imaginary one), zero, and non-squares of Fp2 (rejected)
+    for a0 in [0, 1, 4, p - 1, p - 4, 3, rnd.randrange(p), rnd.randrange(p)]:
+        assert L.twin_bn254_fp2_sqrt(fb(a0) + fb(0), o2)
+        r = (ib(o2.raw[:32]), ib(o2.raw[32:]))
+        assert F.f2_sqr(r) == (a0, 0) and (r[0] == 0 or r[1] == 0)
+    rejected = 0
+    for _ in range(40):
+        x = (rnd.randrange(p), rnd.randrange(1, p))
+        is_sq = pow((x[0] * x[0] + x[1] * x[1]) % p, (p - 1) // 2, p) == 1        # a square of Fp2 iff its norm is one of Fp
+        ok = L.twin_bn254_fp2_sqrt(fb(x[0]) + fb(x[1]), o2)
+        assert bool(ok) == is_sq
+        if ok:
+            assert F.f2_sqr((ib(o2.raw[:32]), ib(o2.raw[32:]))) == x
+        rejected += not ok
+    assert 5 < rejected < 35
 
 
 def test_hash_to_g1_all_branches(L):

@@ -17,6 +17,7 @@ Devegili-Scott-Dahab chain so that the value equals the model's GT element bit f
 
 Usage: python tools/gen_coop.py            -> writes ps-signature-and-el-passo_amd/csrc/elp/coop_prog_bn254.h  (after validating against the model)
 """
+import collections
 import os
 import sys
 
@@ -41,6 +42,7 @@ def naf(k):      # non-adjacent form, least significant digit first (as tools/ge
 NP = 16            # lane pairs per item
 CHUNK = 4          # steps per program chunk staged through LDS by the kernels
 NREG = 120         # Fp2 registers per item in LDS
+BANK_AWARE = True  # register allocation by LDS bank class (schedule)
 
 # ---- operations (SSA).  mul-class: MUL (a*b), MULC (a * constant[c]), MULS (a * Fp scalar = component `sel` of register b)
 #      lin-class: LIN (dst = sum_k M_k x_k: an Fp-linear combination of up to 15 registers, M_k 2x2 matrices of small integers acting on (re, im):
@@ -655,18 +657,57 @@ def schedule(prog, outs, ninputs, np_=None, cv=None):
     for o in outs:
         last[o] = len(steps) + 1
     # registers: inputs are pinned to their slots for the whole program; values get a register at their step and release it after the
-    # step of their last use (a register freed in step s is reusable from step s + 1 on)
+    # step of their last use (a register freed in step s is reusable from step s + 1 on).
+    # Which free register: the one whose LDS BANK CLASS collides least (round 5; profiles/r05_coop_lds_banks.md).  A register is 2 x nl words, an access is one
+    # ds_read_b32 / ds_write_b32 per limb over the 16 lane pairs of a 32-lane half (bank = word mod 32): two slots of a step collide in an access when they touch the same
+    # component of registers that differ by a multiple of 16 (18-word registers; 8 for the 28-word registers of BLS12-381).  `groups` lists, per access of the interpreter (first / second operand of the products, entry t of the
+    # linear combinations, results), the (value, component) pairs it touches; a value's cost for a register = the already placed members of its groups in the same class.
+    def halves(lst):
+        return [lst] if NP_ <= 16 else [lst[k:k + 16] for k in range(0, len(lst), 16)]
+    groups = []
+    groups_of = collections.defaultdict(list)
+    def add_group(members):
+        members = [m for m in members if m[0] >= 0]
+        if len(members) > 1:
+            gi = len(groups)
+            groups.append(members)
+            for v, _ in members:
+                groups_of[v].append(gi)
+    for cls, lst in steps:
+        for part in halves(lst):
+            add_group([(i, c) for i in part for c in (0, 1)])                      # results: both components of every slot in one write
+            if cls == 1:
+                add_group([(ops[i][1], 0) for i in part])                            # first operand, real component (the imaginary one collides alike)
+                add_group([(ops[i][2], c) for i in part for c in (0, 1) if ops[i][0] == MUL])     # second operand: the lane of component c reads b[c], then b[1 - c]
+                add_group([(ops[i][2], ops[i][3]) for i in part if ops[i][0] == MULS])
+            else:
+                lists = []
+                for i in part:
+                    if ops[i][0] == LIN:
+                        for comp in (0, 1):
+                            lists.append([(k, sel) for k, m in ops[i][3] for sel in (0, 1) if m[2 * comp + sel]])
+                for t in range(max((len(l) for l in lists), default=0)):
+                    add_group([l[t] for l in lists if t < len(l)])
     reg = {}
     free = list(range(NREG - 1, ninputs - 1, -1))
     for i in range(len(ops)):
         if ops[i][0] == INPUT:
             reg[i] = ops[i][3]
+    import math
+    cls_mod = 32 // math.gcd(2 * LIMBS[curve_name(cv)][0], 32) if cv is not None else 16      # registers this far apart share their banks (BN254: 16, BLS12-381: 8)
+    def bank_cost(v, r):
+        cost = 0
+        for gi in groups_of.get(v, ()):
+            mine = {c for w, c in groups[gi] if w == v}
+            for w, c in groups[gi]:
+                if w != v and c in mine and w in reg and (reg[w] - r) % cls_mod == 0 and reg[w] != r:
+                    cost += 1
+        return cost
     release = [[] for _ in range(len(steps) + 3)]
     peak = 0
     for si, (_, lst) in enumerate(steps):
         for i in lst:
             if not free:
-                import collections
                 livev = [j for j in reg if ops[j][0] != INPUT and step_of.get(j, 10**9) <= si and last.get(j, -1) >= si]
                 ex = sorted(livev, key=lambda j: step_of[j] - last[j])[:12]
                 for j in ex[:4]:
@@ -675,7 +716,15 @@ def schedule(prog, outs, ninputs, np_=None, cv=None):
                         print("      user %d %s level %d free=%s nterms=%s" % (u, NAMES[ops[u][0]], level[u], free_op[u], len(ops[u][3]) if ops[u][0] == LIN else "-"), file=sys.stderr)
                 hist = collections.Counter((NAMES[ops[j][0]], min(60, (last[j] - step_of[j]) // 10 * 10)) for j in livev)
                 raise RuntimeError("out of LDS registers at step %d; live values by (op, lifetime in steps): %s" % (si, sorted(hist.items())))
-            reg[i] = free.pop()
+            best, best_cost = len(free) - 1, None
+            if BANK_AWARE:
+                for k in range(len(free) - 1, -1, -1):              # ties: the most recently freed register, as the plain allocator would take
+                    c = bank_cost(i, free[k])
+                    if best_cost is None or c < best_cost:
+                        best, best_cost = k, c
+                        if c == 0:
+                            break
+            reg[i] = free.pop(best)
             peak = max(peak, NREG - ninputs - len(free))
             release[min(last.get(i, si), len(steps) + 1)].append(reg[i])
         for r in release[si]:
