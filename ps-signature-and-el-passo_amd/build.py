@@ -59,12 +59,14 @@ def _newest(paths):
 # translation units of libelpasso_hip.so: the two curves compile in parallel (the per-curve units hold the explicit template
 # instantiations of every kernel); per-unit flags: BN254 additionally inlines the Fp6-level routines into Fp12-level leaf
 # functions (+13 % on the verify kernel).  The two-lane BLS12-381 unit takes the same flag since round 5 (el_passo_verify_id 51.8 -> 49.4 ms, PS verification 33.0 -> 29.9 ms per
-# 65 536; +30 MB of code) together with -DELP_NONLEAF_GUARD=1: its Miller loop becomes one 730 KB function, and a LEAF function of that size trips the branch-relaxation
-# bug of profiles/r05_bls_fault.md -- the guard makes it a caller.  tests/test_isa_hazards.py scans the built library for the pattern.
+# 65 536) together with -DELP_NONLEAF_GUARD=1: its Miller loop becomes one 730 KB function, and a LEAF function of that size trips the branch-relaxation
+# bug of profiles/r05_bls_fault.md -- the guard makes it a caller.  tests/test_isa_hazards.py scans the built library for the pattern.  With the inlined routines the
+# unit is also better off with ONE wave per SIMD and 512 registers (-DELP_PAIR_WAVES=1: 50.0 -> 48.6 ms, PS 30.3 -> 27.5 ms; round 3 had measured the opposite for the
+# build with calls); the BN254 two-lane unit is not (98 304 items 25.9 -> 29.5 ms; profiles/r05_bls_fp6_inline_ab.log).
 HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_pair.hip", ["-DELP_FP6_INLINE=1"]),
              ("elpasso_bn254_nizk.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_g2job.hip", ["-DELP_FP6_INLINE=1"]),
              ("elpasso_bn254_g1job.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_stage.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bn254_coop.hip", []),
-             ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", ["-DELP_FP6_INLINE=1", "-DELP_NONLEAF_GUARD=1"]), ("elpasso_bls12_381_g1jobs.hip", []), ("elpasso_bn254_g1jobs.hip", []),
+             ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", ["-DELP_FP6_INLINE=1", "-DELP_NONLEAF_GUARD=1", "-DELP_PAIR_WAVES=1"]), ("elpasso_bls12_381_g1jobs.hip", []), ("elpasso_bn254_g1jobs.hip", []),
              ("elpasso_bls12_381_coop.hip", []), ("elpasso_bls12_381_nizk.hip", []), ("elpasso_bn254_small2.hip", ["-DELP_WAVES_PER_EU=2"]),
              ("elpasso_bn254_pair4.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bls12_381_pair4.hip", ["-DELP_FP6_INLINE=1"])]
 
