@@ -731,6 +731,18 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
                                                                       None, len(wl.ad), d_wfl.data_ptr(), d_cnt.data_ptr())))
     res["verify_id_wire_65536x8attrs"] = {"value": nw / (ms * 1e-3), "unit": "verifications/s", "kernel_ms": ms,
                                           "bytes_per_message": len(msgs) / nw, "parity_ok": bool((d_wfl.cpu().numpy() == vexpect).all())}
+    # lone messages and small / mid-size batches of messages (round 5): decoded into records on the GPU (k_wire_decode), then the record path of that size
+    # (ELP_OPT_WIRE_DECODE = 1, the default) against the fused wire kernels' full round (0)
+    wsm = {}
+    for mode in (0, 1):
+        ctx.set_wire_decode(mode)
+        d_wfl.zero_()
+        for m in (16384, 1, 1024, 16384):      # the first entry warms this mode
+            wms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_wire_batch_dev(ctx.h, stream, m, d_msg.data_ptr(), d_off.data_ptr(), 1, d_ad.data_ptr(),
+                                                                               None, len(wl.ad), d_wfl.data_ptr(), d_cnt.data_ptr())))
+            wsm["verify_id_wire_n%d_%s_ms" % (m, "decoded_to_records" if mode else "fused_wire_kernel")] = wms
+        wsm["parity_ok"] = wsm.get("parity_ok", True) and bool((d_wfl.cpu().numpy()[:16384] == vexpect[:16384]).all())
+    res["wire_small_batches"] = wsm
     # user side: batch prover, its output fed straight to the batch verifier
     recs, mask = wl.prove_id_batch(n, 4, with_retrieval=True)
     d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)
@@ -782,8 +794,8 @@ def host_api(pkg, wl, recs, B, A, H, first, expect, window, device):
                     "wire_packed": {"value": B / (outv[6] * 1e-3), "unit": "verifications/s", "best_ms": outv[6], "median_ms": outv[7]},
                     "objects_pipelined": {"value": B / (outv[8] * 1e-3), "unit": "verifications/s", "ms_per_batch_sustained": outv[8], "ms_one_batch_alone": outv[9],
                                           "note": "PSVerifier::el_passo_verify_id_submit / _collect, two batches in flight: the host packs batch i + 1 and its records cross "
-                                                  "PCIe while the GPU verifies batch i (elp_verify_id_batch_submit / _wait); with several contexts the calls fall back to "
-                                                  "the synchronous path"}}
+                                                  "PCIe while the GPU verifies batch i (elp_verify_id_batch_submit / _wait); with several contexts every context keeps its "
+                                                  "own slots and the shards of a batch are submitted side by side (round 5)"}}
     return res
 
 
