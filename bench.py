@@ -549,7 +549,7 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
            "parity_ok": bool((flags == expect).all()) and int(d_cnt.item()) == 3 * int(expect.sum()),
            "algorithmic_bytes_per_item": rsz + 4,
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "k_verify_id<BLS12_381>", "kernel_ms": float(ms.value)},
+                        "kernel": "k_verify_id_paired<Paired<BLS12_381>>", "kernel_ms": float(ms.value)},
            "valu_bound": valu_bound(ctx, "verify_id_bls12_381" if (A == 8 and H == 4) else None, window, B, float(ms.value), 392),
            "note": "BLS12-381 instantiation (14 limbs of 28 bits): parity unpinned -- no reference oracle exists; checked against the big-int model and the "
                    "C oracle's BLS12-381 build in tests"}
