@@ -89,6 +89,7 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
   }                                                                                                                    \
   int pfx##_fp2_sqrt(const u32* a, u32* o) {                                                                           \
     Fp2<C> x, r;                                                                                                       \
+    r.c0 = r.c1 = fp_zero<C>();      /* a rejected input leaves r alone */                                             \
     x.c0 = fp_from_std<C>(fp_load_w<C>(a));                                                                            \
     x.c1 = fp_from_std<C>(fp_load_w<C>(a + C::N));                                                                     \
     bool ok = fp2_sqrt<C>(r, x);                                                                                       \

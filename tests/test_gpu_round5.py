@@ -195,5 +195,16 @@ def test_wire_batches_take_the_record_paths_after_decoding(gpu_ctx):
         gpu_ctx.set_wire_decode(1)
         fm, cm = gpu_ctx.verify_id_wire_batch(mixed, True, wl.ad)
         assert list(fm) == want and cm == sum(want)
+        # without id-retrieval (three G1 points, one response fewer: the record is shorter, jobs 3 and 4 of the decoder idle) and with another hidden count
+        for n, Hn in ((1, 2), (200, 2), (3100, 5)):
+            recs, mask, expect = wl.verify_id_batch(n, Hn, with_retrieval=False, corrupt_every=6, corrupt_at=3)
+            msgs, moff = wl.wire_messages(recs, n, Hn, with_retrieval=False)
+            moff = np.asarray(moff, dtype=np.int64)
+            mlist = [bytes(msgs[int(moff[i]):int(moff[i + 1])]) for i in range(n)]
+            gpu_ctx.set_wire_decode(1)
+            f1, c1 = gpu_ctx.verify_id_wire_batch(mlist, False, wl.ad)
+            gpu_ctx.set_wire_decode(0)
+            f0, c0 = gpu_ctx.verify_id_wire_batch(mlist, False, wl.ad)
+            assert (f1 == expect).all() and (f0 == expect).all() and c1 == c0 == int(expect.sum()), (n, Hn)
     finally:
         gpu_ctx.set_wire_decode(1)
