@@ -102,11 +102,17 @@ int elp_field_bytes(int curve);               /* F */
  * decompression and attribute hashing as a kernel of job-uniform waves) and verifies the records on the small / mid-size paths above -- a lone wire message ~3 ms
  * instead of ~9 -- when all messages of the batch hide the same attributes (one 16-byte read-back, i.e. one stream synchronisation inside the call); mixed patterns and
  * larger batches take the fused wire kernels.  0 = always the fused kernels.  Verdicts are identical.
+ * ELP_OPT_AGG_TWO_PER_LANE (default 0; round 5; BN254): elp_verify_id_batch_aggregated[_dev] with TWO proofs on a lane -- their Miller loops share the squarings of one
+ * accumulator and multiply their lines pairwise: 8 % fewer instructions per proof, 2 % less time (131 072 proofs 31.5 -> 30.9 ms).  1 = on batches that need fewer rounds of
+ * lanes that way (65 537 ... 131 072 proofs on an MI355X, 196 609 ... 262 144, ...), 2 = always (tests).  Off by default: the kernel's private frame is the largest of the
+ * library, and the first launches after other large-frame kernels make the runtime re-provision scratch memory (hundreds of ms each in a process that uses two streams).
+ * Verdicts, the batch equation and the per-item fallback are unchanged.
  * ELP_OPT_FAULT_INJECT (default 0; a test hook for the error paths of callers): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  * ELP_ERR_STATE before anything is queued; nothing else is affected.
  */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
-       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10, ELP_OPT_WIRE_DECODE = 11 };
+       ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10, ELP_OPT_WIRE_DECODE = 11,
+       ELP_OPT_AGG_TWO_PER_LANE = 12 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 

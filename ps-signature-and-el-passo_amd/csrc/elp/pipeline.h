@@ -579,20 +579,25 @@ ELP_HD inline Scalar agg_multiplier(const uint8_t seed[32], u64 index) {
   k.v[3] |= 0x80000000u;   // exactly 128 bits, never zero
   return k;
 }
+// everything of an item up to its Miller loop: NIZK half, multiplier, [d]sig1 (affine) and K.  false = the item is rejected (aP, aK at infinity, multiplier 0)
 template <class C>
-ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
-                                  const uint8_t* seed, u64 index, Fp12<C>& f, u32* delta_out, u32* sig2_out) {
+ELP_HEAVY bool verify_id_agg_prepare(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
+                                     const uint8_t* seed, u64 index, Aff<F1<C>>& aP, Aff<F2<C>>& aK, u32* delta_out, u32* sig2_out) {
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
-  Aff<F2<C>> kk, aK;
+  Aff<F2<C>> kk;
   Scalar c;
   RecordSrc<C> src;
   src.sub_ = (key.flags & KEY_NO_SUBGROUP_CHECK) == 0;
-  fp12_set_one(f);
+  aff_set_inf(aP);
+  aff_set_inf(aK);
   for (int i = 0; i < 8; i++) delta_out[i] = 0;
   for (int i = 0; i < 2 * C::N; i++) sig2_out[i] = 0;
   if (!src.open(rec, hidden_mask, key.A, retr, sig1, sig2, phi, E1, E2, kk, c)) return false;
   if (!sig1_strict_ok<C>(key.flags, sig1)) return false;
-  if (!verify_id_nizk<C, RecordSrc<C>>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) return false;
+  if (!verify_id_nizk<C, RecordSrc<C>>(key, src, retr, phi, E1, E2, kk, c, ad, ad_len, aK)) {
+    aff_set_inf(aK);
+    return false;
+  }
   // multiplier d = a + b lam (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [d]sig1 = [a]sig1 + [b]phi(sig1) over the affine multiples
   // 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private memory
   const Scalar d = agg_multiplier(seed, index);
@@ -622,16 +627,47 @@ ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidd
       g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
     }
   }
-  Aff<F1<C>> aP;
   jac_to_aff<F1<C>>(aP, P);
+  for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
+  g1_store<C>(sig2_out, sig2);
+  return true;
+}
+template <class C>
+ELP_HEAVY bool verify_id_agg_item(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
+                                  const uint8_t* seed, u64 index, Fp12<C>& f, u32* delta_out, u32* sig2_out) {
+  Aff<F1<C>> aP;
+  Aff<F2<C>> aK;
+  fp12_set_one(f);
+  if (!verify_id_agg_prepare<C>(key, rec, hidden_mask, retr, ad, ad_len, seed, index, aP, aK, delta_out, sig2_out)) return false;
   Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);
   Fp12<C>& fm = fh ? *fh : f;
   const LineMem<C>* no_lines[1] = {key.gg_lines};          // never read (no fixed pair); real pointers keep the fused loop compilable
   miller_loop<C, 1, 0>(fm, &aP, &aK, &aP, no_lines);
   if (fh) f = fm;
-  for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
-  g1_store<C>(sig2_out, sig2);
   return true;
+}
+// TWO items of one lane (batches of more than one full round: elp_verify_id_batch_aggregated_dev_t): both NIZK halves, then ONE Miller loop for the two pairs
+// (pairing.h miller_loop_two); f = the product of the two Miller values, ok[k] = item k passed its NIZK half.  `rec1` may be null (an odd batch's last lane).
+template <class C>
+ELP_HEAVY void verify_id_agg_item2(const KeyCtx<C>& key, const u32* rec0, const u32* rec1, u64 hidden_mask, bool retr, const uint8_t* ad0, size_t ad_len0,
+                                   const uint8_t* ad1, size_t ad_len1, const uint8_t* seed, u64 index0, Fp12<C>& f, u32* delta_out0, u32* sig2_out0,
+                                   u32* delta_out1, u32* sig2_out1, bool* ok) {
+  Aff<F1<C>> aP[2];
+  Aff<F2<C>> aK[2];
+  ok[0] = verify_id_agg_prepare<C>(key, rec0, hidden_mask, retr, ad0, ad_len0, seed, index0, aP[0], aK[0], delta_out0, sig2_out0);
+  ok[1] = false;
+  aff_set_inf(aP[1]);
+  aff_set_inf(aK[1]);
+  if (rec1) ok[1] = verify_id_agg_prepare<C>(key, rec1, hidden_mask, retr, ad1, ad_len1, seed, index0 + 1, aP[1], aK[1], delta_out1, sig2_out1);
+  if constexpr (C::TWIST_D && C::IS_BN && fp_roomy<C>()) {
+    miller_loop_two<C>(f, aP, aK, ok, key.hot);      // the hot slot is free between the NIZK half and the wave's product
+  } else {                                  // other curves: two loops and a product (not dispatched to; kept so that the template is complete)
+    const LineMem<C>* no_lines[1] = {key.gg_lines};
+    Fp12<C> g;
+    miller_loop<C, 1, 0>(f, &aP[0], &aK[0], &aP[0], no_lines);
+    miller_loop<C, 1, 0>(g, &aP[1], &aK[1], &aP[1], no_lines);
+    fp12_mul<C>(f, f, g);
+  }
 }
 
 template <class C>

@@ -86,6 +86,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   if (const char* e = getenv("ELP_PHASE_MIX")) c->phase_mix = atoi(e);                                                      // A/B runs: KEY_PHASE_MIX
   if (const char* e = getenv("ELP_SMALL_DENSE_FROM")) c->small_dense_from = (size_t)atol(e);                               // A/B runs: k_vid_small2 above this many items
   if (const char* e = getenv("ELP_PAIR4_TWO_LAUNCHES")) c->mid_two_launches = atoi(e);                                      // A/B runs: the mid-size path as two launches
+  if (const char* e = getenv("ELP_AGG_TWO")) c->agg_two = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));      // A/B runs: ELP_OPT_AGG_TWO_PER_LANE from the environment
   if (const char* e = getenv("ELP_SMALL_ONE_MAX")) c->small_one_max = (size_t)atol(e);                                    // A/B runs: one launch (k_vid_small) up to this many items
   if (const char* e = getenv("ELP_OVERLAP")) c->overlap = atoi(e) != 0;                                                   // A/B runs: second-stream overlap inside a call
   if (const char* e = getenv("ELP_STAGE")) c->stage_records = atoi(e) != 0;                                              // A/B runs: coalesced record loads
@@ -162,6 +163,10 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_STREAM_OVERLAP: c->overlap = value ? 1 : 0; return ELP_OK;
     case ELP_OPT_FAULT_INJECT: c->fail_submits = value > 0 ? value : 0; return ELP_OK;
     case ELP_OPT_WIRE_DECODE: c->wire_decode = value ? 1 : 0; return ELP_OK;
+    case ELP_OPT_AGG_TWO_PER_LANE:
+      if (value < 0 || value > 2) return ELP_ERR_ARG;
+      c->agg_two = value;
+      return ELP_OK;
     case ELP_OPT_PAIR4:
       if (value < 0 || value > 2) return ELP_ERR_ARG;
       c->pair4 = value;

@@ -11,6 +11,7 @@
 #include <sys/random.h>
 
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -1659,6 +1660,35 @@ __global__ void ELP_LAUNCH_BOUNDS k_verify_id_agg(KeyCtx<C> key, const u32* recs
   if (threadIdx.x == 0) wave_prod[blockIdx.x] = f;
 }
 
+// The same with TWO items per lane (items 2 t and 2 t + 1 on lane t): for batches of more than one full round of lanes the two Miller loops of a lane share the
+// squarings of one accumulator and multiply their lines pairwise (elp/pairing.h miller_loop_two) -- about 6 % fewer instructions per item.  Half as many waves: n / 128.
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_verify_id_agg2(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr,
+                                                              const uint8_t* ad, const u32* ad_off, u32 ad_len, AggSeed seed,
+                                                              uint8_t* nizk_flags, u32* deltas, u32* sig2s, Fp12<C>* wave_prod, size_t n) {
+  __shared__ __attribute__((aligned(16))) Fp12<C> sh[ELP_BLOCK];
+  key.hot = reinterpret_cast<u32*>(&sh[threadIdx.x]);
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i0 = 2 * t, i1 = 2 * t + 1;
+  Fp12<C> f;
+  fp12_set_one(f);
+  if (i0 < n) {
+    const bool two = i1 < n;
+    const uint8_t* a0 = ad_off ? ad + ad_off[i0] : ad;
+    const size_t al0 = ad_off ? (size_t)(ad_off[i0 + 1] - ad_off[i0]) : (size_t)ad_len;
+    const uint8_t* a1 = (ad_off && two) ? ad + ad_off[i1] : ad;
+    const size_t al1 = (ad_off && two) ? (size_t)(ad_off[i1 + 1] - ad_off[i1]) : (size_t)ad_len;
+    bool ok[2];
+    u32 dummy_d[8], dummy_s[2 * C::N];
+    verify_id_agg_item2<C>(key, recs + i0 * (size_t)rec_words, two ? recs + i1 * (size_t)rec_words : nullptr, mask, retr != 0, a0, al0, a1, al1, seed.b, (u64)i0, f,
+                           deltas + i0 * 8, sig2s + i0 * (size_t)(2 * C::N), two ? deltas + i1 * 8 : dummy_d, two ? sig2s + i1 * (size_t)(2 * C::N) : dummy_s, ok);
+    nizk_flags[i0] = ok[0] ? 1 : 0;
+    if (two) nizk_flags[i1] = ok[1] ? 1 : 0;
+  }
+  wave_fp12_product<C>(f, sh);
+  if (threadIdx.x == 0) wave_prod[blockIdx.x] = f;
+}
+
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_fp12_reduce(const Fp12<C>* in, size_t n, Fp12<C>* out) {
   __shared__ Fp12<C> sh[ELP_BLOCK];
@@ -1889,6 +1919,7 @@ struct elp_ctx {
   int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
   void* wire_ws = nullptr;       // records + verdicts of that path (grown on demand)
   size_t wire_ws_bytes = 0;
+  int agg_two = 0;            // ELP_OPT_AGG_TWO_PER_LANE: aggregated batches put two items on a lane (0 = never -- the default: 2 % at best, and the kernel's larger frame makes the runtime re-provision scratch --, 1 = where it saves rounds of lanes, 2 = always)
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
@@ -2520,7 +2551,14 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   const int H = popcount_mask(mask, c->A);
   if (H < (retr ? 2 : 1)) return ELP_ERR_ARG;
   const int words = verify_id_record_words<C>(c->A, H, retr != 0);
-  const size_t nw = grid_for(n);                       // waves = per-wave Miller products
+  // Two items per lane (k_verify_id_agg2, BN254): a round of lanes then takes 1.89 x the time of a one-item round and holds twice the items -- chosen when it needs
+  // fewer than 1 / 1.89 of the rounds (65 537 ... 131 072 items on a chip of 1 024 SIMDs: one round instead of two; 131 073 ... 196 608: two instead of three does NOT pay)
+  bool two_per_lane = false;
+  if constexpr (std::is_same<C, BN254>::value) {
+    const size_t round = (size_t)64 * c->simds, r1 = (n + round - 1) / round, r2 = (n + 2 * round - 1) / (2 * round);
+    two_per_lane = c->agg_two == 2 || (c->agg_two == 1 && 189 * r2 < 100 * r1);
+  }
+  const size_t nw = two_per_lane ? grid_for((n + 1) / 2) : grid_for(n);                       // waves = per-wave Miller products
   const size_t nw2 = grid_for(nw);
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_flags = 0, o_delta = al(n), o_sig2 = o_delta + al(n * 32), o_f1 = o_sig2 + al(n * Sizes<C>::G1),
@@ -2561,9 +2599,14 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     return ELP_ERR_STATE;
   }
   KeyCtx<C> key = make_key_ws<C>(c, stream, (size_t)nw * ELP_BLOCK);
-  hipLaunchKernelGGL((k_verify_id_agg<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
-                     (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
-                     (Fp12<C>*)(ws + o_f1), n);
+  if (two_per_lane)
+    hipLaunchKernelGGL((k_verify_id_agg2<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                       (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
+                       (Fp12<C>*)(ws + o_f1), n);
+  else
+    hipLaunchKernelGGL((k_verify_id_agg<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+                       (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
+                       (Fp12<C>*)(ws + o_f1), n);
   key.vtab = nullptr;   // the kernels below do not advance the pointer to their lane (the rare per-item fallback keeps its tables in private memory)
   // The two halves of the tail are independent -- the product of the per-wave Miller values (nw -> nw2 -> 1) and S2 = sum d_i sig2_i (Pippenger) -- and
   // neither fills the chip: with ELP_OPT_STREAM_OVERLAP the product runs on the context's second stream beside the sum.
@@ -2614,7 +2657,7 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     }
   }
   if (!tail_done) hipLaunchKernelGGL((k_agg_final<C>), dim3(1), dim3(ELP_BLOCK), 0, stream, key, F, (const u32*)(ws + o_s2), c->agg_ok);
-  hipLaunchKernelGGL((k_agg_finish<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
+  hipLaunchKernelGGL((k_agg_finish<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                      (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, (const uint8_t*)(ws + o_flags), (const int*)c->agg_ok,
                      (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
   HIPCHK(c, hipGetLastError());

@@ -21,6 +21,7 @@ OPT_STREAM_OVERLAP = 8
 OPT_FAULT_INJECT = 9
 OPT_PAIR4 = 10
 OPT_WIRE_DECODE = 11
+OPT_AGG_TWO_PER_LANE = 12
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -196,6 +197,10 @@ class Context:
     def set_wire_decode(self, on):
         """ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages through a decode kernel + the record paths (default) or always through the fused wire kernels."""
         self._chk(self.lib.elp_set_option(self.h, OPT_WIRE_DECODE, int(bool(on))))
+
+    def set_agg_two_per_lane(self, mode):
+        """ELP_OPT_AGG_TWO_PER_LANE: aggregated verification with two proofs per lane (0 never -- the default --, 1 where it saves rounds of lanes, 2 always)."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_AGG_TWO_PER_LANE, int(mode)))
 
     def set_split_phases(self, on):
         """ELP_OPT_SPLIT_PHASES (default 0): 1 / 2 = one-lane-per-item verify_id as phase-split kernels (NIZK jobs, then the pairing); identical results."""

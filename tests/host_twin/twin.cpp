@@ -36,6 +36,28 @@ struct TwinCtx {
   }
 };
 
+// miller_loop_two (pairing.h; BN254 only) beside the product of the two single loops: o_two / o_prod = the two Miller values in canonical form
+template <class C>
+static int twin_miller_two(const u32* P0, const u32* Q0, const u32* P1, const u32* Q1, int live_mask, u32* o_two, u32* o_prod) {
+  if constexpr (C::TWIST_D && C::IS_BN && fp_roomy<C>()) {
+    Aff<F1<C>> p[2];
+    Aff<F2<C>> q[2];
+    if (!g1_load<C>(p[0], P0) || !g2_load<C>(q[0], Q0) || !g1_load<C>(p[1], P1) || !g2_load<C>(q[1], Q1)) return 0;
+    const bool live[2] = {(live_mask & 1) != 0, (live_mask & 2) != 0};
+    Fp12<C> f2, fa, fb;
+    miller_loop_two<C>(f2, p, q, live);
+    fp12_set_one(fa);
+    fp12_set_one(fb);
+    if (live[0]) miller_loop<C, 1, 0>(fa, &p[0], &q[0], (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0);
+    if (live[1]) miller_loop<C, 1, 0>(fb, &p[1], &q[1], (const Aff<F1<C>>*)0, (const LineCoef<C>* const*)0);
+    fp12_mul<C>(fa, fa, fb);
+    gt_store<C>(o_two, f2);
+    gt_store<C>(o_prod, fa);
+    return 1;
+  } else {
+    return -1;
+  }
+}
 // one table entry per window for the digits of `k`: entry (j, d_j) = d_j * 2^(W j) * base, exactly what jac_acc_fixed will read
 template <class F>
 static void touch_entries(Aff<F>* base_tbl, const Aff<F>& base, int W, int nwin, int per, const Scalar& k) {
@@ -221,6 +243,9 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     }                                                                                                                  \
     gt_store<C>(o, g);                                                                                                 \
     return 1;                                                                                                          \
+  }                                                                                                                    \
+  int pfx##_miller_two(const u32* P0, const u32* Q0, const u32* P1, const u32* Q1, int live_mask, u32* o_two, u32* o_prod) {        \
+    return twin_miller_two<C>(P0, Q0, P1, Q1, live_mask, o_two, o_prod);                                               \
   }                                                                                                                    \
   /* same pairing but with Q's lines precomputed (checks the fixed-argument path) */                                   \
   int pfx##_pairing_fixedq(const u32* P, const u32* Q, u32* o) {                                                       \

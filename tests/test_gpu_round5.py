@@ -208,3 +208,50 @@ def test_wire_batches_take_the_record_paths_after_decoding(gpu_ctx):
             assert (f1 == expect).all() and (f0 == expect).all() and c1 == c0 == int(expect.sum()), (n, Hn)
     finally:
         gpu_ctx.set_wire_decode(1)
+
+
+def test_aggregated_verification_with_two_items_per_lane(gpu_ctx):
+    """ELP_OPT_AGG_TWO_PER_LANE (round 5; k_verify_id_agg2 + pairing.h miller_loop_two): forced on, batches of 1 ... 1 001 items -- odd sizes leave the last lane one
+    item --: (a) a batch whose bad items fail the NIZK half only (every ninth, so most lanes meet a dead neighbour): the batch equation holds and the verdicts are
+    the per-item path's; (b) signatures tampered behind the NIZK's back: the equation fails and the per-item fallback decides; (c) per-item associated data; and
+    mode 1 (two per lane only where it saves rounds) leaves these sizes on the one-item kernel with the same answers."""
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=77, window_bits=8)
+    seed = bytes(range(32))
+    try:
+        for n in (1, 2, 3, 64, 129, 1001):
+            recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=9, corrupt_at=min(4, n - 1) if n < 9 else 4)
+            ref, rc = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
+            assert (ref == expect).all()
+            for mode in (2, 1):
+                gpu_ctx.set_agg_two_per_lane(mode)
+                fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad, seed)
+                assert held and (fl == expect).all() and cnt == rc, (n, mode)
+            if n >= 64:
+                rsz = len(recs) // n
+                r = bytearray(recs)
+                a, b = 10, 11                                        # two accepted neighbours of one lane: swap their sig2
+                assert expect[a] and expect[b]
+                r[a * rsz + 64:a * rsz + 128], r[b * rsz + 64:b * rsz + 128] = r[b * rsz + 64:b * rsz + 128], r[a * rsz + 64:a * rsz + 128]
+                r[20 * rsz:20 * rsz + 128] = bytes(128)                 # (inf, inf): accepted by the reference's VerifyID (non-strict fixture)
+                bad = bytes(r)
+                rf, rcnt = gpu_ctx.verify_id_batch(bad, mask, True, wl.ad)
+                assert rf[a] == 0 and rf[b] == 0
+                for mode in (2, 1):
+                    gpu_ctx.set_agg_two_per_lane(mode)
+                    fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(bad, mask, True, wl.ad, seed)
+                    assert not held and (fl == rf).all() and cnt == rcnt, (n, mode)
+        # per-item associated data
+        n = 131
+        recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=7, corrupt_at=2)
+        ads = [wl.ad] * n
+        gpu_ctx.set_agg_two_per_lane(2)
+        fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, ads, seed)
+        assert held and (fl == expect).all()
+        ads[5] = b"another session"                                 # item 5 was bound to other associated data: its NIZK half fails
+        fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, ads, seed)
+        want = expect.copy()
+        want[5] = 0
+        assert held and (fl == want).all()
+    finally:
+        gpu_ctx.set_agg_two_per_lane(0)

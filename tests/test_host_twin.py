@@ -110,6 +110,32 @@ def test_pairing_value_and_cyclotomic(L):
     assert L.twin_bn254_pairing_fixedq(g1b(P), g2b(Q), og) == 1 and og.raw == want
 
 
+def test_two_miller_loops_on_one_accumulator(L):
+    """pairing.h miller_loop_two (aggregated verification with two items per lane, round 5): the Miller value of two variable pairs walked together -- one squaring of the
+    accumulator per step, the two lines multiplied pairwise -- equals the product of the two single loops bit for bit; a pair that is not live contributes 1 (it walks the
+    loop on a copy of the other pair and feeds the neutral line); after the final exponentiation the value is the model's e(P0, Q0) e(P1, Q1)."""
+    d = load_golden("bn254_oracle_flows.json")
+    pk = CD.pk_decode(base64.b64decode(d["scenarios"][0]["pk"]))
+    o2, op, og = ctypes.create_string_buffer(384), ctypes.create_string_buffer(384), ctypes.create_string_buffer(384)
+    zero = bytes(384)
+    rnd = random.Random(7)
+    for _ in range(3):
+        P0, Q0 = G.g1_mul(pk.g, rnd.randrange(1, M.r)), G.g2_mul(pk.gg, rnd.randrange(1, M.r))
+        P1, Q1 = G.g1_mul(pk.g, rnd.randrange(1, M.r)), G.g2_mul(pk.gg, rnd.randrange(1, M.r))
+        for mask in (3, 1, 2, 0):
+            assert L.twin_bn254_miller_two(g1b(P0), g2b(Q0), g1b(P1), g2b(Q1), mask, o2, op) == 1
+            assert o2.raw == op.raw and o2.raw != zero, mask
+        L.twin_bn254_miller_two(g1b(P0), g2b(Q0), g1b(P1), g2b(Q1), 3, o2, op)
+        L.twin_bn254_fp12_op(6, 0, o2.raw, o2.raw, og)            # final exponentiation of the joint Miller value
+        e = G.F.f12_mul(G.pairing(P0, Q0), G.pairing(P1, Q1))
+        assert og.raw == b"".join(fb(e[k][0]) + fb(e[k][1]) for k in [0, 2, 4, 1, 3, 5])
+    # a point at infinity in a live pair: contributes 1 as in the single loop
+    inf1, inf2 = bytes(64), bytes(128)
+    assert L.twin_bn254_miller_two(inf1, g2b(Q0), g1b(P1), g2b(Q1), 3, o2, op) == 1 and o2.raw == op.raw
+    assert L.twin_bn254_miller_two(g1b(P0), g2b(Q0), g1b(P1), inf2, 3, o2, op) == 1 and o2.raw == op.raw
+    assert L.twin_bn254_miller_two(inf1, inf2, inf1, inf2, 3, o2, op) == 1 and o2.raw == op.raw
+
+
 def test_verify_id_golden(L):
     d = load_golden("bn254_oracle_flows.json")
     n = 0

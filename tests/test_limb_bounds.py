@@ -24,6 +24,7 @@ def test_flows_stay_within_limb_bounds(tmp_path):
         T.test_fp_arith(L)
         T.test_group_ops(L)
         T.test_pairing_value_and_cyclotomic(L)
+        T.test_two_miller_loops_on_one_accumulator(L)
         T.test_glv_gls_scalar_multiplication(L)
         T.test_ps_verify_and_provide_id(L)
         T.test_verify_id_with_retrieval_golden(L)

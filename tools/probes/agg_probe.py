@@ -1,5 +1,5 @@
 """Aggregated verification at the headline size, a few calls (run under rocprofv3 --kernel-trace --stats to see its kernels).
-Usage: [CURVE=bls] python tools/probes/agg_probe.py [batch] [window] [ELP_COOP value]"""
+Usage: [CURVE=bls] [AGG_TWO=0|1|2] python tools/probes/agg_probe.py [batch] [window] [ELP_COOP value]      (AGG_TWO: ELP_OPT_AGG_TWO_PER_LANE)"""
 import importlib
 import os
 import sys
@@ -23,6 +23,8 @@ d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
 d_flags = torch.zeros(B, dtype=torch.uint8, device=dev)
 d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
+if os.environ.get("AGG_TWO"):
+    ctx.set_agg_two_per_lane(int(os.environ["AGG_TWO"]))
 for it in range(4):
     d_cnt.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
