@@ -134,7 +134,8 @@ void elp_destroy(elp_ctx* c) {
     if (a.h_cnt) (void)hipHostFree(a.h_cnt);
   }
   if (c->coop_consts) (void)hipFree(c->coop_consts);
-  if (c->wire_ws) (void)hipFree(c->wire_ws);
+  for (auto& e : c->wire_ws)
+    if (e.p) (void)hipFree(e.p);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
   for (int i = 0; i < 4; i++)
     if (c->jev[i]) (void)hipEventDestroy(c->jev[i]);

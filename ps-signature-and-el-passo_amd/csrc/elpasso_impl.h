@@ -1917,8 +1917,6 @@ struct elp_ctx {
   int fail_submits = 0;          // ELP_OPT_FAULT_INJECT
   int mid_two_launches = 0;      // experiments (ELP_PAIR4_TWO_LAUNCHES=1): the mid-size path as k_vid_nizk4 then k_pair4 instead of the one launch k_vid_mid
   int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
-  void* wire_ws = nullptr;       // records + verdicts of that path (grown on demand)
-  size_t wire_ws_bytes = 0;
   int agg_two = 0;            // ELP_OPT_AGG_TWO_PER_LANE: aggregated batches put two items on a lane (0 = never -- the default: 2 % at best, and the kernel's larger frame makes the runtime re-provision scratch --, 1 = where it saves rounds of lanes, 2 = always)
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
@@ -1928,6 +1926,7 @@ struct elp_ctx {
     size_t bytes;
   };
   std::vector<VtabWs> vtab_ws;
+  std::vector<VtabWs> wire_ws;       // records + verdicts of the decoded wire path, one block per launch stream like vtab_ws (grown on demand)
   int use_vtab = 1;           // ELP_VTAB=0 in the environment keeps the tables in private memory (A/B measurements)
   int split = 0;              // ELP_OPT_SPLIT_PHASES: 1 = el_passo_verify_id as two kernels (k_vid_nizk, k_vid_pair) where the curve has them; 2 = the two jobs
                               // of the first phase as concurrent kernels on two streams (k_vid_g2 || k_vid_g1, then k_vid_pair2)
@@ -3055,18 +3054,26 @@ int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const voi
       const int words = verify_id_record_words<C>(c->A, retr ? 2 : 1, retr != 0);      // the record's size does not depend on the number of hidden attributes
       const size_t rec_bytes = (n * (size_t)words * 4 + 255) & ~(size_t)255, ok_bytes = (((size_t)WIRE_DECODE_JOBS + 1) * n + 255) & ~(size_t)255;
       const size_t need = rec_bytes + ok_bytes + 256;
-      if (c->wire_ws_bytes < need) {
-        if (c->wire_ws) HIPCHK(c, hipFree(c->wire_ws));
-        c->wire_ws = nullptr;
-        c->wire_ws_bytes = 0;
-        HIPCHK(c, hipMalloc(&c->wire_ws, need + need / 4));
-        c->wire_ws_bytes = need + need / 4;
+      elp_ctx::VtabWs* ww = nullptr;
+      for (auto& e : c->wire_ws)
+        if (e.stream == (hipStream_t)stream) ww = &e;
+      if (!ww) {
+        c->wire_ws.push_back({(hipStream_t)stream, nullptr, 0});
+        ww = &c->wire_ws.back();
       }
+      if (ww->bytes < need) {
+        if (ww->p) HIPCHK(c, hipFree(ww->p));        // hipFree waits for the work that may still read it
+        ww->p = nullptr;
+        ww->bytes = 0;
+        HIPCHK(c, hipMalloc(&ww->p, need + need / 4));
+        ww->bytes = need + need / 4;
+      }
+      uint8_t* const wsb = (uint8_t*)ww->p;
       hipStream_t st = (hipStream_t)stream;
-      u32* recs = (u32*)c->wire_ws;
-      uint8_t* okj = (uint8_t*)c->wire_ws + rec_bytes;
+      u32* recs = (u32*)wsb;
+      uint8_t* okj = wsb + rec_bytes;
       uint8_t* verdict = okj + (size_t)WIRE_DECODE_JOBS * n;
-      unsigned long long* agg = (unsigned long long*)((uint8_t*)c->wire_ws + rec_bytes + ok_bytes);
+      unsigned long long* agg = (unsigned long long*)(wsb + rec_bytes + ok_bytes);
       HIPCHK(c, hipMemsetAsync(recs, 0, rec_bytes, st));       // a message that does not decode leaves an all-zero (rejected) record, not stale memory
       HIPCHK(c, hipMemsetAsync(agg, 0xff, 8, st));
       HIPCHK(c, hipMemsetAsync(agg + 1, 0, 8, st));

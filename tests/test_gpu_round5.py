@@ -255,3 +255,34 @@ def test_aggregated_verification_with_two_items_per_lane(gpu_ctx):
         assert held and (fl == want).all()
     finally:
         gpu_ctx.set_agg_two_per_lane(0)
+
+
+def test_decoded_wire_batches_on_two_streams_keep_their_own_workspace(gpu_ctx):
+    """The decoded wire path keeps its records per launch stream (like the per-stream table workspace of the record entry points): batches of different messages issued
+    back to back on two streams of one context -- the record kernels of one still running while the other decodes -- must not see each other's records."""
+    import torch
+    A, H = 8, 4
+    dev = torch.device("cuda", 0)
+    wl = synth.Workload(gpu_ctx, A, seed=4242, window_bits=8)
+    sets = []
+    for n, ce, ca in ((700, 5, 1), (900, 7, 3)):
+        recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=ce, corrupt_at=ca, first_item=1000 * ce)
+        msgs, moff = wl.wire_messages(recs, n, H, first_item=1000 * ce, with_retrieval=True)
+        sets.append((n, expect, torch.from_numpy(np.frombuffer(msgs, dtype=np.uint8).copy()).to(dev),
+                     torch.from_numpy(np.asarray(moff, dtype=np.uint32).view(np.int32).copy()).to(dev), torch.zeros(n, dtype=torch.uint8, device=dev)))
+    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
+    d_cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    gpu_ctx.set_wire_decode(1)
+    reps = 6
+    for _ in range(reps):
+        for q in (0, 1):
+            n, expect, d_msg, d_off, d_fl = sets[q]
+            gpu_ctx._chk(gpu_ctx.lib.elp_verify_id_wire_batch_dev(gpu_ctx.h, streams[q].cuda_stream, n, d_msg.data_ptr(), d_off.data_ptr(), 1, d_ad.data_ptr(), None,
+                                                                  len(wl.ad), d_fl.data_ptr(), d_cnt.data_ptr() + 8 * q))
+    torch.cuda.synchronize()
+    for q in (0, 1):
+        n, expect, _, _, d_fl = sets[q]
+        assert (d_fl.cpu().numpy() == expect).all(), q
+        assert int(d_cnt[q].item()) == reps * int(expect.sum()), q
