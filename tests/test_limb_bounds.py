@@ -10,8 +10,13 @@ from elp_testlib import ROOT
 
 
 def test_flows_stay_within_limb_bounds(tmp_path):
-    so = os.path.join(str(tmp_path), "libtwin_chk.so")
-    elp_testlib.build_twin(so, ["-O1", "-DELP_BOUND_CHECK"])
+    # built beside the ordinary twin and rebuilt only when a header or the twin's source is newer (as elp_testlib.twin() does)
+    so = os.path.join(ROOT, "tests", "host_twin", "libtwin.chk.so")
+    inc = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc")
+    newest = max([os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(inc) for f in fs if f.endswith(".h")] +
+                 [os.path.getmtime(os.path.join(ROOT, "tests", "host_twin", "twin.cpp")), os.path.getmtime(os.path.join(ROOT, "tests", "elp_testlib.py"))])
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        elp_testlib.build_twin(so, ["-O1", "-DELP_BOUND_CHECK"])
     L = ctypes.CDLL(so)
     L.twin_bn254_ctx_new.restype = ctypes.c_void_p
     L.twin_bls_ctx_new.restype = ctypes.c_void_p
