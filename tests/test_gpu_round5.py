@@ -206,6 +206,17 @@ def test_wire_batches_take_the_record_paths_after_decoding(gpu_ctx):
             gpu_ctx.set_wire_decode(0)
             f0, c0 = gpu_ctx.verify_id_wire_batch(mlist, False, wl.ad)
             assert (f1 == expect).all() and (f0 == expect).all() and c1 == c0 == int(expect.sum()), (n, Hn)
+        # a 16-attribute key (config 5's shape): longer records, more revealed-attribute hashes per message
+        wl16 = synth.Workload(gpu_ctx, 16, seed=99, window_bits=8)
+        n = 333
+        recs, mask, expect = wl16.verify_id_batch(n, 4, with_retrieval=True, corrupt_every=8, corrupt_at=5)
+        msgs, moff = wl16.wire_messages(recs, n, 4, with_retrieval=True)
+        moff = np.asarray(moff, dtype=np.int64)
+        mlist = [bytes(msgs[int(moff[i]):int(moff[i + 1])]) for i in range(n)]
+        for mode in (1, 0):
+            gpu_ctx.set_wire_decode(mode)
+            fl, cnt = gpu_ctx.verify_id_wire_batch(mlist, True, wl16.ad)
+            assert (fl == expect).all() and cnt == int(expect.sum()), mode
     finally:
         gpu_ctx.set_wire_decode(1)
 
@@ -259,30 +270,55 @@ def test_aggregated_verification_with_two_items_per_lane(gpu_ctx):
 
 def test_decoded_wire_batches_on_two_streams_keep_their_own_workspace(gpu_ctx):
     """The decoded wire path keeps its records per launch stream (like the per-stream table workspace of the record entry points): batches of different messages issued
-    back to back on two streams of one context -- the record kernels of one still running while the other decodes -- must not see each other's records."""
-    import torch
+    back to back on two streams of one context -- the record kernels of one still running while the other decodes -- must not see each other's records.
+    (Device buffers and streams straight from the HIP runtime the library is linked against: no second runtime in the process.)"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    vp = ctypes.c_void_p
+
+    def chk(rc):
+        assert rc == 0, "HIP error %d" % rc
+
+    def dev_copy(host_bytes):
+        p = vp()
+        chk(hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(max(1, len(host_bytes)))))
+        chk(hip.hipMemcpy(p, host_bytes, ctypes.c_size_t(len(host_bytes)), 1))          # hipMemcpyHostToDevice
+        return p
+
     A, H = 8, 4
-    dev = torch.device("cuda", 0)
     wl = synth.Workload(gpu_ctx, A, seed=4242, window_bits=8)
-    sets = []
+    sets, bufs = [], []
     for n, ce, ca in ((700, 5, 1), (900, 7, 3)):
         recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=ce, corrupt_at=ca, first_item=1000 * ce)
         msgs, moff = wl.wire_messages(recs, n, H, first_item=1000 * ce, with_retrieval=True)
-        sets.append((n, expect, torch.from_numpy(np.frombuffer(msgs, dtype=np.uint8).copy()).to(dev),
-                     torch.from_numpy(np.asarray(moff, dtype=np.uint32).view(np.int32).copy()).to(dev), torch.zeros(n, dtype=torch.uint8, device=dev)))
-    d_ad = torch.from_numpy(np.frombuffer(wl.ad, dtype=np.uint8).copy()).to(dev)
-    d_cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    torch.cuda.synchronize()
-    gpu_ctx.set_wire_decode(1)
-    reps = 6
-    for _ in range(reps):
+        d_msg, d_off = dev_copy(bytes(msgs)), dev_copy(np.asarray(moff, dtype=np.uint32).tobytes())
+        d_fl = dev_copy(bytes(n))
+        sets.append((n, expect, d_msg, d_off, d_fl))
+        bufs += [d_msg, d_off, d_fl]
+    d_ad, d_cnt = dev_copy(bytes(wl.ad)), dev_copy(bytes(16))
+    bufs += [d_ad, d_cnt]
+    streams = [vp(), vp()]
+    for st in streams:
+        chk(hip.hipStreamCreate(ctypes.byref(st)))
+    try:
+        chk(hip.hipDeviceSynchronize())
+        gpu_ctx.set_wire_decode(1)
+        reps = 6
+        for _ in range(reps):
+            for q in (0, 1):
+                n, expect, d_msg, d_off, d_fl = sets[q]
+                gpu_ctx._chk(gpu_ctx.lib.elp_verify_id_wire_batch_dev(gpu_ctx.h, streams[q], n, d_msg, d_off, 1, d_ad, None, len(wl.ad), d_fl,
+                                                                      vp(d_cnt.value + 8 * q)))
+        chk(hip.hipDeviceSynchronize())
+        cnt = (ctypes.c_uint64 * 2)()
+        chk(hip.hipMemcpy(cnt, d_cnt, ctypes.c_size_t(16), 2))                           # hipMemcpyDeviceToHost
         for q in (0, 1):
-            n, expect, d_msg, d_off, d_fl = sets[q]
-            gpu_ctx._chk(gpu_ctx.lib.elp_verify_id_wire_batch_dev(gpu_ctx.h, streams[q].cuda_stream, n, d_msg.data_ptr(), d_off.data_ptr(), 1, d_ad.data_ptr(), None,
-                                                                  len(wl.ad), d_fl.data_ptr(), d_cnt.data_ptr() + 8 * q))
-    torch.cuda.synchronize()
-    for q in (0, 1):
-        n, expect, _, _, d_fl = sets[q]
-        assert (d_fl.cpu().numpy() == expect).all(), q
-        assert int(d_cnt[q].item()) == reps * int(expect.sum()), q
+            n, expect, _, _, d_fl = sets[q]
+            fl = (ctypes.c_uint8 * n)()
+            chk(hip.hipMemcpy(fl, d_fl, ctypes.c_size_t(n), 2))
+            assert (np.frombuffer(fl, dtype=np.uint8) == expect).all(), q
+            assert int(cnt[q]) == reps * int(expect.sum()), q
+    finally:
+        for st in streams:
+            hip.hipStreamDestroy(st)
+        for b_ in bufs:
+            hip.hipFree(b_)
