@@ -715,6 +715,48 @@ ELP_HEAVY void g2_mul_gls_with(Jac<F2<C>>& r, const Tab& tab, const Scalar& k_in
   }
   r = acc;
 }
+// ONE dimension of the same multiplication: r = [m_j] psi^j(P) with the digits of g2_mul_gls_with, so that the sum over j = 0 .. 3 is [k]P.  Four lanes of an item run one
+// dimension each (64 doublings + 17 additions instead of 64 + 68) and add their results (the G2 job of the smallest batches, round 5: elpasso_impl.h vid_job_g2_quad).
+template <class C, class Tab>
+ELP_HEAVY void g2_mul_gls_dim(Jac<F2<C>>& r, const Tab& tab, const Scalar& k_in, int j) {
+  typedef F2<C> F;
+  u32 m[4][3];
+  bool neg[4];
+  lattice_split<4, 7, 3>(scalar_mod_r<C>(k_in), m, neg, Gls2Lat<C>());
+  for (int q = 0; q < 4; q++) limbs_add_eights<3, 17>(m[q]);
+  u32 mj[3] = {0, 0, 0};
+  bool negj = false;
+  for (int q = 0; q < 4; q++)
+    if (q == j) {
+      for (int i = 0; i < 3; i++) mj[i] = m[q][i];
+      negj = neg[q];
+    }
+  Jac<F> acc;
+  jac_set_inf(acc);
+  auto fetch = [&](int d) -> Aff<F> { return tab(j, d == 0 ? 0 : (d < 0 ? -d : d) - 1); };
+  int dg = limbs_window<3>(mj, 4 * 16, 4) - 8;
+  Aff<F> t = fetch(dg);
+  ELP_NOUNROLL
+  for (int w = 16; w >= 0; w--) {
+    if (w != 16) {
+      ELP_NOUNROLL
+      for (int d = 0; d < 4; d++) jac_dbl_inl<F>(acc, acc);
+    }
+    int dgn = 0;
+    Aff<F> tn = t;
+    if (w > 0) {
+      dgn = limbs_window<3>(mj, 4 * (w - 1), 4) - 8;
+      tn = fetch(dgn);
+    }
+    if (dg != 0 && !aff_is_inf(t)) {
+      if (negj != (dg < 0)) t.y = fp2_neg(t.y);
+      jac_madd_inl<F>(acc, acc, t);
+    }
+    dg = dgn;
+    t = tn;
+  }
+  r = acc;
+}
 template <class C>
 ELP_INL void g2_mul_gls_tab(Jac<F2<C>>& r, const Aff<F2<C>>* tab, const Scalar& k_in) {
   g2_mul_gls_with<C, PrivTab<F2<C>>>(r, PrivTab<F2<C>>{tab}, k_in);

@@ -966,7 +966,8 @@ ELP_HEAVY void vid_nizk_jobs(const KeyCtx<C>& key, int role, const u32* rec, u64
 // `pre` (the fixed-base sums of k_vid_fixed_coop) is required.
 template <class C>
 ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u64 hidden_mask, bool retr, VidShared<C>& sh, VidNizkState<C>& st,
-                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre, bool k_done = false, bool table_ready = false) {      // k_done: K and the table of multiples of k were already made by the kernels that ran before (k_vid_fixed_coop, k_vid_ktab)
+                              Aff<F2<C>>& aK, const Jac<F2<C>>* pre, bool k_done = false, bool table_ready = false,
+                              bool g2_by_caller = false) {      // k_done: K and the table of multiples of k were already made by the kernels that ran before (k_vid_fixed_coop, k_vid_ktab); g2_by_caller: role 0 leaves the G2 job to its caller (four lanes per item: elpasso_impl.h vid_job_g2_quad)
   Aff<F1<C>> sig1, sig2, phi, E1, E2;
   Aff<F2<C>> kk;
   // every lane decodes the record (range and on-curve tests: cheap); the SUBGROUP tests of a curve with a G1 cofactor are dealt out, one per lane -- role 0:
@@ -985,7 +986,7 @@ ELP_HEAVY void vid_nizk_jobs4(const KeyCtx<C>& key, int role, const u32* rec, u6
   sh.ok_role[role] = st.ok ? 1u : 0u;
   u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
   if (role == 0) {
-    if (st.ok) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre, table_ready);
+    if (st.ok && !g2_by_caller) vid_job_g2<C, RecordSrc<C>>(key, st.src, retr, kk, st.c, sh.vk, pre, table_ready);
   } else if (role == 1) {
     aff_set_inf(aK);
     if (st.ok) {

@@ -185,13 +185,46 @@ struct Nizk4Lds {
   static constexpr size_t HOT_BYTES = (size_t)192 * HOTW * 4;
   static constexpr size_t BYTES = HOT_BYTES + 64 * sizeof(VidShared<C>);
 };
+// The G2 job of an item on FOUR lanes (round 5; batches of at most 16 items, where the job wave of a lone call is the longest thing in the launch): lane j of the quad
+// multiplies by dimension j of the GLS decomposition of c (curve.h g2_mul_gls_dim: 64 doublings + 17 additions instead of 64 + 68, the psi-images read from the table
+// k_vid_prep built), the four results are added through lane exchanges, lane 0 adds the fixed-base part and serialises V_k.  Every lane of the wave must call (the exchanges).
+template <class C>
+__device__ __forceinline__ void vid_job_g2_quad(const KeyCtx<C>& key, const Scalar& c, u32* vk, const Jac<F2<C>>* pre, int sub, bool live) {
+  typedef F2<C> G2F;
+  Jac<G2F> Vk;
+  jac_set_inf(Vk);
+  if (live) g2_mul_gls_dim<C, WsTabPsi<G2F>>(Vk, WsTabPsi<G2F>{key.vtab, key.vpsi}, c, sub);
+  ELP_NOUNROLL
+  for (int m = 1; m < 4; m <<= 1) {
+    Jac<G2F> o;
+    {
+      constexpr int NW = (int)(sizeof(Jac<G2F>) / 4);
+      const i32* src = reinterpret_cast<const i32*>(&Vk);
+      i32* dst = reinterpret_cast<i32*>(&o);
+      ELP_UNROLL
+      for (int w = 0; w < NW; w++) dst[w] = __shfl_xor(src[w], m);
+    }
+    if (live && (sub & (2 * m - 1)) == 0) jac_add<G2F>(Vk, Vk, o);
+  }
+  if (live && sub == 0) {
+    Jac<G2F> S = *pre;
+    jac_add<G2F>(Vk, Vk, S);
+    Aff<G2F> aVk;
+    jac_to_aff<G2F>(aVk, Vk);
+    uint8_t b[2 * C::FBYTES];
+    g2_serialize<C>(b, aVk);
+    bytes_to_words(vk, b, 2 * C::FBYTES);
+  }
+}
 // body of k_vid_nizk4 for workgroup `block` (256 lanes); hot_lds / sh: Nizk4Lds<C>::HOT_BYTES and 64 VidShared of LDS
 template <class C>
 __device__ __forceinline__ void vid_nizk4_body(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
                                                uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre, int k_done, size_t block, u32* hot_lds,
-                                               VidShared<C>* sh) {
+                                               VidShared<C>* sh, bool quad = false) {      // quad: the G2 job wave gives every item four lanes (n <= 16, psi tables present)
   constexpr int HOTW = Nizk4Lds<C>::HOTW;
-  const int role = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const int role = (int)(threadIdx.x >> 6), lane0 = (int)(threadIdx.x & 63);
+  const bool quad0 = quad && role == 0;
+  const int sub = quad0 ? (lane0 & 3) : 0, lane = quad0 ? (lane0 >> 2) : lane0;      // `lane`: the item's row of the workgroup
   key.hot = role == 0 ? nullptr : hot_lds + (threadIdx.x - 64) * HOTW;
   // A PARTIALLY FILLED WAVE RUNS ITS IDLE LANES ON A COPY OF THE LAST ITEM (round 4).  Private memory is interleaved by lane: one dword of all 64 lanes is one
   // 256-byte row.  With a single active lane every spill / table store is a 4-byte write into a row nobody else touches -- a partial-line write that the memory
@@ -207,11 +240,14 @@ __device__ __forceinline__ void vid_nizk4_body(KeyCtx<C> key, const u32* recs, i
   st.ok = false;
   {
     Aff<F2<C>> aK;
-    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i, k_done != 0, k_done == 1);
+    vid_nizk_jobs4<C>(key, role, recs + i * (size_t)rec_words, mask, retr != 0, sh[lane], st, aK, pre + 2 * i, k_done != 0, k_done == 1, quad0);
     if (real && role == 1 && !k_done) vid_store_k<C>(kws, kstride, i, aK);
   }
+  if (quad) {      // uniform over the workgroup: the wave of role 0 runs the exchanges, the others skip
+    if (role == 0) vid_job_g2_quad<C>(key, st.c, sh[lane].vk, pre + 2 * i, sub, st.ok);
+  }
   __syncthreads();
-  if (role == 0 && real) {
+  if (role == 0 && real && sub == 0) {
     const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
     const size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
     nizk_ok[i] = vid_nizk_finish<C>(sh[lane], st, retr != 0, a, al) ? 1 : 0;
@@ -597,6 +633,10 @@ __device__ unsigned long long elp_dbg_small[32];
 // Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them)
 // of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
 // run them side by side without a second stream.
+#ifndef ELP_QUAD_G2
+#define ELP_QUAD_G2 1      /* 0: the G2 job of the smallest batches stays on one lane per item (A/B builds) */
+#endif
+static constexpr bool elp_quad_g2_on = ELP_QUAD_G2 != 0;
 #define ELP_VID_SMALL_PARAMS                                                                                                                                     \
   KeyCtx<C> key, const Fp2<C>*consts, const u32 *recs, int rec_words, u64 mask, int retr, const uint8_t *ad, const u32 *ad_off, u32 ad_len, uint8_t *nizk_ok,          \
       const uint8_t *kvalid, const u32 *kws, size_t kstride, uint8_t *pair_ok, uint8_t *done, size_t n, const Jac<F2<C>>*pre, unsigned nb_nizk
@@ -605,7 +645,7 @@ __device__ __forceinline__ void vid_small_body(ELP_VID_SMALL_PARAMS, unsigned ch
   typedef CoopLds<C, NP, 256> L;              // all four waves of a pairing workgroup interpret: 8 (4) items per workgroup
   if (blockIdx.x < nb_nizk) {
     vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
-                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES));
+                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES), NP == 32 && n <= 16 && key.vtab != nullptr && key.vpsi != nullptr && elp_quad_g2_on);
   } else {
     // the workgroup carries the NIZK half's register budget, so all four waves interpret: a compute unit then holds half the items of
     // k_pair_coop's sixteen on half its waves, each wave alone on its SIMD (round 4; before, two of the four waves only kept the barriers company)

@@ -178,7 +178,17 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     g2_mul_gls_with<C, WsTabPsi<G>, true>(j, WsTabPsi<G>{tab, psi}, scalar_load_w(k));                                 \
     jac_to_aff<G>(r, j);                                                                                               \
     g2_store<C>(o, r);                                                                                                 \
-    return 1;                                                                                                          \
+    /* the four-lane form: one dimension per lane (g2_mul_gls_dim), folded pairwise as the lanes of a quad do: must give the same point */ \
+    Jac<G> d[4];                                                                                                       \
+    for (int q = 0; q < 4; q++) g2_mul_gls_dim<C, WsTabPsi<G>>(d[q], WsTabPsi<G>{tab, psi}, scalar_load_w(k), q);      \
+    jac_add<G>(d[0], d[0], d[1]);                                                                                      \
+    jac_add<G>(d[2], d[2], d[3]);                                                                                      \
+    jac_add<G>(d[0], d[0], d[2]);                                                                                      \
+    Aff<G> r4;                                                                                                         \
+    jac_to_aff<G>(r4, d[0]);                                                                                           \
+    u32 o4[4 * C::N];                                                                                                  \
+    g2_store<C>(o4, r4);                                                                                               \
+    return memcmp(o4, o, sizeof o4) == 0 ? 1 : -4;                                                                     \
   }                                                                                                                    \
   int pfx##_g1_add(const u32* P, const u32* Q, u32* o) {                                                               \
     Aff<F1<C>> p, q, r;                                                                                                \

@@ -322,3 +322,35 @@ def test_decoded_wire_batches_on_two_streams_keep_their_own_workspace(gpu_ctx):
             hip.hipStreamDestroy(st)
         for b_ in bufs:
             hip.hipFree(b_)
+
+
+def test_g2_job_on_four_lanes_for_the_smallest_batches(gpu_ctx):
+    """Batches of at most 16 items give the G2 job of the NIZK half four lanes per item (vid_job_g2_quad: one GLS dimension per lane, results added through lane
+    exchanges; a lone call 2.15 -> 1.87 ms).  n = 1 ... 17 (17: back on one lane) with NIZK-corrupted items, a commitment k at infinity, a k off the curve, the degenerate
+    item whose first table addition is a doubling: verdicts equal the generator's expectation and the per-lane kernels' (cooperative path off; those are checked against the C oracle in tests/test_gpu_round3.py)."""
+    A, H = 8, 4
+    wl = synth.Workload(gpu_ctx, A, seed=515, window_bits=8)
+    n = 17
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=4, corrupt_at=2, degenerate_items=(5,))
+    rsz = len(recs) // n
+    r = bytearray(recs)
+    koff = 5 * 64
+    r[7 * rsz + koff:7 * rsz + koff + 128] = bytes(128)          # k = infinity
+    r[9 * rsz + koff + 40] ^= 1                                    # k off the curve
+    bad = bytes(r)
+    try:
+        gpu_ctx.set_coop_pairing(0)
+        ref, _ = gpu_ctx.verify_id_batch(bad, mask, True, wl.ad)
+    finally:
+        gpu_ctx.set_coop_pairing(1)
+    assert ref[9] == 0 and ref[5] == 1 and (ref[[0, 1, 3, 4]] == expect[[0, 1, 3, 4]]).all()
+    for m in list(range(1, 18)):
+        fl, cnt = gpu_ctx.verify_id_batch(bad[:m * rsz], mask, True, wl.ad)
+        assert (fl == ref[:m]).all() and cnt == int(ref[:m].sum()), m
+    # without the table workspace the job falls back to one lane (tables in private memory)
+    try:
+        gpu_ctx.set_table_workspace(False)
+        fl, cnt = gpu_ctx.verify_id_batch(bad[:5 * rsz], mask, True, wl.ad)
+        assert (fl == ref[:5]).all()
+    finally:
+        gpu_ctx.set_table_workspace(True)

@@ -47,7 +47,7 @@ def test_group_ops(L):
         assert L.twin_bls_g1_mul(g1b(BLS_G1, N), fb(k), o) and g1u(o.raw, N) == G.g1_mul(BLS_G1, k)
     for k in [0, 1, 5, M.r - 1, rnd.randrange(M.r)]:
         assert L.twin_bls_g2_mul(g2b(BLS_G2, N), fb(k), o2) and g2u(o2.raw, N) == G.g2_mul(BLS_G2, k)
-        assert L.twin_bls_g2_mul_gls_psi(g2b(BLS_G2, N), fb(k), o2) and g2u(o2.raw, N) == G.g2_mul(BLS_G2, k)      # GLS with the psi-images read from a table (WsTabPsi)
+        assert L.twin_bls_g2_mul_gls_psi(g2b(BLS_G2, N), fb(k), o2) == 1 and g2u(o2.raw, N) == G.g2_mul(BLS_G2, k)      # GLS with the psi-images read from a table (WsTabPsi)
     P = G.g1_mul(BLS_G1, 5)
     for a, b in [(P, BLS_G1), (P, P), (P, G.g1_neg(P)), (P, None), (None, None)]:
         assert L.twin_bls_g1_add(g1b(a, N), g1b(b, N), o) and g1u(o.raw, N) == G.g1_add(a, b)
