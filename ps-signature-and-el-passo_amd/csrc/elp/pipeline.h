@@ -48,7 +48,7 @@ struct KeyCtx {
 // The reference's el_passo_verify_id accepts sig1 = sig2 = infinity with a self-made NIZK (e(O,K) e(O,gg) = 1: a universal forgery;
 // golden case "sig_both_zero", src/ps-verifier.cc:133-137 has no isZero test although PSVerifier::verify :16-18 has one).  The library
 // rejects it by default (elp_set_option(ELP_OPT_STRICT_SIGNATURE)); reference-compatible behaviour is opt-in.
-enum { KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2, KEY_PHASE_MIX = 4 };   // KEY_PHASE_MIX: the second half of a two-lane launch's workgroups runs the pairing check BEFORE the NIZK half (verify_id_item_paired)
+enum { KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2, KEY_PHASE_MIX = 4, KEY_QUAD_G2 = 8 };      // KEY_QUAD_G2 (set by the launcher of k_vid_small for this launch only): NIZK workgroups of 16 items, the G2 job on four lanes per item   // KEY_PHASE_MIX: the second half of a two-lane launch's workgroups runs the pairing check BEFORE the NIZK half (verify_id_item_paired)
 //   // KEY_NO_SUBGROUP_CHECK: skip g1_in_subgroup on prover-supplied points (ELP_OPT_SUBGROUP_CHECK = 0)
 // words of workspace per lane: 1P .. 8P of k and of up to three G1 points
 template <class C>

@@ -20,6 +20,21 @@
 #include "elp/params_bn254.h"
 #include "elp/pipeline.h"
 
+// The G2 job of the NIZK half on four lanes per item (vid_job_g2_quad) for the one-launch batches of at most ELP_QUAD_G2_MAX (1 280) items
+#ifndef ELP_QUAD_G2
+#define ELP_QUAD_G2 1      /* 0: the G2 job of the smallest batches stays on one lane per item (A/B builds) */
+#endif
+static constexpr bool elp_quad_g2_on = ELP_QUAD_G2 != 0;
+static inline long elp_quad_g2_max() {      // largest batch whose G2 jobs run on four lanes (ELP_QUAD_G2_MAX in the environment: A/B runs)
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("ELP_QUAD_G2_MAX");
+    v = e ? atol(e) : 1280;      // 0.75 waves per item (NIZK workgroups of 16 items + pairing workgroups of 8): 1 280 items are 960 waves on 1 024 SIMDs; 1 536 need a second round (4.1 instead of 2.4 ms)
+    if (v < 0) v = 0;
+  }
+  return v;
+}
+
 using namespace elp;
 
 // ------------------------------------------------------------------------------------------------------------
@@ -220,22 +235,27 @@ __device__ __forceinline__ void vid_job_g2_quad(const KeyCtx<C>& key, const Scal
 template <class C>
 __device__ __forceinline__ void vid_nizk4_body(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off, u32 ad_len,
                                                uint8_t* nizk_ok, u32* kws, size_t kstride, size_t n, const Jac<F2<C>>* pre, int k_done, size_t block, u32* hot_lds,
-                                               VidShared<C>* sh, bool quad = false) {      // quad: the G2 job wave gives every item four lanes (n <= 16, psi tables present)
+                                               VidShared<C>* sh, bool quad = false) {      // quad: the G2 job wave gives every item four lanes; the workgroup then serves 16 items (psi tables required)
   constexpr int HOTW = Nizk4Lds<C>::HOTW;
   const int role = (int)(threadIdx.x >> 6), lane0 = (int)(threadIdx.x & 63);
   const bool quad0 = quad && role == 0;
-  const int sub = quad0 ? (lane0 & 3) : 0, lane = quad0 ? (lane0 >> 2) : lane0;      // `lane`: the item's row of the workgroup
+  const int rows = quad ? 16 : 64;                                                     // items of this workgroup
+  const int sub = quad0 ? (lane0 & 3) : 0, lane = quad0 ? (lane0 >> 2) : lane0;      // `lane`: the item's row of the workgroup (rows and up: lanes that only keep the wave's memory rows full)
   key.hot = role == 0 ? nullptr : hot_lds + (threadIdx.x - 64) * HOTW;
   // A PARTIALLY FILLED WAVE RUNS ITS IDLE LANES ON A COPY OF THE LAST ITEM (round 4).  Private memory is interleaved by lane: one dword of all 64 lanes is one
   // 256-byte row.  With a single active lane every spill / table store is a 4-byte write into a row nobody else touches -- a partial-line write that the memory
   // side turns into read-modify-write -- and a lone el_passo_verify_id took 3.2-4.9 ms in this kernel, depending on which CU (which scratch addresses) it landed
   // on, against 2.17 ms for the same wave with 64 items (profiles/r04_lone_call.md: per-wave times, same clocks).  Full rows cost nothing extra: the idle lanes
   // share the wave's instruction stream anyway.  Copies use their own workspace slices and LDS rows and publish nothing.
-  const size_t slot = block * 64 + lane;
-  const bool real = slot < n;
-  const size_t i = real ? slot : n - 1;
-  if (key.vtab) key.vtab += slot * (size_t)vtab_words<C>();     // one slice per lane: the G2 job uses its first part, each G1 job its own third of the rest
-  if (key.vpsi) key.vpsi += slot * (size_t)(24 * vtab_entry_words<F2<C>>());
+  const size_t slot = block * rows + (lane < rows ? lane : rows - 1);
+  const bool real = lane < rows && slot < n;
+  const size_t i = slot < n ? slot : n - 1;
+  // workspace slices.  One item per lane (64 rows): slice = the lane's slot, written by k_vid_prep (G2 part) and by the G1 jobs (their parts).  Four lanes per G2 job
+  // (16 rows): the G2 job READS the table and psi-images of its item's slot; the G1 job lanes -- 16 real ones and 48 that keep the rows full -- write tables of their own
+  // and get a slice per lane of the launch (block * 64 + lane0: the launcher provides 4 x the slices)
+  const size_t gslot = quad ? i : block * 64 + lane0, tslot = quad ? (role == 0 ? i : block * 64 + lane0) : block * 64 + lane0;
+  if (key.vtab) key.vtab += tslot * (size_t)vtab_words<C>();
+  if (key.vpsi) key.vpsi += gslot * (size_t)(24 * vtab_entry_words<F2<C>>());
   VidNizkState<C> st;
   st.ok = false;
   {
@@ -633,10 +653,6 @@ __device__ unsigned long long elp_dbg_small[32];
 // Small batches of el_passo_verify_id: the NIZK half (vid_nizk4_body, workgroups [0, nb_nizk)) and the pairing check (pair_coop_body, the workgroups after them)
 // of the SAME launch -- the two are independent once K, the fixed-base sums and the table of multiples of k exist, and one launch lets the chip
 // run them side by side without a second stream.
-#ifndef ELP_QUAD_G2
-#define ELP_QUAD_G2 1      /* 0: the G2 job of the smallest batches stays on one lane per item (A/B builds) */
-#endif
-static constexpr bool elp_quad_g2_on = ELP_QUAD_G2 != 0;
 #define ELP_VID_SMALL_PARAMS                                                                                                                                     \
   KeyCtx<C> key, const Fp2<C>*consts, const u32 *recs, int rec_words, u64 mask, int retr, const uint8_t *ad, const u32 *ad_off, u32 ad_len, uint8_t *nizk_ok,          \
       const uint8_t *kvalid, const u32 *kws, size_t kstride, uint8_t *pair_ok, uint8_t *done, size_t n, const Jac<F2<C>>*pre, unsigned nb_nizk
@@ -645,7 +661,7 @@ __device__ __forceinline__ void vid_small_body(ELP_VID_SMALL_PARAMS, unsigned ch
   typedef CoopLds<C, NP, 256> L;              // all four waves of a pairing workgroup interpret: 8 (4) items per workgroup
   if (blockIdx.x < nb_nizk) {
     vid_nizk4_body<C>(key, recs, rec_words, mask, retr, ad, ad_off, ad_len, nizk_ok, (u32*)nullptr, kstride, n, pre, 1, blockIdx.x, (u32*)smem,
-                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES), NP == 32 && n <= 16 && key.vtab != nullptr && key.vpsi != nullptr && elp_quad_g2_on);
+                      (VidShared<C>*)(smem + Nizk4Lds<C>::HOT_BYTES), (key.flags & KEY_QUAD_G2) != 0 && key.vtab != nullptr && key.vpsi != nullptr);
   } else {
     // the workgroup carries the NIZK half's register budget, so all four waves interpret: a compute unit then holds half the items of
     // k_pair_coop's sixteen on half its waves, each wave alone on its SIMD (round 4; before, two of the four waves only kept the barriers company)
@@ -1090,7 +1106,8 @@ template <class B>
 void launch_vid_small(hipStream_t stream, const KeyCtx<B>& key, const void* d_consts, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
                       const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, uint8_t* done,
                       const void* pre) {
-  const unsigned nb_nizk = grid_for(n);
+  const bool quad = (key.flags & KEY_QUAD_G2) != 0 && key.vtab != nullptr && key.vpsi != nullptr;      // the caller sized the table workspace for it
+  const unsigned nb_nizk = quad ? (unsigned)((n + 15) / 16) : grid_for(n);
   if (n <= 512)
     hipLaunchKernelGGL((k_vid_small<B, 32>), dim3(nb_nizk + (unsigned)((n + 3) / 4)), dim3(256), 0, stream, key, (const Fp2<B>*)d_consts, (const u32*)d_records, words, (u64)mask,
                        retr, (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, nizk_ok, kvalid, kws, kstride, pair_ok, done, n, (const Jac<F2<B>>*)pre, nb_nizk);
@@ -2869,7 +2886,12 @@ int elp_verify_id_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
       void* extra = nullptr;
       const size_t pre_bytes = (lanes * 2 * sizeof(Jac<F2<C>>) + 255) & ~(size_t)255;      // fixed-base parts of V_k and K per item (k_vid_fixed_coop)
       const size_t psi_bytes = lanes * (size_t)(24 * vtab_entry_words<F2<C>>()) * 4;        // psi^j images of the multiples of k (k_vid_ktab -> the G2 job): a multiple of 16 per lane
-      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes, k_bytes + pre_bytes + ((4 * lanes + 255) & ~(size_t)255) + psi_bytes, &extra);
+      // four lanes per G2 job (round 5): batches of the one-launch path up to 512 items cut their NIZK half into workgroups of 16 items; the G1 job lanes of those
+      // workgroups -- 64 per 16 items -- keep a table slice each, so the table workspace is provided for 4 x the lanes
+      const bool quadx = elp_quad_g2_on && !mid && !(c->overlap) && c->use_vtab && n <= c->small_dense_from && n <= c->small_one_max && n <= (size_t)elp_quad_g2_max();
+      const size_t lanes_tab = quadx && ((n + 15) / 16) * 64 > lanes ? ((n + 15) / 16) * 64 : lanes;
+      KeyCtx<C> key = make_key_ws<C>(c, (hipStream_t)stream, lanes_tab, k_bytes + pre_bytes + ((4 * lanes + 255) & ~(size_t)255) + psi_bytes, &extra);
+      if (quadx && key.vtab) key.flags |= KEY_QUAD_G2;
       if (consts && extra) {
         // ... where the NIZK workgroup is the critical path of the call (one round of pairing workgroups: a lone call 2.36 -> 2.23 ms, 64 items 2.48 -> 2.31, 1 024 items
         // 2.69 -> 2.42); above, the 24 extra entries per item only cost k_vid_prep time (4 096 items: 4.96 against 4.62 ms)

@@ -325,9 +325,9 @@ def test_decoded_wire_batches_on_two_streams_keep_their_own_workspace(gpu_ctx):
 
 
 def test_g2_job_on_four_lanes_for_the_smallest_batches(gpu_ctx):
-    """Batches of at most 16 items give the G2 job of the NIZK half four lanes per item (vid_job_g2_quad: one GLS dimension per lane, results added through lane
-    exchanges; a lone call 2.15 -> 1.87 ms).  n = 1 ... 17 (17: back on one lane) with NIZK-corrupted items, a commitment k at infinity, a k off the curve, the degenerate
-    item whose first table addition is a doubling: verdicts equal the generator's expectation and the per-lane kernels' (cooperative path off; those are checked against the C oracle in tests/test_gpu_round3.py)."""
+    """One-launch batches of at most 1 280 items give the G2 job of the NIZK half four lanes per item (vid_job_g2_quad: one GLS dimension per lane, results added through
+    lane exchanges; NIZK workgroups of 16 items; a lone call 2.15 -> 1.87 ms, 1 024 items 2.35 -> 2.13 ms).  n = 1 ... 17 and ragged / boundary sizes up to 1 281 (back on
+    one lane) with NIZK-corrupted items, a commitment k at infinity, a k off the curve, the degenerate item whose first table addition is a doubling: verdicts equal the generator's expectation and the per-lane kernels' (cooperative path off; those are checked against the C oracle in tests/test_gpu_round3.py)."""
     A, H = 8, 4
     wl = synth.Workload(gpu_ctx, A, seed=515, window_bits=8)
     n = 17
@@ -347,6 +347,13 @@ def test_g2_job_on_four_lanes_for_the_smallest_batches(gpu_ctx):
     for m in list(range(1, 18)):
         fl, cnt = gpu_ctx.verify_id_batch(bad[:m * rsz], mask, True, wl.ad)
         assert (fl == ref[:m]).all() and cnt == int(ref[:m].sum()), m
+    # more than one NIZK workgroup of 16 items, ragged ends, both launch shapes (32 / 16 lane pairs per pairing check) and the limit
+    nbig = 1281
+    recs2, mask2, expect2 = wl.verify_id_batch(nbig, H, with_retrieval=True, corrupt_every=5, corrupt_at=3, degenerate_items=(20, 600))
+    rsz2 = len(recs2) // nbig
+    for m in (18, 31, 33, 64, 65, 255, 512, 513, 1000, 1280, 1281):
+        fl, cnt = gpu_ctx.verify_id_batch(recs2[:m * rsz2], mask2, True, wl.ad)
+        assert (fl == expect2[:m]).all() and cnt == int(expect2[:m].sum()), m
     # without the table workspace the job falls back to one lane (tables in private memory)
     try:
         gpu_ctx.set_table_workspace(False)
