@@ -77,8 +77,8 @@ int elp_field_bytes(int curve);               /* F */
  * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
  * (pair) per item, and the NIZK half of el_passo_verify_id spreads its jobs over four waves per 64 items with the fixed-base G2 sums on 8 lanes each, in the same launch
  * as the pairing check: measured (round 4), a lone PS verification takes 1.5 ms instead of 5.1, 4096 of them 2.9 ms instead of 4.6; el_passo_verify_id: 1 item 2.1 ms, 64 items 2.2,
- * 1024 items 2.4, 4096 items 4.6, 8192 items 7.0 ms instead of 8.8-9.2 at any of these sizes (round 5: 1 item 1.9 ms -- up to 16 items the G2 commitment of the NIZK half runs on
- * four lanes per item --, 4096 items 3.8, 8192 items 4.3 ms on the four-lane path of ELP_OPT_PAIR4).  Results are identical.  0 = off.
+ * 1024 items 2.4, 4096 items 4.6, 8192 items 7.0 ms instead of 8.8-9.2 at any of these sizes (round 5: 1 item 1.9 ms, 64 items 2.05, 1024 items 2.1 -- up to 1280 items the G2 commitment of the
+ * NIZK half runs on four lanes per item --, 4096 items 3.8, 8192 items 4.3 ms on the four-lane path of ELP_OPT_PAIR4).  Results are identical.  0 = off.
  * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
  * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.
  * Needs records of a multiple of 16 bytes, at most 1152, at a 16-byte aligned address; otherwise the in-place kernel runs.  Results are identical and so is the
