@@ -508,7 +508,11 @@ def valu_bound(ctx, ops_key, window, B, kern_ms, macs_per_mul):
                 vb.update({"fp_mul_equivalents_per_verification": per_item, "multiply_adds_per_verification": ops[key]["multiply_adds"],
                            "op_count_source": "profiles/op_counts.json[%s][%s]%s" % (ops_key, key, " (extrapolated)" if ops[key].get("extrapolated") else " (counted)"),
                            "achieved": ach, "frac": ach / peak})
-        pj = next((q for q in (os.path.join(ROOT, "profiles", t + "_summary.json") for t in ("r04", "r03", "r02")) if os.path.exists(q)), "")
+        import glob
+        import re
+        cands = sorted((q for q in glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")) if re.match(r"r\d+_summary\.json$", os.path.basename(q))),
+                       key=lambda q: int(re.match(r"r(\d+)_", os.path.basename(q)).group(1)))
+        pj = cands[-1] if cands else ""                   # the newest round's PMC summary
         if ops_key == "verify_id" and pj:
             try:
                 pm = json.load(open(pj))
@@ -643,12 +647,15 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     d_mrec = torch.from_numpy(np.frombuffer(mrecs, dtype=np.uint8).copy()).to(dev)
     d_mfl = torch.zeros(nm, dtype=torch.uint8, device=dev)
     mid = {}
+    mid_ok = True
     for mode in (0, 1):
         ctx.set_pair4(mode)
         for m in (8192, 12288, 16384):
+            d_mfl.zero_()
             mms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, m, d_mrec.data_ptr(), 3, d_mfl.data_ptr(), d_cnt.data_ptr())))
             mid["ps_verify_n%d_%s_ms" % (m, "four_lanes" if mode else "two_lanes")] = mms
-    mid["parity_ok"] = bool((d_mfl.cpu().numpy() == mexpect).all())
+            mid_ok = mid_ok and bool((d_mfl.cpu().numpy()[:m] == mexpect[:m]).all())      # every (mode, size) run is checked, not only the last
+    mid["parity_ok"] = mid_ok
     res["mid_batches_ps_verify"] = mid
     # small batches and lone items, cooperative kernels on / off (ELP_OPT_COOP_PAIRING): latency, not throughput
     lat = {}
@@ -683,13 +690,16 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     d_mvrec = torch.from_numpy(np.frombuffer(mvrecs, dtype=np.uint8).copy()).to(dev)
     d_mvfl = torch.zeros(nmid, dtype=torch.uint8, device=dev)
     midv = {}
+    midv_ok = True
     for mode in (0, 1):
         ctx.set_pair4(mode)
         for m in (9217, 12288, 16384):
+            d_mvfl.zero_()
             mms = timed(lambda: ctx._chk(ctx.lib.elp_verify_id_batch_dev(ctx.h, stream, m, d_mvrec.data_ptr(), mvmask, 1, d_ad.data_ptr(), None, len(wl.ad),
                                                                           d_mvfl.data_ptr(), d_cnt.data_ptr())))
             midv["verify_id_n%d_%s_ms" % (m, "four_lanes" if mode else "two_lanes")] = mms
-    midv["parity_ok"] = bool((d_mvfl.cpu().numpy() == mvexpect).all())
+            midv_ok = midv_ok and bool((d_mvfl.cpu().numpy()[:m] == mvexpect[:m]).all())
+    midv["parity_ok"] = midv_ok
     res["mid_batches_verify_id"] = midv
     if os.environ.get("ELP_BENCH_SMALL_OVERLAP"):      # experiment: the two-stream form of the same calls (ELP_OPT_STREAM_OVERLAP) inside this process
         ctx.set_coop_pairing(1)

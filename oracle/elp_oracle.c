@@ -26,10 +26,11 @@
  *
  * Second build, -DELPO_BLS12_381 (libelp_oracle_bls.so): the same restatement over BLS12-381 (6 x 64-bit limbs, y^2 = x^3 + 4, M-type twist
  * y^2 = x^3 + 4 xi, Miller loop over |z| = 0xd201000000010000, final exponentiation by the Hayashida-Hayasaka-Teruya chain AND, as a
- * self-check, by plain square-and-multiply with the integer (p^4-p^2+1)/r).  PARITY UNPINNED: the reference never runs on this curve
- * and mcl is absent, so nothing reference-made pins it; its role is to be a second, independently written implementation beside
- * oracle/pymodel.py for the HIP path's BLS12-381 instantiation (equal GT values, signatures, verdicts) and the CPU baseline of that
- * curve.  hashAndMapToG1 follows this project's own convention for the curve (csrc/elp/encode.h), not mcl's.
+ * self-check, by plain square-and-multiply with the integer (p^4-p^2+1)/r).  Pinning: the reference's prebuilt wasm is mcl built with
+ * MCL_MAX_BIT_SIZE=384 (/root/reference/Makefile:65); with mcl's default CurveParam overwritten in its linear memory before initPairing()
+ * (oracle/wasm_curve.js) it runs the whole protocol on BLS12-381, and tests/test_oracle_bls_golden.py checks this build against every vector
+ * so produced (tests/golden/bls12_381_*.json): verdicts of the RP and IdP modules, hashAndMapToG1 as mcl defines it for this curve (SHA-512
+ * Fp::setHashOf, Shallue-van de Woestijne map with b = 4, cofactor (z-1)^2/3) and mcl's GLV G1::mul on points outside G1.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -538,6 +539,49 @@ static fp CURVE_B;
 DEFINE_GROUP(g1, fp, FP_ZERO, FP_ONE)
 DEFINE_GROUP(g2, fp2, F2_ZERO, F2_ONE)
 
+/* G1::mul as mcl evaluates it (every G1::mul call site of the reference goes through this one).
+   BN254: E(Fp) = G1, any correct method gives [k]P: the window method above.
+   BLS12-381: mcl's G1::mul is the GLV method with psi(x, y) = (beta x, y) = [L] on G1, L = z^2 - 1: k mod r is split by plain division,
+   k = a + b L (0 <= a < L), and the result is [a]P + [b]psi(P).  Inside G1 that is [k]P.  For a point of E(Fp) outside G1 -- mcl's default
+   accepts one on deserialisation -- it is not (psi fixes the order-3 points (0, +-2): that component is multiplied by a + b), and the
+   reference's verdict on such inputs follows this split: pinned by 20 crafted proofs / requests in tests/golden/bls12_381_oracle_{edge,requests}.json. */
+#ifdef ELPO_BLS12_381
+static const u64 GLV_L[2] = {0x00000000ffffffffull, 0xac45a4010001a402ull};                 /* z^2 - 1 */
+static const u64 GLV_BETA[NL] = {0x8bfd00000000aaacull, 0x409427eb4f49fffdull, 0x897d29650fb85f9bull, 0xaa0d857d89759ad4ull, 0xec02408663d4de85ull,
+                                 0x1a0111ea397fe699ull};
+static void g1_mul_ref(g1j* r, const g1a* p, const u64* k) {
+  u64 e[4] = {k[0], k[1], k[2], k[3]};
+  for (int rep = 0; rep < 3; rep++) {                 /* k < 2^256 < 3 r */
+    int ge = 1;
+    for (int i = 3; i >= 0; i--) { if (e[i] > RORD[i]) break; if (e[i] < RORD[i]) { ge = 0; break; } }
+    if (!ge) break;
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) { u128 t = (u128)e[i] - RORD[i] - br; e[i] = (u64)t; br = (t >> 64) & 1; }
+  }
+  /* b, a = divmod(e, L): schoolbook binary long division (a < L < 2^128 throughout) */
+  u64 q[4] = {0, 0, 0, 0};
+  u128 rem = 0;
+  const u128 Lv = ((u128)GLV_L[1] << 64) | GLV_L[0];
+  for (int i = 255; i >= 0; i--) {
+    int top = (int)(rem >> 127);
+    rem = (rem << 1) | ((e[i >> 6] >> (i & 63)) & 1);
+    if (top || rem >= Lv) { rem -= Lv; q[i >> 6] |= 1ull << (i & 63); }
+  }
+  u64 a[4] = {(u64)rem, (u64)(rem >> 64), 0, 0};
+  g1a psi = *p;
+  fp beta;
+  fp_from_le(&beta, (const uint8_t*)GLV_BETA);
+  fp_mul(&psi.x, &psi.x, &beta);
+  g1j ra, rb;
+  g1_mul(&ra, p, a);
+  g1_mul(&rb, &psi, q);
+  if (p->inf) { g1_set_inf(r); return; }
+  g1_add(r, &ra, &rb);
+}
+#else
+static void g1_mul_ref(g1j* r, const g1a* p, const u64* k) { g1_mul(r, p, k); }
+#endif
+
 static int g1_on_curve(const g1a* p) {
   if (p->inf) return 1;
   fp l, r;
@@ -821,48 +865,88 @@ static int g2_de(g2a* p, const uint8_t in[2 * FB]) {
   if ((y[0] & 1) != odd) fp2_neg(&p->y, &p->y);
   return 1;
 }
+/* ------------------------------------------------------------------------------------------------ SHA-512 (Fp::setHashOf of a field wider than 256 bits) */
 #ifdef ELPO_BLS12_381
-/* hashAndMapToG1 on BLS12-381 -- this PROJECT's convention (csrc/elp/encode.h hash_and_map_to_g1; mcl's is pinned by nothing):
-   x_ctr = the first 48 bytes of SHA256(msg | ctr | 0) | SHA256(msg | ctr | 1) as a little-endian integer, masked to 381 bits and to 380 if still >= p;
-   the first ctr with x^3 + 4 a square wins, y = the root with even canonical value; the point is multiplied by the cofactor (z-1)^2/3. */
-static void g1_mul(g1j* r, const g1a* p, const u64* k);
-static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
-  for (unsigned ctr = 0;; ctr++) {
-    uint8_t d[64];
-    for (int half = 0; half < 2; half++) {
-      sha256_t s;
-      uint8_t c[2] = {(uint8_t)ctr, (uint8_t)half};
-      sha_init(&s); sha_update(&s, msg, len); sha_update(&s, c, 2); sha_final(&s, d + 32 * half);
-    }
-    u64 t[NL];
-    memcpy(t, d, FB);
-    t[NL - 1] &= (1ull << (PBITS - 64 * (NL - 1))) - 1;
-    if (geq_p(t)) t[NL - 1] &= (1ull << (PBITS - 1 - 64 * (NL - 1))) - 1;
-    fp x, y, rhs;
-    fp_from_le(&x, (const uint8_t*)t);
-    fp_sqr(&rhs, &x); fp_mul(&rhs, &rhs, &x); fp_add(&rhs, &rhs, &CURVE_B);
-    if (!fp_sqrt(&y, &rhs)) continue;
-    uint8_t yb[FB];
-    fp_to_le(yb, &y);
-    if (yb[0] & 1) fp_neg(&y, &y);
-    g1a pt;
-    memset(&pt, 0, sizeof pt);
-    pt.x = x; pt.y = y;
-    g1j j;
-    g1_mul(&j, &pt, G1_COFACTOR);
-    if (g1_is_inf(&j)) continue;
-    g1_to_aff(out, &j);
-    return;
+static const u64 SK512[80] = {
+    0x428a2f98d728ae22ull, 0x7137449123ef65cdull, 0xb5c0fbcfec4d3b2full, 0xe9b5dba58189dbbcull, 0x3956c25bf348b538ull, 0x59f111f1b605d019ull,
+    0x923f82a4af194f9bull, 0xab1c5ed5da6d8118ull, 0xd807aa98a3030242ull, 0x12835b0145706fbeull, 0x243185be4ee4b28cull, 0x550c7dc3d5ffb4e2ull,
+    0x72be5d74f27b896full, 0x80deb1fe3b1696b1ull, 0x9bdc06a725c71235ull, 0xc19bf174cf692694ull, 0xe49b69c19ef14ad2ull, 0xefbe4786384f25e3ull,
+    0x0fc19dc68b8cd5b5ull, 0x240ca1cc77ac9c65ull, 0x2de92c6f592b0275ull, 0x4a7484aa6ea6e483ull, 0x5cb0a9dcbd41fbd4ull, 0x76f988da831153b5ull,
+    0x983e5152ee66dfabull, 0xa831c66d2db43210ull, 0xb00327c898fb213full, 0xbf597fc7beef0ee4ull, 0xc6e00bf33da88fc2ull, 0xd5a79147930aa725ull,
+    0x06ca6351e003826full, 0x142929670a0e6e70ull, 0x27b70a8546d22ffcull, 0x2e1b21385c26c926ull, 0x4d2c6dfc5ac42aedull, 0x53380d139d95b3dfull,
+    0x650a73548baf63deull, 0x766a0abb3c77b2a8ull, 0x81c2c92e47edaee6ull, 0x92722c851482353bull, 0xa2bfe8a14cf10364ull, 0xa81a664bbc423001ull,
+    0xc24b8b70d0f89791ull, 0xc76c51a30654be30ull, 0xd192e819d6ef5218ull, 0xd69906245565a910ull, 0xf40e35855771202aull, 0x106aa07032bbd1b8ull,
+    0x19a4c116b8d2d0c8ull, 0x1e376c085141ab53ull, 0x2748774cdf8eeb99ull, 0x34b0bcb5e19b48a8ull, 0x391c0cb3c5c95a63ull, 0x4ed8aa4ae3418acbull,
+    0x5b9cca4f7763e373ull, 0x682e6ff3d6b2b8a3ull, 0x748f82ee5defb2fcull, 0x78a5636f43172f60ull, 0x84c87814a1f0ab72ull, 0x8cc702081a6439ecull,
+    0x90befffa23631e28ull, 0xa4506cebde82bde9ull, 0xbef9a3f7b2c67915ull, 0xc67178f2e372532bull, 0xca273eceea26619cull, 0xd186b8c721c0c207ull,
+    0xeada7dd6cde0eb1eull, 0xf57d4f7fee6ed178ull, 0x06f067aa72176fbaull, 0x0a637dc5a2c898a6ull, 0x113f9804bef90daeull, 0x1b710b35131c471bull,
+    0x28db77f523047d84ull, 0x32caab7b40c72493ull, 0x3c9ebe0a15c9bebcull, 0x431d67c49c100d4cull, 0x4cc5d4becb3e42b6ull, 0x597f299cfc657e2aull,
+    0x5fcb6fab3ad6faecull, 0x6c44198c4a475817ull};
+#define ROR64(x, n) (((x) >> (n)) | ((x) << (64 - (n))))
+static void sha512_block(u64 h[8], const uint8_t* b) {
+  u64 w[80], v[8];
+  for (int i = 0; i < 16; i++) {
+    w[i] = 0;
+    for (int j = 0; j < 8; j++) w[i] = (w[i] << 8) | b[8 * i + j];
   }
+  for (int i = 16; i < 80; i++) {
+    u64 s0 = ROR64(w[i - 15], 1) ^ ROR64(w[i - 15], 8) ^ (w[i - 15] >> 7), s1 = ROR64(w[i - 2], 19) ^ ROR64(w[i - 2], 61) ^ (w[i - 2] >> 6);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  memcpy(v, h, 64);
+  for (int i = 0; i < 80; i++) {
+    u64 t1 = v[7] + (ROR64(v[4], 14) ^ ROR64(v[4], 18) ^ ROR64(v[4], 41)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + SK512[i] + w[i];
+    u64 t2 = (ROR64(v[0], 28) ^ ROR64(v[0], 34) ^ ROR64(v[0], 39)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+    v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+  }
+  for (int i = 0; i < 8; i++) h[i] += v[i];
 }
+static void sha512(uint8_t out[64], const uint8_t* msg, size_t len) {
+  u64 h[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+              0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+  size_t off = 0;
+  for (; off + 128 <= len; off += 128) sha512_block(h, msg + off);
+  uint8_t tail[256];
+  size_t rem = len - off, tl = rem + 17 <= 128 ? 128 : 256;
+  memset(tail, 0, sizeof tail);
+  memcpy(tail, msg + off, rem);
+  tail[rem] = 0x80;
+  u64 bits = (u64)len * 8;                       /* the upper 64 bits of the 128-bit length field stay 0 */
+  for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+  for (size_t o = 0; o < tl; o += 128) sha512_block(h, tail + o);
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(h[i] >> (56 - 8 * j));
+}
+#endif
+
+/* Fp::setHashOf: the digest (SHA-256 for a modulus of at most 256 bits, SHA-512 for the 381-bit field of BLS12-381 -- mcl picks the hash by the
+   bit size of the modulus), its first FB bytes as an LE integer, masked to PBITS bits and to one bit less if still >= p. */
+static void fp_set_hash_of(fp* r, const uint8_t* msg, size_t len) {
+  u64 t[NL];
+#ifdef ELPO_BLS12_381
+  uint8_t d[64];
+  sha512(d, msg, len);
 #else
-/* hashAndMapToG1 on BN curves: t = Fp::setHashOf(msg), then the Shallue-van de Woestijne map */
+  uint8_t d[32];
+  sha256_t s;
+  sha_init(&s); sha_update(&s, msg, len); sha_final(&s, d);
+#endif
+  memcpy(t, d, FB);
+  t[NL - 1] &= (1ull << (PBITS - 64 * (NL - 1))) - 1;
+  if (geq_p(t)) t[NL - 1] &= (1ull << (PBITS - 1 - 64 * (NL - 1))) - 1;
+  fp_from_le(r, (const uint8_t*)t);
+}
+/* hashAndMapToG1 (call sites src/ps-verifier.cc:94,186, src/ps-requester.cc:185,336): t = Fp::setHashOf(msg), the Shallue-van de Woestijne map
+   (mcl MapTo::calcBN; mcl's default, non-ETH mode uses it for BLS12-381 too), then -- BLS12-381 only -- multiplication by the G1 cofactor
+   (z-1)^2/3.  Pinned on both curves by the reference wasm's proofs (tests/golden/{bn254,bls12_381}_oracle_flows.json, section hash_to_g1:
+   32 service names, all six branch / sign cases). */
 static fp SVDW_C1, SVDW_C2;
+#ifdef ELPO_BLS12_381
+static void g1_mul(g1j* r, const g1a* p, const u64* k);
+#endif
 static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
-  u64 tv[4];
-  set_hash_of(tv, msg, len, P);
   fp t, w, x, y, one = FP_ONE, tmp;
-  fp_from_le(&t, (const uint8_t*)tv);
+  fp_set_hash_of(&t, msg, len);
   int neg = fp_legendre(&t) < 0;
   fp_sqr(&w, &t); fp_add(&w, &w, &CURVE_B); fp_add(&w, &w, &one);
   fp_inv(&w, &w); fp_mul(&w, &w, &t); fp_mul(&w, &w, &SVDW_C1);
@@ -874,10 +958,17 @@ static void hash_and_map_g1(g1a* out, const uint8_t* msg, size_t len) {
     if (fp_sqrt(&y, &tmp)) break;
   }
   if (neg) fp_neg(&y, &y);
+#ifdef ELPO_BLS12_381
+  g1a pt;
+  memset(&pt, 0, sizeof pt);
+  pt.x = x; pt.y = y;
+  g1j j;
+  g1_mul(&j, &pt, G1_COFACTOR);
+  g1_to_aff(out, &j);
+#else
   out->x = x; out->y = y; out->inf = 0;
-}
-
 #endif
+}
 
 /* ------------------------------------------------------------------------------------------------ init */
 void elpo_init(void) {
@@ -930,17 +1021,13 @@ void elpo_init(void) {
     fp2_mul(&a3, &a3, &a);        /* a^(1+p+p^2) */
     FROB[1][k] = a; FROB[2][k] = a2; FROB[3][k] = a3;
   }
-#ifndef ELPO_BLS12_381
-  /* SvdW constants: c1 = sqrt(-3) (the root mcl uses has even canonical value ...04), c2 = (c1 - 1)/2 */
+  /* SvdW constants: c1 = sqrt(-3) = (-3)^((p+1)/4), the root fp_sqrt returns (BN254: ...0004, BLS12-381: ...fffdfffd; both pinned by the
+     golden vectors), c2 = (c1 - 1)/2 */
   fp m3, two, half;
   fp_from_u64(&m3, 3); fp_neg(&m3, &m3);
   fp_sqrt(&SVDW_C1, &m3);
-  uint8_t c1b[32];
-  fp_to_le(c1b, &SVDW_C1);
-  if (c1b[0] != 0x04) fp_neg(&SVDW_C1, &SVDW_C1);
   fp_from_u64(&two, 2); fp_inv(&half, &two);
   fp_sub(&SVDW_C2, &SVDW_C1, &FP_ONE); fp_mul(&SVDW_C2, &SVDW_C2, &half);
-#endif
   g_init = 1;
 }
 
@@ -979,7 +1066,7 @@ static void k_load(u64 k[4], const uint8_t* b) { memcpy(k, b, 32); }
 int elpo_g1_mul(const uint8_t* P_, const uint8_t* k_, uint8_t* out) {
   g1a p, r; g1j j; u64 k[4];
   if (!g1_load(&p, P_)) return 0;
-  k_load(k, k_); g1_mul(&j, &p, k); g1_to_aff(&r, &j); g1_store(out, &r);
+  k_load(k, k_); g1_mul_ref(&j, &p, k); g1_to_aff(&r, &j); g1_store(out, &r);
   return 1;
 }
 int elpo_g2_mul(const uint8_t* P_, const uint8_t* k_, uint8_t* out) {
@@ -1068,7 +1155,7 @@ elpo_key* elpo_key_new(int A, const uint8_t* g1_bases, const uint8_t* g2_bases) 
 }
 void elpo_key_free(elpo_key* k) { if (k) { free(k->Yi); free(k->YYi); free(k); } }
 
-static void g1_mul_add(g1j* acc, const g1a* base, const u64* k) { g1j t; g1_mul(&t, base, k); g1_add(acc, acc, &t); }
+static void g1_mul_add(g1j* acc, const g1a* base, const u64* k) { g1j t; g1_mul_ref(&t, base, k); g1_add(acc, acc, &t); }
 static void g2_mul_add(g2j* acc, const g2a* base, const u64* k) { g2j t; g2_mul(&t, base, k); g2_add(acc, acc, &t); }
 static void fr_one_minus(u64 out[4], const u64 c[4]) { /* (1 - c) mod r, c < r */
   u64 one[4] = {1, 0, 0, 0};
@@ -1086,8 +1173,9 @@ static void challenge(u64 out[4], sha256_t* s, const uint8_t* ad, size_t adl) {
 #ifdef ELPO_BLS12_381
 /* Project policy on this curve (G1 cofactor (z-1)^2/3 != 1; include/elpasso.h ELP_OPT_SUBGROUP_CHECK): prover-supplied G1 points must lie in the
    order-r subgroup.  Checked here by the definition, [r]P == O, with plain double-and-add (the HIP path uses the endomorphism test). */
+static int elpo_subgroup_check;
 static int g1_in_subgroup(const g1a* p) {
-  if (p->inf) return 1;
+  if (p->inf || !elpo_subgroup_check) return 1;
   g1j acc, base;
   g1_set_inf(&acc);
   g1_from_aff(&base, p);
@@ -1107,6 +1195,11 @@ static int sig1_admissible(const g1a* s) { return !s->inf && g1_in_subgroup(s); 
 /* the library's ELP_OPT_STRICT_SIGNATURE for el_passo_verify_id: 0 (default here) = the reference's behaviour, 1 = sig1 must be admissible as in PSVerifier::verify */
 static int elpo_strict = 0;
 void elpo_set_strict(int on) { elpo_strict = on; }
+/* the library's ELP_OPT_SUBGROUP_CHECK (BLS12-381): 1 (default here, as in the library) = the project's policy above, a DELIBERATE divergence from the
+   reference; 0 = the reference's behaviour -- mcl's default does not test the order of a deserialised G1 point; together with g1_mul_ref this
+   build then reproduces every verdict of the reference's wasm on points outside G1 (tests/test_oracle_bls.py) */
+static int elpo_subgroup_check = 1;
+void elpo_set_subgroup_check(int on) { elpo_subgroup_check = on; }
 
 /* record: sig1 | sig2 | phi | [E1 | E2] | k | c | rs[..] | m[..]   (same as elp_verify_id_batch) */
 int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask, int retr, const uint8_t* ad, size_t adl) {
@@ -1142,14 +1235,14 @@ int elpo_verify_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mask
   g2_mul_add(&Vk, &key->XX, s);
   /* V_phi = phi^c * H1(svc)^{r_0}                              ps-verifier.cc:91-96 */
   g1j Vphi, VE1, VE2;
-  g1_mul(&Vphi, &phi, c);
+  g1_mul_ref(&Vphi, &phi, c);
   k_load(s, rs);
   g1_mul_add(&Vphi, &key->hs, s);
   if (retr) {
     u64 re[4];
     k_load(re, rs + 32 * (nrs - 1));
-    g1_mul(&VE1, &E1, c); g1_mul_add(&VE1, &key->g_eg, re);                 /* :99-101 */
-    g1_mul(&VE2, &E2, c); g1_mul_add(&VE2, &key->apk, re);                  /* :104-108 */
+    g1_mul_ref(&VE1, &E1, c); g1_mul_add(&VE1, &key->g_eg, re);                 /* :99-101 */
+    g1_mul_ref(&VE2, &E2, c); g1_mul_add(&VE2, &key->apk, re);                  /* :104-108 */
     k_load(s, rs + 32); g1_mul_add(&VE2, &key->h, s);
   }
   /* c' = Hr(SHA256(hex(k) hex(phi) [hex(E1) hex(E2)] hex(V_k) hex(V_phi) [hex(V_E1) hex(V_E2)] ad))   :111-122 */
@@ -1216,7 +1309,7 @@ int elpo_provide_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mas
   const uint8_t* ms = p; p += 32 * (A - H);
   k_load(u, p);
   g1j V;
-  g1_mul(&V, &Ac, c);                                                     /* :83 */
+  g1_mul_ref(&V, &Ac, c);                                                     /* :83 */
   k_load(s, rs); g1_mul_add(&V, &key->g, s);                              /* :85-86 */
   int j = 1;
   for (int i = 0; i < A; i++)
@@ -1238,12 +1331,12 @@ int elpo_provide_id(const elpo_key* key, const uint8_t* rec, uint64_t hidden_mas
       if (!((hidden_mask >> i) & 1)) { k_load(s, ms + 32 * j); j++; g1_mul_add(&Ap, &key->Yi[i], s); }
   }
   g1j s1, s2, X;
-  g1_mul(&s1, &key->g, u);                                                /* :138 */
+  g1_mul_ref(&s1, &key->g, u);                                                /* :138 */
   g1_from_aff(&X, &key->skX);
   g1_add(&Ap, &Ap, &X);                                                   /* :140 */
   g1a aAp, r1, r2;
   g1_to_aff(&aAp, &Ap);
-  g1_mul(&s2, &aAp, u);                                                   /* :141 */
+  g1_mul_ref(&s2, &aAp, u);                                                   /* :141 */
   g1_to_aff(&r1, &s1); g1_to_aff(&r2, &s2);
   g1_store(out, &r1); g1_store(out + G1B, &r2);
   return 1;

@@ -241,6 +241,27 @@ class Groups:
         self.cv = cv
         self.F = Field(cv)
         self.p = cv.p
+        if not cv.is_bn:
+            # GLV data of G1 (see g1_mul): L = z^2 - 1 satisfies L^2 + L + 1 = 0 mod r; beta = the cube root of unity in Fp with (beta x, y) = [L](x, y) on G1
+            self.glv_L = cv.z * cv.z - 1
+            assert (self.glv_L * self.glv_L + self.glv_L + 1) % cv.r == 0
+            p = cv.p
+            g = 2
+            while pow(g, (p - 1) // 3, p) == 1:
+                g += 1
+            w = pow(g, (p - 1) // 3, p)
+            # a point of G1: clear the cofactor of the first curve point found from x = 1, 2, ...
+            x = 1
+            while True:
+                y = self.F.sqrt((x * x * x + cv.b) % p)
+                if y is not None:
+                    Q = self.g1_mul_plain((x, y), (cv.z - 1) ** 2 // 3)
+                    if Q is not None:
+                        break
+                x += 1
+            want = self.g1_mul_plain(Q, self.glv_L)
+            self.glv_beta = w if (w * Q[0] % p, Q[1]) == want else w * w % p
+            assert (self.glv_beta * Q[0] % p, Q[1]) == want
 
     # ---- G1
     def g1_on_curve(self, P):
@@ -270,13 +291,18 @@ class Groups:
         return (x3, (lam * (x1 - x3) - y1) % p)
 
     def g1_mul(self, P, k):
+        """G1::mul as mcl evaluates it.  On BN254 E(Fp) = G1 and any correct method gives [k mod r]P.  On BLS12-381 mcl's G1::mul is the GLV
+        method with the endomorphism psi(x, y) = (beta x, y) = [L] on G1, L = z^2 - 1: k mod r is split by plain division, b, a = divmod(k, L),
+        and the result is [a]P + [b]psi(P).  Inside G1 that is [k]P; for a point of E(Fp) OUTSIDE G1 (which mcl's default accepts on
+        deserialisation) it is not -- e.g. psi fixes the points (0, +-2) of order 3, so the order-3 component is multiplied by a + b instead of
+        k.  The split is pinned by the reference wasm's verdicts on 20 crafted proofs / requests (tests/golden/bls12_381_oracle_edge.json
+        "crafted_phi_c_mod_3", bls12_381_oracle_requests.json "crafted_A_c_mod_3": accepted iff 3 | a + b)."""
         k %= self.cv.r
-        R = None
-        for bit in bin(k)[2:] if k else "":
-            R = self.g1_add(R, R)
-            if bit == "1":
-                R = self.g1_add(R, P)
-        return R
+        if self.cv.is_bn or P is None:
+            return self.g1_mul_plain(P, k)
+        b, a = divmod(k, self.glv_L)
+        psiP = (self.glv_beta * P[0] % self.p, P[1])
+        return self.g1_add(self.g1_mul_plain(P, a), self.g1_mul_plain(psiP, b))
 
     def g1_mul_plain(self, P, k):          # [k]P for any integer k >= 0, no reduction modulo r (points outside the order-r subgroup)
         R = None
@@ -433,18 +459,21 @@ class Mcl:
         self.F = self.G.F
         self.p, self.r = cv.p, cv.r
         self.fb = cv.fbytes
+        F = self.F
+        # SvdW constants for y^2 = x^3 + b (mcl MapTo: the same Shallue-van de Woestijne routine serves BN254 and, in mcl's default
+        # (non-ETH) mode, BLS12-381): c1 = sqrt(-3) = (-3)^((p+1)/4), c2 = (c1 - 1)/2
+        c1 = F.sqrt((-3) % self.p)
+        self.c1 = c1
+        self.c2 = (c1 - 1) * F.inv(2) % self.p
         if cv.is_bn:
-            F = self.F
-            # SvdW constants for y^2 = x^3 + b  (mcl MapTo for BN curves): c1 = sqrt(-3), c2 = (c1 - 1)/2
-            c1 = F.sqrt((-3) % self.p)
-            # mcl picks the root reproduced by the golden vectors:
-            want = 0x252364824000000126CD890000000003CF0F0000000000060C00000000000004
-            if c1 != want:
-                c1 = self.p - c1
-            assert c1 == want
-            self.c1 = c1
-            self.c2 = (c1 - 1) * F.inv(2) % self.p
+            # pinned by tests/golden/bn254_*.json
+            assert self.c1 == 0x252364824000000126CD890000000003CF0F0000000000060C00000000000004
             assert self.c2 == 0x25236482400000017080EB4000000006181800000000000CD98000000000000B
+            self.g1_cofactor = 1
+        else:
+            # pinned by tests/golden/bls12_381_*.json (reference wasm with mcl's BLS12-381 CurveParam, oracle/wasm_curve.js)
+            assert self.c1 == 0xBE32CE5FBEED9CA374D38C0ED41EEFD5BB675277CDF12D11BC2FB026C41400045C03FFFFFFFDFFFD
+            self.g1_cofactor = (cv.z - 1) ** 2 // 3
 
     # ---- scalars
     def fr_ser(self, x):
@@ -454,9 +483,11 @@ class Mcl:
         return int.from_bytes(b, "little")
 
     def _set_hash_of(self, msg: bytes, mod: int) -> int:
-        """Fr/Fp::setHashOf: SHA-256 -> LE integer -> mask to bitlen(mod) bits -> if >= mod clear top bit."""
-        h = int.from_bytes(hashlib.sha256(msg).digest(), "little")
+        """Fr/Fp::setHashOf: SHA-256 (modulus of at most 256 bits) or SHA-512 (wider: the 381-bit Fp of BLS12-381) -> the first
+        ceil(bitlen/8) bytes as an LE integer -> mask to bitlen(mod) bits -> if >= mod clear the top bit."""
         nb = mod.bit_length()
+        d = hashlib.sha256(msg).digest() if nb <= 256 else hashlib.sha512(msg).digest()
+        h = int.from_bytes(d[:(nb + 7) // 8], "little")
         h &= (1 << nb) - 1
         if h >= mod:
             h &= (1 << (nb - 1)) - 1
@@ -538,39 +569,15 @@ class Mcl:
             return "0"
         return "1 %d %d" % (P[0], P[1])
 
-    # ---- hash to G1 (BN: Shallue-van de Woestijne as in mcl MapTo::calcBN)
+    # ---- hash to G1: mcl's hashAndMapToG1 = Fp::setHashOf -> Shallue-van de Woestijne map (MapTo::calcBN) -> cofactor clearing
+    #      (cofactor 1 on BN254; (z-1)^2/3 on BLS12-381).  Call sites: src/ps-verifier.cc:94,186, src/ps-requester.cc:185,336.
     def hash_to_g1(self, msg):
         if isinstance(msg, str):
             msg = msg.encode()
-        if not self.cv.is_bn:
-            return self.hash_to_g1_tai(msg)      # BLS12-381: project-defined map (mcl's is unpinned), see csrc/elp/encode.h
-        t = self.fp_hash(msg)
-        return self.map_to_g1(t)
-
-    def hash_to_g1_tai(self, msg: bytes):
-        """Try-and-increment + cofactor clearing (mirrors hash_and_map_to_g1 for non-BN curves in csrc/elp/encode.h)."""
-        p, b, n = self.p, self.cv.b, self.fb
-        h1 = (self.cv.z - 1) ** 2 // 3
-        ctr = 0
-        while True:
-            d = hashlib.sha256(msg + bytes([ctr & 0xFF, 0])).digest() + hashlib.sha256(msg + bytes([ctr & 0xFF, 1])).digest()
-            ctr += 1
-            x = int.from_bytes(d[:n], "little") & ((1 << p.bit_length()) - 1)
-            if x >= p:
-                x &= (1 << (p.bit_length() - 1)) - 1
-            y = self.F.sqrt((x * x * x + b) % p)
-            if y is None:
-                continue
-            if y & 1:
-                y = p - y
-            R = None
-            for bit in bin(h1)[2:]:
-                R = self.G.g1_add(R, R)
-                if bit == "1":
-                    R = self.G.g1_add(R, (x, y))
-            if R is None:
-                continue
-            return R
+        P = self.map_to_g1(self.fp_hash(msg))
+        if self.g1_cofactor != 1:
+            P = self.G.g1_mul_plain(P, self.g1_cofactor)
+        return P
 
     def map_to_g1(self, t):
         p, b = self.p, self.cv.b
@@ -803,6 +810,10 @@ class Protocol:
         # the library's ELP_OPT_STRICT_SIGNATURE for el_passo_verify_id (include/elpasso.h): False = the reference's behaviour (sig1 = sig2 = O passes,
         # golden case "sig_both_zero"), True = sig1 must be admissible as in PSVerifier::verify
         self.strict = False
+        # the library's ELP_OPT_SUBGROUP_CHECK (BLS12-381 only; default 1 in the library): True = prover-supplied G1 points must lie in the order-r
+        # subgroup (project policy, a DELIBERATE divergence from the reference: mcl's default does not test the order of a deserialised G1 point --
+        # what the reference's wasm answers on such inputs is recorded in tests/golden/bls12_381_oracle_edge.json), False = no test.
+        self.subgroup_check = True
 
     # sigma_1 must not be the identity of G1 (src/ps-verifier.cc:16-18).  On a curve with a G1 cofactor (BLS12-381) that is asked of the order-r component:
     # a point of E(Fp) whose order divides the cofactor pairs to 1 with everything, so "sig1 is not the point at infinity" alone admits the forgery
@@ -847,6 +858,8 @@ class Protocol:
     # prover-supplied G1 points must lie in the order-r subgroup (csrc/elp/pipeline.h g1_in_subgroup, include/elpasso.h ELP_OPT_SUBGROUP_CHECK).
     # Here by the definition, [r]P == O.
     def in_g1(self, P) -> bool:
+        if not self.subgroup_check:
+            return True
         return P is None or self.G.g1_mul_plain(P, self.m.r) is None
 
     # -- el_passo_verify_id (src/ps-verifier.cc:37-138)

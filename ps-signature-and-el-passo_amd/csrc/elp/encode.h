@@ -7,6 +7,7 @@
 #pragma once
 #include "curve.h"
 #include "sha256.h"
+#include "sha512.h"
 
 namespace elp {
 
@@ -184,38 +185,37 @@ ELP_HEAVY bool g2_deserialize(Aff<F2<C>>& p, const uint8_t* in, bool* canon_flag
   return true;
 }
 
-// ---- hashAndMapToG1
-// BN curves: Fp::setHashOf + Shallue-van de Woestijne map exactly as mcl does it (pinned by golden vectors, all 6 branches).
-// BLS12-381: mcl's map for this curve is not pinned by any reference artefact (the reference never runs on it, SURVEY.md
-// section 0.2); we define a deterministic try-and-increment map with cofactor clearing (see hash_and_map_to_g1 below).
+// ---- hashAndMapToG1 (src/ps-verifier.cc:94,186, src/ps-requester.cc:185,336), as mcl evaluates it on either curve:
+//   t = Fp::setHashOf(msg)   SHA-256 (BN254) / SHA-512 (BLS12-381: mcl hashes with SHA-512 when the modulus is wider than 256 bits); the first
+//                            FBYTES bytes as a little-endian integer, masked to bitlen(p) bits, one more bit cleared if still >= p
+//   P = SvdW(t)              Shallue-van de Woestijne map for y^2 = x^3 + b (mcl MapTo::calcBN; mcl's default, non-ETH mode uses it for
+//                            BLS12-381 too): c1 = sqrt(-3) = (-3)^((p+1)/4), c2 = (c1 - 1)/2, y negated iff Legendre(t) = -1
+//   BLS12-381: P <- [(z-1)^2/3] P   (cofactor clearing; the cofactor of BN254's E(Fp) is 1)
+// Pinned on BOTH curves by proofs made by the reference's wasm (tests/golden/{bn254,bls12_381}_oracle_flows.json "hash_to_g1": 32 service
+// names, all six branch / sign cases; the BLS12-381 run of the wasm: oracle/wasm_curve.js).
 template <class C>
 ELP_HEAVY void map_to_g1_svdw(Aff<F1<C>>& out, const Fp<C>& t) {  // t != 0, Montgomery form
-  if constexpr (C::IS_BN) {
-    Fp<C> c1, c2, b, one = fp_one<C>();
-    ELP_LOAD_FP(c1, C::svdw_c1(i_));
-    ELP_LOAD_FP(c2, C::svdw_c2(i_));
-    ELP_LOAD_FP(b, C::curve_b(i_));
-    bool neg = fp_legendre<C>(t) < 0;
-    Fp<C> w = fp_add(fp_add(fp_sqr<C>(t), b), one);
-    w = fp_mul<C>(fp_mul<C>(c1, t), fp_inv<C>(w));
-    Fp<C> x, y;
-    for (int i = 0; i < 3; i++) {
-      if (i == 0)
-        x = fp_sub(c2, fp_mul<C>(t, w));
-      else if (i == 1)
-        x = fp_sub(fp_neg(x), one);
-      else
-        x = fp_add(one, fp_inv<C>(fp_sqr<C>(w)));
-      Fp<C> rhs = fp_add(fp_mul<C>(fp_sqr<C>(x), x), b);
-      if (fp_sqrt<C>(y, rhs)) break;
-    }
-    if (neg) y = fp_neg(y);
-    out.x = x;
-    out.y = y;
-  } else {
-    (void)t;
-    aff_set_inf(out);
+  Fp<C> c1, c2, b, one = fp_one<C>();
+  ELP_LOAD_FP(c1, C::svdw_c1(i_));
+  ELP_LOAD_FP(c2, C::svdw_c2(i_));
+  ELP_LOAD_FP(b, C::curve_b(i_));
+  bool neg = fp_legendre<C>(t) < 0;
+  Fp<C> w = fp_add(fp_add(fp_sqr<C>(t), b), one);
+  w = fp_mul<C>(fp_mul<C>(c1, t), fp_inv<C>(w));
+  Fp<C> x, y;
+  for (int i = 0; i < 3; i++) {
+    if (i == 0)
+      x = fp_sub(c2, fp_mul<C>(t, w));
+    else if (i == 1)
+      x = fp_sub(fp_neg(x), one);
+    else
+      x = fp_add(one, fp_inv<C>(fp_sqr<C>(w)));
+    Fp<C> rhs = fp_add(fp_mul<C>(fp_sqr<C>(x), x), b);
+    if (fp_sqrt<C>(y, rhs)) break;
   }
+  if (neg) y = fp_neg(y);
+  out.x = x;
+  out.y = y;
 }
 // digest -> canonical integer below p, mcl setHashOf style: take FBYTES little-endian bytes, mask to bitlen(p) bits, clear one
 // more bit if still >= p.
@@ -229,7 +229,7 @@ ELP_INL StdFp<C> std_from_hash_bytes(const uint8_t* d) {
 }
 template <class C>
 ELP_HEAVY void hash_and_map_to_g1(Aff<F1<C>>& out, const uint8_t* msg, size_t len) {
-  if constexpr (C::IS_BN) {
+  if constexpr (C::PBITS <= 256) {
     Sha256 s;
     sha256_init(s);
     sha256_update(s, msg, len);
@@ -237,36 +237,18 @@ ELP_HEAVY void hash_and_map_to_g1(Aff<F1<C>>& out, const uint8_t* msg, size_t le
     sha256_final(s, d);
     map_to_g1_svdw<C>(out, fp_from_std<C>(std_from_hash_bytes<C>(d)));   // BN254: FBYTES == 32
   } else {
-    // x_ctr = setHashOf-style reduction of  SHA256(msg || ctr || 0) || SHA256(msg || ctr || 1)  (first FBYTES bytes);
-    // first ctr with x^3 + b a square wins, y = the root with even canonical value; the result is multiplied by the
-    // G1 cofactor so that it lies in the order-r subgroup.
-    Fp<C> b;
-    ELP_LOAD_FP(b, C::curve_b(i_));
-    for (u32 ctr = 0;; ctr++) {
-      uint8_t d[64];
-      for (int half = 0; half < 2; half++) {
-        Sha256 s;
-        sha256_init(s);
-        sha256_update(s, msg, len);
-        sha256_put(s, (uint8_t)ctr);
-        sha256_put(s, (uint8_t)half);
-        sha256_final(s, d + 32 * half);
-      }
-      Fp<C> x = fp_from_std<C>(std_from_hash_bytes<C>(d));
-      Fp<C> y, rhs = fp_add(fp_mul<C>(fp_sqr<C>(x), x), b);
-      if (!fp_sqrt<C>(y, rhs)) continue;
-      if (fp_to_std<C>(y).w[0] & 1) y = fp_neg(y);
-      Aff<F1<C>> p;
-      p.x = x;
-      p.y = y;
-      Scalar h;
-      for (int i = 0; i < 8; i++) h.v[i] = C::g1_cofactor(i);
-      Jac<F1<C>> j;
-      jac_mul_var<F1<C>>(j, p, h);
-      if (jac_is_inf(j)) continue;
-      jac_to_aff<F1<C>>(out, j);
-      return;
-    }
+    Sha512 s;
+    sha512_init(s);
+    sha512_update(s, msg, len);
+    uint8_t d[64];
+    sha512_final(s, d);
+    Aff<F1<C>> p;
+    map_to_g1_svdw<C>(p, fp_from_std<C>(std_from_hash_bytes<C>(d)));     // BLS12-381: the first 48 of the 64 digest bytes
+    Scalar h;
+    for (int i = 0; i < 8; i++) h.v[i] = C::g1_cofactor(i);
+    Jac<F1<C>> j;
+    jac_mul_var<F1<C>>(j, p, h, 32);                                     // plain 4-bit windows over the 126-bit cofactor: p is not in G1 yet
+    jac_to_aff<F1<C>>(out, j);
   }
 }
 

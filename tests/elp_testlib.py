@@ -191,7 +191,7 @@ _oracle_bls = None
 
 def oracle_bls():
     """The C oracle built for BLS12-381 (oracle/elp_oracle.c -DELPO_BLS12_381 -> libelp_oracle_bls.so): same entry points, 48-byte coordinates.
-    Parity unpinned (no reference artefact exists for this curve): a second implementation beside oracle/pymodel.py."""
+    Pinned to the reference's own wasm run on this curve by tests/test_oracle_bls_golden.py (tests/golden/bls12_381_*.json)."""
     global _oracle_bls
     if _oracle_bls is None:
         import subprocess

@@ -1,6 +1,7 @@
-"""GPU tests of the BLS12-381 instantiation (the north-star curve).  No reference oracle exists for this curve (the
-reference runs on BN254): results are compared with the independent big-int model and checked through algebraic
-known-answer properties; the synthetic batches are checked against the generator's expectation."""
+"""GPU tests of the BLS12-381 instantiation (the north-star curve): results are compared with the big-int model and the C oracle's BLS12-381
+build and checked through algebraic known-answer properties; the synthetic batches are checked against the generator's expectation.  Both
+checkers are pinned to the reference's own wasm run on this curve by tests/test_oracle_bls_golden.py; the reference-made vectors themselves
+go through the GPU in tests/test_gpu_bls_golden.py."""
 import copy
 import importlib
 import random
@@ -172,7 +173,7 @@ def test_msm_wire_and_aggregated_paths_on_bls(bls_ctx):
 
 
 def test_batch_against_the_c_oracle_bls_build(bls_ctx):
-    """The second independent implementation for this curve (oracle/elp_oracle.c -DELPO_BLS12_381; parity unpinned, tests/test_oracle_bls.py pins it to the
+    """The second independent implementation for this curve (oracle/elp_oracle.c -DELPO_BLS12_381; pinned to the reference's wasm by tests/test_oracle_bls_golden.py; tests/test_oracle_bls.py ties it to the
     model): synthetic el_passo_verify_id and PS / issuance batches, every GPU verdict and every issued signature equal to the C oracle's, GT bytes equal."""
     import ctypes
     import importlib
@@ -295,7 +296,7 @@ def test_cofactor_sig1_forgery_rejected_on_gpu(bls_ctx):
 def test_headline_size_batch_w20_against_the_c_oracle(bls_ctx):
     """BLS12-381 at its benchmarked configuration: 65 536 el_passo_verify_id proofs, 8 attributes with 4 hidden, id-retrieval, W = 20 tables,
     the two-lanes-per-item kernel this curve always uses -- every verdict against the generator's expectation and 1 024+ of them (a stride + EVERY corrupted item)
-    against the C oracle's BLS12-381 build.  PARITY UNPINNED (no reference artefact exists for this curve): the oracle is a second implementation, not the reference."""
+    against the C oracle's BLS12-381 build.  The oracle is pinned to the reference's wasm run on this curve (tests/test_oracle_bls_golden.py)."""
     import ctypes
     synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
     L = oracle_bls()
@@ -326,7 +327,7 @@ def test_small_batches_cooperative_on_bls(bls_ctx):
     k_vid_prep -> k_vid_small / k_vid_nizk4 + k_pair_coop -> k_vid_combine, k_ps_k_coop + k_pair_coop for PS verification, k_agg_final_coop as the tail of aggregated
     verification).  el_passo_verify_id and PS verification at n = 1, 63, 64, 65, 600 and 1100 (both program widths): verdicts equal the two-lanes-per-item kernels'
     (ELP_OPT_COOP_PAIRING off), the generator's expectation and the C oracle's BLS12-381 build; tampered signatures, sig2 = infinity and the cofactor forgery included.
-    PARITY UNPINNED (no reference artefact exists for this curve)."""
+    The oracle is pinned to the reference's wasm run on this curve (tests/test_oracle_bls_golden.py)."""
     import ctypes
     import os
     from test_oracle_bls import _small_order_point
@@ -387,7 +388,7 @@ def test_small_batches_cooperative_on_bls(bls_ctx):
 def test_phase_mix_experiment_keeps_the_verdicts(elp, bls_ctx):
     """ELP_PHASE_MIX (experiment, off by default; profiles/r04_bls_ceiling.md): the second half of a two-lane launch's workgroups checks the pairing BEFORE the NIZK half.
     Same verdicts as the default order on a batch with corrupted NIZK responses, a swapped sig2, sig2 = infinity and the cofactor forgery -- items of both halves of the
-    launch.  PARITY UNPINNED like everything on this curve."""
+    launch."""
     import os
     from test_oracle_bls import _small_order_point
     synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
@@ -425,7 +426,7 @@ def test_four_lane_path_on_bls12_381(bls_ctx):
     """Round 5: el_passo_verify_id of 3 073 ... 16 384 items and PS verifications of 4 097 ... 16 384 run the pairing check on FOUR lanes per item (k_vid_mid / k_pair4,
     ELP_OPT_PAIR4; elp/quad.h, pair4.h with the M-type line product and the Hayashida-Hayasaka-Teruya chain cubed).  n = 3 100 and 8 200: verdicts equal the option-off
     paths', the generator's expectation and -- on a stride plus every corrupted / crafted item -- the C oracle's BLS12-381 build; tampered signature, sig2 = infinity and
-    the cofactor forgery (sig1 of order 3, sig2 = O) included.  PARITY UNPINNED (no reference artefact exists for this curve)."""
+    the cofactor forgery (sig1 of order 3, sig2 = O) included.  (What the reference's wasm answers on these inputs: tests/test_oracle_bls_golden.py.)"""
     import ctypes
     import os
     from test_oracle_bls import _small_order_point

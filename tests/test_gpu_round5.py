@@ -225,15 +225,30 @@ def test_aggregated_verification_with_two_items_per_lane(gpu_ctx):
     """ELP_OPT_AGG_TWO_PER_LANE (round 5; k_verify_id_agg2 + pairing.h miller_loop_two): forced on, batches of 1 ... 1 001 items -- odd sizes leave the last lane one
     item --: (a) a batch whose bad items fail the NIZK half only (every ninth, so most lanes meet a dead neighbour): the batch equation holds and the verdicts are
     the per-item path's; (b) signatures tampered behind the NIZK's back: the equation fails and the per-item fallback decides; (c) per-item associated data; and
-    mode 1 (two per lane only where it saves rounds) leaves these sizes on the one-item kernel with the same answers."""
+    mode 1 (two per lane only where it saves rounds) leaves these sizes on the one-item kernel with the same answers.  Every verdict of every batch -- the clean ones,
+    the tampered ones the fallback decides, the per-item associated data -- is also asked of the C oracle (elpo_verify_id_batch, src/ps-verifier.cc:37-138)."""
+    L = oracle()
     A, H = 8, 4
     wl = synth.Workload(gpu_ctx, A, seed=77, window_bits=8)
+    key = _oracle_key(L, wl, gpu_ctx, A)
     seed = bytes(range(32))
+
+    def oracle_verdicts(recs_, n_, mask_, ads_=None):
+        rsz_ = len(recs_) // n_
+        ofl = np.zeros(n_, dtype=np.uint8)
+        if ads_ is None:
+            L.elpo_verify_id_batch(key, n_, recs_, rsz_, mask_, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+        else:
+            for i_ in range(n_):
+                ofl[i_] = L.elpo_verify_id(key, recs_[i_ * rsz_:(i_ + 1) * rsz_], mask_, 1, ads_[i_], len(ads_[i_]))
+        return ofl
+
     try:
         for n in (1, 2, 3, 64, 129, 1001):
             recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=9, corrupt_at=min(4, n - 1) if n < 9 else 4)
             ref, rc = gpu_ctx.verify_id_batch(recs, mask, True, wl.ad)
             assert (ref == expect).all()
+            assert (oracle_verdicts(recs, n, mask) == expect).all(), n
             for mode in (2, 1):
                 gpu_ctx.set_agg_two_per_lane(mode)
                 fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad, seed)
@@ -248,6 +263,7 @@ def test_aggregated_verification_with_two_items_per_lane(gpu_ctx):
                 bad = bytes(r)
                 rf, rcnt = gpu_ctx.verify_id_batch(bad, mask, True, wl.ad)
                 assert rf[a] == 0 and rf[b] == 0
+                assert (oracle_verdicts(bad, n, mask) == rf).all() and rf[20] == 1, n      # the oracle's verdicts on the tampered batch, (inf, inf) included
                 for mode in (2, 1):
                     gpu_ctx.set_agg_two_per_lane(mode)
                     fl, cnt, held = gpu_ctx.verify_id_batch_aggregated(bad, mask, True, wl.ad, seed)
@@ -264,8 +280,10 @@ def test_aggregated_verification_with_two_items_per_lane(gpu_ctx):
         want = expect.copy()
         want[5] = 0
         assert held and (fl == want).all()
+        assert (oracle_verdicts(recs, n, mask, ads) == want).all()
     finally:
         gpu_ctx.set_agg_two_per_lane(0)
+        L.elpo_key_free(key)
 
 
 def test_decoded_wire_batches_on_two_streams_keep_their_own_workspace(gpu_ctx):
@@ -327,9 +345,12 @@ def test_decoded_wire_batches_on_two_streams_keep_their_own_workspace(gpu_ctx):
 def test_g2_job_on_four_lanes_for_the_smallest_batches(gpu_ctx):
     """One-launch batches of at most 1 280 items give the G2 job of the NIZK half four lanes per item (vid_job_g2_quad: one GLS dimension per lane, results added through
     lane exchanges; NIZK workgroups of 16 items; a lone call 2.15 -> 1.87 ms, 1 024 items 2.35 -> 2.13 ms).  n = 1 ... 17 and ragged / boundary sizes up to 1 281 (back on
-    one lane) with NIZK-corrupted items, a commitment k at infinity, a k off the curve, the degenerate item whose first table addition is a doubling: verdicts equal the generator's expectation and the per-lane kernels' (cooperative path off; those are checked against the C oracle in tests/test_gpu_round3.py)."""
+    one lane) with NIZK-corrupted items, a commitment k at infinity, a k off the curve, the degenerate item whose first table addition is a doubling: verdicts equal the
+    C oracle's for EVERY item of every case (elpo_verify_id_batch, src/ps-verifier.cc:72-88 for the V_k job in question), the generator's expectation and the per-lane kernels' (cooperative path off)."""
+    L = oracle()
     A, H = 8, 4
     wl = synth.Workload(gpu_ctx, A, seed=515, window_bits=8)
+    key = _oracle_key(L, wl, gpu_ctx, A)
     n = 17
     recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=4, corrupt_at=2, degenerate_items=(5,))
     rsz = len(recs) // n
@@ -344,6 +365,9 @@ def test_g2_job_on_four_lanes_for_the_smallest_batches(gpu_ctx):
     finally:
         gpu_ctx.set_coop_pairing(1)
     assert ref[9] == 0 and ref[5] == 1 and (ref[[0, 1, 3, 4]] == expect[[0, 1, 3, 4]]).all()
+    ofl = np.zeros(n, dtype=np.uint8)
+    L.elpo_verify_id_batch(key, n, bad, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+    assert (ofl == ref).all() and ofl[7] == ref[7] and ofl[9] == 0 and ofl[5] == 1      # k = infinity, k off the curve, the doubling item: the oracle's verdicts
     for m in list(range(1, 18)):
         fl, cnt = gpu_ctx.verify_id_batch(bad[:m * rsz], mask, True, wl.ad)
         assert (fl == ref[:m]).all() and cnt == int(ref[:m].sum()), m
@@ -351,6 +375,10 @@ def test_g2_job_on_four_lanes_for_the_smallest_batches(gpu_ctx):
     nbig = 1281
     recs2, mask2, expect2 = wl.verify_id_batch(nbig, H, with_retrieval=True, corrupt_every=5, corrupt_at=3, degenerate_items=(20, 600))
     rsz2 = len(recs2) // nbig
+    ofl2 = np.zeros(nbig, dtype=np.uint8)
+    L.elpo_verify_id_batch(key, nbig, recs2, rsz2, mask2, 1, wl.ad, len(wl.ad), ofl2.ctypes.data, NT)
+    assert (ofl2 == expect2).all() and ofl2[20] == 1 and ofl2[600] == 1                # all 1 281 items, the two doubling items included
+    L.elpo_key_free(key)
     for m in (18, 31, 33, 64, 65, 255, 512, 513, 1000, 1280, 1281):
         fl, cnt = gpu_ctx.verify_id_batch(recs2[:m * rsz2], mask2, True, wl.ad)
         assert (fl == expect2[:m]).all() and cnt == int(expect2[:m].sum()), m

@@ -1,8 +1,9 @@
 """The C oracle's BLS12-381 build (oracle/elp_oracle.c -DELPO_BLS12_381) against the independent big-int model (oracle/pymodel.py).
-PARITY UNPINNED: the reference never runs on BLS12-381 and mcl is absent, so no reference-made vector exists for this curve; these
-tests establish that TWO independently written implementations (C: 6 x 64-bit Montgomery limbs, Jacobian lines, HHT chain; Python:
+These tests establish that TWO independently written implementations (C: 6 x 64-bit Montgomery limbs, Jacobian lines, HHT chain; Python:
 big integers, affine formulas, plain exponentiation) agree bit for bit on primitives, GT values, issued signatures and verdicts --
-the pair then serves as the checker of the HIP path's BLS12-381 instantiation (tests/test_gpu_bls.py) and as its CPU baseline."""
+the pair then serves as the checker of the HIP path's BLS12-381 instantiation (tests/test_gpu_bls.py) and as its CPU baseline.  Both are
+pinned to the reference's own wasm run on this curve in tests/test_oracle_bls_golden.py; the subgroup / strict-signature tests below state
+the library's POLICY on points outside G1, which differs from the reference's behaviour on purpose (same file)."""
 import copy
 import ctypes
 import random
@@ -38,7 +39,7 @@ def test_primitives_equal_the_model():
         assert L.elpo_g2_compress(g2b(X, N), w2) and w2.raw == M.g2_ser(X)
         assert L.elpo_g2_decompress(M.g2_ser(X), o2) and g2u(o2.raw, N) == X
     assert not L.elpo_g1_mul(g1b((1, 1), N), fb(3), o)               # not on the curve
-    # hashes: Fr::setHashOf masking to 255 / 254 bits, and this project's hash-to-curve convention for the curve
+    # hashes: Fr::setHashOf masking to 255 / 254 bits, and mcl's hashAndMapToG1 for the curve (SHA-512 setHashOf, SvdW, cofactor)
     h = ctypes.create_string_buffer(32)
     for s in (b"", b"abc", b"attribute-7", b"x" * 100):
         L.elpo_fr_set_hash_of(s, len(s), h)

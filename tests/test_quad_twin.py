@@ -1,7 +1,7 @@
 """The FOUR-LANES-PER-ITEM layer (csrc/elp/quad.h, pair4.h; round 5) on the CPU: the host twin runs the four lanes of a quad as four threads with rendezvous
 exchanges and compares every Fp12-level routine with the one-lane routine of tower.h / pairing.h on the same inputs (canonical words, bit for bit), and the
 four-lane pairing check e(sig1, K) e(-sig2, gg) == 1 (src/ps-verifier.cc:31-34, 132-137) with the one-lane check and with the big-int model's verdict --
-accepting and rejecting signatures, points at infinity.  BN254 (the parity curve) and BLS12-381 (parity unpinned: model only)."""
+accepting and rejecting signatures, points at infinity.  BN254 (the parity curve) and BLS12-381 (against the model, itself pinned by tests/test_oracle_bls_golden.py)."""
 import base64
 import ctypes
 import os

@@ -19,6 +19,19 @@ if os.path.exists(f"{src}/bench_headline.json"):
     shutil.copy(f"{src}/bench_headline.json", f"{dst}/{tag}_bench_headline.json")
 shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/summary.json", f"{dst}/{tag}_summary.json")
+# registers of the dominant kernel from the CODE OBJECT (build/ does not travel to the GPU box where summarize_profile.py ran)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_resources  # noqa: E402
+_s = json.load(open(f"{dst}/{tag}_summary.json"))
+_m = _s.get("k_verify_id", {})
+if "code_object" not in _m or "error" in _m.get("code_object", {}):
+    for name, f in kernel_resources.kernel_fields(os.path.join(root, "build", "obj", "elpasso_bn254_stage.o"), "k_verify_id_staged").items():
+        tot, acc = int(f["vgpr_count"]), int(f.get("agpr_count", 0))
+        _m["code_object"] = {"kernel": name, "vgpr_count": tot, "arch_vgpr": tot - acc, "agpr_count": acc, "private_segment_fixed_size": int(f["private_segment_fixed_size"]),
+                             "vgpr_spill_count": int(f["vgpr_spill_count"]), "sgpr_spill_count": int(f["sgpr_spill_count"]), "lds_bytes": int(f["group_segment_fixed_size"]),
+                             "source": "build/obj/elpasso_bn254_stage.o (tools/kernel_resources.py)"}
+    _s["k_verify_id"] = _m
+    json.dump(_s, open(f"{dst}/{tag}_summary.json", "w"), indent=1)
 
 
 def filt(inp, out):

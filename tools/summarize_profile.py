@@ -33,6 +33,20 @@ for sub in ("pmc_a", "pmc_b", "pmc_c"):
         v = sorted(v)
         pmc[k] = v[len(v) // 2] if len(v) % 2 else (v[len(v) // 2 - 1] + v[len(v) // 2]) / 2      # median over the dispatches: the first dispatch of a pass can carry
                                                                                                     # cycles counted before it started (GRBM_GUI_ACTIVE)
+# rocprofv3's VGPR_Count / Accum_VGPR_Count columns are the dispatch packet's granule encoding (236 / 0 for this kernel), not the allocation: the
+# registers judged are the code object's (.vgpr_count = arch + accumulation registers of the unified file)
+meta = {("rocprof_" + k if k in ("vgpr", "agpr") else k): v for k, v in meta.items()}
+try:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kernel_resources
+    obj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", "obj", "elpasso_bn254_stage.o")
+    for name, f in kernel_resources.kernel_fields(obj, "k_verify_id_staged").items():
+        tot, acc = int(f["vgpr_count"]), int(f.get("agpr_count", 0))
+        meta["code_object"] = {"kernel": name, "vgpr_count": tot, "arch_vgpr": tot - acc, "agpr_count": acc, "private_segment_fixed_size": int(f["private_segment_fixed_size"]),
+                               "vgpr_spill_count": int(f["vgpr_spill_count"]), "sgpr_spill_count": int(f["sgpr_spill_count"]),
+                               "lds_bytes": int(f["group_segment_fixed_size"]), "source": "build/obj/elpasso_bn254_stage.o (tools/kernel_resources.py)"}
+except Exception as e:  # the object is absent on the GPU box (build/ does not travel): tools/publish_profile.py fills this in
+    meta["code_object"] = {"error": str(e)}
 out["k_verify_id"] = meta
 out["pmc_per_launch"] = pmc
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
