@@ -45,71 +45,55 @@ int elp_device_count(void);
 void elp_destroy(elp_ctx* ctx);
 const char* elp_last_error(const elp_ctx* ctx);
 int elp_field_bytes(int curve);               /* F */
-/* Options.  ELP_OPT_STRICT_SIGNATURE (default 1): el_passo_verify_id rejects proofs whose sig1 is the point at infinity.  The
- * reference accepts sig1 = sig2 = infinity with a self-made NIZK (src/ps-verifier.cc:133-137 has no isZero test; golden case
- * "sig_both_zero"), which is a universal forgery since e(O,K) e(O,gg) = 1, although PSVerifier::verify rejects it
- * (src/ps-verifier.cc:16-18).  Set to 0 for bit-for-bit reference behaviour on that input.
- * On a curve with a G1 cofactor (BLS12-381) "not the point at infinity" is asked of the ORDER-r COMPONENT: sig1 must also lie in G1 (unless
- * ELP_OPT_SUBGROUP_CHECK = 0) -- a point whose order divides the cofactor pairs to 1 with everything, so (sig1, sig2) = (T, O) would satisfy the pairing
- * equation for any K.  elp_ps_verify_batch applies the same rule whatever ELP_OPT_STRICT_SIGNATURE says (PSVerifier::verify always rejects sigma_1 = 1).
- * NOTE: the order-r half of the rule is the ELP_OPT_SUBGROUP_CHECK test of sig1.  With ELP_OPT_SUBGROUP_CHECK = 0 it is off on EVERY path (record, wire,
- * aggregated, cooperative, elp_ps_verify_batch), and on BLS12-381 (sig1 of order 3, sig2 = O) is a universal forgery again: turn the check off only for
- * inputs whose sig1 (and phi, E1, E2) the caller has already validated to lie in G1.
- * ELP_OPT_PAIRED_LAYOUT: which kernel layout verifies (results are identical).  0 = one lane per item; 1 = two lanes per item (the
- * Fp2 tower split over a lane pair, half the latency per item, 2 waves per SIMD; BN254 builds); 2 (default) = by batch size: the
- * two-lane kernel when the last round of 64 x SIMDs items would be at most half full (small batches, odd remainders) and always on
- * BLS12-381, the one-lane kernel otherwise.
- * ELP_OPT_TABLE_WORKSPACE (default 1): the verify_id kernels keep the per-item tables of their variable-base multiplications in a
- * launch workspace in device memory (3 KB per item, see the *_dev entry points) instead of the lanes' private memory; results are
- * identical, 0 saves the memory at a few per cent of throughput.
- * ELP_OPT_SPLIT_PHASES (default 0; BN254 builds): 1 = the one-lane-per-item el_passo_verify_id runs as two kernels -- the NIZK half as independent jobs on two
- * job waves per workgroup, then the pairing check; 2 = the G2 job and the G1 jobs as concurrent kernels on two streams, then the pairing check.  Results are
- * identical; measured not faster than the fused kernel at full batches, faster at a light load.
- * 3 (both curves; where the two-lanes-per-item kernel runs): the base-field jobs of a verification -- the three commitments V_phi, V_E1, V_E2 and, on
- * BLS12-381, the four subgroup tests -- as a kernel of their own with one lane per job (k_vid_g1jobs), then the two-lane kernel over Fp2.  Results identical;
- * measured on BLS12-381: 13.6 + 38.0 ms against 49.9 ms fused at 65 536 items: opt-in.
- * ELP_OPT_SUBGROUP_CHECK (default 1; BLS12-381 only, BN254 has G1 cofactor 1): the prover-supplied G1 points of a proof or request (phi, E1, E2;
- * the commitment A of el_passo_provide_id; sig1 under ELP_OPT_STRICT_SIGNATURE and in elp_ps_verify_batch) must lie in the order-r subgroup, otherwise the
- * item is rejected (one [z^2]P per point, ~9 % of a verification; the sig1 test rides in a slot of the lane pair that was idle).  phi is the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several
- * pseudonyms or an undecryptable token.  The reference never meets the case (it runs on BN254); mcl's default does not check.  0 = no check.
- * ELP_OPT_COOP_PAIRING (default 1; both curves since round 4 -- on BLS12-381 a lone el_passo_verify_id takes 6.3 instead of 23.7 ms): small batches -- PS verifications of at most 4096
- * items, el_passo_verify_id of at most 9216 (BLS12-381: 8192); value > 1: that many for both -- and the closing step of aggregated verification run
- * the pairing check COOPERATIVELY -- 32 lanes per item, an Fp2 register file in LDS, a level-scheduled program (csrc/elp/coop.h) -- instead of one lane
- * (pair) per item, and the NIZK half of el_passo_verify_id spreads its jobs over four waves per 64 items with the fixed-base G2 sums on 8 lanes each, in the same launch
- * as the pairing check: measured (round 4), a lone PS verification takes 1.5 ms instead of 5.1, 4096 of them 2.9 ms instead of 4.6; el_passo_verify_id: 1 item 2.1 ms, 64 items 2.2,
- * 1024 items 2.4, 4096 items 4.6, 8192 items 7.0 ms instead of 8.8-9.2 at any of these sizes (round 5: 1 item 1.9 ms, 64 items 2.05, 1024 items 2.1 -- up to 1280 items the G2 commitment of the
- * NIZK half runs on four lanes per item --, 4096 items 3.8, 8192 items 4.3 ms on the four-lane path of ELP_OPT_PAIR4).  Results are identical.  0 = off.
- * ELP_OPT_COALESCED_RECORDS (default 1; BN254 builds; record entry points of el_passo_verify_id, plain layout): the 64 records of a workgroup are fetched as one contiguous
- * block with 16-byte loads through LDS into a per-lane private copy (k_verify_id_staged) instead of being read in place at a lane stride of one record.
- * Needs records of a multiple of 16 bytes, at most 1152, at a 16-byte aligned address; otherwise the in-place kernel runs.  Results are identical and so is the
- * kernel time (measured: 17.3 ms either way at 65 536 items).  0 = read in place.
- * ELP_OPT_STREAM_OVERLAP (default 0): kernels of ONE call that do not depend on each other -- for small batches of el_passo_verify_id the pairing check beside the
- * NIZK half, for aggregated verification the Fp12 product beside the Pippenger sum -- run on a second stream owned by the context, joined by events before the
- * call's last kernel; the caller's stream semantics are unchanged.  Measured in a process of its own: 64 verifications 2.6 instead of 2.8 ms, 2048 of them
- * 5.0-5.5 instead of 5.7, aggregated 65 536 17.5 instead of 17.7-18.1 ms.  Off by default (the default path gets the same overlap from one launch).
- * The second stream only carries kernels with SMALL private frames: the second-long stalls seen in round 3 were the runtime reclaiming private-memory
- * (scratch) blocks between hardware queues -- scratch is provisioned per queue, ~1 GB for a headline-sized launch of a kernel with a 14-16 KB frame -- and the
- * rule since round 4 is that large-frame kernels of a call stay on the caller's stream (profiles/r04_scratch_stall.md).  The same rule for callers: launch
- * verification batches of one process from ONE stream (two at most: aggregated batches pipelined over two streams overlap their serial tails); more
- * processes or more GPUs scale, more streams run into the reclaim.
- * ELP_OPT_PAIR4 (default 1; round 5): the pairing check e(sig1, K) e(-sig2, gg) == 1 on FOUR lanes per item (a DPP quad: the Fp12 value of the Miller loop and of the
- * final exponentiation spread over four lanes, 27 / 42 registers per lane, no private memory in the loops; csrc/elp/quad.h, pair4.h) for batches between the range of the
- * cooperative interpreter and the batches that fill the chip at one or two lanes per item: el_passo_verify_id of 3 073 ... 16 384 items -- NIZK half in the
- * job kernels of the small-batch path and the four-lane check as workgroup ranges of ONE launch (k_vid_mid) -- and PS verifications of 4 097 ... 16 384 items
- * (k_ps_k_coop, then k_pair4); up to 16 384 items the quads run one wave per SIMD.  Measured on BN254: 8 192 proofs 7.08 -> 4.38 ms, 16 384 proofs 9.45 -> 6.9 ms;
- * BLS12-381: 8 192 proofs 19.4 -> 11.6 ms.  0 = off (the interpreter / the two-lane kernels take these sizes), 2 = wherever the path exists (any batch up to
- * 131 072 items; for A/B measurements).  Verdicts are identical.
- * ELP_OPT_WIRE_DECODE (default 1; round 5): elp_verify_id_wire_batch[_dev] with at most 16 384 messages decodes them into records first (T-L-V parse, point
- * decompression and attribute hashing as a kernel of job-uniform waves) and verifies the records on the small / mid-size paths above -- a lone wire message ~3 ms
- * instead of ~9 -- when all messages of the batch hide the same attributes (one 16-byte read-back, i.e. one stream synchronisation inside the call); mixed patterns and
- * larger batches take the fused wire kernels.  0 = always the fused kernels.  Verdicts are identical.
- * ELP_OPT_AGG_TWO_PER_LANE (default 0; round 5; BN254): elp_verify_id_batch_aggregated[_dev] with TWO proofs on a lane -- their Miller loops share the squarings of one
- * accumulator and multiply their lines pairwise: 8 % fewer instructions per proof, 2 % less time (131 072 proofs 31.5 -> 30.9 ms).  1 = on batches that need fewer rounds of
- * lanes that way (65 537 ... 131 072 proofs on an MI355X, 196 609 ... 262 144, ...), 2 = always (tests).  Off by default: the kernel's private frame is the largest of the
- * library, and the first launches after other large-frame kernels make the runtime re-provision scratch memory (hundreds of ms each in a process that uses two streams).
- * Verdicts, the batch equation and the per-item fallback are unchanged.
- * ELP_OPT_FAULT_INJECT (default 0; a test hook for the error paths of callers): the next `value` calls of elp_verify_id_batch_submit on this context fail with
- * ELP_ERR_STATE before anything is queued; nothing else is affected.
+/* Options (elp_set_option).  Every option except the two POLICY options selects among kernels whose verdicts are identical; which kernel serves which
+ * batch size, and the measurements behind each default, are in DESIGN.md section 5 and profiles/option_history.md.
+ *
+ * POLICY (what is accepted):
+ * ELP_OPT_STRICT_SIGNATURE (default 1): el_passo_verify_id rejects a proof whose sig1 is the point at infinity and, on BLS12-381 with
+ *   ELP_OPT_SUBGROUP_CHECK on, a sig1 outside G1.  The reference has no such test in el_passo_verify_id (src/ps-verifier.cc:133-137): it accepts
+ *   sig1 = sig2 = infinity with a self-made NIZK (golden case "sig_both_zero", both curves) and, run on BLS12-381, (sig1, sig2) = (T, O) with T of
+ *   order 3 as well as sig1 + T (tests/golden/bls12_381_oracle_edge.json "sig_T3_O", "sig1_plus_T3") -- universal forgeries, since a point whose
+ *   order divides the cofactor pairs to 1 with everything.  0 = the reference's behaviour bit for bit (together with ELP_OPT_SUBGROUP_CHECK = 0 on
+ *   BLS12-381).  elp_ps_verify_batch always rejects sig1 = infinity as PSVerifier::verify does (src/ps-verifier.cc:16-18) and, with the subgroup check on,
+ *   sig1 outside G1.
+ * ELP_OPT_SUBGROUP_CHECK (default 1; BLS12-381 only -- E(Fp) of BN254 has prime order): the prover-supplied G1 points of a proof or request -- phi, E1,
+ *   E2, the commitment A of el_passo_provide_id, and sig1 where the strict rule applies -- must lie in the order-r subgroup, otherwise the item is
+ *   rejected.  A DELIBERATE divergence from the reference: mcl's default does not test the order of a deserialised G1 point.  What the reference's own
+ *   wasm answers when run on this curve (tests/golden/bls12_381_oracle_edge.json, _requests.json): phi + T with an honest transcript: rejected; a crafted
+ *   phi + T3 or A + T3 with 3 | c: accepted iff mcl's GLV split c = a + b (z^2 - 1) has 3 | a + b (about one in three); sig1 / sig2 + T: accepted.  phi is
+ *   the user's pseudonym and (E1, E2) the identity-retrieval token: a small-order component would give one user several pseudonyms or an undecryptable
+ *   token, hence the check.  0 = no check, on EVERY path: for inputs the caller has validated.  The sig1 cases are then accepted exactly as the reference
+ *   accepts them; the verdict on a phi / E1 / E2 / A outside G1 is implementation-defined (the device's GLV split is not mcl's), and (sig1 of order 3,
+ *   sig2 = O) verifies.
+ *
+ * KERNEL SELECTION (verdicts identical):
+ * ELP_OPT_PAIRED_LAYOUT: 0 = one lane per item; 1 = two lanes per item (the Fp2 tower split over a lane pair; BN254 builds); 2 (default) = by batch
+ *   size: two lanes when the last round of 64 x SIMDs items would be at most half full and always on BLS12-381, one lane otherwise.
+ * ELP_OPT_TABLE_WORKSPACE (default 1): the per-item tables of the variable-base multiplications live in a launch workspace in device memory (3 KB per
+ *   item, see the *_dev entry points) instead of the lanes' private memory; 0 saves the memory at a few per cent of throughput.
+ * ELP_OPT_SPLIT_PHASES (default 0): 1 = the one-lane el_passo_verify_id as two kernels (NIZK half as independent jobs, then the pairing check; BN254);
+ *   2 = the G2 job and the G1 jobs as concurrent kernels on two streams, then the pairing check (BN254); 3 = the base-field jobs (V_phi, V_E1, V_E2 and,
+ *   on BLS12-381, the subgroup tests) as a kernel of their own in front of the two-lane kernel (both curves).
+ * ELP_OPT_COOP_PAIRING (default 1): small batches -- PS verifications of at most 4096 items, el_passo_verify_id of at most 9216 (BLS12-381: 8192);
+ *   value > 1: that many for both -- and the closing step of aggregated verification run the pairing check cooperatively (32 lanes per item, an Fp2
+ *   register file in LDS, a level-scheduled program, csrc/elp/coop.h), with the NIZK half spread over job waves in the same launch.  0 = off.
+ * ELP_OPT_COALESCED_RECORDS (default 1; BN254, plain layout): the 64 records of a workgroup are fetched as one contiguous block through LDS
+ *   (k_verify_id_staged) instead of being read in place.  Needs records of a multiple of 16 bytes, at most 1152, 16-byte aligned; otherwise the
+ *   in-place kernel runs.
+ * ELP_OPT_STREAM_OVERLAP (default 0): independent kernels of ONE call run on a second stream owned by the context, joined by events before the call's
+ *   last kernel; the caller's stream semantics are unchanged.  Only kernels with small private frames go there (scratch memory is provisioned per
+ *   hardware queue; profiles/r04_scratch_stall.md).  Rule for callers: launch the verification batches of one process from ONE stream (two at most).
+ * ELP_OPT_PAIR4 (default 1): the pairing check on FOUR lanes per item (a DPP quad; csrc/elp/quad.h, pair4.h) for el_passo_verify_id of 3 073 ... 16 384
+ *   items (k_vid_mid) and PS verifications of 4 097 ... 16 384 items (k_pair4).  0 = off, 2 = wherever the path exists (up to 131 072 items; A/B runs).
+ * ELP_OPT_WIRE_DECODE (default 1): elp_verify_id_wire_batch[_dev] with at most 16 384 messages decodes them into records first (k_wire_decode) and
+ *   verifies the records on the small / mid-size paths when all messages hide the same attributes; mixed patterns and larger batches take the fused wire
+ *   kernels.  NOTE: the decision needs one 16-byte read-back, so on this path the _dev entry point SYNCHRONISES the caller's stream once inside the call
+ *   (it does not overlap with work queued behind it), and a single message with another hidden pattern sends the whole batch to the fused kernels
+ *   (about 3x slower at these sizes): callers who cannot trust their senders to use one pattern should group messages by pattern or set 0.
+ * ELP_OPT_AGG_TWO_PER_LANE (default 0; BN254): elp_verify_id_batch_aggregated[_dev] with two proofs on a lane (shared squarings).  1 = on batches that
+ *   need fewer rounds of lanes that way, 2 = always (tests).  Off by default: largest private frame of the library (scratch re-provisioning).
+ * ELP_OPT_FAULT_INJECT (default 0; test hook for callers' error paths): the next `value` calls of elp_verify_id_batch_submit on this context fail with
+ *   ELP_ERR_STATE before anything is queued.  No other entry point consumes or honours the counter.
  */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
        ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10, ELP_OPT_WIRE_DECODE = 11,
@@ -150,7 +134,8 @@ int elp_g2_msm_fixed(elp_ctx* ctx, size_t n, int nterms, const int32_t* base_ids
  * it (mcl's mulVec is unused there); it is the general MSM operator and the building block of aggregated verification. */
 int elp_g1_msm(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
 int elp_g2_msm(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
-/* hashAndMapToG1 (src/ps-verifier.cc:94; BN254: mcl's Shallue-van de Woestijne map). msgs concatenated, offsets[n+1]. */
+/* hashAndMapToG1 (src/ps-verifier.cc:94,186; src/ps-requester.cc:185,336) as mcl evaluates it: Fp::setHashOf (SHA-256 on BN254, SHA-512 on BLS12-381),
+ * the Shallue-van de Woestijne map, and on BLS12-381 the cofactor (z-1)^2/3; pinned on both curves by reference-made proofs. msgs concatenated, offsets[n+1]. */
 int elp_hash_to_g1(elp_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, uint8_t* out);
 /* pairing(GT&, G1, G2) (src/ps-verifier.cc:32-33) */
 int elp_pairing(elp_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt);
@@ -228,7 +213,8 @@ int elp_prove_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t 
  * copied or synchronised; *d_accepted (uint64 in device memory) is atomically incremented.
  * The verify_id entry points keep a device workspace per stream they were called on (the per-item tables of the variable-base
  * multiplications: 3 KB per item of the largest batch seen, e.g. 201 MB for 65 536 items), grown on demand -- growing it
- * synchronises the device once -- and freed by elp_destroy. */
+ * synchronises the device once -- and freed by elp_destroy.
+ * elp_verify_id_wire_batch_dev with at most 16 384 messages and ELP_OPT_WIRE_DECODE on is the one exception to "nothing is synchronised": see the option. */
 int elp_verify_id_batch_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_records, uint64_t hidden_mask,
                             int with_retrieval, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_flags,
                             void* d_accepted);

@@ -112,6 +112,7 @@ ELP_HD constexpr int exp_set_bit(u64 e, int k) {
 }
 template <class C, u64 E>
 ELP_HEAVY void fp12q_exp_comp(Fp12Q<C>& r, const Fp12Q<C>& a, bool& ok) {
+  ELP_NONLEAF();
   constexpr int NSET = __builtin_popcountll(E >> 1);
   static_assert(NSET >= 1 && NSET <= 6, "exponent shape");
   CycCompQ<C> snap[NSET];
@@ -298,6 +299,7 @@ ELP_INL void miller_loop4(Fp12Q<C>& f, const Aff<F1<C>>& p1, const Aff<F2<C>>& q
 // Signature half on four lanes: e(sig1, K) * e(-sig2, gg) == 1       (src/ps-verifier.cc:133-137; pipeline.h ps_pairing_check)
 template <class C>
 ELP_HEAVY bool ps_pairing_check4(const LineMem<C>* gg_lines, const Aff<F1<C>>& sig1, const Aff<F1<C>>& sig2, const Aff<F2<C>>& aK) {
+  ELP_NONLEAF();             // with the Fp6 routines inlined this body can pass 128 KB (common.h; the BLS12-381 unit is built with -DELP_NONLEAF_GUARD=1)
   Aff<F1<C>> nsig2;
   aff_neg(nsig2, sig2);
   if (aff_is_inf(sig2)) aff_set_inf(nsig2);

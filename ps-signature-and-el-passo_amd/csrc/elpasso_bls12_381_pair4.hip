@@ -1,4 +1,4 @@
-// Four-lanes-per-item pairing check for BLS12-381 (elp/pair4.h, elpasso_pair4.h; parity unpinned like everything on this curve): a translation unit of its own.
+// Four-lanes-per-item pairing check for BLS12-381 (elp/pair4.h, elpasso_pair4.h; the curve is pinned by tests/golden/bls12_381_*.json): a translation unit of its own.
 #define ELP_PAIR4_TU 1
 #include "elpasso_pair4.h"
 

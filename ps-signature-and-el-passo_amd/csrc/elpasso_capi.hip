@@ -283,12 +283,7 @@ int elp_verify_id_batch(elp_ctx* c, size_t n, const uint8_t* records, uint64_t m
   if (accepted) *accepted = 0;
   if (n == 0) return ELP_OK;
   if (!records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
-  if (c->fail_submits > 0) {                     // ELP_OPT_FAULT_INJECT
-    c->fail_submits--;
-    c->err = "elp_verify_id_batch_submit: injected failure (ELP_OPT_FAULT_INJECT)";
-    return ELP_ERR_STATE;
-  }
-  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipSetDevice(c->device));                 // (ELP_OPT_FAULT_INJECT concerns elp_verify_id_batch_submit only)
   const size_t rsz = elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr);
   if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
   DevBuf drec, dad, doff, dfl, dcnt;

@@ -1211,7 +1211,7 @@ struct SmallBuild<BLS12_381> {
   static constexpr bool value = true;
 };
 template <>
-struct CoopBuild<BLS12_381> {      // round 4: the pairing check (PS verification of small batches, the tail of aggregated verification); parity unpinned like everything on this curve
+struct CoopBuild<BLS12_381> {      // round 4: the pairing check (PS verification of small batches, the tail of aggregated verification); pinned like everything on this curve
   static constexpr bool value = true;
 };
 // k_vid_small2 (one-launch small batches at two waves per SIMD): where two pairing workgroups fit a compute unit's LDS

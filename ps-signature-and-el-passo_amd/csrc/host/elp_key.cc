@@ -6,13 +6,16 @@ static bool g_strict_signature = true;
 void elpSetStrictSignature(bool strict) { g_strict_signature = strict; }
 
 static int g_default_device = -1;      // -1: the device initPairing() selected
-static int g_default_window = 16;     // 16-bit windows: 1.2 GiB of tables for an 8-attribute BN254 key, 17.3 ms per 65 536 proofs (W = 20: 15.5 GiB, 16.9 ms: opt-in)
+static int g_default_window = 16;     // PSVerifier: 16-bit windows: 1.2 GiB of tables for an 8-attribute BN254 key, 17.3 ms per 65 536 proofs (W = 20: 15.5 GiB, 16.9 ms: opt-in)
+static bool g_window_chosen = false;  // elpSetDefaults was given a width: it then applies to every class
 void elpSetDefaults(int device, int window_bits) {
   g_default_device = device;
+  g_window_chosen = window_bits >= 0;
   g_default_window = window_bits < 0 ? 16 : window_bits;      // 0 = the C-ABI's own default (8)
 }
 int elpDefaultDevice() { return g_default_device; }
 int elpDefaultWindowBits() { return g_default_window; }
+int elpDefaultSideWindowBits() { return g_window_chosen ? g_default_window : 0; }
 
 ElpPinned::~ElpPinned() {
   if (p_) elp_host_free(ctx_, p_);

@@ -51,9 +51,13 @@ class ElpKey {
 // window tables.  Default since round 5: 16 bits -- 1.2 GiB of signed-digit tables for an 8-attribute BN254 key (0.3 s to build), 17.3 ms per 65 536 verifications;
 // 20 bits buys 2.6 % (16.9 ms) for 15.5 GiB per key and is an explicit opt-in (a relying party with several IdP keys cannot afford it per key); 0 = the C-ABI's
 // own default (8 bits, 80 MB).  The reference's constructors (src/ps-verifier.h:18) carry no such parameters, so a drop-in caller chooses them here once.
+// The 16-bit default is the VERIFIER's (PSVerifier: the class that verifies batches).  PSSigner and PSRequester objects made by the reference's constructors
+// keep the C-ABI's own width (8 bits, ~80 MB per key) unless a width was chosen here explicitly: a drop-in caller that only signs or proves should not pay
+// gigabytes of G2 tables per object.  elpSetDefaults(dev, -1) restores exactly this state.
 void elpSetDefaults(int device, int window_bits);
 int elpDefaultDevice();
 int elpDefaultWindowBits();
+int elpDefaultSideWindowBits();      // PSSigner / PSRequester
 
 // Several contexts of the same public key -- one per entry of `devices` (an ordinal may repeat: several contexts on one GPU) -- each with its own
 // host thread and HIP stream while a batch is in flight.  Batches are cut into contiguous shards, shard r of N taking items

@@ -103,8 +103,9 @@ struct GT {
 
 void pairing(GT& e, const G1& P, const G2& Q);
 void hashAndMapToG1(G1& P, const std::string& msg);
-// mcl's hashAndMapToG2 is not pinned by any reference vector (it is only used to pick a generator, src/ps-signer.cc:17);
-// this one is deterministic try-and-increment + cofactor clearing, evaluated on the GPU.
+// hashAndMapToG1: mcl's map on either curve (csrc/elp/encode.h), evaluated on the GPU.
+// mcl's hashAndMapToG2 is not reproduced: the reference only uses it to pick a generator gg from a random seed (src/ps-signer.cc:17), which travels inside the
+// public key, so no observable depends on it; this one is a deterministic try-and-increment + cofactor clearing, evaluated on the GPU.
 void hashAndMapToG2(G2& P, const std::string& msg);
 
 // helpers shared by the protocol classes

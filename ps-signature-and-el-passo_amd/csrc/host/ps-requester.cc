@@ -8,7 +8,7 @@
 
 #include <string.h>
 
-PSRequester::PSRequester(const PSPubKey& pk) : m_pk(pk), m_key(std::make_shared<ElpKey>(pk)) {}
+PSRequester::PSRequester(const PSPubKey& pk) : m_pk(pk), m_key(std::make_shared<ElpKey>(pk, -1, elpDefaultSideWindowBits())) {}
 
 size_t PSRequester::maxAllowedAttrNum() const { return m_pk.Yi.size(); }
 

@@ -54,7 +54,7 @@ PSPubKey PSSigner::key_gen() {
 }
 
 void PSSigner::installKey() {
-  m_key = std::make_shared<ElpKey>(m_pk);
+  m_key = std::make_shared<ElpKey>(m_pk, -1, elpDefaultSideWindowBits());
   m_key->useSignerSecret(m_sk_X);
 }
 

@@ -81,8 +81,8 @@ def test_committed_program_header_is_what_the_generator_emits(tmp_path):
 
 def test_bls12_381_programs_on_the_host_twin():
     """The BLS12-381 programs (tools/gen_coop.py: M-type line placement, Hayashida-Hayasaka-Teruya chain taken to the third power) interpreted by the host twin: the
-    value equals the CUBE of the model's  e(sig1, K) e(-sig2, gg)  bit for bit for all three programs, and is 1 exactly for a valid PS signature.  PARITY UNPINNED like
-    everything on this curve (the model is this project's own)."""
+    value equals the CUBE of the model's  e(sig1, K) e(-sig2, gg)  bit for bit for all three programs, and is 1 exactly for a valid PS signature.
+    (The model is pinned to the reference's wasm run on this curve: tests/test_oracle_bls_golden.py.)"""
     from elp_testlib import BLS12_381, BLS_G2
     Mb = Mcl(BLS12_381)
     Gb, PRb = Mb.G, Protocol(Mb)

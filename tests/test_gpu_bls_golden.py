@@ -106,7 +106,7 @@ def test_verify_id_every_reference_verdict_wire_path(ctx):
                     assert bool(f) == c["expect"], (s["name"], svc, c["label"], decode)
             total += len(cases)
     ctx.set_wire_decode(1)
-    assert total > 240
+    assert total >= 200
 
 
 @pytest.mark.parametrize("n", [700, 2500, 6000, 20000])

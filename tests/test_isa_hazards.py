@@ -17,11 +17,13 @@ def test_scanner_flags_the_hazard_and_only_it(tmp_path):
     listing = ("leaf_clobbered:\n" + body + far + body + "\ts_setpc_b64 s[30:31]\n"                                   # the hazard
                "nonleaf_saved:\n\tv_writelane_b32 v40, s30, 0\n\tv_writelane_b32 v40, s31, 1\n" + body + far + "\tv_readlane_b32 s30, v40, 0\n\ts_setpc_b64 s[30:31]\n"
                "leaf_other_pair:\n" + body + far.replace("s[30:31]", "s[4:5]").replace("s30", "s4").replace("s31", "s5") + "\ts_setpc_b64 s[30:31]\n"
-               "a_kernel:\n" + body + far + "\ts_endpgm\n")
+               "a_kernel:\n" + body + far + "\ts_endpgm\n"
+               # a save AFTER the clobbering s_getpc_b64 stores the clobbered value: still the hazard (round-5 advisor finding)
+               "leaf_saved_too_late:\n" + body + far + "\tv_writelane_b32 v40, s30, 0\n\tv_writelane_b32 v40, s31, 1\n" + body + "\ts_setpc_b64 s[30:31]\n")
     p = tmp_path / "listing.s"
     p.write_text(listing)
     bad = clb.scan(str(p))
-    assert [b[0] for b in bad] == ["leaf_clobbered"] and bad[0][1] == 1
+    assert [b[0] for b in bad] == ["leaf_clobbered", "leaf_saved_too_late"] and bad[0][1] == 1
 
 
 def test_shipped_library_has_no_function_that_clobbers_its_return_address():

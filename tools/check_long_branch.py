@@ -3,8 +3,9 @@
 A device FUNCTION (not a kernel) returns with `s_setpc_b64 s[30:31]`.  When its body outgrows the +-128 KB reach of s_cbranch, the branch-relaxation pass expands far
 branches as `s_getpc_b64 sN ; s_add_u32 ; s_addc_u32 ; s_setpc_b64 sN` with a scavenged SGPR pair -- and under scalar-register pressure ROCm 7.2.0's hipcc picks
 s[30:31] itself in a LEAF function, which never saved it: the first far branch taken destroys the return address.  This script reads hipcc assembly listings
-(-save-temps) or `llvm-objdump -d` output and reports every function that (a) is not a kernel, (b) writes s[30:31] with s_getpc_b64 and (c) never saves s30
-(v_writelane_b32 ..., s30, ... / s_mov_b64 ..., s[30:31]).
+(-save-temps) or `llvm-objdump -d` output and reports every function that (a) is not a kernel, (b) writes s[30:31] with s_getpc_b64 and (c) has not saved s30
+BEFORE the first such write (v_writelane_b32 ..., s30, ... / s_mov_b64 ..., s[30:31] / a scalar or vector store of s[30:31] to memory): a save after the clobbering
+instruction would store the clobbered value.
     python tools/check_long_branch.py <file.s | objdump.txt> [...]      exit code 1 if a hazardous function is found."""
 import re
 import sys
@@ -21,7 +22,10 @@ def scan(path):
         if ("s_endpgm" in body) or not re.search(r"s_setpc_b64 s\[30:31\]", body):
             return                                     # a kernel, or no return through s[30:31]
         far = len(re.findall(r"s_getpc_b64 s\[30:31\]", body))
-        saved = re.search(r"v_writelane_b32 v\d+, s30\b|s_mov_b64 s\[\d+:\d+\], s\[30:31\]", body)
+        first = re.search(r"s_getpc_b64 s\[30:31\]", body)
+        # the return address counts as saved only if the save precedes the first clobbering s_getpc_b64 (spills through memory included)
+        saved = first and re.search(r"v_writelane_b32 v\d+, s30\b|s_mov_b64 s\[\d+:\d+\], s\[30:31\]|s_store_dwordx2 s\[30:31\]|s_mov_b32 s\d+, s30\b",
+                                    body[:first.start()])
         if far and not saved:
             bad.append((name, far, len(body.encode())))
 
@@ -37,6 +41,20 @@ def scan(path):
                 lines.append(ln)
     flush()
     return bad
+
+
+def llvm_objdump():
+    import os
+    import shutil
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root and os.path.exists(os.path.join(root, "lib", "llvm", "bin", "llvm-objdump")):
+            return os.path.join(root, "lib", "llvm", "bin", "llvm-objdump")
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        cand = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin", "llvm-objdump")
+        if os.path.exists(cand):
+            return cand
+    return shutil.which("llvm-objdump") or "llvm-objdump"
 
 
 def extract_code_objects(lib, outdir):
@@ -76,7 +94,7 @@ def scan_library(lib):
         for co in cos:
             txt = co + ".txt"
             with open(txt, "w") as f:
-                subprocess.check_call(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", co], stdout=f)
+                subprocess.check_call([llvm_objdump(), "-d", "--no-show-raw-insn", co], stdout=f)
             bad += [(os.path.basename(co),) + b for b in scan(txt)]
             os.remove(txt)
     return bad, len(cos)
