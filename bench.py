@@ -129,7 +129,7 @@ def workload_config(args, world):
     A, H, B = args.attrs, args.hidden, args.batch
     return {"workload": "BASELINE.json config %d: batch of %d EL PASSO RP el_passo_verify_id per GPU, %d attributes with %d hidden, id-retrieval, "
                         "curve %s" % (args.config, B, A, H, "BN254 (the reference's actual mcl default; golden-vector pinned)" if args.curve == "bn254"
-                                      else "BLS12-381 (north-star curve; no reference oracle, model-checked)"),
+                                      else "BLS12-381 (north-star curve; pinned by vectors of the reference's own wasm run on this curve, tests/golden/bls12_381_*.json)"),
             "baseline_config": args.config, "batch_per_gpu": B, "attrs": A, "hidden": H, "curve": args.curve.upper(), "window_bits": args.window or 8,
             "parallelism": "independent shards x%d + RCCL count all-reduce" % world}
 
@@ -555,8 +555,9 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "k_verify_id_paired<Paired<BLS12_381>>", "kernel_ms": float(ms.value)},
            "valu_bound": valu_bound(ctx, "verify_id_bls12_381" if (A == 8 and H == 4) else None, window, B, float(ms.value), 392),
-           "note": "BLS12-381 instantiation (14 limbs of 28 bits): parity unpinned -- no reference oracle exists; checked against the big-int model and the "
-                   "C oracle's BLS12-381 build in tests"}
+           "note": "BLS12-381 instantiation (14 limbs of 28 bits).  Parity: the reference's own wasm run on this curve (oracle/wasm_curve.js) produced "
+                   "tests/golden/bls12_381_*.json; model, C oracle, host build of the device code and the GPU reproduce every verdict "
+                   "(tests/test_oracle_bls_golden.py, tests/test_gpu_bls_golden.py); hashAndMapToG1 is mcl's (SHA-512 setHashOf, SvdW, cofactor)"}
     tf = os.path.join(ROOT, "profiles", "hbm_traffic_bls12_381.json")      # per-launch HBM bytes of the round's separate --pmc passes over this kernel
     if os.path.exists(tf):
         try:
@@ -569,7 +570,7 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
         ncore = usable_cores()
         res["cpu_baseline"] = cpu_baseline(wl, ctx, recs, rsz, mask, flags, min(B, max(768, 24 * ncore)), bls=True)
         res["cpu_baseline"]["kind"] = "port"
-        res["cpu_baseline"]["note"] = "parity unpinned: the oracle for this curve is this project's own second implementation, not a reference artefact"
+        res["cpu_baseline"]["note"] = "the C oracle's BLS12-381 build (reference structure), pinned to the reference's wasm run on this curve by tests/test_oracle_bls_golden.py"
     except Exception as e:  # pragma: no cover
         res["cpu_baseline"] = {"error": str(e)}
     ctx.close()
@@ -768,8 +769,76 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     res["prove_id_65536x8attrs"] = {"value": n / (ms * 1e-3), "unit": "proofs/s", "kernel_ms": ms,
                                     "parity_ok": produced == n and int(d_cnt.item()) == n,
                                     "note": "every proof of the batch prover is accepted by the batch verifier"}
+    # the general single-output multi-scalar multiplication (north_star's "Pippenger bucket MSM"; elp_g1_msm_dev, round 6): points and 256-bit scalars resident in HBM
+    try:
+        res.update(msm_lines(ctx, wl, dev, stream, timed))
+    except Exception as e:  # pragma: no cover
+        res["msm_g1"] = {"error": str(e)}
     ctx.close()
     return res
+
+
+def msm_lines(ctx, wl, dev, stream, timed):
+    """secondary.msm_g1_<n>: sum_i k_i P_i over n = 65 536 and 1 048 576 DISTINCT points of G1 with full-width scalars, device buffers, the caller's workspace.
+    Checked through linearity, a size-independent property: MSM(P, k) + MSM(P, k') == MSM(P, k + k' mod r) on the full size, and against the sum of n elp_g1_mul
+    results at 4 096 points."""
+    import numpy as np
+    import torch
+    out = {}
+    R = 0x2523648240000001BA344D8000000007FF9F800000000010A10000000000000D
+    G1 = ctx.G1
+    nmax = 1 << 20
+    rng = np.random.default_rng(20216)
+    # distinct points: P_i = s_i g with 64-bit s_i (made on the GPU in slices through elp_g1_mul)
+    pts = bytearray()
+    for lo in range(0, nmax, 1 << 16):
+        ks = np.zeros((1 << 16, 32), dtype=np.uint8)
+        ks[:, :8] = rng.integers(1, 256, size=(1 << 16, 8), dtype=np.uint8)
+        pts += ctx.g1_mul(bytes(wl.g) * (1 << 16), ks.tobytes())
+    k1 = rng.integers(0, 256, size=(nmax, 32), dtype=np.uint8)
+    k1[:, 31] &= 0x1F                                   # < 2^253 < r
+    k2 = rng.integers(0, 256, size=(nmax, 32), dtype=np.uint8)
+    k2[:, 31] &= 0x1F
+    ksum = bytearray()                                  # k1 + k2 mod r
+    for i0 in range(0, nmax, 1 << 14):
+        for row1, row2 in zip(k1[i0:i0 + (1 << 14)], k2[i0:i0 + (1 << 14)]):
+            ksum += ((int.from_bytes(row1.tobytes(), "little") + int.from_bytes(row2.tobytes(), "little")) % R).to_bytes(32, "little")
+    d_pts = torch.from_numpy(np.frombuffer(bytes(pts), dtype=np.uint8).copy()).to(dev)
+    d_k = [torch.from_numpy(x.reshape(-1).copy()).to(dev) for x in (k1, k2)] + [torch.from_numpy(np.frombuffer(bytes(ksum), dtype=np.uint8).copy()).to(dev)]
+    d_out = torch.zeros(3 * G1, dtype=torch.uint8, device=dev)
+    fm = ctypes.c_float()
+    lanes, iters = 256 * 4 * 64 * 8, 1000
+    ctx._chk(ctx.lib.elp_bench_fp_mul(ctx.h, lanes, iters, ctypes.byref(fm)))
+    peak = lanes * iters * 2 / (fm.value * 1e-3)
+    for n in (1 << 16, 1 << 20):
+        wsb = ctx.lib.elp_msm_workspace_bytes(ctx.curve, 1, n)
+        d_ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        ms = timed(lambda: ctx._chk(ctx.lib.elp_g1_msm_dev(ctx.h, stream, n, d_pts.data_ptr(), d_k[0].data_ptr(), d_ws.data_ptr(), d_out.data_ptr())))
+        for t in range(3):
+            ctx._chk(ctx.lib.elp_g1_msm_dev(ctx.h, stream, n, d_pts.data_ptr(), d_k[t].data_ptr(), d_ws.data_ptr(), d_out.data_ptr() + t * G1))
+        torch.cuda.synchronize()
+        o = d_out.cpu().numpy().tobytes()
+        lin = ctx.g1_add(o[:G1], o[G1:2 * G1]) == o[2 * G1:] and o[:G1] != bytes(G1)
+        # 32 windows of 8 bits: one mixed addition (11 field products: 7 M + 4 S) per point and window is the bucket phase; the reductions are O(windows x buckets)
+        per_point = 32 * 11
+        ach = per_point * n / (ms * 1e-3)
+        out["msm_g1_%d" % n] = {"value": n / (ms * 1e-3), "unit": "points/s", "ms": ms, "linearity_ok": bool(lin),
+                                "algorithmic_bytes_per_point": G1 + 32, "hbm_GBps": n * (G1 + 32) / (ms * 1e-3) / 1e9,
+                                "valu_bound": {"fp_mul_equivalents_per_point": per_point, "achieved": ach, "fp_mul_peak_per_s": peak, "frac": ach / peak, "unit": "modmul/s",
+                                               "note": "bucket phase only (32 windows x one mixed addition of 11 field products per point); bucket reductions excluded"},
+                                "kernels": "k_msm_prepare -> k_msm_buckets (LDS histogram + counting sort, one workgroup per window and slice of 8 192 points) -> k_msm_reduce -> k_msm_final"}
+    # small case against the plain sum of scalar multiples
+    n = 4096
+    ref = ctx.g1_mul(bytes(pts[:n * G1]), k1[:n].tobytes())
+    acc = ref
+    while len(acc) > G1:                               # pairwise tree of batched additions
+        h = len(acc) // 2
+        acc = ctx.g1_add(acc[:h], acc[h:])
+    d_ws = torch.zeros(ctx.lib.elp_msm_workspace_bytes(ctx.curve, 1, n), dtype=torch.uint8, device=dev)
+    ctx._chk(ctx.lib.elp_g1_msm_dev(ctx.h, stream, n, d_pts.data_ptr(), d_k[0].data_ptr(), d_ws.data_ptr(), d_out.data_ptr()))
+    torch.cuda.synchronize()
+    out["msm_g1_parity_4096_vs_sum_of_multiples"] = bool(d_out.cpu().numpy().tobytes()[:G1] == acc)
+    return out
 
 
 def host_api(pkg, wl, recs, B, A, H, first, expect, window, device):

@@ -92,12 +92,16 @@ int elp_field_bytes(int curve);               /* F */
  *   (about 3x slower at these sizes): callers who cannot trust their senders to use one pattern should group messages by pattern or set 0.
  * ELP_OPT_AGG_TWO_PER_LANE (default 0; BN254): elp_verify_id_batch_aggregated[_dev] with two proofs on a lane (shared squarings).  1 = on batches that
  *   need fewer rounds of lanes that way, 2 = always (tests).  Off by default: largest private frame of the library (scratch re-provisioning).
+ * ELP_OPT_PAIR16 (round 6; BN254): PS verifications of at most 4 096 items (value > 1: that many) run the pairing check with ONE ITEM PER 16-LANE ROW of a wave --
+ *   12 lanes hold one base-field coefficient each of the Fp12 value, every Fp12-level operation is one inner product per lane over operands published in LDS
+ *   (csrc/elpasso_pair16.h; tools/ubench_row16.hip measured the building blocks at 2.0-2.35 x lower latency than four lanes per item).  0 = the cooperative
+ *   interpreter keeps these sizes.  The library's default is the measured winner (elp_init).
  * ELP_OPT_FAULT_INJECT (default 0; test hook for callers' error paths): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  *   ELP_ERR_STATE before anything is queued.  No other entry point consumes or honours the counter.
  */
 enum { ELP_OPT_STRICT_SIGNATURE = 1, ELP_OPT_PAIRED_LAYOUT = 2, ELP_OPT_TABLE_WORKSPACE = 3, ELP_OPT_SPLIT_PHASES = 4, ELP_OPT_SUBGROUP_CHECK = 5,
        ELP_OPT_COOP_PAIRING = 6, ELP_OPT_COALESCED_RECORDS = 7, ELP_OPT_STREAM_OVERLAP = 8, ELP_OPT_FAULT_INJECT = 9, ELP_OPT_PAIR4 = 10, ELP_OPT_WIRE_DECODE = 11,
-       ELP_OPT_AGG_TWO_PER_LANE = 12 };
+       ELP_OPT_AGG_TWO_PER_LANE = 12, ELP_OPT_PAIR16 = 13 };
 int elp_set_option(elp_ctx* ctx, int option, int value);
 const char* elp_version(void);
 
@@ -134,6 +138,13 @@ int elp_g2_msm_fixed(elp_ctx* ctx, size_t n, int nterms, const int32_t* base_ids
  * it (mcl's mulVec is unused there); it is the general MSM operator and the building block of aggregated verification. */
 int elp_g1_msm(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
 int elp_g2_msm(elp_ctx* ctx, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out);
+/* The same multi-scalar multiplication over DEVICE buffers, asynchronous on `stream` (hipStream_t; NULL = default stream): d_points n affine std points, d_scalars
+ * n x 32 bytes, d_out one affine std point, d_workspace elp_msm_workspace_bytes(curve, group, n) bytes of device memory owned by the caller (group 1 = G1, 2 = G2)
+ * and untouched by others until the result is complete.  Nothing is copied or synchronised.  A point that is not on the curve contributes nothing (the host-buffer
+ * entry points report it as ELP_ERR_POINT; here the caller validates). */
+size_t elp_msm_workspace_bytes(int curve, int group, size_t n);
+int elp_g1_msm_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
+int elp_g2_msm_dev(elp_ctx* ctx, void* stream, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
 /* hashAndMapToG1 (src/ps-verifier.cc:94,186; src/ps-requester.cc:185,336) as mcl evaluates it: Fp::setHashOf (SHA-256 on BN254, SHA-512 on BLS12-381),
  * the Shallue-van de Woestijne map, and on BLS12-381 the cofactor (z-1)^2/3; pinned on both curves by reference-made proofs. msgs concatenated, offsets[n+1]. */
 int elp_hash_to_g1(elp_ctx* ctx, size_t n, const uint8_t* msgs, const uint32_t* offsets, uint8_t* out);
@@ -164,6 +175,12 @@ int elp_verify_id_batch(elp_ctx* ctx, size_t n, const uint8_t* records, uint64_t
 int elp_verify_id_batch_submit(elp_ctx* ctx, int slot, size_t n, const uint8_t* records, uint64_t hidden_mask, int with_retrieval, const uint8_t* ad,
                                const uint32_t* ad_off, size_t ad_len, uint8_t* flags);
 int elp_verify_id_batch_wait(elp_ctx* ctx, int slot, uint64_t* accepted);
+/* Records handed over IN PARTS (round 6): a caller that packs a batch chunk by chunk (PSVerifier::el_passo_verify_id_batch: packing + attribute hashing on host threads)
+ * stages every chunk as soon as it is packed -- the copy of records [first, first + count) of a batch of n_total records of record_size bytes is queued on the context's
+ * copy stream and the call returns --, so that the records cross PCIe while the next chunk is being packed; elp_verify_id_batch_submit with records == NULL then
+ * launches over what was staged (exactly n_total records must have been delivered; parts may arrive in any order, each byte once).  The parts must stay untouched
+ * until _wait returns and should be page-locked (elp_host_alloc).  n_total x record_size must not grow between the first part and the submit. */
+int elp_verify_id_batch_stage(elp_ctx* ctx, int slot, size_t n_total, size_t record_size, size_t first, size_t count, const uint8_t* records_part);
 /* The same verification straight from the reference's wire messages: msgs = concatenated IdProof::toBufferString() bytes
  * (src/ps-encoding.cc:451-467; base64 already removed), message i = msgs[msg_off[i] .. msg_off[i+1]).  T-L-V parsing, point
  * decompression (G?::deserialize, src/ps-encoding.cc:192,224) and Fr::setHashOf of the revealed attributes

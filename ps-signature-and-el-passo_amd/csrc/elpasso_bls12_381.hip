@@ -24,6 +24,8 @@ template int elp_bench_op_t<BLS12_381>(elp_ctx* c, int op, size_t lanes, int ite
 template int elp_bench_fp_mul_t<BLS12_381>(elp_ctx* c, size_t lanes, int iters, float* ms);
 template int msm_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
 template int msm_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+template int msm_dev_t<BLS12_381, 1>(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
+template int msm_dev_t<BLS12_381, 2>(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
 template int elp_verify_id_batch_aggregated_dev_t<BLS12_381>(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, const uint8_t* seed32, void* d_flags, void* d_accepted);
 template int elp_prove_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_proofs, void* d_flags, void* d_accepted);
 template int elp_request_id_batch_dev_t<BLS12_381>(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, const void* d_ad, const void* d_ad_off, size_t ad_len, void* d_requests);

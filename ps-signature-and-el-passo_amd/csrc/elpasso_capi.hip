@@ -7,6 +7,10 @@ extern template int msm_impl_t<BN254, 1>(elp_ctx* c, size_t n, const uint8_t* pt
 extern template int msm_impl_t<BN254, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
 extern template int msm_impl_t<BLS12_381, 1>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
 extern template int msm_impl_t<BLS12_381, 2>(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out);
+extern template int msm_dev_t<BN254, 1>(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
+extern template int msm_dev_t<BN254, 2>(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
+extern template int msm_dev_t<BLS12_381, 1>(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
+extern template int msm_dev_t<BLS12_381, 2>(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out);
 extern template int elp_set_pubkey_t<BN254>(elp_ctx* c, int nattr, const uint8_t* g, const uint8_t* gg, const uint8_t* XX, const uint8_t* Yi, const uint8_t* YYi, int window_bits);
 extern template int elp_set_rp_t<BN254>(elp_ctx* c, const uint8_t* service_name, size_t service_len, const uint8_t* authority_pk, const uint8_t* g, const uint8_t* h);
 extern template int elp_set_signer_secret_t<BN254>(elp_ctx* c, const uint8_t* X);
@@ -55,6 +59,11 @@ extern template int elp_bench_op_t<BLS12_381>(elp_ctx* c, int op, size_t lanes, 
 extern template int elp_bench_fp_mul_t<BLS12_381>(elp_ctx* c, size_t lanes, int iters, float* ms);
 
 
+// ELP_OPT_PAIR16 default (elp_init): 0 until the row-of-16 check is the measured winner for small PS batches
+#ifndef ELP_PAIR16_DEFAULT
+#define ELP_PAIR16_DEFAULT 0
+#endif
+
 // (definitions below get C linkage from their declarations in include/elpasso.h)
 
 const char* elp_version(void) { return "elpasso-hip 0.1 (gfx950)"; }
@@ -91,6 +100,8 @@ int elp_init(int curve, int device, elp_ctx** out) {
   if (const char* e = getenv("ELP_OVERLAP")) c->overlap = atoi(e) != 0;                                                   // A/B runs: second-stream overlap inside a call
   if (const char* e = getenv("ELP_STAGE")) c->stage_records = atoi(e) != 0;                                              // A/B runs: coalesced record loads
   if (const char* e = getenv("ELP_COOP")) c->coop = atoi(e) != 0;                                                      // A/B runs: cooperative pairing for small batches                                            // A/B runs: one fused kernel per verification
+  c->pair16 = ELP_PAIR16_DEFAULT;
+  if (const char* e = getenv("ELP_PAIR16")) c->pair16 = atoi(e) != 0;                                                  // A/B runs: the row-of-16 pairing check for small PS batches
   if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->simds = 4 * prop.multiProcessorCount;
@@ -136,6 +147,7 @@ void elp_destroy(elp_ctx* c) {
   if (c->coop_consts) (void)hipFree(c->coop_consts);
   for (auto& e : c->wire_ws)
     if (e.p) (void)hipFree(e.p);
+  if (c->wire_mask_host) (void)hipHostFree(c->wire_mask_host);
   if (c->jstream) (void)hipStreamDestroy(c->jstream);
   for (int i = 0; i < 4; i++)
     if (c->jev[i]) (void)hipEventDestroy(c->jev[i]);
@@ -171,6 +183,11 @@ int elp_set_option(elp_ctx* c, int option, int value) {
     case ELP_OPT_PAIR4:
       if (value < 0 || value > 2) return ELP_ERR_ARG;
       c->pair4 = value;
+      return ELP_OK;
+    case ELP_OPT_PAIR16:
+      if (value < 0) return ELP_ERR_ARG;
+      c->pair16 = value ? 1 : 0;
+      c->pair16_max = value > 1 ? (size_t)value : 4096;
       return ELP_OK;
     case ELP_OPT_SPLIT_PHASES:
       if (value < 0 || value > 3) return ELP_ERR_ARG;
@@ -338,12 +355,40 @@ static int grow_dev(elp_ctx* c, void** p, size_t* cap, size_t need) {
   *cap = want;
   return ELP_OK;
 }
+// Records of a batch handed over IN PARTS while the caller is still packing the rest (round 6): each call queues the copy of records [first, first + count) into the slot's
+// device buffer on the copy stream and returns; elp_verify_id_batch_submit with records == NULL then launches over what was staged.
+int elp_verify_id_batch_stage(elp_ctx* c, int slot, size_t n_total, size_t record_size, size_t first, size_t count, const uint8_t* records_part) {
+  if (!c || slot < 0 || slot > 1 || n_total == 0 || record_size == 0 || first + count > n_total || (count && !records_part)) return ELP_ERR_ARG;
+  elp_ctx::AsyncSlot& s = c->aslot[slot];
+  if (s.busy) {
+    c->err = "elp_verify_id_batch_stage: the slot has a batch in flight (call elp_verify_id_batch_wait first)";
+    return ELP_ERR_STATE;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
+  if (s.rec_cap < n_total * record_size) {
+    if (s.staged_bytes) {
+      c->err = "elp_verify_id_batch_stage: n_total x record_size grew while parts of the batch were staged";
+      return ELP_ERR_ARG;
+    }
+    int rc = grow_dev(c, &s.drec, &s.rec_cap, n_total * record_size);
+    if (rc) return rc;
+  }
+  if (count) HIPCHK(c, hipMemcpyAsync((uint8_t*)s.drec + first * record_size, records_part, count * record_size, hipMemcpyHostToDevice, c->pstream[0]));
+  s.staged_bytes += count * record_size;
+  return ELP_OK;
+}
 int elp_verify_id_batch_submit(elp_ctx* c, int slot, size_t n, const uint8_t* records, uint64_t mask, int retr, const uint8_t* ad, const uint32_t* ad_off,
                                size_t ad_len, uint8_t* flags) {
   int rc = check_fused(c, mask, need_rp(retr));
   if (rc) return rc;
-  if (slot < 0 || slot > 1 || n == 0 || !records || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
+  if (slot < 0 || slot > 1 || n == 0 || !flags || (!ad && (ad_off ? ad_off[n] : ad_len))) return ELP_ERR_ARG;
   elp_ctx::AsyncSlot& s = c->aslot[slot];
+  if (!records && s.staged_bytes != n * elp_verify_id_record_size(c->curve, c->A, popcount_mask(mask, c->A), retr)) {
+    c->err = "elp_verify_id_batch_submit: records == NULL, but elp_verify_id_batch_stage has not delivered exactly n records";
+    s.staged_bytes = 0;
+    return ELP_ERR_ARG;
+  }
   if (s.busy) {
     c->err = "elp_verify_id_batch_submit: the slot has a batch in flight (call elp_verify_id_batch_wait first)";
     return ELP_ERR_STATE;
@@ -369,7 +414,8 @@ int elp_verify_id_batch_submit(elp_ctx* c, int slot, size_t n, const uint8_t* re
       (ad_off && (rc = grow_dev(c, &s.doff, &s.off_cap, (n + 1) * 4))))
     return rc;
   // copies on the copy stream (they overlap the kernel of the other slot, which runs on the context's stream), then the kernel behind them
-  HIPCHK(c, hipMemcpyAsync(s.drec, records, n * rsz, hipMemcpyHostToDevice, c->pstream[0]));
+  if (records) HIPCHK(c, hipMemcpyAsync(s.drec, records, n * rsz, hipMemcpyHostToDevice, c->pstream[0]));      // NULL: delivered by elp_verify_id_batch_stage
+  s.staged_bytes = 0;
   if (ad_total) HIPCHK(c, hipMemcpyAsync(s.dad, ad, ad_total, hipMemcpyHostToDevice, c->pstream[0]));
   if (ad_off) HIPCHK(c, hipMemcpyAsync(s.doff, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->pstream[0]));
   HIPCHK(c, hipMemsetAsync(s.dcnt, 0, 8, c->pstream[0]));
@@ -577,6 +623,21 @@ int elp_g1_msm(elp_ctx* c, size_t n, const uint8_t* points, const uint8_t* scala
 int elp_g2_msm(elp_ctx* c, size_t n, const uint8_t* points, const uint8_t* scalars, uint8_t* out) {
   if (!c) return ELP_ERR_ARG;
   return c->curve == ELP_CURVE_BN254 ? msm_impl_t<BN254, 2>(c, n, points, scalars, out) : msm_impl_t<BLS12_381, 2>(c, n, points, scalars, out);
+}
+size_t elp_msm_workspace_bytes(int curve, int group, size_t n) {
+  if (group != 1 && group != 2) return 0;
+  if (curve == ELP_CURVE_BLS12_381) return group == 1 ? msm_ws_bytes<BLS12_381, 1>(n) : msm_ws_bytes<BLS12_381, 2>(n);
+  return group == 1 ? msm_ws_bytes<BN254, 1>(n) : msm_ws_bytes<BN254, 2>(n);
+}
+int elp_g1_msm_dev(elp_ctx* c, void* stream, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? msm_dev_t<BN254, 1>(c, stream, n, d_points, d_scalars, d_workspace, d_out)
+                                     : msm_dev_t<BLS12_381, 1>(c, stream, n, d_points, d_scalars, d_workspace, d_out);
+}
+int elp_g2_msm_dev(elp_ctx* c, void* stream, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out) {
+  if (!c) return ELP_ERR_ARG;
+  return c->curve == ELP_CURVE_BN254 ? msm_dev_t<BN254, 2>(c, stream, n, d_points, d_scalars, d_workspace, d_out)
+                                     : msm_dev_t<BLS12_381, 2>(c, stream, n, d_points, d_scalars, d_workspace, d_out);
 }
 
 int elp_verify_id_batch_aggregated_dev(elp_ctx* c, void* stream, size_t n, const void* d_records, uint64_t mask, int retr, const void* d_ad,

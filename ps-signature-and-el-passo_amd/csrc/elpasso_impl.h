@@ -1969,12 +1969,16 @@ struct elp_ctx {
     hipEvent_t copied = nullptr, done = nullptr;
     uint64_t* h_cnt = nullptr;
     bool busy = false;
+    size_t staged_bytes = 0;      // record bytes delivered by elp_verify_id_batch_stage for the next submit of the slot
   };
   AsyncSlot aslot[2];
   int fail_submits = 0;          // ELP_OPT_FAULT_INJECT
   int mid_two_launches = 0;      // experiments (ELP_PAIR4_TWO_LAUNCHES=1): the mid-size path as k_vid_nizk4 then k_pair4 instead of the one launch k_vid_mid
+  unsigned long long* wire_mask_host = nullptr;      // page-locked slot for the decoded wire path's 16-byte read-back
   int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
   int agg_two = 0;            // ELP_OPT_AGG_TWO_PER_LANE: aggregated batches put two items on a lane (0 = never -- the default: 2 % at best, and the kernel's larger frame makes the runtime re-provision scratch --, 1 = where it saves rounds of lanes, 2 = always)
+  int pair16 = 0;                // ELP_OPT_PAIR16 (set by elp_init): PS verifications of at most pair16_max items run the pairing check on one 16-lane row per item
+  size_t pair16_max = 4096;
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
@@ -2580,6 +2584,21 @@ static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, cons
   hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
 }
 
+// elp_g1_msm_dev / elp_g2_msm_dev: the same launch sequence over the caller's device buffers and workspace, asynchronous on the caller's stream
+template <class C, int G>
+int msm_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out) {
+  if (!c || !d_out || (n && (!d_points || !d_scalars || !d_workspace))) return ELP_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) {
+    HIPCHK(c, hipMemsetAsync(d_out, 0, G == 1 ? Sizes<C>::G1 : Sizes<C>::G2, stream));
+    return ELP_OK;
+  }
+  msm_launch<C, G>(stream, n, d_points, d_scalars, d_out, (uint8_t*)d_workspace);
+  HIPCHK(c, hipGetLastError());
+  return ELP_OK;
+}
+
 // Which curves have the paired kernels in this build (their own translation unit, elpasso_<curve>_pair.hip).
 template <class B>
 struct PairedBuild {
@@ -2852,6 +2871,22 @@ extern template void launch_vid_mid<BN254>(hipStream_t stream, const KeyCtx<BN25
 extern template void launch_vid_mid<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, const void* pre);
 extern template void launch_pair4<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 extern template void launch_pair4<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
+#endif
+// the pairing check with ONE ITEM PER 16-LANE ROW (round 6; elpasso_pair16.h, translation unit elpasso_bn254_pair16.hip): 12 lanes hold one base-field coefficient each
+// of the Fp12 value, every operation is one inner product per lane over operands published in LDS; reads K and `todo` like launch_pair4
+template <class B>
+struct Pair16Build {
+  static constexpr bool value = false;
+};
+template <>
+struct Pair16Build<BN254> {
+  static constexpr bool value = true;
+};
+template <class B>
+void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
+                   void* d_accepted);
+#ifndef ELP_PAIR16_TU
+extern template void launch_pair16<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 #endif
 // batch sizes served by the four-lane pairing check by default (ELP_OPT_PAIR4 = 1), from the A/B sweeps of profiles/r05_four_lane.md: up to 16 384 items the quads
 // of a batch run ONE wave per SIMD (256 workgroups of 64 items); el_passo_verify_id from 3 073 items (below, the interpreter's one launch is as fast or faster:
@@ -3141,9 +3176,12 @@ int elp_verify_id_wire_batch_dev_t(elp_ctx* c, void* stream, size_t n, const voi
       HIPCHK(c, hipMemsetAsync(agg + 1, 0, 8, st));
       hipLaunchKernelGGL((k_wire_decode<C>), dim3(grid_for(n) * WIRE_DECODE_JOBS), dim3(ELP_BLOCK), 0, st, c->A, (const uint8_t*)d_msgs, (const u32*)d_msg_off, retr, recs, words,
                          okj, agg, n);
-      unsigned long long h[2] = {0, 1};
+      if (!c->wire_mask_host) HIPCHK(c, hipHostMalloc((void**)&c->wire_mask_host, 16, hipHostMallocDefault));      // page-locked: the read-back is one DMA, not a staged copy
+      unsigned long long* const h = c->wire_mask_host;
+      h[0] = 0;
+      h[1] = 1;
       HIPCHK(c, hipMemcpyAsync(h, agg, 16, hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipStreamSynchronize(st));
+      HIPCHK(c, hipStreamSynchronize(st));      // the ONE synchronisation of this entry point (include/elpasso.h ELP_OPT_WIRE_DECODE)
       if (h[0] == h[1]) {          // one hidden pattern (a batch without a single well-formed message leaves ~0 != 0)
         rc = elp_verify_id_batch_dev_t<C>(c, stream, n, recs, (uint64_t)h[0], retr, d_ad, d_ad_off, ad_len, verdict, nullptr);
         if (rc) return rc;
@@ -3197,7 +3235,12 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         HIPCHK(c, hipMemsetAsync(done, 0, lanes, (hipStream_t)stream));
         const int words = 4 * C::N + 8 * nattr;
         launch_ps_k<C>((hipStream_t)stream, key, n, d_records, words, nattr, todo, kws, lanes);
-        if (mid)
+        bool row16 = false;
+        if constexpr (Pair16Build<C>::value) row16 = c->pair16 != 0 && !mid && n <= c->pair16_max;
+        if (row16) {
+          if constexpr (Pair16Build<C>::value)
+            launch_pair16<C>((hipStream_t)stream, key.gg_lines, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, d_accepted);
+        } else if (mid)
           launch_pair4<C>((hipStream_t)stream, key.gg_lines, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, d_accepted);
         else
           launch_pair_coop<C>((hipStream_t)stream, key, consts, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, done, d_accepted, nullptr);

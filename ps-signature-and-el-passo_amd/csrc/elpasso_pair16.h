@@ -1,0 +1,243 @@
+// Kernel of the pairing check with ONE ITEM PER 16-LANE ROW of a wave (round 6): included by the translation unit elpasso_bn254_pair16.hip only.
+//
+// Replaces, for small batches of PS verifications, the same  pairing() + GT==  of src/ps-verifier.cc:31-34 as the other layouts:  e(sig1, K) e(-sig2, gg) == 1.
+// Twelve of the sixteen lanes of a row hold one base-field coefficient each of the Fp12 value f = sum_k f_k w^k (lane q = 2k + c).  The whole check is a flat PROGRAM
+// of 691 steps (tools/gen_row16.py -> elpasso_pair16_prog.h, generated and SIMULATED against the big-int model there): in every step each lane evaluates ONE inner
+// product  sum_t coeff_t * slot[a_t] * slot[b_t]  with a single Montgomery reduction (quad.h fp_dot) over operands that live in the row's LDS slots -- lane-dependent
+// addresses and small integer coefficients from a table, one instruction stream for all lanes, no interpretation of operations: sums, xi-multiples, conjugations and the
+// constant of the twist were expanded symbolically into the terms by the generator.  An Fp12 product is one step of twelve terms per lane (3.5 us for a lone wave
+// against 7.5 us on four lanes per item, tools/ubench_row16.hip), a Granger-Scott squaring one step of four.
+// A workgroup is one wave = four items; all exchanges go through LDS, the barriers are wave-local.
+#pragma once
+#include "elpasso_impl.h"
+#include "elp/quad.h"
+#define ROW16_DEV __constant__
+#include "elpasso_pair16_prog.h"
+
+namespace elp {
+
+constexpr int R16_NL = BN254::NL;
+constexpr int R16_NLP = (R16_NL + 3) & ~3;                           // limbs of a slot padded to 16-byte words
+constexpr int R16_REG0 = row16::NSLOT;                               // the stored Fp12 values ("registers" of the program) follow the generator's slots
+constexpr int R16_ROW_SLOTS = row16::NSLOT + 12 * row16::NREG;
+constexpr int R16_ROWS = 4;
+constexpr int R16_LDS_WORDS = (R16_ROWS * R16_ROW_SLOTS + row16::NCONST) * R16_NLP;
+
+typedef BN254 R16C;
+
+ELP_INL Fp<R16C> r16_ld(const i32* L, const i32* K, int s) {         // slot s of the row (below CONST_BASE) or of the shared constants
+  const i32* p = s < row16::CONST_BASE ? L + s * R16_NLP : K + (s - row16::CONST_BASE) * R16_NLP;
+  Fp<R16C> r;
+  ELP_UNROLL
+  for (int i = 0; i < R16_NL; i++) r.v[i] = p[i];
+  return r;
+}
+ELP_INL Fp<R16C> r16_ld_row(const i32* L, int s) {                    // a slot of the row by its index, whatever the index (the stored values sit above CONST_BASE)
+  Fp<R16C> r;
+  ELP_UNROLL
+  for (int i = 0; i < R16_NL; i++) r.v[i] = L[s * R16_NLP + i];
+  return r;
+}
+ELP_INL void r16_st(i32* L, int s, const Fp<R16C>& a) {
+  ELP_UNROLL
+  for (int i = 0; i < R16_NL; i++) L[s * R16_NLP + i] = a.v[i];
+}
+ELP_INL Fp<R16C> r16_pair_swap(const Fp<R16C>& a) {                  // the other component of the lane's Fp2 coefficient: DPP quad_perm [1,0,3,2]
+#if defined(__HIP_DEVICE_COMPILE__)
+  Fp<R16C> r;
+  ELP_UNROLL
+  for (int i = 0; i < R16_NL; i++) r.v[i] = __builtin_amdgcn_update_dpp(0, a.v[i], 0xB1, 0xF, 0xF, true);
+  return r;
+#else
+  return a;                                                          // (the host pass only parses the kernel)
+#endif
+}
+template <int NT>
+ELP_INL Fp<R16C> r16_dot(const i32* L, const i32* K, const u32 (&tb)[12]) {
+  Fp<R16C> a[NT], b[NT];
+  ELP_UNROLL
+  for (int t = 0; t < NT; t++) {
+    a[t] = r16_ld(L, K, (int)(tb[t] & 0xFF));
+    b[t] = r16_ld(L, K, (int)((tb[t] >> 8) & 0xFF));
+    const i32 cf = (i32)(tb[t] << 8) >> 24;                          // the signed 8-bit coefficient: +-1, 2, 3, 4, 6, 12
+    ELP_UNROLL
+    for (int i = 0; i < R16_NL; i++) b[t].v[i] *= cf;
+  }
+  return fp_dot<R16C, NT>(a, b);
+}
+
+// flags[i] = todo[i] && sig1, sig2 decode && e(sig1, K) e(-sig2, gg) == 1 for items [4 blockIdx.x, 4 blockIdx.x + 4): one per row
+__global__ void __launch_bounds__(64, 1) k_pair16(const LineMem<R16C>* gg_lines, const u32* recs, int rec_words, const uint8_t* todo, const u32* kws, size_t kstride,
+                                                  uint8_t* flags, unsigned long long* accepted, size_t n, int dbg_pc = -1, i32* dbg = nullptr) {      // dbg: tools/pair16_check.hip
+  __shared__ __attribute__((aligned(16))) i32 lds[R16_LDS_WORDS];
+  const int row = (int)(threadIdx.x >> 4), q = (int)(threadIdx.x & 15), c = q & 1;
+  i32* const L = lds + row * R16_ROW_SLOTS * R16_NLP;
+  i32* const K = lds + R16_ROWS * R16_ROW_SLOTS * R16_NLP;
+  const size_t item0 = (size_t)blockIdx.x * R16_ROWS + row;
+  const bool in_range = item0 < n;
+  const size_t i = in_range ? item0 : n - 1;                       // rows beyond the batch walk the program on a copy of the last item and publish nothing
+  // ---- set-up: constants, zeroed slots, the item's points
+  for (int s = (int)threadIdx.x; s < row16::NCONST; s += 64) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = row16::CONSTS[s][w];
+  }
+  for (int s = q; s < R16_ROW_SLOTS; s += 16) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NLP; w++) L[s * R16_NLP + w] = 0;
+  }
+  __syncthreads();
+  bool ok_in = todo[i] != 0;
+  bool live1 = false, live2 = false;
+  {
+    const u32* rec = recs + i * (size_t)rec_words;
+    // lane 0: sig1 -> P1, lane 1: sig2 -> P2 = (x, -y) (decoded and checked by the lane: range, on the curve); lanes 4..7: the four base-field words of K from the
+    // launch workspace (pipeline.h vid_store_k: word w of the plain-layout Aff<F2> at kws[w * kstride + i]) -> T.X, T.Y and Q; T.Z = 1; f = 1
+    bool ok_pt = true, inf_pt = false;
+    if (q < 2) {
+      Aff<F1<R16C>> pt;
+      ok_pt = g1_load<R16C>(pt, rec + q * 2 * R16C::N);
+      inf_pt = ok_pt && aff_is_inf(pt);
+      if (q == 1) pt.y = fp_neg(pt.y);
+      r16_st(L, (q == 0 ? row16::SLOT_P1 : row16::SLOT_P2), pt.x);
+      r16_st(L, (q == 0 ? row16::SLOT_P1 : row16::SLOT_P2) + 1, pt.y);
+    }
+    bool k_zero = true;
+    if (q >= 4 && q < 8) {
+      Fp<R16C> v;
+      u32 any = 0;
+      ELP_UNROLL
+      for (int w = 0; w < R16_NL; w++) {
+        v.v[w] = (i32)kws[(size_t)((q - 4) * R16_NL + w) * kstride + i];
+        any |= (u32)v.v[w];
+      }
+      k_zero = any == 0;
+      r16_st(L, row16::SLOT_T + (q - 4), v);
+      r16_st(L, row16::SLOT_Q + (q - 4), v);
+    }
+    if (q == 8) {
+      const Fp<R16C> one = r16_ld(L, K, row16::SLOT_ONE);
+      r16_st(L, row16::SLOT_T + 4, one);
+      r16_st(L, row16::SLOT_W0, one);
+      r16_st(L, row16::SLOT_X0, one);                                // xi * 1 = 1 + i
+      r16_st(L, row16::SLOT_X0 + 1, one);
+    }
+    if (q >= 12) r16_st(L, row16::SLOT_E + (q - 12), r16_ld(L, K, row16::CONST_E_INIT + (q - 12)));      // E = 3 b', E3 = 9 b' for Z = 1
+    // the row's verdict on its inputs and which pairs take part: ballots over the wave, this row's 16 bits
+    const unsigned long long b_bad = __ballot(!ok_pt), b_inf = __ballot(inf_pt), b_kz = __ballot(!k_zero);
+    const unsigned sh = 16u * (unsigned)row;
+    const unsigned bad = (unsigned)(b_bad >> sh) & 0x3u, inf = (unsigned)(b_inf >> sh) & 0x3u, knz = (unsigned)(b_kz >> sh) & 0xF0u;
+    ok_in = ok_in && bad == 0;
+    live1 = !(inf & 1u) && knz != 0;                                 // e(O, K) = e(sig1, O) = 1
+    live2 = !(inf & 2u);
+  }
+  __syncthreads();
+  // ---- the program
+  u32 tb[12];
+  u32 e = row16::PROG[0];
+  {
+    const int sid = (int)(e >> 8) & 0xFF;
+    ELP_UNROLL
+    for (int t = 0; t < 12; t++) tb[t] = (e & 0xFF) == 0 ? row16::STEP_TERMS[sid][q][t] : 0u;
+  }
+  bool verdict = false;
+  ELP_NOUNROLL
+  for (int pc = 0; pc < row16::NPROG; pc++) {
+    const u32 e_next = pc + 1 < row16::NPROG ? row16::PROG[pc + 1] : 5u;
+    u32 tb_next[12];
+    {                                                               // the table of the NEXT dot step travels while this step computes
+      const int sidn = (int)(e_next >> 8) & 0xFF;
+      const bool dotn = (e_next & 0xFF) == 0;
+      ELP_UNROLL
+      for (int t = 0; t < 12; t++) tb_next[t] = dotn ? row16::STEP_TERMS[sidn][q][t] : 0u;
+    }
+    const int op = (int)(e & 0xFF), a0 = (int)(e >> 8) & 0xFF, a1 = (int)(e >> 16) & 0xFF;
+    if (dbg && pc == dbg_pc) {                                      // the state BEFORE entry pc of the program: every slot of every row of workgroup 0
+      if (blockIdx.x == 0)
+        for (int s = (int)threadIdx.x; s < R16_ROWS * R16_ROW_SLOTS * R16_NLP; s += 64) dbg[s] = lds[s];
+      return;
+    }
+    if (op == 0) {
+      const int nt = row16::STEP_NT[a0], fl = row16::STEP_FLAGS[a0];
+      const u32 dst = row16::STEP_DEST[a0][q];
+      Fp<R16C> r;
+      switch (nt) {
+        case 1: r = r16_dot<1>(L, K, tb); break;
+        case 2: r = r16_dot<2>(L, K, tb); break;
+        case 3: r = r16_dot<3>(L, K, tb); break;
+        case 4: r = r16_dot<4>(L, K, tb); break;
+        case 6: r = r16_dot<6>(L, K, tb); break;
+        case 8: r = r16_dot<8>(L, K, tb); break;
+        default: r = r16_dot<12>(L, K, tb); break;
+      }
+      if (dst & (1u << 9)) {                                        // Granger-Scott: 3 * (inner product) +- 2 * (the lane's coefficient), weakly reduced
+        const Fp<R16C> own = r16_ld(L, K, (int)(dst & 0xFF));
+        const i32 s2 = (dst & (1u << 10)) ? 2 : -2;
+        ELP_UNROLL
+        for (int w = 0; w < R16_NL; w++) r.v[w] = 3 * r.v[w] + s2 * own.v[w];
+        fp_carry<R16C>(r);
+        fp_reduce_weak<R16C>(r);
+      }
+      const int tag = fl >> 1;
+      const bool dead = (tag == 1 && !live1) || (tag == 2 && !live2);
+      const bool wr = (dst & (1u << 8)) && !(dead && q < 12);
+      Fp<R16C> xr;
+      if (fl & 1) {                                                 // uniform: the exchange is executed by every lane
+        const Fp<R16C> p = r16_pair_swap(r);
+        xr = c == 0 ? fp_sub<R16C>(r, p) : fp_add<R16C>(p, r);
+      }
+      __syncthreads();
+      if (wr) r16_st(L, (int)(dst & 0xFF), r);
+      if ((fl & 1) && wr && q < 12) r16_st(L, row16::SLOT_X0 + q, xr);
+      __syncthreads();
+    } else if (op == 1) {                                           // the fixed line a0: six base-field values of gg's precomputed line -> LF
+      if (q < 6) r16_st(L, row16::SLOT_LF + q, reinterpret_cast<const Fp<R16C>*>(&gg_lines[a0])[q]);
+      __syncthreads();
+    } else if (op == 2) {                                           // one base-field inversion (lane 0 of the row)
+      const Fp<R16C> x = r16_ld(L, K, a0);
+      const Fp<R16C> y = fp_inv<R16C>(x);
+      if (q == 0) r16_st(L, a1, y);
+      __syncthreads();
+    } else if (op == 3) {                                           // stored value a0 -> W0 (with xi * value -> X0) or W1
+      Fp<R16C> v = r16_ld_row(L, R16_REG0 + 12 * a0 + (q < 12 ? q : 0));
+      const Fp<R16C> p = r16_pair_swap(v);
+      if (q < 12) {
+        if (a1 == 0) {
+          r16_st(L, row16::SLOT_W0 + q, v);
+          r16_st(L, row16::SLOT_X0 + q, c == 0 ? fp_sub<R16C>(v, p) : fp_add<R16C>(p, v));
+        } else {
+          r16_st(L, row16::SLOT_W1 + q, v);
+        }
+      }
+      __syncthreads();
+    } else if (op == 4) {                                           // W0 -> stored value a0
+      if (q < 12) r16_st(L, R16_REG0 + 12 * a0 + q, r16_ld(L, K, row16::SLOT_W0 + q));
+      __syncthreads();
+    } else {                                                        // the result is 1 <=> every coefficient of W0 - 1 is zero modulo p
+      Fp<R16C> v = r16_ld(L, K, row16::SLOT_W0 + (q < 12 ? q : 1));
+      if (q == 0) v = fp_sub<R16C>(v, r16_ld(L, K, row16::SLOT_ONE));
+      const bool z = fp_is_zero<R16C>(v);
+      const unsigned long long bz = __ballot(z);
+      verdict = (((unsigned)(bz >> (16u * (unsigned)row))) & 0xFFFu) == 0xFFFu;
+    }
+    e = e_next;
+    ELP_UNROLL
+    for (int t = 0; t < 12; t++) tb[t] = tb_next[t];
+  }
+  const bool ok = ok_in && verdict && in_range;
+  if (in_range && q == 0) flags[item0] = ok ? 1 : 0;
+  if (accepted) {
+    const unsigned long long b = __ballot(ok && q == 0);
+    if (threadIdx.x == 0 && b != 0) atomicAdd(accepted, (unsigned long long)__popcll(b));
+  }
+}
+
+}  // namespace elp
+
+template <class B>
+void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
+                   void* d_accepted) {
+  static_assert(std::is_same<B, elp::BN254>::value, "generated for BN254");
+  if (n == 0) return;
+  hipLaunchKernelGGL(elp::k_pair16, dim3((unsigned)((n + elp::R16_ROWS - 1) / elp::R16_ROWS)), dim3(64), 0, stream, (const elp::LineMem<elp::BN254>*)gg_lines,
+                     (const u32*)d_records, words, todo, kws, kstride, d_flags, (unsigned long long*)d_accepted, n);
+}

@@ -4,6 +4,8 @@
 // pattern so that one launch covers every proof with the same pattern.
 #include "ps-verifier.h"
 
+#include <atomic>
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -60,8 +62,98 @@ bool PSVerifier::verify(const PSCredential& sig, const std::vector<std::string>&
   return verify_batch({sig}, {all_attributes})[0];
 }
 
+namespace {
+// one record (csrc/elp/pipeline.h verify_id record) from an IdProof; the revealed attributes are hashed here (src/ps-verifier.cc:224)
+inline void packRecord(uint8_t* w, const IdProof& p, bool retr, size_t S1, size_t S2) {
+  auto put = [&](const uint8_t* src, size_t len) {
+    memcpy(w, src, len);
+    w += len;
+  };
+  put(p.sig1.b, S1);
+  put(p.sig2.b, S1);
+  put(p.phi.b, S1);
+  if (retr) {
+    put(p.E1->b, S1);
+    put(p.E2->b, S1);
+  }
+  put(p.k.b, S2);
+  put(p.c.b, 32);
+  for (const Fr& r : p.rs) put(r.b, 32);
+  for (const std::string& a : p.attributes)
+    if (!a.empty()) {
+      Fr m;
+      m.setHashOf(a);
+      put(m.b, 32);
+    }
+}
+}  // namespace
+// The synchronous batch call on ONE context when every proof hides the same attributes (the usual case): host threads pack contiguous ranges of records chunk by
+// chunk -- validating each proof against the pattern of the first one on the way -- and hand every packed chunk to elp_verify_id_batch_stage at once, so that the
+// records cross PCIe while the rest is still being packed and hashed; the kernel is queued behind the last part (round 6: packing + hashing used to run to the
+// end before the first byte was copied).  Returns false -- nothing queued that outlives the call -- when a proof deviates; the caller then takes the grouped path.
+bool PSVerifier::verifyIdStaged(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retr, std::vector<bool>& out) const {
+  const size_t n = proofs.size(), A = m_key->attrs();
+  if (m_set->size() != 1 || n < 4096 || m_stage->slot[0].busy) return false;
+  const IdProof& p0 = proofs[0];
+  if (p0.attributes.size() != A) return false;
+  const uint64_t mask = elpHiddenMask(p0.attributes);
+  const size_t H = (size_t)__builtin_popcountll(mask);
+  if (H < (retr ? 2u : 1u)) return false;
+  const size_t S1 = G1::size(), S2 = G2::size();
+  const size_t rsz = elp_verify_id_record_size(curveId(), (int)A, (int)H, retr ? 1 : 0);
+  elp_ctx* ctx = m_key->ctx();
+  std::vector<uint32_t> adoff(n + 1, 0);
+  for (size_t j = 0; j < n; j++) adoff[j + 1] = adoff[j] + (uint32_t)ads[j].size();
+  uint8_t* const recs = m_stage->recs.get(ctx, n * rsz);
+  uint8_t* const adbuf = m_stage->ads.get(ctx, adoff[n] ? adoff[n] : 1);
+  uint8_t* const flags = m_stage->flags.get(ctx, n);
+  const int slot = 0;
+  elpCheck(ctx, elp_verify_id_batch_stage(ctx, slot, n, rsz, 0, 0, nullptr), "elp_verify_id_batch_stage");      // sizes the device buffer before the workers start
+  std::atomic<bool> deviates{false};
+  std::mutex stage_mu;                                                                                           // the C-ABI takes one call at a time per context
+  std::exception_ptr stage_err;
+  const size_t CHUNK = 1024;      // 52 KB ... 800 KB per part: small enough that the copies start early, large enough that a part is one efficient DMA
+  elpParallelFor(n, CHUNK, [&](size_t lo, size_t hi) {
+    for (size_t c0 = lo; c0 < hi && !deviates.load(std::memory_order_relaxed); c0 += CHUNK) {
+      const size_t c1 = c0 + CHUNK < hi ? c0 + CHUNK : hi;
+      for (size_t j = c0; j < c1; j++) {
+        const IdProof& p = proofs[j];
+        if ((retr && (!p.E1.has_value() || !p.E2.has_value())) || p.attributes.size() != A || p.rs.size() != H + (retr ? 2 : 1) || elpHiddenMask(p.attributes) != mask) {
+          deviates.store(true);
+          return;
+        }
+        packRecord(recs + j * rsz, p, retr, S1, S2);
+        const std::string& ad = ads[j];
+        if (!ad.empty()) memcpy(adbuf + adoff[j], ad.data(), ad.size());
+      }
+      std::lock_guard<std::mutex> g(stage_mu);
+      if (stage_err) return;
+      try {
+        elpCheck(ctx, elp_verify_id_batch_stage(ctx, slot, n, rsz, c0, c1 - c0, recs + c0 * rsz), "elp_verify_id_batch_stage");
+      } catch (...) {
+        stage_err = std::current_exception();
+        return;
+      }
+    }
+  });
+  if (stage_err || deviates.load()) {
+    // drop what was staged: a submit that does not find exactly n records resets the slot's staging (and fails, on purpose)
+    (void)elp_verify_id_batch_submit(ctx, slot, n + 1, nullptr, mask, retr ? 1 : 0, adbuf, adoff.data(), 0, flags);
+    if (stage_err) std::rethrow_exception(stage_err);
+    return false;
+  }
+  elpCheck(ctx, elp_verify_id_batch_submit(ctx, slot, n, nullptr, mask, retr ? 1 : 0, adbuf, adoff.data(), 0, flags), "elp_verify_id_batch_submit");
+  uint64_t acc = 0;
+  elpCheck(ctx, elp_verify_id_batch_wait(ctx, slot, &acc), "elp_verify_id_batch_wait");
+  out.assign(n, false);
+  for (size_t j = 0; j < n; j++) out[j] = flags[j] != 0;
+  return true;
+}
+
 std::vector<bool> PSVerifier::verifyIdImpl(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retr) const {
   std::vector<bool> out(proofs.size(), false);
+  if (!proofs.empty() && verifyIdStaged(proofs, ads, retr, out)) return out;
+  out.assign(proofs.size(), false);
   const size_t A = m_key->attrs();
   std::map<uint64_t, std::vector<size_t>> groups;
   for (size_t i = 0; i < proofs.size(); i++) {
@@ -146,31 +238,6 @@ std::vector<bool> PSVerifier::el_passo_verify_id_batch(const std::vector<IdProof
   return verifyIdImpl(proofs, ads, true);
 }
 // ---- pipelined form (include/elpasso.h elp_verify_id_batch_submit / _wait)
-namespace {
-// one record (csrc/elp/pipeline.h verify_id record) from an IdProof; the revealed attributes are hashed here (src/ps-verifier.cc:224)
-inline void packRecord(uint8_t* w, const IdProof& p, bool retr, size_t S1, size_t S2) {
-  auto put = [&](const uint8_t* src, size_t len) {
-    memcpy(w, src, len);
-    w += len;
-  };
-  put(p.sig1.b, S1);
-  put(p.sig2.b, S1);
-  put(p.phi.b, S1);
-  if (retr) {
-    put(p.E1->b, S1);
-    put(p.E2->b, S1);
-  }
-  put(p.k.b, S2);
-  put(p.c.b, 32);
-  for (const Fr& r : p.rs) put(r.b, 32);
-  for (const std::string& a : p.attributes)
-    if (!a.empty()) {
-      Fr m;
-      m.setHashOf(a);
-      put(m.b, 32);
-    }
-}
-}  // namespace
 size_t PSVerifier::el_passo_verify_id_submit(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, const std::string& service_name,
                                              const G1& authority_pk, const G1& g, const G1& h) const {
   if (ads.size() != proofs.size()) throw std::runtime_error("associated data count does not match");

@@ -62,6 +62,7 @@ class PSVerifier {
 
  private:
   std::vector<bool> verifyIdImpl(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retrieval) const;
+  bool verifyIdStaged(const std::vector<IdProof>& proofs, const std::vector<std::string>& ads, bool retr, std::vector<bool>& out) const;
   void useRpAll(const std::string& service, const G1* authority_pk, const G1* g, const G1* h) const;
   PSPubKey m_pk;
   std::shared_ptr<ElpShardSet> m_set;    // the contexts of this verifier (one unless constructed with a device list)

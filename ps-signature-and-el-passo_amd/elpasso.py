@@ -22,6 +22,7 @@ OPT_FAULT_INJECT = 9
 OPT_PAIR4 = 10
 OPT_WIRE_DECODE = 11
 OPT_AGG_TWO_PER_LANE = 12
+OPT_PAIR16 = 13
 
 _c = ctypes
 _u8p = _c.c_void_p
@@ -30,6 +31,7 @@ _SIGS = {
     "elp_device_count": (_c.c_int, []),
     "elp_verify_id_batch_submit": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_void_p, _c.c_uint64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "elp_verify_id_batch_wait": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint64)]),
+    "elp_verify_id_batch_stage": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t, _c.c_size_t, _c.c_size_t, _c.c_size_t, _c.c_void_p]),
     "elp_destroy": (None, [_c.c_void_p]),
     "elp_last_error": (_c.c_char_p, [_c.c_void_p]),
     "elp_field_bytes": (_c.c_int, [_c.c_int]),
@@ -51,6 +53,9 @@ _SIGS = {
     "elp_g2_msm_fixed": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
     "elp_g1_msm": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_g2_msm": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
+    "elp_msm_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_size_t]),
+    "elp_g1_msm_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "elp_g2_msm_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "elp_hash_to_g1": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_pairing": (_c.c_int, [_c.c_void_p, _c.c_size_t, _u8p, _u8p, _u8p]),
     "elp_pairing_check": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _u8p, _u8p, _u8p]),
@@ -197,6 +202,10 @@ class Context:
     def set_wire_decode(self, on):
         """ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages through a decode kernel + the record paths (default) or always through the fused wire kernels."""
         self._chk(self.lib.elp_set_option(self.h, OPT_WIRE_DECODE, int(bool(on))))
+
+    def set_pair16(self, value):
+        """ELP_OPT_PAIR16: small PS-verification batches on one 16-lane row per item (0 off, 1 on up to 4 096 items, > 1: up to that many)."""
+        self._chk(self.lib.elp_set_option(self.h, OPT_PAIR16, int(value)))
 
     def set_agg_two_per_lane(self, mode):
         """ELP_OPT_AGG_TWO_PER_LANE: aggregated verification with two proofs per lane (0 never -- the default --, 1 where it saves rounds of lanes, 2 always)."""
