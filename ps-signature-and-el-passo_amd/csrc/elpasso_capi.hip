@@ -59,9 +59,9 @@ extern template int elp_bench_op_t<BLS12_381>(elp_ctx* c, int op, size_t lanes, 
 extern template int elp_bench_fp_mul_t<BLS12_381>(elp_ctx* c, size_t lanes, int iters, float* ms);
 
 
-// ELP_OPT_PAIR16 default (elp_init): 0 until the row-of-16 check is the measured winner for small PS batches
+// ELP_OPT_PAIR16 default (elp_init): on -- 4 096 PS verifications 2.77 -> 2.02 ms, 64: 1.88 -> 1.73 ms (profiles/r06_pair16.md)
 #ifndef ELP_PAIR16_DEFAULT
-#define ELP_PAIR16_DEFAULT 0
+#define ELP_PAIR16_DEFAULT 1
 #endif
 
 // (definitions below get C linkage from their declarations in include/elpasso.h)
@@ -101,6 +101,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   if (const char* e = getenv("ELP_STAGE")) c->stage_records = atoi(e) != 0;                                              // A/B runs: coalesced record loads
   if (const char* e = getenv("ELP_COOP")) c->coop = atoi(e) != 0;                                                      // A/B runs: cooperative pairing for small batches                                            // A/B runs: one fused kernel per verification
   c->pair16 = ELP_PAIR16_DEFAULT;
+  if (const char* e = getenv("ELP_PAIR16_MIN")) c->pair16_min = (size_t)atol(e);                                       // A/B runs
   if (const char* e = getenv("ELP_PAIR16")) c->pair16 = atoi(e) != 0;                                                  // A/B runs: the row-of-16 pairing check for small PS batches
   if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
   hipDeviceProp_t prop;

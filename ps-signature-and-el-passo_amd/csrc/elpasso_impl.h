@@ -1978,7 +1978,7 @@ struct elp_ctx {
   int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
   int agg_two = 0;            // ELP_OPT_AGG_TWO_PER_LANE: aggregated batches put two items on a lane (0 = never -- the default: 2 % at best, and the kernel's larger frame makes the runtime re-provision scratch --, 1 = where it saves rounds of lanes, 2 = always)
   int pair16 = 0;                // ELP_OPT_PAIR16 (set by elp_init): PS verifications of at most pair16_max items run the pairing check on one 16-lane row per item
-  size_t pair16_max = 4096;
+  size_t pair16_max = 4096, pair16_min = 4;      // below pair16_min (less than one wave of rows) the interpreter's 32 lane pairs per item are a little faster: 1.60 vs 1.72 ms for a lone item
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
   struct VtabWs {
@@ -2714,8 +2714,14 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm, true);
   if (c->overlap) HIPCHK(c, hipStreamWaitEvent(stream, c->jev[1], 0));
   bool tail_done = false;
+  if constexpr (Pair16Build<C>::value) {
+    if (c->pair16) {                                          // the serial tail on one 16-lane row (round 6): 472 steps of one inner product per lane
+      launch_agg_final16<C>(stream, key.gg_lines, F, ws + o_s2, c->agg_ok);
+      tail_done = true;
+    }
+  }
   if constexpr (CoopBuild<C>::value) {
-    if (c->coop) {                                            // the serial tail on 32 lanes (level-scheduled program): ~4x faster than a lane pair
+    if (!tail_done && c->coop) {                              // the serial tail on 32 lanes (level-scheduled program): ~4x faster than a lane pair
       const void* consts = coop_consts_for<C>(c, stream);
       if (consts) {
         launch_agg_final_coop<C>(stream, key, consts, F, ws + o_s2, c->agg_ok);
@@ -2885,7 +2891,11 @@ struct Pair16Build<BN254> {
 template <class B>
 void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
                    void* d_accepted);
+// ... and the closing step of aggregated verification on one row (k_agg_final16): the fixed pair's Miller loop, the product with F, the final exponentiation
+template <class B>
+void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
 #ifndef ELP_PAIR16_TU
+extern template void launch_agg_final16<BN254>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
 extern template void launch_pair16<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 #endif
 // batch sizes served by the four-lane pairing check by default (ELP_OPT_PAIR4 = 1), from the A/B sweeps of profiles/r05_four_lane.md: up to 16 384 items the quads
@@ -3236,7 +3246,7 @@ int elp_ps_verify_batch_dev_t(elp_ctx* c, void* stream, size_t n, const void* d_
         const int words = 4 * C::N + 8 * nattr;
         launch_ps_k<C>((hipStream_t)stream, key, n, d_records, words, nattr, todo, kws, lanes);
         bool row16 = false;
-        if constexpr (Pair16Build<C>::value) row16 = c->pair16 != 0 && !mid && n <= c->pair16_max;
+        if constexpr (Pair16Build<C>::value) row16 = c->pair16 != 0 && !mid && n <= c->pair16_max && n >= c->pair16_min;
         if (row16) {
           if constexpr (Pair16Build<C>::value)
             launch_pair16<C>((hipStream_t)stream, key.gg_lines, n, d_records, words, todo, kws, lanes, (uint8_t*)d_flags, d_accepted);

@@ -25,6 +25,14 @@ constexpr int R16_LDS_WORDS = (R16_ROWS * R16_ROW_SLOTS + row16::NCONST) * R16_N
 
 typedef BN254 R16C;
 
+// A workgroup is ONE wave: its LDS instructions are issued and executed in program order, so a step's writes cannot overtake the reads that precede them and the next
+// step's reads see them -- no s_barrier and, above all, no s_waitcnt on the table loads that are in flight for the NEXT step.  Only the compiler must keep the order.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define R16_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#else
+#define R16_SYNC() ((void)0)
+#endif
+
 ELP_INL Fp<R16C> r16_ld(const i32* L, const i32* K, int s) {         // slot s of the row (below CONST_BASE) or of the shared constants
   const i32* p = s < row16::CONST_BASE ? L + s * R16_NLP : K + (s - row16::CONST_BASE) * R16_NLP;
   Fp<R16C> r;
@@ -64,6 +72,109 @@ ELP_INL Fp<R16C> r16_dot(const i32* L, const i32* K, const u32 (&tb)[12]) {
     for (int i = 0; i < R16_NL; i++) b[t].v[i] *= cf;
   }
   return fp_dot<R16C, NT>(a, b);
+}
+
+// The program loop shared by the two kernels (TAIL: the closing step of aggregated verification).  Returns the row's verdict.
+template <bool TAIL>
+ELP_INL bool r16_run(i32* lds, i32* L, const i32* K, int row, int q, int c, bool live1, bool live2, const LineMem<R16C>* gg_lines, const Fp12<R16C>* Fglob, int dbg_pc,
+                     i32* dbg) {
+  const u32* const prog = TAIL ? row16::PROG_TAIL : row16::PROG;
+  const int nprog = TAIL ? row16::NPROG_TAIL : row16::NPROG;
+  u32 tb[12];
+  u32 e = prog[0];
+  {
+    const int sid = (int)(e >> 8) & 0xFF;
+    ELP_UNROLL
+    for (int t = 0; t < 12; t++) tb[t] = (e & 0xFF) == 0 ? row16::STEP_TERMS[sid][q][t] : 0u;
+  }
+  bool verdict = false;
+  ELP_NOUNROLL
+  for (int pc = 0; pc < nprog; pc++) {
+    const u32 e_next = pc + 1 < nprog ? prog[pc + 1] : 5u;
+    u32 tb_next[12];
+    {                                                               // the table of the NEXT dot step travels while this step computes
+      const int sidn = (int)(e_next >> 8) & 0xFF;
+      const bool dotn = (e_next & 0xFF) == 0;
+      ELP_UNROLL
+      for (int t = 0; t < 12; t++) tb_next[t] = dotn ? row16::STEP_TERMS[sidn][q][t] : 0u;
+    }
+    const int op = (int)(e & 0xFF), a0 = (int)(e >> 8) & 0xFF, a1 = (int)(e >> 16) & 0xFF;
+    if (dbg && pc == dbg_pc) {                                      // the state BEFORE entry pc of the program: every slot of every row of workgroup 0
+      if (blockIdx.x == 0)
+        for (int s = (int)threadIdx.x; s < R16_ROWS * R16_ROW_SLOTS * R16_NLP; s += 64) dbg[s] = lds[s];
+      return false;
+    }
+    if (op == 0) {
+      const int nt = row16::STEP_NT[a0], fl = row16::STEP_FLAGS[a0];
+      const u32 dst = row16::STEP_DEST[a0][q];
+      Fp<R16C> r;
+      switch (nt) {
+        case 1: r = r16_dot<1>(L, K, tb); break;
+        case 2: r = r16_dot<2>(L, K, tb); break;
+        case 3: r = r16_dot<3>(L, K, tb); break;
+        case 4: r = r16_dot<4>(L, K, tb); break;
+        case 6: r = r16_dot<6>(L, K, tb); break;
+        case 8: r = r16_dot<8>(L, K, tb); break;
+        default: r = r16_dot<12>(L, K, tb); break;
+      }
+      if (dst & (1u << 9)) {                                        // Granger-Scott: 3 * (inner product) +- 2 * (the lane's coefficient), weakly reduced
+        const Fp<R16C> own = r16_ld(L, K, (int)(dst & 0xFF));
+        const i32 s2 = (dst & (1u << 10)) ? 2 : -2;
+        ELP_UNROLL
+        for (int w = 0; w < R16_NL; w++) r.v[w] = 3 * r.v[w] + s2 * own.v[w];
+        fp_carry<R16C>(r);
+        fp_reduce_weak<R16C>(r);
+      }
+      const int tag = fl >> 1;
+      const bool dead = (tag == 1 && !live1) || (tag == 2 && !live2);
+      const bool wr = (dst & (1u << 8)) && !(dead && q < 12);
+      Fp<R16C> xr;
+      if (fl & 1) {                                                 // uniform: the exchange is executed by every lane
+        const Fp<R16C> p = r16_pair_swap(r);
+        xr = c == 0 ? fp_sub<R16C>(r, p) : fp_add<R16C>(p, r);
+      }
+      R16_SYNC();
+      if (wr) r16_st(L, (int)(dst & 0xFF), r);
+      if ((fl & 1) && wr && q < 12) r16_st(L, row16::SLOT_X0 + q, xr);
+      R16_SYNC();
+    } else if (op == 1) {                                           // the fixed line a0: six base-field values of gg's precomputed line -> LF
+      if (q < 6) r16_st(L, row16::SLOT_LF + q, reinterpret_cast<const Fp<R16C>*>(&gg_lines[a0])[q]);
+      R16_SYNC();
+    } else if (op == 2) {                                           // one base-field inversion (lane 0 of the row)
+      const Fp<R16C> x = r16_ld(L, K, a0);
+      const Fp<R16C> y = fp_inv<R16C>(x);
+      if (q == 0) r16_st(L, a1, y);
+      R16_SYNC();
+    } else if (op == 3) {                                           // stored value a0 -> W0 (with xi * value -> X0) or W1
+      Fp<R16C> v = r16_ld_row(L, R16_REG0 + 12 * a0 + (q < 12 ? q : 0));
+      const Fp<R16C> p = r16_pair_swap(v);
+      if (q < 12) {
+        if (a1 == 0) {
+          r16_st(L, row16::SLOT_W0 + q, v);
+          r16_st(L, row16::SLOT_X0 + q, c == 0 ? fp_sub<R16C>(v, p) : fp_add<R16C>(p, v));
+        } else {
+          r16_st(L, row16::SLOT_W1 + q, v);
+        }
+      }
+      R16_SYNC();
+    } else if (op == 4) {                                           // W0 -> stored value a0
+      if (q < 12) r16_st(L, R16_REG0 + 12 * a0 + q, r16_ld(L, K, row16::SLOT_W0 + q));
+      R16_SYNC();
+    } else if (op == 6) {                                           // W1 <- F, the product of the batch's Miller values (plain layout: c0 <-> w^0, w^2, w^4; c1 <-> w^1, w^3, w^5)
+      if (q < 12) r16_st(L, row16::SLOT_W1 + q, reinterpret_cast<const Fp<R16C>*>(Fglob)[((q >> 1) & 1) * 6 + (q >> 2) * 2 + (q & 1)]);
+      R16_SYNC();
+    } else {                                                        // the result is 1 <=> every coefficient of W0 - 1 is zero modulo p
+      Fp<R16C> v = r16_ld(L, K, row16::SLOT_W0 + (q < 12 ? q : 1));
+      if (q == 0) v = fp_sub<R16C>(v, r16_ld(L, K, row16::SLOT_ONE));
+      const bool z = fp_is_zero<R16C>(v);
+      const unsigned long long bz = __ballot(z);
+      verdict = (((unsigned)(bz >> (16u * (unsigned)row))) & 0xFFFu) == 0xFFFu;
+    }
+    e = e_next;
+    ELP_UNROLL
+    for (int t = 0; t < 12; t++) tb[t] = tb_next[t];
+  }
+  return verdict;
 }
 
 // flags[i] = todo[i] && sig1, sig2 decode && e(sig1, K) e(-sig2, gg) == 1 for items [4 blockIdx.x, 4 blockIdx.x + 4): one per row
@@ -131,98 +242,7 @@ __global__ void __launch_bounds__(64, 1) k_pair16(const LineMem<R16C>* gg_lines,
     live2 = !(inf & 2u);
   }
   __syncthreads();
-  // ---- the program
-  u32 tb[12];
-  u32 e = row16::PROG[0];
-  {
-    const int sid = (int)(e >> 8) & 0xFF;
-    ELP_UNROLL
-    for (int t = 0; t < 12; t++) tb[t] = (e & 0xFF) == 0 ? row16::STEP_TERMS[sid][q][t] : 0u;
-  }
-  bool verdict = false;
-  ELP_NOUNROLL
-  for (int pc = 0; pc < row16::NPROG; pc++) {
-    const u32 e_next = pc + 1 < row16::NPROG ? row16::PROG[pc + 1] : 5u;
-    u32 tb_next[12];
-    {                                                               // the table of the NEXT dot step travels while this step computes
-      const int sidn = (int)(e_next >> 8) & 0xFF;
-      const bool dotn = (e_next & 0xFF) == 0;
-      ELP_UNROLL
-      for (int t = 0; t < 12; t++) tb_next[t] = dotn ? row16::STEP_TERMS[sidn][q][t] : 0u;
-    }
-    const int op = (int)(e & 0xFF), a0 = (int)(e >> 8) & 0xFF, a1 = (int)(e >> 16) & 0xFF;
-    if (dbg && pc == dbg_pc) {                                      // the state BEFORE entry pc of the program: every slot of every row of workgroup 0
-      if (blockIdx.x == 0)
-        for (int s = (int)threadIdx.x; s < R16_ROWS * R16_ROW_SLOTS * R16_NLP; s += 64) dbg[s] = lds[s];
-      return;
-    }
-    if (op == 0) {
-      const int nt = row16::STEP_NT[a0], fl = row16::STEP_FLAGS[a0];
-      const u32 dst = row16::STEP_DEST[a0][q];
-      Fp<R16C> r;
-      switch (nt) {
-        case 1: r = r16_dot<1>(L, K, tb); break;
-        case 2: r = r16_dot<2>(L, K, tb); break;
-        case 3: r = r16_dot<3>(L, K, tb); break;
-        case 4: r = r16_dot<4>(L, K, tb); break;
-        case 6: r = r16_dot<6>(L, K, tb); break;
-        case 8: r = r16_dot<8>(L, K, tb); break;
-        default: r = r16_dot<12>(L, K, tb); break;
-      }
-      if (dst & (1u << 9)) {                                        // Granger-Scott: 3 * (inner product) +- 2 * (the lane's coefficient), weakly reduced
-        const Fp<R16C> own = r16_ld(L, K, (int)(dst & 0xFF));
-        const i32 s2 = (dst & (1u << 10)) ? 2 : -2;
-        ELP_UNROLL
-        for (int w = 0; w < R16_NL; w++) r.v[w] = 3 * r.v[w] + s2 * own.v[w];
-        fp_carry<R16C>(r);
-        fp_reduce_weak<R16C>(r);
-      }
-      const int tag = fl >> 1;
-      const bool dead = (tag == 1 && !live1) || (tag == 2 && !live2);
-      const bool wr = (dst & (1u << 8)) && !(dead && q < 12);
-      Fp<R16C> xr;
-      if (fl & 1) {                                                 // uniform: the exchange is executed by every lane
-        const Fp<R16C> p = r16_pair_swap(r);
-        xr = c == 0 ? fp_sub<R16C>(r, p) : fp_add<R16C>(p, r);
-      }
-      __syncthreads();
-      if (wr) r16_st(L, (int)(dst & 0xFF), r);
-      if ((fl & 1) && wr && q < 12) r16_st(L, row16::SLOT_X0 + q, xr);
-      __syncthreads();
-    } else if (op == 1) {                                           // the fixed line a0: six base-field values of gg's precomputed line -> LF
-      if (q < 6) r16_st(L, row16::SLOT_LF + q, reinterpret_cast<const Fp<R16C>*>(&gg_lines[a0])[q]);
-      __syncthreads();
-    } else if (op == 2) {                                           // one base-field inversion (lane 0 of the row)
-      const Fp<R16C> x = r16_ld(L, K, a0);
-      const Fp<R16C> y = fp_inv<R16C>(x);
-      if (q == 0) r16_st(L, a1, y);
-      __syncthreads();
-    } else if (op == 3) {                                           // stored value a0 -> W0 (with xi * value -> X0) or W1
-      Fp<R16C> v = r16_ld_row(L, R16_REG0 + 12 * a0 + (q < 12 ? q : 0));
-      const Fp<R16C> p = r16_pair_swap(v);
-      if (q < 12) {
-        if (a1 == 0) {
-          r16_st(L, row16::SLOT_W0 + q, v);
-          r16_st(L, row16::SLOT_X0 + q, c == 0 ? fp_sub<R16C>(v, p) : fp_add<R16C>(p, v));
-        } else {
-          r16_st(L, row16::SLOT_W1 + q, v);
-        }
-      }
-      __syncthreads();
-    } else if (op == 4) {                                           // W0 -> stored value a0
-      if (q < 12) r16_st(L, R16_REG0 + 12 * a0 + q, r16_ld(L, K, row16::SLOT_W0 + q));
-      __syncthreads();
-    } else {                                                        // the result is 1 <=> every coefficient of W0 - 1 is zero modulo p
-      Fp<R16C> v = r16_ld(L, K, row16::SLOT_W0 + (q < 12 ? q : 1));
-      if (q == 0) v = fp_sub<R16C>(v, r16_ld(L, K, row16::SLOT_ONE));
-      const bool z = fp_is_zero<R16C>(v);
-      const unsigned long long bz = __ballot(z);
-      verdict = (((unsigned)(bz >> (16u * (unsigned)row))) & 0xFFFu) == 0xFFFu;
-    }
-    e = e_next;
-    ELP_UNROLL
-    for (int t = 0; t < 12; t++) tb[t] = tb_next[t];
-  }
+  const bool verdict = r16_run<false>(lds, L, K, row, q, c, live1, live2, gg_lines, nullptr, dbg_pc, dbg);
   const bool ok = ok_in && verdict && in_range;
   if (in_range && q == 0) flags[item0] = ok ? 1 : 0;
   if (accepted) {
@@ -231,8 +251,50 @@ __global__ void __launch_bounds__(64, 1) k_pair16(const LineMem<R16C>* gg_lines,
   }
 }
 
+// The closing step of aggregated verification on one row: agg_ok = [ F f_gg(-S2) ]^((p^12-1)/r) == 1     (S2 = sum d_i sig2_i, std affine; F: plain layout)
+__global__ void __launch_bounds__(64, 1) k_agg_final16(const LineMem<R16C>* gg_lines, const Fp12<R16C>* F, const u32* s2_std, int* agg_ok) {
+  __shared__ __attribute__((aligned(16))) i32 lds[R16_LDS_WORDS];
+  const int row = (int)(threadIdx.x >> 4), q = (int)(threadIdx.x & 15), c = q & 1;
+  i32* const L = lds + row * R16_ROW_SLOTS * R16_NLP;
+  i32* const K = lds + R16_ROWS * R16_ROW_SLOTS * R16_NLP;
+  for (int s = (int)threadIdx.x; s < row16::NCONST; s += 64) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = row16::CONSTS[s][w];
+  }
+  for (int s = q; s < R16_ROW_SLOTS; s += 16) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NLP; w++) L[s * R16_NLP + w] = 0;
+  }
+  __syncthreads();
+  bool ok_pt = true, inf_pt = false;
+  if (q == 1) {
+    Aff<F1<R16C>> pt;
+    ok_pt = g1_load<R16C>(pt, s2_std);
+    inf_pt = ok_pt && aff_is_inf(pt);
+    r16_st(L, row16::SLOT_P2, pt.x);
+    r16_st(L, row16::SLOT_P2 + 1, fp_neg(pt.y));
+  }
+  if (q == 8) {
+    const Fp<R16C> one = r16_ld(L, K, row16::SLOT_ONE);
+    r16_st(L, row16::SLOT_W0, one);
+    r16_st(L, row16::SLOT_X0, one);
+    r16_st(L, row16::SLOT_X0 + 1, one);
+  }
+  const unsigned long long b_bad = __ballot(!ok_pt), b_inf = __ballot(inf_pt);
+  const bool ok_in = ((unsigned)b_bad & 0x2u) == 0;                     // row 0 decides (the other rows walk the program on zeros)
+  const bool live2 = ((unsigned)(b_inf >> (16u * (unsigned)row)) & 0x2u) == 0;
+  __syncthreads();
+  const bool verdict = r16_run<true>(lds, L, K, row, q, c, false, live2, gg_lines, F, -1, nullptr);
+  if (threadIdx.x == 0) *agg_ok = (ok_in && verdict) ? 1 : 0;
+}
+
 }  // namespace elp
 
+template <class B>
+void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok) {
+  static_assert(std::is_same<B, elp::BN254>::value, "generated for BN254");
+  hipLaunchKernelGGL(elp::k_agg_final16, dim3(1), dim3(64), 0, stream, (const elp::LineMem<elp::BN254>*)gg_lines, (const elp::Fp12<elp::BN254>*)F, (const u32*)s2_std, agg_ok);
+}
 template <class B>
 void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
                    void* d_accepted) {

@@ -618,37 +618,55 @@ def test_prover_irregular_pattern_and_sixteen_attributes(gpu_ctx):
 
 def test_msm_device_buffer_entry_points(gpu_ctx):
     """elp_g1_msm_dev / elp_g2_msm_dev (round 6): the Pippenger sequence over the caller's device buffers and workspace == the host-buffer entry point == the oracle
-    model's sum of multiples; n = 0, 1, a ragged size, points at infinity and zero scalars included."""
+    model's sum of multiples; n = 0, 1, a ragged size, points at infinity and zero scalars included.  (Device buffers straight from the HIP runtime the library is
+    linked against: no second runtime in the process.)"""
     import ctypes
-    import torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    vp = ctypes.c_void_p
+
+    def chk(rc):
+        assert rc == 0, "HIP error %d" % rc
+
+    def dev_alloc(nbytes, fill=None):
+        p = vp()
+        chk(hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(max(1, nbytes))))
+        if fill is not None:
+            chk(hip.hipMemcpy(p, fill, ctypes.c_size_t(len(fill)), 1))
+        return p
+
     pk = _pk0()
     rnd = random.Random(77)
-    dev = torch.device("cuda:0")
-    stream = torch.cuda.current_stream().cuda_stream
-    for grp, base, ser, sz, msm_host, fn in ((1, pk.g, g1b, 64, gpu_ctx.g1_msm, gpu_ctx.lib.elp_g1_msm_dev), (2, pk.gg, g2b, 128, gpu_ctx.g2_msm, gpu_ctx.lib.elp_g2_msm_dev)):
-        mul = G.g1_mul if grp == 1 else G.g2_mul
-        add = G.g1_add if grp == 1 else G.g2_add
-        un = g1u if grp == 1 else g2u
-        for n in (0, 1, 37, 300):
-            pts = [mul(base, rnd.randrange(1, 1 << 40)) for _ in range(n)]
-            ks = [rnd.randrange(M.r) for _ in range(n)]
-            if n >= 37:
-                pts[3], ks[5], ks[6] = None, 0, 1
-            pb, kb = b"".join(ser(P) for P in pts), b"".join(fb(k) for k in ks)
-            want = None
-            for P, k in zip(pts[:40], ks[:40]):
-                want = add(want, mul(P, k))
-            d_p = torch.from_numpy(np.frombuffer(pb or b"\0", dtype=np.uint8).copy()).to(dev)
-            d_k = torch.from_numpy(np.frombuffer(kb or b"\0", dtype=np.uint8).copy()).to(dev)
-            d_ws = torch.zeros(max(1, gpu_ctx.lib.elp_msm_workspace_bytes(gpu_ctx.curve, grp, n)), dtype=torch.uint8, device=dev)
-            d_o = torch.full((sz,), 7, dtype=torch.uint8, device=dev)
-            gpu_ctx._chk(fn(gpu_ctx.h, stream, n, d_p.data_ptr(), d_k.data_ptr(), d_ws.data_ptr(), d_o.data_ptr()))
-            torch.cuda.synchronize()
-            got = d_o.cpu().numpy().tobytes()
-            if n:
-                assert got == msm_host(pb, kb), (grp, n)
-            else:
-                assert got == bytes(sz)
-            if n <= 40:
-                assert un(got) == want, (grp, n)
-    assert gpu_ctx.lib.elp_msm_workspace_bytes(gpu_ctx.curve, 3, 10) == 0
+    bufs = []
+    try:
+        for grp, base, ser, sz, msm_host, fn in ((1, pk.g, g1b, 64, gpu_ctx.g1_msm, gpu_ctx.lib.elp_g1_msm_dev), (2, pk.gg, g2b, 128, gpu_ctx.g2_msm, gpu_ctx.lib.elp_g2_msm_dev)):
+            mul = G.g1_mul if grp == 1 else G.g2_mul
+            add = G.g1_add if grp == 1 else G.g2_add
+            un = g1u if grp == 1 else g2u
+            for n in (0, 1, 37, 300):
+                pts = [mul(base, rnd.randrange(1, 1 << 40)) for _ in range(n)]
+                ks = [rnd.randrange(M.r) for _ in range(n)]
+                if n >= 37:
+                    pts[3], ks[5], ks[6] = None, 0, 1
+                pb, kb = b"".join(ser(P) for P in pts), b"".join(fb(k) for k in ks)
+                want = None
+                for P, k in zip(pts[:40], ks[:40]):
+                    want = add(want, mul(P, k))
+                d_p, d_k = dev_alloc(len(pb), pb or None), dev_alloc(len(kb), kb or None)
+                d_ws = dev_alloc(gpu_ctx.lib.elp_msm_workspace_bytes(gpu_ctx.curve, grp, n))
+                d_o = dev_alloc(sz, b"\x07" * sz)
+                bufs += [d_p, d_k, d_ws, d_o]
+                gpu_ctx._chk(fn(gpu_ctx.h, None, n, d_p, d_k, d_ws, d_o))
+                chk(hip.hipDeviceSynchronize())
+                out = (ctypes.c_uint8 * sz)()
+                chk(hip.hipMemcpy(out, d_o, ctypes.c_size_t(sz), 2))
+                got = bytes(out)
+                if n:
+                    assert got == msm_host(pb, kb), (grp, n)
+                else:
+                    assert got == bytes(sz)
+                if n <= 40:
+                    assert un(got) == want, (grp, n)
+        assert gpu_ctx.lib.elp_msm_workspace_bytes(gpu_ctx.curve, 3, 10) == 0
+    finally:
+        for b_ in bufs:
+            hip.hipFree(b_)

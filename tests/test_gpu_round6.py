@@ -1,0 +1,90 @@
+"""GPU parity tests added in round 6 (pytest -m gpu on the MI355X box), all through the C-ABI.
+  * the ROW-OF-16 pairing check (k_pair16, ELP_OPT_PAIR16; csrc/elpasso_pair16.h, tools/gen_row16.py) behind PSVerifier::verify (src/ps-verifier.cc:13-35) for small
+    batches: every verdict against the C oracle, against the cooperative interpreter it replaces, on valid, tampered, infinite and undecodable signatures;
+  * records handed over in parts (elp_verify_id_batch_stage) == the one-piece submit."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+
+from elp_testlib import oracle
+
+pytestmark = pytest.mark.gpu
+synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+try:
+    NT = max(1, min(32, len(__import__("os").sched_getaffinity(0))))
+except Exception:
+    NT = 4
+
+
+def _oracle_key(L, wl, ctx, A):
+    g1 = wl.g + wl.Yi + ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+    return ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
+
+
+def test_row_of_16_pairing_check_vs_oracle(gpu_ctx):
+    """PS verification, A = 3 (BASELINE config 2's shape) at n = 1 ... 4 096 and A = 8: the row-of-16 kernel (default for at most 4 096 items) must give the C oracle's
+    verdict (elpo_ps_verify) on EVERY item -- honest signatures, randomised ones, a wrong attribute, sig1 = infinity (rejected, src/ps-verifier.cc:16-18), sig2 = infinity,
+    (sig1, sig2) swapped, a coordinate off the curve, a coordinate >= p -- and the cooperative interpreter's (ELP_OPT_PAIR16 = 0)."""
+    L = oracle()
+    for A, sizes in ((3, (1, 2, 3, 4, 5, 17, 63, 64, 65, 257, 1000, 4096)), (8, (7, 300))):
+        wl = synth.Workload(gpu_ctx, A, seed=606 + A, window_bits=8)
+        nmax = max(sizes)
+        recs, expect = wl.ps_verify_batch(nmax)
+        rsz = len(recs) // nmax
+        r = bytearray(recs)
+        step = 64 if nmax >= 64 else 1                                # the tampered items sit in the first 16 of every 64: every size above sees them
+        for base in range(0, nmax - 15, max(step, 16)):
+            r[(base + 1) * rsz:(base + 1) * rsz + 64] = bytes(64)                                   # sig1 = infinity
+            r[(base + 2) * rsz + 64:(base + 2) * rsz + 128] = bytes(64)                              # sig2 = infinity
+            a = bytes(r[(base + 3) * rsz:(base + 3) * rsz + 64])
+            r[(base + 3) * rsz:(base + 3) * rsz + 64] = r[(base + 3) * rsz + 64:(base + 3) * rsz + 128]
+            r[(base + 3) * rsz + 64:(base + 3) * rsz + 128] = a                                      # sig1 <-> sig2
+            r[(base + 4) * rsz + 5] ^= 1                                                             # sig1.x: off the curve
+            r[(base + 5) * rsz + 32:(base + 5) * rsz + 64] = b"\xff" * 32                            # sig1.y >= p
+            r[(base + 6) * rsz + 128 + 3] ^= 1                                                       # a different attribute hash
+            r[(base + 7) * rsz + 64 + 40] ^= 4                                                       # sig2.y: off the curve
+        recs = bytes(r)
+        key = _oracle_key(L, wl, gpu_ctx, A)
+        want = np.array([L.elpo_ps_verify(key, recs[i * rsz:(i + 1) * rsz], A) for i in range(nmax)], dtype=np.uint8)
+        assert want[0] == 1 and (nmax < 16 or (not want[1:8].any() and want[8:13].all()))
+        try:
+            for n in sizes:
+                gpu_ctx.set_pair16(1)
+                fl, cnt = gpu_ctx.ps_verify_batch(recs[:n * rsz], A)
+                assert (fl == want[:n]).all() and cnt == int(want[:n].sum()), (A, n, np.nonzero(fl != want[:n])[0][:8])
+                gpu_ctx.set_pair16(0)
+                fl0, cnt0 = gpu_ctx.ps_verify_batch(recs[:n * rsz], A)
+                assert (fl0 == fl).all() and cnt0 == cnt, (A, n)
+        finally:
+            gpu_ctx.set_pair16(1)
+            L.elpo_key_free(key)
+
+
+def test_records_staged_in_parts_equal_one_piece_submit(gpu_ctx):
+    """elp_verify_id_batch_stage (round 6): the records of a batch delivered in ragged parts, out of order, then submitted with records == NULL, give the verdicts of
+    the one-piece submit and of the generator; a submit after an incomplete staging fails without leaving the slot busy."""
+    A, H, n = 8, 4, 5000
+    wl = synth.Workload(gpu_ctx, A, seed=99, window_bits=8)
+    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=11, corrupt_at=3)
+    rsz = len(recs) // n
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    buf = np.frombuffer(recs, dtype=np.uint8).copy()
+    ad = np.frombuffer(wl.ad, dtype=np.uint8).copy()
+    flags = np.zeros(n, dtype=np.uint8)
+    acc = ctypes.c_uint64(0)
+    parts = [(0, 1), (4000, 1000), (1, 1999), (2000, 2000)]
+    for first, count in parts:
+        gpu_ctx._chk(lib.elp_verify_id_batch_stage(h, 0, n, rsz, first, count, buf.ctypes.data + first * rsz))
+    gpu_ctx._chk(lib.elp_verify_id_batch_submit(h, 0, n, None, mask, 1, ad.ctypes.data, None, len(wl.ad), flags.ctypes.data))
+    gpu_ctx._chk(lib.elp_verify_id_batch_wait(h, 0, ctypes.byref(acc)))
+    assert (flags == expect).all() and acc.value == int(expect.sum())
+    # incomplete staging: refused, and the slot is free afterwards
+    gpu_ctx._chk(lib.elp_verify_id_batch_stage(h, 0, n, rsz, 0, 10, buf.ctypes.data))
+    assert lib.elp_verify_id_batch_submit(h, 0, n, None, mask, 1, ad.ctypes.data, None, len(wl.ad), flags.ctypes.data) != 0
+    flags[:] = 0
+    gpu_ctx._chk(lib.elp_verify_id_batch_submit(h, 0, n, buf.ctypes.data, mask, 1, ad.ctypes.data, None, len(wl.ad), flags.ctypes.data))
+    gpu_ctx._chk(lib.elp_verify_id_batch_wait(h, 0, ctypes.byref(acc)))
+    assert (flags == expect).all()
+    assert lib.elp_verify_id_batch_stage(h, 0, n, rsz, n - 1, 2, buf.ctypes.data) != 0              # a part beyond the batch

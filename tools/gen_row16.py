@@ -522,68 +522,93 @@ s_copy = step("w1_from_w0")                              # W1 <- W0
 s_copy.out12([f2mulfp(x, one) for x in f], W1)
 s_one = step("is_one")                                   # placeholder type for the final comparison (no table use)
 
-# easy part: f1 = conj(f) * f^-1; f2 = frob2(f1) * f1
-for s_ in (s_norm, s_i2, s_i3, s_i4):
-    PROG.append(("dot", s_.id))
-PROG.append(("inv", AD + 14, AD + 15))
-for s_ in (s_i6, s_i7, s_i8, s_conj, s_mul):
-    PROG.append(("dot", s_.id))                          # W1 = f^-1; W0 = conj(f); W0 = W0 * W1
-PROG.append(("dot", s_copy.id))                          # W1 = f1
-PROG.append(("dot", FROB[2].id))                         # W0 = f1^(p^2)
-PROG.append(("dot", s_mul.id))                           # W0 = f2: in the cyclotomic subgroup from here on
+def final_exp_entries(prog):
+    """appends the easy part, the hard part (Fuentes-Castaneda-Knapp-Rodriguez multiple) and the comparison with 1; W0 holds the Miller value on entry"""
+    def exp_z(base_reg):                                     # W0 <- W0^z with W0 = reg[base_reg] on entry (z < 0: conjugate at the end)
+        prog.append(("ld", base_reg, 1))                     # W1 = base
+        for b_ in bin(ZABS)[3:]:
+            prog.append(("dot", s_cyc.id))
+            if b_ == "1":
+                prog.append(("dot", s_mul.id))
+        prog.append(("dot", s_conj.id))
+
+    def ld0(r):
+        prog.append(("ld", r, 0))
+
+    def st(r):
+        prog.append(("st", r))
+
+    def mul_by(r, conj=False):
+        prog.append(("ld", r, 1))
+        prog.append(("dot", (s_mulc if conj else s_mul).id))
+
+    def d(s_):
+        prog.append(("dot", s_.id))
+
+    # easy part: f1 = conj(f) * f^-1; f2 = frob2(f1) * f1
+    for s_ in (s_norm, s_i2, s_i3, s_i4):
+        d(s_)
+    prog.append(("inv", AD + 14, AD + 15))
+    for s_ in (s_i6, s_i7, s_i8, s_conj, s_mul):
+        d(s_)                                                # W1 = f^-1; W0 = conj(f); W0 = W0 * W1
+    d(s_copy)                                                # W1 = f1
+    d(FROB[2])                                               # W0 = f1^(p^2)
+    d(s_mul)                                                 # W0 = f2: in the cyclotomic subgroup from here on
+    st(R_F)
+    exp_z(R_F); st(R_FZ)                                     # fz
+    d(s_cyc); st(R_F2Z)                                      # f2z
+    d(s_cyc)                                                 # f4z
+    mul_by(R_F2Z); st(R_F6Z)                                 # f6z
+    exp_z(R_F6Z); st(R_F6Z2)                                 # f6z2
+    d(s_cyc)                                                 # f12z2
+    st(R_FZ)                                                 # (fz is dead: its register carries the base of the next power)
+    exp_z(R_FZ)                                              # f12z3
+    mul_by(R_F6Z2)
+    mul_by(R_F6Z); st(R_A)                                   # a = f^l2
+    mul_by(R_F2Z, conj=True); st(R_B)                        # b = f^l1
+    ld0(R_A)
+    mul_by(R_F6Z2)
+    mul_by(R_F); st(R_FZ)                                    # r = f^l0            (kept in the free register)
+    ld0(R_B); d(FROB[1]); d(s_copy); ld0(R_FZ); d(s_mul); st(R_FZ)      # r *= b^p
+    ld0(R_A); d(FROB[2]); d(s_copy); ld0(R_FZ); d(s_mul); st(R_FZ)      # r *= a^(p^2)
+    ld0(R_B); mul_by(R_F, conj=True)                         # f^l3 = b conj(f)
+    d(FROB[3]); d(s_copy); ld0(R_FZ); d(s_mul)               # r *= (f^l3)^(p^3)
+    prog.append(("check",))
+
+
 R_F, R_FZ, R_F2Z, R_F6Z, R_F6Z2, R_A, R_B = range(7)
 ZABS = abs(CV.z)
+final_exp_entries(PROG)
 
-
-def exp_z(base_reg):
-    """W0 <- W0^z with W0 = reg[base_reg] on entry (z < 0: conjugate at the end)"""
-    bits = bin(ZABS)[3:]
-    PROG.append(("ld", base_reg, 1))                     # W1 = base
-    for b in bits:
-        PROG.append(("dot", s_cyc.id))
-        if b == "1":
-            PROG.append(("dot", s_mul.id))
-    PROG.append(("dot", s_conj.id))
-
-
-def ld0(r):
-    PROG.append(("ld", r, 0))
-
-
-def st(r):
-    PROG.append(("st", r))
-
-
-def mul_by(r, conj=False):
-    PROG.append(("ld", r, 1))
-    PROG.append(("dot", (s_mulc if conj else s_mul).id))
-
-
-st(R_F)
-exp_z(R_F); st(R_FZ)                                      # fz
-PROG.append(("dot", s_cyc.id)); st(R_F2Z)                 # f2z
-PROG.append(("dot", s_cyc.id))                            # f4z
-mul_by(R_F2Z); st(R_F6Z)                                  # f6z
-exp_z(R_F6Z); st(R_F6Z2)                                  # f6z2
-PROG.append(("dot", s_cyc.id))                            # f12z2
-st(R_FZ)                                                  # (fz is dead: its register carries the base of the next power)
-exp_z(R_FZ)                                               # f12z3
-mul_by(R_F6Z2)
-mul_by(R_F6Z); st(R_A)                                    # a = f^l2
-mul_by(R_F2Z, conj=True); st(R_B)                         # b = f^l1
-ld0(R_A)
-mul_by(R_F6Z2)
-mul_by(R_F); st(R_FZ)                                     # r = f^l0            (kept in the free register)
-ld0(R_B); PROG.append(("dot", FROB[1].id)); PROG.append(("dot", s_copy.id)); ld0(R_FZ); PROG.append(("dot", s_mul.id)); st(R_FZ)      # r *= b^p
-ld0(R_A); PROG.append(("dot", FROB[2].id)); PROG.append(("dot", s_copy.id)); ld0(R_FZ); PROG.append(("dot", s_mul.id)); st(R_FZ)      # r *= a^(p^2)
-ld0(R_B); mul_by(R_F, conj=True)                          # f^l3 = b conj(f)
-PROG.append(("dot", FROB[3].id)); PROG.append(("dot", s_copy.id)); ld0(R_FZ); PROG.append(("dot", s_mul.id))                           # r *= (f^l3)^(p^3)
-PROG.append(("check",))
+# ---- the closing step of AGGREGATED verification (SURVEY.md section 8f rank 4): [ F f_gg(P2) ]^((p^12-1)/r) == 1 with F = the product of the batch's Miller values
+# (loaded into W1 by the entry "ldf") and P2 = -sum d_i sig2_i: the fixed pair's Miller loop alone (no point arithmetic), one product, the same final exponentiation
+s_scale = step("scale_lf")                                   # the fixed line evaluated at P2 where no other step carries it on its spare lanes
+for j, (src, pt) in enumerate(((lfa[0], yP2), (lfa[1], yP2), (lfb[0], xP2), (lfb[1], xP2))):
+    s_scale.out(12 + j, lmul(src, pt), LFS + j)
+PROG_TAIL = []
+ln = 0
+for i, dgt in enumerate(DIG):
+    PROG_TAIL.append(("line", ln)); ln += 1
+    PROG_TAIL.append(("dot", s_sqr.id))
+    PROG_TAIL.append(("dot", s_lf.id))
+    if dgt:
+        PROG_TAIL.append(("line", ln)); ln += 1
+        PROG_TAIL.append(("dot", s_scale.id))
+        PROG_TAIL.append(("dot", s_lf.id))
+PROG_TAIL.append(("dot", s_conj.id))
+for _ in range(2):
+    PROG_TAIL.append(("line", ln)); ln += 1
+    PROG_TAIL.append(("dot", s_scale.id))
+    PROG_TAIL.append(("dot", s_lf.id))
+assert ln == NLINES
+PROG_TAIL.append(("ldf",))
+PROG_TAIL.append(("dot", s_mul.id))
+final_exp_entries(PROG_TAIL)
 
 # ---------------------------------------------------------------------------------------------------------------- simulator
 
 
-def simulate(sig1, sig2n, K, lines, trace=None):
+def simulate(sig1, sig2n, K, lines, trace=None, prog=None, Fval=None):
     """Runs PROG over big integers for one item: sig1 = (x, y), sig2n = -sig2 = (x, y) or None, K = ((xr, xi), (yr, yi)) or None; lines[n] = (a, b, c) Fp2 triples of gg.
     Returns True iff the result is 1."""
     slot = [0] * 128
@@ -605,7 +630,7 @@ def simulate(sig1, sig2n, K, lines, trace=None):
     slot[X0], slot[X0 + 1] = 1, 1
     slot[L1 + 4], slot[L1 + 5], slot[L1 + 6], slot[L1 + 7] = 3 % P, -3 % P, 9 % P, -9 % P      # E = 3 b', E3 = 9 b' for Z = 1
     regs = [[0] * 12 for _ in range(NREG)]
-    for ent in PROG:
+    for ent in (prog or PROG):
         if ent[0] == "dot":
             s_ = STEPS[ent[1]]
             dead = (s_.tag == 1 and not live1) or (s_.tag == 2 and not live2)
@@ -640,6 +665,8 @@ def simulate(sig1, sig2n, K, lines, trace=None):
                     slot[X0 + 2 * k], slot[X0 + 2 * k + 1] = (a - b) % P, (a + b) % P
             else:
                 slot[W1:W1 + 12] = regs[ent[1]]
+        elif ent[0] == "ldf":
+            slot[W1:W1 + 12] = list(Fval)
         elif ent[0] == "check":
             return slot[W0:W0 + 12] == [1] + [0] * 11
         if trace is not None:
@@ -732,6 +759,12 @@ def self_test():
         assert good is True and bad is False, (trial, good, bad)
         n_ok += 1
     assert simulate(sig1, None, K, lines) is False        # e(sig1, K) != 1
+    # the aggregated tail: F = the model's Miller value of (sig1, K) (w-basis coefficients), P2 = -sig2
+    fm = G.miller_loop(sig1, K)
+    Fv = [c_ for k_ in range(6) for c_ in fm[k_]]
+    assert simulate(None, G.g1_neg(sig2), None, lines, prog=PROG_TAIL, Fval=Fv) is True
+    assert simulate(None, G.g1_neg(G.g1_add(sig2, g1)), None, lines, prog=PROG_TAIL, Fval=Fv) is False
+    assert simulate(None, None, None, lines, prog=PROG_TAIL, Fval=[1] + [0] * 11) is True
     assert simulate(None, None, K, lines) is True         # nothing live: the empty product
     # the Miller value itself against the model, after the easy part (which removes the subfield factors of the projective lines): checked through the verdicts above
     # and directly on one item
@@ -810,21 +843,29 @@ def emit(path):
         A("  {%s}," % ",".join("0x%x" % v for v in row))
     A("};")
     A("// program: op | arg0 << 8 | arg1 << 16;  op 0 = dot(step), 1 = load fixed line(n), 2 = invert(src, dst), 3 = load register(reg, area), 4 = store register(reg), 5 = check")
-    ops = []
-    for ent in PROG:
-        if ent[0] == "dot":
-            ops.append(0 | (ent[1] << 8))
-        elif ent[0] == "line":
-            ops.append(1 | (ent[1] << 8))
-        elif ent[0] == "inv":
-            ops.append(2 | (ent[1] << 8) | (ent[2] << 16))
-        elif ent[0] == "ld":
-            ops.append(3 | (ent[1] << 8) | (ent[2] << 16))
-        elif ent[0] == "st":
-            ops.append(4 | (ent[1] << 8))
-        else:
-            ops.append(5)
-    A("ROW16_DEV uint32_t PROG[NPROG] = {%s};" % ",".join("0x%x" % o for o in ops))
+    def enc_prog(prog):
+        ops = []
+        for ent in prog:
+            if ent[0] == "dot":
+                ops.append(0 | (ent[1] << 8))
+            elif ent[0] == "line":
+                ops.append(1 | (ent[1] << 8))
+            elif ent[0] == "inv":
+                ops.append(2 | (ent[1] << 8) | (ent[2] << 16))
+            elif ent[0] == "ld":
+                ops.append(3 | (ent[1] << 8) | (ent[2] << 16))
+            elif ent[0] == "st":
+                ops.append(4 | (ent[1] << 8))
+            elif ent[0] == "ldf":
+                ops.append(6)
+            else:
+                ops.append(5)
+        return ops
+
+    A("ROW16_DEV uint32_t PROG[NPROG] = {%s};" % ",".join("0x%x" % o for o in enc_prog(PROG)))
+    A("// the closing step of aggregated verification: op 6 = load F (the product of the batch's Miller values) into W1")
+    A("constexpr int NPROG_TAIL = %d;" % len(PROG_TAIL))
+    A("ROW16_DEV uint32_t PROG_TAIL[NPROG_TAIL] = {%s};" % ",".join("0x%x" % o for o in enc_prog(PROG_TAIL)))
     A("}  // namespace row16")
     with open(path, "w") as fh:
         fh.write("\n".join(L) + "\n")

@@ -1,0 +1,28 @@
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+pkg = importlib.import_module("ps-signature-and-el-passo_amd")
+synth = importlib.import_module("ps-signature-and-el-passo_amd.synth")
+dev = torch.device("cuda:0")
+ctx = pkg.Context(pkg.CURVE_BN254, 0)
+wl = synth.Workload(ctx, 3, seed=20211, window_bits=16)
+stream = torch.cuda.current_stream().cuda_stream
+recs, expect = wl.ps_verify_batch(4096)
+d_rec = torch.from_numpy(np.frombuffer(recs, dtype=np.uint8).copy()).to(dev)
+d_fl = torch.zeros(4096, dtype=torch.uint8, device=dev)
+d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+def timed(n, reps=5):
+    f = lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr()))
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+for rnd in range(2):
+    for n in (1, 64, 1000, 4096):
+        print("default n=%d %.3f ms" % (n, timed(n)), flush=True)
+ctx.set_pair16(1)
+for n in (64, 4096): print("row16 n=%d %.3f ms" % (n, timed(n)), flush=True)
+ctx.set_pair16(0)
+for n in (64, 4096): print("default again n=%d %.3f ms" % (n, timed(n)), flush=True)
