@@ -638,7 +638,9 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, n, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
     res["ps_verify_4096x3attrs"] = {"value": n / (ms * 1e-3), "unit": "verifications/s", "kernel_ms": ms,
                                     "parity_ok": bool((d_fl.cpu().numpy() == expect).all()),
-                                    "path": "cooperative kernels (k_ps_k_coop: K on 8 lanes per item; k_pair_coop: pairing check on 32 lanes per item)",
+                                    "path": "k_ps_k_coop (K on 8 lanes per item) + k_pair16 (round 6: the pairing check with one item per 16-lane row of a wave, every Fp12-level "
+                                            "operation one inner product per lane over operands in LDS; ELP_OPT_PAIR16, csrc/elpasso_pair16.h, profiles/r06_pair16.md); "
+                                            "round 5 ran the 32-lane-pair interpreter here: 2.77-2.84 ms",
                                     "valu_bound": valu_frac(ctx, "ps_verify", window, n, ms),
                                     "roofline": {"bound": "hbm", "achieved": n * 228 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": n * 228 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_item": 228}}
@@ -661,12 +663,14 @@ def secondary_workloads(pkg, synth, local_rank, dev, window):
     # small batches and lone items, cooperative kernels on / off (ELP_OPT_COOP_PAIRING): latency, not throughput
     lat = {}
     ctx.set_pair4(0)          # this section compares the interpreter with the per-lane kernels; the four-lane path has the sections mid_batches_*
-    for coop in (1, 0):
+    for coop, row16, tag in ((1, 1, "row_of_16"), (1, 0, "interpreter"), (0, 0, "per_lane")):      # row_of_16 = the default since round 6 (4 ... 4 096 items)
         ctx.set_coop_pairing(coop)
-        for m in (4096, 1, 1024, 4096):       # the first entry warms tables and TLBs for this mode (its time is overwritten by the last)
+        ctx.set_pair16(row16)
+        for m in (4096, 1, 64, 1024, 4096):       # the first entry warms tables and TLBs for this mode (its time is overwritten by the last)
             ms = timed(lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, m, d_rec.data_ptr(), 3, d_fl.data_ptr(), d_cnt.data_ptr())))
-            lat["ps_verify_n%d_%s_ms" % (m, "cooperative" if coop else "per_lane")] = ms
+            lat["ps_verify_n%d_%s_ms" % (m, tag)] = ms
     ctx.set_coop_pairing(1)
+    ctx.set_pair16(1)
     ctx.close()
     ctx = pkg.Context(pkg.CURVE_BN254, local_rank)
     ctx.set_pair4(0)

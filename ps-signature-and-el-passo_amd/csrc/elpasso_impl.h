@@ -2599,6 +2599,26 @@ int msm_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_points, const v
   return ELP_OK;
 }
 
+// the pairing check with ONE ITEM PER 16-LANE ROW (round 6; elpasso_pair16.h, translation unit elpasso_bn254_pair16.hip): 12 lanes hold one base-field coefficient each
+// of the Fp12 value, every operation is one inner product per lane over operands published in LDS; reads K and `todo` like launch_pair4
+template <class B>
+struct Pair16Build {
+  static constexpr bool value = false;
+};
+template <>
+struct Pair16Build<BN254> {
+  static constexpr bool value = true;
+};
+template <class B>
+void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
+                   void* d_accepted);
+// ... and the closing step of aggregated verification on one row (k_agg_final16): the fixed pair's Miller loop, the product with F, the final exponentiation
+template <class B>
+void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
+#ifndef ELP_PAIR16_TU
+extern template void launch_agg_final16<BN254>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
+extern template void launch_pair16<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
+#endif
 // Which curves have the paired kernels in this build (their own translation unit, elpasso_<curve>_pair.hip).
 template <class B>
 struct PairedBuild {
@@ -2877,26 +2897,6 @@ extern template void launch_vid_mid<BN254>(hipStream_t stream, const KeyCtx<BN25
 extern template void launch_vid_mid<BLS12_381>(hipStream_t stream, const KeyCtx<BLS12_381>& key, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, uint8_t* nizk_ok, const uint8_t* kvalid, const u32* kws, size_t kstride, uint8_t* pair_ok, const void* pre);
 extern template void launch_pair4<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 extern template void launch_pair4<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
-#endif
-// the pairing check with ONE ITEM PER 16-LANE ROW (round 6; elpasso_pair16.h, translation unit elpasso_bn254_pair16.hip): 12 lanes hold one base-field coefficient each
-// of the Fp12 value, every operation is one inner product per lane over operands published in LDS; reads K and `todo` like launch_pair4
-template <class B>
-struct Pair16Build {
-  static constexpr bool value = false;
-};
-template <>
-struct Pair16Build<BN254> {
-  static constexpr bool value = true;
-};
-template <class B>
-void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
-                   void* d_accepted);
-// ... and the closing step of aggregated verification on one row (k_agg_final16): the fixed pair's Miller loop, the product with F, the final exponentiation
-template <class B>
-void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
-#ifndef ELP_PAIR16_TU
-extern template void launch_agg_final16<BN254>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
-extern template void launch_pair16<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 #endif
 // batch sizes served by the four-lane pairing check by default (ELP_OPT_PAIR4 = 1), from the A/B sweeps of profiles/r05_four_lane.md: up to 16 384 items the quads
 // of a batch run ONE wave per SIMD (256 workgroups of 64 items); el_passo_verify_id from 3 073 items (below, the interpreter's one launch is as fast or faster:
