@@ -574,6 +574,32 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
     except Exception as e:  # pragma: no cover
         res["cpu_baseline"] = {"error": str(e)}
     ctx.close()
+    try:     # BASELINE config 2's shape on this curve: 4 096 PS verifications, A = 3 -- the row-of-16 pairing check (round 6) against the interpreter
+        ctx = pkg.Context(pkg.CURVE_BLS12_381, local_rank)
+        wl3 = synth.Workload(ctx, 3, seed=20211, window_bits=16)
+        n = 4096
+        precs, pexpect = wl3.ps_verify_batch(n)
+        d_prec = torch.from_numpy(np.frombuffer(precs, dtype=np.uint8).copy()).to(dev)
+        d_pfl = torch.zeros(n, dtype=torch.uint8, device=dev)
+        out = {}
+        for mode, tag in ((1, "row_of_16"), (0, "interpreter")):
+            ctx.set_pair16(mode)
+            f = lambda: ctx._chk(ctx.lib.elp_ps_verify_batch_dev(ctx.h, stream, n, d_prec.data_ptr(), 3, d_pfl.data_ptr(), d_cnt.data_ptr()))
+            f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            out["ms_" + tag] = e0.elapsed_time(e1) / 3
+            out["parity_ok"] = out.get("parity_ok", True) and bool((d_pfl.cpu().numpy() == pexpect).all())
+        out["value"] = n / (out["ms_row_of_16"] * 1e-3)
+        out["unit"] = "verifications/s"
+        res["ps_verify_4096x3attrs"] = out
+        ctx.close()
+    except Exception as e:  # pragma: no cover
+        res["ps_verify_4096x3attrs"] = {"error": str(e)}
     return res
 
 

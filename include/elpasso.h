@@ -92,10 +92,11 @@ int elp_field_bytes(int curve);               /* F */
  *   (about 3x slower at these sizes): callers who cannot trust their senders to use one pattern should group messages by pattern or set 0.
  * ELP_OPT_AGG_TWO_PER_LANE (default 0; BN254): elp_verify_id_batch_aggregated[_dev] with two proofs on a lane (shared squarings).  1 = on batches that
  *   need fewer rounds of lanes that way, 2 = always (tests).  Off by default: largest private frame of the library (scratch re-provisioning).
- * ELP_OPT_PAIR16 (round 6; BN254): PS verifications of at most 4 096 items (value > 1: that many) run the pairing check with ONE ITEM PER 16-LANE ROW of a wave --
+ * ELP_OPT_PAIR16 (default 1; round 6): PS verifications of at most 4 096 items (value > 1: that many) run the pairing check with ONE ITEM PER 16-LANE ROW of a wave --
  *   12 lanes hold one base-field coefficient each of the Fp12 value, every Fp12-level operation is one inner product per lane over operands published in LDS
- *   (csrc/elpasso_pair16.h; tools/ubench_row16.hip measured the building blocks at 2.0-2.35 x lower latency than four lanes per item).  0 = the cooperative
- *   interpreter keeps these sizes.  The library's default is the measured winner (elp_init).
+ *   (csrc/elpasso_pair16.h; tables and program generated and simulated by tools/gen_row16.py for both curves) -- from the size at which that wins: 4 items on BN254,
+ *   2 049 on BLS12-381 (below, the cooperative interpreter's 32 lane pairs per item are faster); on BN254 also the closing step of aggregated verification.
+ *   0 = the interpreter keeps these sizes.  Measurements: profiles/r06_pair16.md.
  * ELP_OPT_FAULT_INJECT (default 0; test hook for callers' error paths): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  *   ELP_ERR_STATE before anything is queued.  No other entry point consumes or honours the counter.
  */

@@ -69,15 +69,16 @@ HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=
              ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", ["-DELP_FP6_INLINE=1", "-DELP_NONLEAF_GUARD=1", "-DELP_PAIR_WAVES=1"]), ("elpasso_bls12_381_g1jobs.hip", []), ("elpasso_bn254_g1jobs.hip", []),
              ("elpasso_bls12_381_coop.hip", []), ("elpasso_bls12_381_nizk.hip", []), ("elpasso_bn254_small2.hip", ["-DELP_WAVES_PER_EU=2"]),
              ("elpasso_bn254_pair4.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bls12_381_pair4.hip", ["-DELP_FP6_INLINE=1", "-DELP_NONLEAF_GUARD=1"]),
-             ("elpasso_bn254_pair16.hip", [])]
+             ("elpasso_bn254_pair16.hip", []), ("elpasso_bls12_381_pair16.hip", [])]
 
 
 def build_hip(force=False, verbose=False):
-    deps = [os.path.join(CSRC, u) for u, _ in HIP_UNITS] + [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elpasso_pair4.h"), os.path.join(CSRC, "elpasso_pair16.h"), os.path.join(CSRC, "elp"),
+    deps = [os.path.join(CSRC, u) for u, _ in HIP_UNITS] + [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elpasso_pair4.h"), os.path.join(CSRC, "elpasso_pair16.h"), os.path.join(CSRC, "elpasso_pair16_prog.h"), os.path.join(CSRC, "elpasso_pair16_prog_bls12_381.h"), os.path.join(CSRC, "elp"),
                                                            os.path.join(HERE, "..", "include")]
     # rebuild key = hash of the sources and flags (per unit: the shared headers + that unit's own file), not modification times
     shared = [os.path.join(CSRC, "elpasso_impl.h"), os.path.join(CSRC, "elp"), os.path.join(HERE, "..", "include")]
-    unit_headers = {"elpasso_bn254_pair4.hip": ["elpasso_pair4.h"], "elpasso_bls12_381_pair4.hip": ["elpasso_pair4.h"], "elpasso_bn254_pair16.hip": ["elpasso_pair16.h"]}      # headers only these units include
+    unit_headers = {"elpasso_bn254_pair4.hip": ["elpasso_pair4.h"], "elpasso_bls12_381_pair4.hip": ["elpasso_pair4.h"], "elpasso_bn254_pair16.hip": ["elpasso_pair16.h", "elpasso_pair16_prog.h"],
+                    "elpasso_bls12_381_pair16.hip": ["elpasso_pair16.h", "elpasso_pair16_prog_bls12_381.h"]}      # headers only these units include
     unit_extra = {u: os.environ.get("ELP_EXTRA_FLAGS_" + u.split(".")[0].upper(), "").split() for u, _ in HIP_UNITS}     # experiments only
     lib_digest = _digest(deps, [(u, f, unit_extra[u]) for u, f in HIP_UNITS])
     if not force and _stamp_ok(LIB, lib_digest):

@@ -1978,6 +1978,7 @@ struct elp_ctx {
   int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
   int agg_two = 0;            // ELP_OPT_AGG_TWO_PER_LANE: aggregated batches put two items on a lane (0 = never -- the default: 2 % at best, and the kernel's larger frame makes the runtime re-provision scratch --, 1 = where it saves rounds of lanes, 2 = always)
   int pair16 = 0;                // ELP_OPT_PAIR16 (set by elp_init): PS verifications of at most pair16_max items run the pairing check on one 16-lane row per item
+  int pair16_tail = 1;           // the closing step of aggregated verification on one row (elp_init: BN254 yes; BLS12-381 no -- a lone item is faster on the interpreter there)
   size_t pair16_max = 4096, pair16_min = 4;      // below pair16_min (less than one wave of rows) the interpreter's 32 lane pairs per item are a little faster: 1.60 vs 1.72 ms for a lone item
   int pair4 = 1;                 // ELP_OPT_PAIR4: 0 = off, 1 = by batch size (default), 2 = wherever the path exists
   // per-lane tables of the variable-base multiplications (KeyCtx::vtab): one workspace per stream that launched a verification, grown on demand
@@ -2609,6 +2610,10 @@ template <>
 struct Pair16Build<BN254> {
   static constexpr bool value = true;
 };
+template <>
+struct Pair16Build<BLS12_381> {
+  static constexpr bool value = true;
+};
 template <class B>
 void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
                    void* d_accepted);
@@ -2617,6 +2622,8 @@ template <class B>
 void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
 #ifndef ELP_PAIR16_TU
 extern template void launch_agg_final16<BN254>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
+extern template void launch_agg_final16<BLS12_381>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
+extern template void launch_pair16<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 extern template void launch_pair16<BN254>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
 #endif
 // Which curves have the paired kernels in this build (their own translation unit, elpasso_<curve>_pair.hip).
@@ -2735,7 +2742,7 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
   if (c->overlap) HIPCHK(c, hipStreamWaitEvent(stream, c->jev[1], 0));
   bool tail_done = false;
   if constexpr (Pair16Build<C>::value) {
-    if (c->pair16) {                                          // the serial tail on one 16-lane row (round 6): 472 steps of one inner product per lane
+    if (c->pair16 && c->pair16_tail) {                        // the serial tail on one 16-lane row (round 6): 472 steps of one inner product per lane
       launch_agg_final16<C>(stream, key.gg_lines, F, ws + o_s2, c->agg_ok);
       tail_done = true;
     }

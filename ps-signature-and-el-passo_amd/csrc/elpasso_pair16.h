@@ -12,18 +12,28 @@
 #include "elpasso_impl.h"
 #include "elp/quad.h"
 #define ROW16_DEV __constant__
+// one translation unit per curve: elpasso_bn254_pair16.hip, elpasso_bls12_381_pair16.hip (the latter defines R16_BLS); tables and program from tools/gen_row16.py --curve ...
+#ifdef R16_BLS
+#include "elpasso_pair16_prog_bls12_381.h"
+namespace r16t = row16_bls;
+#else
 #include "elpasso_pair16_prog.h"
+namespace r16t = row16;
+#endif
 
 namespace elp {
 
-constexpr int R16_NL = BN254::NL;
-constexpr int R16_NLP = (R16_NL + 3) & ~3;                           // limbs of a slot padded to 16-byte words
-constexpr int R16_REG0 = row16::NSLOT;                               // the stored Fp12 values ("registers" of the program) follow the generator's slots
-constexpr int R16_ROW_SLOTS = row16::NSLOT + 12 * row16::NREG;
-constexpr int R16_ROWS = 4;
-constexpr int R16_LDS_WORDS = (R16_ROWS * R16_ROW_SLOTS + row16::NCONST) * R16_NLP;
-
+#ifdef R16_BLS
+typedef BLS12_381 R16C;
+#else
 typedef BN254 R16C;
+#endif
+constexpr int R16_NL = R16C::NL;
+constexpr int R16_NLP = (R16_NL + 3) & ~3;                           // limbs of a slot padded to 16-byte words
+constexpr int R16_REG0 = r16t::NSLOT;                               // the stored Fp12 values ("registers" of the program) follow the generator's slots
+constexpr int R16_ROW_SLOTS = r16t::NSLOT + 12 * r16t::NREG;
+constexpr int R16_ROWS = 4;
+constexpr int R16_LDS_WORDS = (R16_ROWS * R16_ROW_SLOTS + r16t::NCONST) * R16_NLP;
 
 // A workgroup is ONE wave: its LDS instructions are issued and executed in program order, so a step's writes cannot overtake the reads that precede them and the next
 // step's reads see them -- no s_barrier and, above all, no s_waitcnt on the table loads that are in flight for the NEXT step.  Only the compiler must keep the order.
@@ -34,7 +44,7 @@ typedef BN254 R16C;
 #endif
 
 ELP_INL Fp<R16C> r16_ld(const i32* L, const i32* K, int s) {         // slot s of the row (below CONST_BASE) or of the shared constants
-  const i32* p = s < row16::CONST_BASE ? L + s * R16_NLP : K + (s - row16::CONST_BASE) * R16_NLP;
+  const i32* p = s < r16t::CONST_BASE ? L + s * R16_NLP : K + (s - r16t::CONST_BASE) * R16_NLP;
   Fp<R16C> r;
   ELP_UNROLL
   for (int i = 0; i < R16_NL; i++) r.v[i] = p[i];
@@ -78,14 +88,14 @@ ELP_INL Fp<R16C> r16_dot(const i32* L, const i32* K, const u32 (&tb)[12]) {
 template <bool TAIL>
 ELP_INL bool r16_run(i32* lds, i32* L, const i32* K, int row, int q, int c, bool live1, bool live2, const LineMem<R16C>* gg_lines, const Fp12<R16C>* Fglob, int dbg_pc,
                      i32* dbg) {
-  const u32* const prog = TAIL ? row16::PROG_TAIL : row16::PROG;
-  const int nprog = TAIL ? row16::NPROG_TAIL : row16::NPROG;
+  const u32* const prog = TAIL ? r16t::PROG_TAIL : r16t::PROG;
+  const int nprog = TAIL ? r16t::NPROG_TAIL : r16t::NPROG;
   u32 tb[12];
   u32 e = prog[0];
   {
     const int sid = (int)(e >> 8) & 0xFF;
     ELP_UNROLL
-    for (int t = 0; t < 12; t++) tb[t] = (e & 0xFF) == 0 ? row16::STEP_TERMS[sid][q][t] : 0u;
+    for (int t = 0; t < 12; t++) tb[t] = (e & 0xFF) == 0 ? r16t::STEP_TERMS[sid][q][t] : 0u;
   }
   bool verdict = false;
   ELP_NOUNROLL
@@ -96,7 +106,7 @@ ELP_INL bool r16_run(i32* lds, i32* L, const i32* K, int row, int q, int c, bool
       const int sidn = (int)(e_next >> 8) & 0xFF;
       const bool dotn = (e_next & 0xFF) == 0;
       ELP_UNROLL
-      for (int t = 0; t < 12; t++) tb_next[t] = dotn ? row16::STEP_TERMS[sidn][q][t] : 0u;
+      for (int t = 0; t < 12; t++) tb_next[t] = dotn ? r16t::STEP_TERMS[sidn][q][t] : 0u;
     }
     const int op = (int)(e & 0xFF), a0 = (int)(e >> 8) & 0xFF, a1 = (int)(e >> 16) & 0xFF;
     if (dbg && pc == dbg_pc) {                                      // the state BEFORE entry pc of the program: every slot of every row of workgroup 0
@@ -105,8 +115,8 @@ ELP_INL bool r16_run(i32* lds, i32* L, const i32* K, int row, int q, int c, bool
       return false;
     }
     if (op == 0) {
-      const int nt = row16::STEP_NT[a0], fl = row16::STEP_FLAGS[a0];
-      const u32 dst = row16::STEP_DEST[a0][q];
+      const int nt = r16t::STEP_NT[a0], fl = r16t::STEP_FLAGS[a0];
+      const u32 dst = r16t::STEP_DEST[a0][q];
       Fp<R16C> r;
       switch (nt) {
         case 1: r = r16_dot<1>(L, K, tb); break;
@@ -135,10 +145,10 @@ ELP_INL bool r16_run(i32* lds, i32* L, const i32* K, int row, int q, int c, bool
       }
       R16_SYNC();
       if (wr) r16_st(L, (int)(dst & 0xFF), r);
-      if ((fl & 1) && wr && q < 12) r16_st(L, row16::SLOT_X0 + q, xr);
+      if ((fl & 1) && wr && q < 12) r16_st(L, r16t::SLOT_X0 + q, xr);
       R16_SYNC();
     } else if (op == 1) {                                           // the fixed line a0: six base-field values of gg's precomputed line -> LF
-      if (q < 6) r16_st(L, row16::SLOT_LF + q, reinterpret_cast<const Fp<R16C>*>(&gg_lines[a0])[q]);
+      if (q < 6) r16_st(L, r16t::SLOT_LF + q, reinterpret_cast<const Fp<R16C>*>(&gg_lines[a0])[q]);
       R16_SYNC();
     } else if (op == 2) {                                           // one base-field inversion (lane 0 of the row)
       const Fp<R16C> x = r16_ld(L, K, a0);
@@ -150,22 +160,22 @@ ELP_INL bool r16_run(i32* lds, i32* L, const i32* K, int row, int q, int c, bool
       const Fp<R16C> p = r16_pair_swap(v);
       if (q < 12) {
         if (a1 == 0) {
-          r16_st(L, row16::SLOT_W0 + q, v);
-          r16_st(L, row16::SLOT_X0 + q, c == 0 ? fp_sub<R16C>(v, p) : fp_add<R16C>(p, v));
+          r16_st(L, r16t::SLOT_W0 + q, v);
+          r16_st(L, r16t::SLOT_X0 + q, c == 0 ? fp_sub<R16C>(v, p) : fp_add<R16C>(p, v));
         } else {
-          r16_st(L, row16::SLOT_W1 + q, v);
+          r16_st(L, r16t::SLOT_W1 + q, v);
         }
       }
       R16_SYNC();
     } else if (op == 4) {                                           // W0 -> stored value a0
-      if (q < 12) r16_st(L, R16_REG0 + 12 * a0 + q, r16_ld(L, K, row16::SLOT_W0 + q));
+      if (q < 12) r16_st(L, R16_REG0 + 12 * a0 + q, r16_ld(L, K, r16t::SLOT_W0 + q));
       R16_SYNC();
     } else if (op == 6) {                                           // W1 <- F, the product of the batch's Miller values (plain layout: c0 <-> w^0, w^2, w^4; c1 <-> w^1, w^3, w^5)
-      if (q < 12) r16_st(L, row16::SLOT_W1 + q, reinterpret_cast<const Fp<R16C>*>(Fglob)[((q >> 1) & 1) * 6 + (q >> 2) * 2 + (q & 1)]);
+      if (q < 12) r16_st(L, r16t::SLOT_W1 + q, reinterpret_cast<const Fp<R16C>*>(Fglob)[((q >> 1) & 1) * 6 + (q >> 2) * 2 + (q & 1)]);
       R16_SYNC();
     } else {                                                        // the result is 1 <=> every coefficient of W0 - 1 is zero modulo p
-      Fp<R16C> v = r16_ld(L, K, row16::SLOT_W0 + (q < 12 ? q : 1));
-      if (q == 0) v = fp_sub<R16C>(v, r16_ld(L, K, row16::SLOT_ONE));
+      Fp<R16C> v = r16_ld(L, K, r16t::SLOT_W0 + (q < 12 ? q : 1));
+      if (q == 0) v = fp_sub<R16C>(v, r16_ld(L, K, r16t::SLOT_ONE));
       const bool z = fp_is_zero<R16C>(v);
       const unsigned long long bz = __ballot(z);
       verdict = (((unsigned)(bz >> (16u * (unsigned)row))) & 0xFFFu) == 0xFFFu;
@@ -188,9 +198,9 @@ __global__ void __launch_bounds__(64, 1) k_pair16(const LineMem<R16C>* gg_lines,
   const bool in_range = item0 < n;
   const size_t i = in_range ? item0 : n - 1;                       // rows beyond the batch walk the program on a copy of the last item and publish nothing
   // ---- set-up: constants, zeroed slots, the item's points
-  for (int s = (int)threadIdx.x; s < row16::NCONST; s += 64) {
+  for (int s = (int)threadIdx.x; s < r16t::NCONST; s += 64) {
     ELP_UNROLL
-    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = row16::CONSTS[s][w];
+    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = r16t::CONSTS[s][w];
   }
   for (int s = q; s < R16_ROW_SLOTS; s += 16) {
     ELP_UNROLL
@@ -209,8 +219,8 @@ __global__ void __launch_bounds__(64, 1) k_pair16(const LineMem<R16C>* gg_lines,
       ok_pt = g1_load<R16C>(pt, rec + q * 2 * R16C::N);
       inf_pt = ok_pt && aff_is_inf(pt);
       if (q == 1) pt.y = fp_neg(pt.y);
-      r16_st(L, (q == 0 ? row16::SLOT_P1 : row16::SLOT_P2), pt.x);
-      r16_st(L, (q == 0 ? row16::SLOT_P1 : row16::SLOT_P2) + 1, pt.y);
+      r16_st(L, (q == 0 ? r16t::SLOT_P1 : r16t::SLOT_P2), pt.x);
+      r16_st(L, (q == 0 ? r16t::SLOT_P1 : r16t::SLOT_P2) + 1, pt.y);
     }
     bool k_zero = true;
     if (q >= 4 && q < 8) {
@@ -222,17 +232,17 @@ __global__ void __launch_bounds__(64, 1) k_pair16(const LineMem<R16C>* gg_lines,
         any |= (u32)v.v[w];
       }
       k_zero = any == 0;
-      r16_st(L, row16::SLOT_T + (q - 4), v);
-      r16_st(L, row16::SLOT_Q + (q - 4), v);
+      r16_st(L, r16t::SLOT_T + (q - 4), v);
+      r16_st(L, r16t::SLOT_Q + (q - 4), v);
     }
     if (q == 8) {
-      const Fp<R16C> one = r16_ld(L, K, row16::SLOT_ONE);
-      r16_st(L, row16::SLOT_T + 4, one);
-      r16_st(L, row16::SLOT_W0, one);
-      r16_st(L, row16::SLOT_X0, one);                                // xi * 1 = 1 + i
-      r16_st(L, row16::SLOT_X0 + 1, one);
+      const Fp<R16C> one = r16_ld(L, K, r16t::SLOT_ONE);
+      r16_st(L, r16t::SLOT_T + 4, one);
+      r16_st(L, r16t::SLOT_W0, one);
+      r16_st(L, r16t::SLOT_X0, one);                                // xi * 1 = 1 + i
+      r16_st(L, r16t::SLOT_X0 + 1, one);
     }
-    if (q >= 12) r16_st(L, row16::SLOT_E + (q - 12), r16_ld(L, K, row16::CONST_E_INIT + (q - 12)));      // E = 3 b', E3 = 9 b' for Z = 1
+    if (q >= 12) r16_st(L, r16t::SLOT_E + (q - 12), r16_ld(L, K, r16t::CONST_E_INIT + (q - 12)));      // E = 3 b', E3 = 9 b' for Z = 1
     // the row's verdict on its inputs and which pairs take part: ballots over the wave, this row's 16 bits
     const unsigned long long b_bad = __ballot(!ok_pt), b_inf = __ballot(inf_pt), b_kz = __ballot(!k_zero);
     const unsigned sh = 16u * (unsigned)row;
@@ -257,9 +267,9 @@ __global__ void __launch_bounds__(64, 1) k_agg_final16(const LineMem<R16C>* gg_l
   const int row = (int)(threadIdx.x >> 4), q = (int)(threadIdx.x & 15), c = q & 1;
   i32* const L = lds + row * R16_ROW_SLOTS * R16_NLP;
   i32* const K = lds + R16_ROWS * R16_ROW_SLOTS * R16_NLP;
-  for (int s = (int)threadIdx.x; s < row16::NCONST; s += 64) {
+  for (int s = (int)threadIdx.x; s < r16t::NCONST; s += 64) {
     ELP_UNROLL
-    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = row16::CONSTS[s][w];
+    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = r16t::CONSTS[s][w];
   }
   for (int s = q; s < R16_ROW_SLOTS; s += 16) {
     ELP_UNROLL
@@ -271,14 +281,14 @@ __global__ void __launch_bounds__(64, 1) k_agg_final16(const LineMem<R16C>* gg_l
     Aff<F1<R16C>> pt;
     ok_pt = g1_load<R16C>(pt, s2_std);
     inf_pt = ok_pt && aff_is_inf(pt);
-    r16_st(L, row16::SLOT_P2, pt.x);
-    r16_st(L, row16::SLOT_P2 + 1, fp_neg(pt.y));
+    r16_st(L, r16t::SLOT_P2, pt.x);
+    r16_st(L, r16t::SLOT_P2 + 1, fp_neg(pt.y));
   }
   if (q == 8) {
-    const Fp<R16C> one = r16_ld(L, K, row16::SLOT_ONE);
-    r16_st(L, row16::SLOT_W0, one);
-    r16_st(L, row16::SLOT_X0, one);
-    r16_st(L, row16::SLOT_X0 + 1, one);
+    const Fp<R16C> one = r16_ld(L, K, r16t::SLOT_ONE);
+    r16_st(L, r16t::SLOT_W0, one);
+    r16_st(L, r16t::SLOT_X0, one);
+    r16_st(L, r16t::SLOT_X0 + 1, one);
   }
   const unsigned long long b_bad = __ballot(!ok_pt), b_inf = __ballot(inf_pt);
   const bool ok_in = ((unsigned)b_bad & 0x2u) == 0;                     // row 0 decides (the other rows walk the program on zeros)
@@ -292,14 +302,14 @@ __global__ void __launch_bounds__(64, 1) k_agg_final16(const LineMem<R16C>* gg_l
 
 template <class B>
 void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok) {
-  static_assert(std::is_same<B, elp::BN254>::value, "generated for BN254");
-  hipLaunchKernelGGL(elp::k_agg_final16, dim3(1), dim3(64), 0, stream, (const elp::LineMem<elp::BN254>*)gg_lines, (const elp::Fp12<elp::BN254>*)F, (const u32*)s2_std, agg_ok);
+  static_assert(std::is_same<B, elp::R16C>::value, "this translation unit holds the other curve's tables");
+  hipLaunchKernelGGL(elp::k_agg_final16, dim3(1), dim3(64), 0, stream, (const elp::LineMem<elp::R16C>*)gg_lines, (const elp::Fp12<elp::R16C>*)F, (const u32*)s2_std, agg_ok);
 }
 template <class B>
 void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
                    void* d_accepted) {
-  static_assert(std::is_same<B, elp::BN254>::value, "generated for BN254");
+  static_assert(std::is_same<B, elp::R16C>::value, "this translation unit holds the other curve's tables");
   if (n == 0) return;
-  hipLaunchKernelGGL(elp::k_pair16, dim3((unsigned)((n + elp::R16_ROWS - 1) / elp::R16_ROWS)), dim3(64), 0, stream, (const elp::LineMem<elp::BN254>*)gg_lines,
+  hipLaunchKernelGGL(elp::k_pair16, dim3((unsigned)((n + elp::R16_ROWS - 1) / elp::R16_ROWS)), dim3(64), 0, stream, (const elp::LineMem<elp::R16C>*)gg_lines,
                      (const u32*)d_records, words, todo, kws, kstride, d_flags, (unsigned long long*)d_accepted, n);
 }

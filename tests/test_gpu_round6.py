@@ -62,6 +62,56 @@ def test_row_of_16_pairing_check_vs_oracle(gpu_ctx):
             L.elpo_key_free(key)
 
 
+def test_row_of_16_pairing_check_bls12_381_vs_oracle(elp):
+    """The same kernel generated for BLS12-381 (M-type lines, loop over |z|, the cubed Hayashida-Hayasaka-Teruya chain): PS verification at n = 4 ... 4 096 against the C
+    oracle's BLS12-381 build on every item and against the interpreter, with the tamperings of the BN254 test plus a sig1 outside G1 (rejected: subgroup check on)."""
+    import os
+    from elp_testlib import oracle_bls
+    L = oracle_bls()
+    os.environ["ELP_PAIR16_MIN"] = "1"            # the rows at every size (the library's default on this curve starts them at 2 049 items, where they win)
+    try:
+        ctx = elp.Context(elp.CURVE_BLS12_381, 0)
+    finally:
+        del os.environ["ELP_PAIR16_MIN"]
+    try:
+        A = 3
+        wl = synth.Workload(ctx, A, seed=707, window_bits=8)
+        nmax = 4096
+        recs, expect = wl.ps_verify_batch(nmax)
+        rsz = len(recs) // nmax
+        r = bytearray(recs)
+        G1B = 96
+        for base in range(0, nmax - 15, 64):
+            r[(base + 1) * rsz:(base + 1) * rsz + G1B] = bytes(G1B)                                   # sig1 = infinity
+            r[(base + 2) * rsz + G1B:(base + 2) * rsz + 2 * G1B] = bytes(G1B)                         # sig2 = infinity
+            a = bytes(r[(base + 3) * rsz:(base + 3) * rsz + G1B])
+            r[(base + 3) * rsz:(base + 3) * rsz + G1B] = r[(base + 3) * rsz + G1B:(base + 3) * rsz + 2 * G1B]
+            r[(base + 3) * rsz + G1B:(base + 3) * rsz + 2 * G1B] = a                                  # sig1 <-> sig2
+            r[(base + 4) * rsz + 5] ^= 1                                                              # sig1.x: off the curve
+            r[(base + 6) * rsz + 2 * G1B + 3] ^= 1                                                    # a different attribute hash
+        # sig1 = (0, p - 2): on the curve, order 3 (outside G1)
+        p381 = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+        r[7 * rsz:7 * rsz + G1B] = bytes(48) + (p381 - 2).to_bytes(48, "little")
+        recs = bytes(r)
+        g1 = wl.g + wl.Yi + ctx.hash_to_g1([wl.service]) + wl.g + wl.apk + wl.h + wl.X
+        key = ctypes.c_void_p(L.elpo_key_new(A, g1, wl.gg + wl.XX + wl.YYi))
+        idx = sorted(set(list(range(0, 80)) + list(range(80, nmax, 13))))
+        want = {i: L.elpo_ps_verify(key, recs[i * rsz:(i + 1) * rsz], A) for i in idx}
+        assert want[0] == 1 and not any(want[i] for i in (1, 2, 3, 4, 6, 7))
+        for n in (4, 5, 64, 65, 1000, 4096):
+            ctx.set_pair16(1)
+            fl, cnt = ctx.ps_verify_batch(recs[:n * rsz], A)
+            for i in idx:
+                if i < n:
+                    assert fl[i] == want[i], (n, i)
+            ctx.set_pair16(0)
+            fl0, cnt0 = ctx.ps_verify_batch(recs[:n * rsz], A)
+            assert (fl0 == fl).all() and cnt0 == cnt, n
+        L.elpo_key_free(key)
+    finally:
+        ctx.close()
+
+
 def test_records_staged_in_parts_equal_one_piece_submit(gpu_ctx):
     """elp_verify_id_batch_stage (round 6): the records of a batch delivered in ragged parts, out of order, then submitted with records == NULL, give the verdicts of
     the one-piece submit and of the generator; a submit after an incomplete staging fails without leaving the slot busy."""

@@ -15,7 +15,9 @@ This file (build tooling, runs in the build container; output committed):
   * a SIMULATOR of the generated tables over big integers, checked against the big-int model's pairing (oracle/pymodel.py) on valid and invalid signatures before
     anything is written: the device executes exactly these tables,
   * the emitter of the tables and the program as C arrays.
-Only BN254 (D-type twist, 29-bit limbs: an inner product may accumulate 13 limb products per column, checked per lane below).
+Both curves: python tools/gen_row16.py [--curve bn254|bls12_381]  (BN254: D-type twist, 29-bit limbs, 13 limb products per accumulator column, 6z + 2 with two closing
+Frobenius additions, FKR hard part; BLS12-381: M-type twist, 28-bit limbs, 35 products per column, loop over |z|, the Hayashida-Hayasaka-Teruya hard part taken to the third
+power as elp/pairing.h does for verdicts).  The headroom is checked per lane below.
 """
 import os
 import random
@@ -23,13 +25,19 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
-from oracle.pymodel import BN254, Groups, Mcl  # noqa: E402
+from oracle.pymodel import BLS12_381, BN254, Groups, Mcl  # noqa: E402
 
-CV = BN254
+CURVE = "bn254"
+if "--curve" in sys.argv:
+    CURVE = sys.argv[sys.argv.index("--curve") + 1].lower()
+assert CURVE in ("bn254", "bls12_381")
+CV = BN254 if CURVE == "bn254" else BLS12_381
+IS_BN = CV.is_bn
 G = Groups(CV)
 F = G.F
 P = CV.p
-HEADROOM = 13          # limb products per accumulator column (params_bn254.h HEADROOM - 1)
+NLIMB, LBITS = (9, 29) if IS_BN else (14, 28)        # params_<curve>.h NL, LB
+HEADROOM = 13 if IS_BN else 35                       # limb products per accumulator column (params_<curve>.h HEADROOM - 1)
 ALLOWED = (1, 2, 3, 4, 6, 12)
 
 # ---------------------------------------------------------------------------------------------------------------- slots
@@ -58,7 +66,7 @@ AD = alloc("AD", 16)          # addition step: theta, mu, D, Ct, lc, E, F, G    
 W0 = alloc("W0", 12)
 X0 = alloc("X0", 12)          # xi * W0
 W1 = alloc("W1", 12)
-W2 = alloc("W2", 12)
+EQ = alloc("EQ", 2)           # BLS12-381: xi Z^2, the first link of the chain that makes E = 3 b' Z^2 = 12 xi Z^2 within the accumulator's headroom
 NSLOT = _next[0]
 assert NSLOT <= 120, NSLOT
 CONST_BASE = 128
@@ -73,7 +81,7 @@ def const(name, value):
 
 ZERO = const("zero", 0)
 ONE = const("one", 1)
-E_INIT = [const("e_init%d" % i, v) for i, v in enumerate((3, -3, 9, -9))]      # E = 3 b', E3 = 9 b' of a point with Z = 1
+E_INIT = None      # (set once TB3 is known: E = 3 b', E3 = 9 b' of a point with Z = 1)
 
 # ---------------------------------------------------------------------------------------------------------------- symbolic forms
 
@@ -281,21 +289,25 @@ U, Bv, E, E3, H, Lb = (f2(L1 + 2 * i) for i in range(6))
 lva, lvb = f2(LV), f2(LV + 2)
 lfa, lfb, lfc = f2(LF), f2(LF + 2), f2(LF + 4)
 lfsa, lfsb = f2(LFS), f2(LFS + 2)
-TB3 = (3, -3)                        # 3 b' = 3 * 2 / (1 + i) = 3 - 3 i   (BN254: b = 2, D-type twist)
-assert F.f2_muls(F.b2, 3) == (3, P - 3), F.b2
+TB3 = (3, -3) if IS_BN else (12, 12)
+E_INIT = [const("e_init%d" % i_, v_) for i_, v_ in enumerate((TB3[0], TB3[1], 3 * TB3[0], 3 * TB3[1]))]
+TB3 = TB3   # 3 b': BN254 b' = 2 / (1 + i) = 1 - i (D-type twist); BLS12-381 b' = 4 (1 + i) (M-type twist)
+assert F.f2_muls(F.b2, 3) == (TB3[0] % P, TB3[1] % P), F.b2
 
 
 def f2mulc(x, c):                    # Fp2 (linear) times the small constant c[0] + c[1] i
     return (x[0].scale(c[0]) - x[1].scale(c[1]), x[0].scale(c[1]) + x[1].scale(c[0]))
 
 
-def line_product(a, b, c):
-    """f * (a + b w + c w^3) with a, b, c Fp2 linear forms: h_k = a f_k + b F_{k-1} + c F_{k-3},  F_j = f_j (j >= 0), xi f_{j+6} (j < 0)"""
+def line_product(la, lb, lc):
+    """f * line for the line (l.a y_P, l.b x_P, l.c) of elp/pairing.h (ml_apply_line): D-type twist (BN254) line = l.a y_P + l.b x_P w + l.c w^3; M-type twist
+    (BLS12-381) line = l.c + l.b x_P w^2 + l.a y_P w^3.  h_k = sum_pos coef_pos F_{k - pos},  F_j = f_j (j >= 0), xi f_{j+6} (j < 0)"""
+    placed = ((0, la), (1, lb), (3, lc)) if IS_BN else ((0, lc), (2, lb), (3, la))
     out = []
     for k in range(6):
-        acc = f2mul(f[k], a)
-        acc = q2add(acc, f2mul(f[k - 1] if k >= 1 else xf[k + 5], b))
-        acc = q2add(acc, f2mul(f[k - 3] if k >= 3 else xf[k + 3], c))
+        acc = (Quad(), Quad())
+        for pos, coef in placed:
+            acc = q2add(acc, f2mul(f[k - pos] if k >= pos else xf[k - pos + 6], coef))
         out.append(acc)
     return out
 
@@ -312,12 +324,21 @@ zz = f2mul(Z, Z)
 e_q = (zz[0].scale(TB3[0]) - zz[1].scale(TB3[1]), zz[0].scale(TB3[1]) + zz[1].scale(TB3[0]))      # E = 3 b' Z^2
 
 
-def spare_e(s_):
-    s_.out2(12, e_q, L1 + 4)
+Eq = f2(EQ)
 
 
-def spare_e3(s_):
-    s_.out2(12, q2scale(f2mulfp(E, S(ONE)), 3), L1 + 6)
+def spare_e(s_):          # on the spare lanes of the variable line's product: BN254 E itself (12 limb products per column); BLS12-381 xi Z^2 (E = 12 xi Z^2 would be 48)
+    if IS_BN:
+        s_.out2(12, e_q, L1 + 4)
+    else:
+        s_.out2(12, f2mul(f2xi(Z), Z), EQ)
+
+
+def spare_e3(s_):         # on the spare lanes of the fixed line's product: BN254 3 E; BLS12-381 E = 12 (xi Z^2)
+    if IS_BN:
+        s_.out2(12, q2scale(f2mulfp(E, S(ONE)), 3), L1 + 6)
+    else:
+        s_.out2(12, q2scale(f2mulfp(Eq, S(ONE)), 12), L1 + 4)
 
 
 s_d1 = step("dbl1")
@@ -325,6 +346,8 @@ s_d1.out2(0, f2mul(X, Y), L1 + 0)                          # U
 s_d1.out2(2, f2mul(Y, Y), L1 + 2)                          # B
 s_d1.out2(4, q2scale(f2mul(Y, Z), 2), L1 + 8)              # H = 2 Y Z
 s_d1.out2(6, q2scale(f2mul(X, X), -3), L1 + 10)            # Lb = -3 X^2
+if not IS_BN:
+    s_d1.out2(8, q2scale(f2mulfp(E, S(ONE)), 3), L1 + 6)     # BLS12-381: 3 E, the last link of the chain (level 2 reads it)
 # S3: doubling, level 2 (+ the variable line evaluated at P1 on the spare lanes)
 s_d2 = step("dbl2")
 s_d2.out2(0, q2scale(f2mul(U, f2sub(Bv, E3)), 2), T_ + 0)                                   # 4 X' = 2 U (B - 3E)
@@ -410,7 +433,7 @@ def naf(k):
 
 
 DIG = list(reversed(naf(CV.ate_loop)[:-1]))
-assert len(DIG) == 65, len(DIG)
+assert len(DIG) == (65 if IS_BN else 64), len(DIG)
 line_no = 0
 for i, d in enumerate(DIG):
     PROG.append(("line", line_no))
@@ -429,26 +452,27 @@ for i, d in enumerate(DIG):
         line_no += 1
 assert CV.z < 0
 PROG.append(("dot", s_conj.id))
-# closing additions: T <- -T (sign carried by the tables of the first one), Q1 = pi(Q), Q2 = -pi^2(Q)
-PROG.append(("dot", s_q1.id))
-PROG.append(("line", line_no))
-for s_ in ADD[(1, -1)]:
-    PROG.append(("dot", s_.id))
-PROG.append(("dot", s_lva.id))
-PROG.append(("dot", s_lf.id))
-line_no += 1
-PROG.append(("dot", s_q2.id))
-PROG.append(("line", line_no))
-for s_ in ADD[(-1, 1)]:
-    PROG.append(("dot", s_.id))
-PROG.append(("dot", s_lva.id))
-PROG.append(("dot", s_lf.id))
-line_no += 1
+if IS_BN:
+    # closing additions: T <- -T (sign carried by the tables of the first one), Q1 = pi(Q), Q2 = -pi^2(Q)
+    PROG.append(("dot", s_q1.id))
+    PROG.append(("line", line_no))
+    for s_ in ADD[(1, -1)]:
+        PROG.append(("dot", s_.id))
+    PROG.append(("dot", s_lva.id))
+    PROG.append(("dot", s_lf.id))
+    line_no += 1
+    PROG.append(("dot", s_q2.id))
+    PROG.append(("line", line_no))
+    for s_ in ADD[(-1, 1)]:
+        PROG.append(("dot", s_.id))
+    PROG.append(("dot", s_lva.id))
+    PROG.append(("dot", s_lf.id))
+    line_no += 1
 NLINES = line_no
 
 # ---------------------------------------------------------------------------------------------------------------- final exponentiation
 # registers: each lane keeps its coefficient of up to NREG stored Fp12 values; ("st", r): reg r <- the lane's coefficient of W0; ("ld", r, area): area (0 = W0 with X0, 1 = W1) <- reg r
-NREG = 7
+NREG = 7 if IS_BN else 4
 w1 = v12(W1)
 s_mul = step("mul_w0_w1", wx=True)                       # W0 <- W0 * W1
 s_mul.out12(mul12(f, xf, w1), W0)
@@ -554,29 +578,47 @@ def final_exp_entries(prog):
     d(s_copy)                                                # W1 = f1
     d(FROB[2])                                               # W0 = f1^(p^2)
     d(s_mul)                                                 # W0 = f2: in the cyclotomic subgroup from here on
-    st(R_F)
-    exp_z(R_F); st(R_FZ)                                     # fz
-    d(s_cyc); st(R_F2Z)                                      # f2z
-    d(s_cyc)                                                 # f4z
-    mul_by(R_F2Z); st(R_F6Z)                                 # f6z
-    exp_z(R_F6Z); st(R_F6Z2)                                 # f6z2
-    d(s_cyc)                                                 # f12z2
-    st(R_FZ)                                                 # (fz is dead: its register carries the base of the next power)
-    exp_z(R_FZ)                                              # f12z3
-    mul_by(R_F6Z2)
-    mul_by(R_F6Z); st(R_A)                                   # a = f^l2
-    mul_by(R_F2Z, conj=True); st(R_B)                        # b = f^l1
-    ld0(R_A)
-    mul_by(R_F6Z2)
-    mul_by(R_F); st(R_FZ)                                    # r = f^l0            (kept in the free register)
-    ld0(R_B); d(FROB[1]); d(s_copy); ld0(R_FZ); d(s_mul); st(R_FZ)      # r *= b^p
-    ld0(R_A); d(FROB[2]); d(s_copy); ld0(R_FZ); d(s_mul); st(R_FZ)      # r *= a^(p^2)
-    ld0(R_B); mul_by(R_F, conj=True)                         # f^l3 = b conj(f)
-    d(FROB[3]); d(s_copy); ld0(R_FZ); d(s_mul)               # r *= (f^l3)^(p^3)
+    if IS_BN:
+        st(R_F)
+        exp_z(R_F); st(R_FZ)                                     # fz
+        d(s_cyc); st(R_F2Z)                                      # f2z
+        d(s_cyc)                                                 # f4z
+        mul_by(R_F2Z); st(R_F6Z)                                 # f6z
+        exp_z(R_F6Z); st(R_F6Z2)                                 # f6z2
+        d(s_cyc)                                                 # f12z2
+        st(R_FZ)                                                 # (fz is dead: its register carries the base of the next power)
+        exp_z(R_FZ)                                              # f12z3
+        mul_by(R_F6Z2)
+        mul_by(R_F6Z); st(R_A)                                   # a = f^l2
+        mul_by(R_F2Z, conj=True); st(R_B)                        # b = f^l1
+        ld0(R_A)
+        mul_by(R_F6Z2)
+        mul_by(R_F); st(R_FZ)                                    # r = f^l0            (kept in the free register)
+        ld0(R_B); d(FROB[1]); d(s_copy); ld0(R_FZ); d(s_mul); st(R_FZ)      # r *= b^p
+        ld0(R_A); d(FROB[2]); d(s_copy); ld0(R_FZ); d(s_mul); st(R_FZ)      # r *= a^(p^2)
+        ld0(R_B); mul_by(R_F, conj=True)                         # f^l3 = b conj(f)
+        d(FROB[3]); d(s_copy); ld0(R_FZ); d(s_mul)               # r *= (f^l3)^(p^3)
+    else:
+        # BLS12-381 (Hayashida-Hayasaka-Teruya, cubed as in elp/pairing.h final_exp<C, false>): 3 (p^4-p^2+1)/r = (z-1)^2 (z+p) (z^2+p^2-1) + 3
+        st(R_F)
+        exp_z(R_F)                                           # f^z
+        mul_by(R_F, conj=True); st(R_A)                      # a = f^(z-1)
+        exp_z(R_A)
+        mul_by(R_A, conj=True); st(R_A)                      # a = a^(z-1)
+        exp_z(R_A); st(R_T)                                  # t = a^z
+        ld0(R_A); d(FROB[1]); mul_by(R_T); st(R_B)           # b = a^p a^z = a^(z+p)
+        exp_z(R_B); st(R_T)
+        exp_z(R_T); st(R_T)                                  # t = b^(z^2)
+        ld0(R_B); d(FROB[2]); mul_by(R_T); mul_by(R_B, conj=True); st(R_T)      # c = b^(p^2) b^(z^2) b^-1
+        ld0(R_F); d(s_cyc); mul_by(R_F)                      # f^3
+        mul_by(R_T)                                          # c f^3
     prog.append(("check",))
 
 
 R_F, R_FZ, R_F2Z, R_F6Z, R_F6Z2, R_A, R_B = range(7)
+R_T = 1                                                      # BLS12-381 uses four: f (0), t (1), a (2), b (3)
+if not IS_BN:
+    R_A, R_B = 2, 3
 ZABS = abs(CV.z)
 final_exp_entries(PROG)
 
@@ -596,7 +638,7 @@ for i, dgt in enumerate(DIG):
         PROG_TAIL.append(("dot", s_scale.id))
         PROG_TAIL.append(("dot", s_lf.id))
 PROG_TAIL.append(("dot", s_conj.id))
-for _ in range(2):
+for _ in range(2 if IS_BN else 0):
     PROG_TAIL.append(("line", ln)); ln += 1
     PROG_TAIL.append(("dot", s_scale.id))
     PROG_TAIL.append(("dot", s_lf.id))
@@ -628,7 +670,7 @@ def simulate(sig1, sig2n, K, lines, trace=None, prog=None, Fval=None):
         slot[P2], slot[P2 + 1] = sig2n
     slot[W0] = 1
     slot[X0], slot[X0 + 1] = 1, 1
-    slot[L1 + 4], slot[L1 + 5], slot[L1 + 6], slot[L1 + 7] = 3 % P, -3 % P, 9 % P, -9 % P      # E = 3 b', E3 = 9 b' for Z = 1
+    slot[L1 + 4], slot[L1 + 5], slot[L1 + 6], slot[L1 + 7] = TB3[0] % P, TB3[1] % P, 3 * TB3[0] % P, 3 * TB3[1] % P      # E = 3 b', E3 = 9 b' for Z = 1
     regs = [[0] * 12 for _ in range(NREG)]
     for ent in (prog or PROG):
         if ent[0] == "dot":
@@ -718,34 +760,41 @@ def model_lines(Q):
         out.append(dbl())
         if d:
             out.append(add(Q[0], Q[1] if d > 0 else F.f2_neg(Q[1])))
-    Y_ = F.f2_neg(Y_)
-    q1 = G.g2_frob(Q)
-    q2 = G.g2_frob(q1)
-    out.append(add(q1[0], q1[1]))
-    out.append(add(q2[0], F.f2_neg(q2[1])))
+    if IS_BN:
+        Y_ = F.f2_neg(Y_)
+        q1 = G.g2_frob(Q)
+        q2 = G.g2_frob(q1)
+        out.append(add(q1[0], q1[1]))
+        out.append(add(q2[0], F.f2_neg(q2[1])))
     return out
+
+
+def g2_point():
+    """a point of G2: the twist point from the first x = 1, 2, ... that works, cofactor cleared"""
+    if IS_BN:
+        h2 = 2 * CV.p - CV.r
+    else:
+        z = CV.z
+        h2 = (z**8 - 4 * z**7 + 5 * z**6 - 4 * z**4 + 6 * z**3 - 4 * z**2 - 4 * z + 13) // 9
+    x = (1, 0)
+    while True:
+        y = F.f2_sqrt(F.f2_add(F.f2_mul(F.f2_sqr(x), x), F.b2))
+        if y is not None:
+            R = None
+            for bit in bin(h2)[2:]:
+                R = G.g2_add(R, R)
+                if bit == "1":
+                    R = G.g2_add(R, (x, y))
+            if R is not None:
+                return R
+        x = ((x[0] + 1) % P, 0)
 
 
 def self_test():
     M = Mcl(CV)
     rnd = random.Random(2026)
     g1 = M.hash_to_g1(b"row16")
-    # a G2 generator: the model's twist point of order r from a fixed x (first that works), cofactor cleared
-    x = (1, 0)
-    while True:
-        y = F.f2_sqrt(F.f2_add(F.f2_mul(F.f2_sqr(x), x), F.b2))
-        if y is not None:
-            Qg = (x, y)
-            h2 = 2 * CV.p - CV.r
-            R = None
-            for bit in bin(h2)[2:]:
-                R = G.g2_add(R, R)
-                if bit == "1":
-                    R = G.g2_add(R, Qg)
-            if R is not None:
-                gg = R
-                break
-        x = ((x[0] + 1) % P, 0)
+    gg = g2_point()
     lines = model_lines(gg)
     assert len(lines) == NLINES, (len(lines), NLINES)
     n_ok = 0
@@ -773,10 +822,11 @@ def self_test():
 
 # ---------------------------------------------------------------------------------------------------------------- emitter
 def mont(v):
-    return v * (1 << (29 * 9)) % P
+    return v * (1 << (LBITS * NLIMB)) % P
 
 
-def balanced(x, nl=9, w=29):
+def balanced(x, nl=None, w=None):
+    nl, w = nl or NLIMB, w or LBITS
     out = []
     for i in range(nl):
         if i == nl - 1:
@@ -798,18 +848,18 @@ def enc_term(a, b, c):
 def emit(path):
     L = []
     A = L.append
-    A("// GENERATED by tools/gen_row16.py -- do not edit.  Tables and program of the row-of-16 pairing check (BN254); see the generator for the formulas.")
+    A("// GENERATED by tools/gen_row16.py --curve %s -- do not edit.  Tables and program of the row-of-16 pairing check; see the generator for the formulas." % CURVE)
     A("#pragma once")
     A("#include <stdint.h>")
     A("#ifndef ROW16_DEV")
     A("#define ROW16_DEV static const      /* the device translation unit defines it as __constant__ */")
     A("#endif")
-    A("namespace row16 {")
+    A("namespace %s {" % ("row16" if IS_BN else "row16_bls"))
     A("constexpr int NSLOT = %d, NCONST = %d, CONST_BASE = %d, NSTEP = %d, NPROG = %d, NLINES = %d, NREG = %d;" % (NSLOT, len(CONSTS), CONST_BASE, len(STEPS), len(PROG), NLINES, NREG))
     A("constexpr int SLOT_T = %d, SLOT_Q = %d, SLOT_P1 = %d, SLOT_P2 = %d, SLOT_LF = %d, SLOT_W0 = %d, SLOT_X0 = %d, SLOT_W1 = %d, SLOT_ONE = %d, SLOT_E = %d;" % (T_, Q_, P1, P2, LF, W0, X0, W1, ONE, L1 + 4))
     A("constexpr int CONST_E_INIT = %d;      // four constants: E = 3 b' and E3 = 9 b' of a point with Z = 1" % E_INIT[0])
-    A("// constants in Montgomery form, balanced 29-bit limbs")
-    A("ROW16_DEV int32_t CONSTS[NCONST][9] = {")
+    A("// constants in Montgomery form, balanced %d-bit limbs" % LBITS)
+    A("ROW16_DEV int32_t CONSTS[NCONST][%d] = {" % NLIMB)
     for name, (idx, val) in sorted(CONSTS.items(), key=lambda kv: kv[1][0]):
         A("  {%s},  // %d %s" % (",".join(str(v) for v in balanced(mont(val))), idx, name))
     A("};")
@@ -866,7 +916,7 @@ def emit(path):
     A("// the closing step of aggregated verification: op 6 = load F (the product of the batch's Miller values) into W1")
     A("constexpr int NPROG_TAIL = %d;" % len(PROG_TAIL))
     A("ROW16_DEV uint32_t PROG_TAIL[NPROG_TAIL] = {%s};" % ",".join("0x%x" % o for o in enc_prog(PROG_TAIL)))
-    A("}  // namespace row16")
+    A("}  // namespace")
     with open(path, "w") as fh:
         fh.write("\n".join(L) + "\n")
     print("wrote %s: %d step types, %d program entries, %d constants, %d slots per row" % (path, len(STEPS), len(PROG), len(CONSTS), NSLOT))
@@ -875,7 +925,7 @@ def emit(path):
 if __name__ == "__main__":
     n = self_test()
     print("simulator: %d valid + %d invalid signatures agree with the model's pairing semantics" % (n, n))
-    emit(os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elpasso_pair16_prog.h"))
+    emit(os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elpasso_pair16_prog.h" if IS_BN else "elpasso_pair16_prog_bls12_381.h"))
 
 
 # ---------------------------------------------------------------------------------------------------------------- debugging aid: tools/pair16_check.hip
