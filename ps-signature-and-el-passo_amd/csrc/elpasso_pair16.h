@@ -70,8 +70,62 @@ ELP_INL Fp<R16C> r16_pair_swap(const Fp<R16C>& a) {                  // the othe
   return a;                                                          // (the host pass only parses the kernel)
 #endif
 }
+// One inner product of NT terms.  Two forms with the same multiply-adds and the same bounds (quad.h fp_dot): COLUMN-scanning keeps all 2 NT operands in registers and
+// walks the columns with one accumulator (fp_dot itself); OPERAND-scanning keeps 2 NL - 1 column accumulators and takes the terms one at a time -- 2 x NL + 2 (2 NL - 1)
+// registers instead of 2 NT NL, which is what the 14-limb field needs (336 operand registers for a twelve-term product otherwise: 27 spilled, 212 parked in AGPRs).
+#ifndef R16_DOT_OS
+#ifdef R16_BLS
+#define R16_DOT_OS 1
+#else
+#define R16_DOT_OS 0
+#endif
+#endif
 template <int NT>
 ELP_INL Fp<R16C> r16_dot(const i32* L, const i32* K, const u32 (&tb)[12]) {
+#if R16_DOT_OS
+  typedef R16C C;
+  constexpr int NL = R16_NL;
+  i64 col[2 * NL - 1];
+  ELP_UNROLL
+  for (int k = 0; k < 2 * NL - 1; k++) col[k] = 0;
+  ELP_UNROLL
+  for (int t = 0; t < NT; t++) {
+    const Fp<R16C> a = r16_ld(L, K, (int)(tb[t] & 0xFF));
+    Fp<R16C> b = r16_ld(L, K, (int)((tb[t] >> 8) & 0xFF));
+    const i32 cf = (i32)(tb[t] << 8) >> 24;
+    ELP_UNROLL
+    for (int i = 0; i < NL; i++) b.v[i] *= cf;
+    ELP_UNROLL
+    for (int i = 0; i < NL; i++) {
+      ELP_UNROLL
+      for (int j = 0; j < NL; j++) ELP_MAC(col[i + j], a.v[i], b.v[j]);
+    }
+  }
+  i32 m[NL], pl[NL];
+  ELP_UNROLL
+  for (int i = 0; i < NL; i++) pl[i] = elp_opaque(C::modl(i));
+  Fp<R16C> r;
+  i64 acc = 0;
+  ELP_UNROLL
+  for (int k = 0; k < NL; k++) {
+    acc += col[k];
+    ELP_UNROLL
+    for (int i = 0; i < k; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
+    m[k] = elp_balanced30((u32)acc * C::INVL);
+    ELP_MAC_S(acc, m[k], pl[0]);
+    acc >>= ELP_LIMB_BITS;
+  }
+  ELP_UNROLL
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    acc += col[k];
+    ELP_UNROLL
+    for (int i = k - NL + 1; i < NL; i++) ELP_MAC_S(acc, m[i], pl[k - i]);
+    r.v[k - NL] = elp_balanced30((u32)acc);
+    acc = (acc + ELP_LIMB_HALF) >> ELP_LIMB_BITS;
+  }
+  r.v[NL - 1] = (i32)acc;
+  return r;
+#else
   Fp<R16C> a[NT], b[NT];
   ELP_UNROLL
   for (int t = 0; t < NT; t++) {
@@ -82,6 +136,7 @@ ELP_INL Fp<R16C> r16_dot(const i32* L, const i32* K, const u32 (&tb)[12]) {
     for (int i = 0; i < R16_NL; i++) b[t].v[i] *= cf;
   }
   return fp_dot<R16C, NT>(a, b);
+#endif
 }
 
 // The program loop shared by the two kernels (TAIL: the closing step of aggregated verification).  Returns the row's verdict.
