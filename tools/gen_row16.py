@@ -925,7 +925,16 @@ def emit(path):
 if __name__ == "__main__":
     n = self_test()
     print("simulator: %d valid + %d invalid signatures agree with the model's pairing semantics" % (n, n))
-    emit(os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elpasso_pair16_prog.h" if IS_BN else "elpasso_pair16_prog_bls12_381.h"))
+    target = os.path.join(ROOT, "ps-signature-and-el-passo_amd", "csrc", "elpasso_pair16_prog.h" if IS_BN else "elpasso_pair16_prog_bls12_381.h")
+    if "--check" in sys.argv:      # the committed header must be what the (simulated) tables emit: tests/test_row16_gen.py
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            tmp = os.path.join(td, "prog.h")
+            emit(tmp)
+            same = open(tmp).read() == open(target).read()
+        print("committed header %s the generator's output" % ("equals" if same else "DIFFERS from"))
+        sys.exit(0 if same else 1)
+    emit(target)
 
 
 # ---------------------------------------------------------------------------------------------------------------- debugging aid: tools/pair16_check.hip
