@@ -371,6 +371,7 @@ int elp_verify_id_batch_stage(elp_ctx* c, int slot, size_t n_total, size_t recor
   }
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->pstream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->pstream[0], hipStreamNonBlocking));
+  if (first == 0 && count == 0) s.staged_bytes = 0;      // the sizing call that opens a batch also forgets parts a failed earlier batch may have left behind
   if (s.rec_cap < n_total * record_size) {
     if (s.staged_bytes) {
       c->err = "elp_verify_id_batch_stage: n_total x record_size grew while parts of the batch were staged";
