@@ -1521,9 +1521,23 @@ __global__ void ELP_LAUNCH_BOUNDS k_pairing_check(const u32* g1, const u32* g2, 
 //   k_msm_buckets : one 256-thread workgroup per (window, slice of <= 8192 points): LDS histogram of the window's digits
 //                   (byte w of each scalar), shfl-based exclusive scan, LDS counting sort of the slice's indices by digit, then
 //                   lane b sums the points of bucket b (no elliptic-curve atomics, no divergence inside the additions)
+//   k_msm_combine : (more than eight slices per window) the slices' bucket sums combined by 32 lanes per bucket
 //   k_msm_reduce  : per window: slices combined, then sum_b b*B_b as a suffix scan + tree reduction through LDS
 //   k_msm_final   : Horner over the non-empty windows (of 32), normalisation, one std affine point out
 #define ELP_MSM_SLICE 8192
+// Slices per window: at least ceil(n / ELP_MSM_SLICE) (the LDS sort buffer), more -- down to 1 024 points per slice -- while the launch would otherwise leave compute
+// units idle: nwin x S workgroups should reach two per compute unit (65 536 points, 16 windows: 8 -> 32 slices, the bucket phase 0.62 -> see profiles/r06_aggregated.md)
+static inline int msm_slices(size_t n, int nwin) {
+  static const size_t target = [] {
+    const char* e = getenv("ELP_MSM_WORKGROUPS");           // (measurements)
+    const long v = e ? atol(e) : 0;
+    return (size_t)(v > 0 ? v : 512);
+  }();
+  size_t s = (n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE;
+  const size_t want = (target + (size_t)nwin - 1) / (size_t)nwin, most = (n + 1023) / 1024;
+  if (s < want) s = want < most ? want : most;
+  return (int)(s ? s : 1);
+}
 #define ELP_MSM_TPB 256
 
 template <class C, int G>
@@ -1592,12 +1606,33 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
   partial[(size_t)blockIdx.x * 256 + tid] = acc;
 }
 
+// More than eight slices per window: their bucket sums are combined by 32 lanes per bucket (a tree of five additions through LDS) instead of one lane walking all of
+// them in k_msm_reduce (32 slices: 31 additions in sequence there, 0.41 ms against 0.21 with this kernel in front; profiles/r06_aggregated.md).  A workgroup takes eight
+// neighbouring buckets of one window (thread = 8 * lane-of-the-bucket + bucket); the sum lands IN PLACE in slice 0 -- a bucket's slots are touched by its 32 lanes only.
 template <class F>
-__global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S, Jac<F>* win) {
+__global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_combine(Jac<F>* partial, int S) {
+  __shared__ Jac<F> sh[256];
+  const int tid = threadIdx.x, j = tid >> 3, w = blockIdx.x >> 5, b = ((blockIdx.x & 31) << 3) | (tid & 7);
+  Jac<F> acc;
+  jac_set_inf(acc);
+  if (j < S) acc = partial[((size_t)w * S + j) * 256 + b];
+  for (int s = j + 32; s < S; s += 32) jac_add<F>(acc, acc, partial[((size_t)w * S + s) * 256 + b]);
+  for (int d = 16; d >= 1; d >>= 1) {
+    sh[tid] = acc;
+    __syncthreads();
+    if (j < d) jac_add<F>(acc, acc, sh[tid + 8 * d]);
+    __syncthreads();
+  }
+  if (j == 0) partial[((size_t)w * S) * 256 + b] = acc;
+}
+
+// partial: slice s of window w at [(w * stride + s) * 256, + 256)
+template <class F>
+__global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S, int stride, Jac<F>* win) {
   __shared__ Jac<F> sh[256];
   const int tid = threadIdx.x, w = blockIdx.x;
-  Jac<F> acc = partial[((size_t)w * S) * 256 + tid];
-  for (int s = 1; s < S; s++) jac_add<F>(acc, acc, partial[((size_t)w * S + s) * 256 + tid]);
+  Jac<F> acc = partial[((size_t)w * stride) * 256 + tid];
+  for (int s = 1; s < S; s++) jac_add<F>(acc, acc, partial[((size_t)w * stride + s) * 256 + tid]);
   // suffix scan: acc_b = sum_{j >= b} B_j
   for (int d = 1; d < 256; d <<= 1) {
     sh[tid] = acc;
@@ -1613,6 +1648,14 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S,
     __syncthreads();
   }
   if (tid == 0) win[w] = acc;
+}
+
+// bucket sums per (window, slice) -> [slices combined] -> one sum per window
+template <class F>
+static void msm_windows(hipStream_t stream, int nwin, int S, const Aff<F>* aff, const uint8_t* ks, size_t n, Jac<F>* part, Jac<F>* win) {
+  hipLaunchKernelGGL((k_msm_buckets<F>), dim3(nwin * S), dim3(ELP_MSM_TPB), 0, stream, aff, ks, n, S, part);
+  if (S > 8) hipLaunchKernelGGL((k_msm_combine<F>), dim3(nwin * 32), dim3(ELP_MSM_TPB), 0, stream, part, S);
+  hipLaunchKernelGGL((k_msm_reduce<F>), dim3(nwin), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S > 8 ? 1 : S, S, win);
 }
 
 // Closing step for the multipliers of aggregated verification, d_i = a_i + b_i lam with a_i in scalar bytes 0-7 and b_i in bytes 8-15 (pipeline.h
@@ -2431,7 +2474,7 @@ int msm_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint
     memset(out, 0, P);
     return ELP_OK;
   }
-  const int S = (int)((n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE);
+  const int S = msm_slices(n, 32);
   DevBuf dpts, dks, daff, dpart, dwin, dbad, dout;
   HIPCHK(c, dpts.alloc(n * P));
   HIPCHK(c, dks.alloc(n * 32));
@@ -2446,14 +2489,10 @@ int msm_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint
   hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)dpts.p, daff.p, (int*)dbad.p, n);
   if (G == 1) {
     typedef F1<C> F;
-    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, c->stream, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, S,
-                       (Jac<F>*)dpart.p);
-    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, c->stream, (const Jac<F>*)dpart.p, S, (Jac<F>*)dwin.p);
+    msm_windows<F>(c->stream, 32, S, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, (Jac<F>*)dpart.p, (Jac<F>*)dwin.p);
   } else {
     typedef F2<C> F;
-    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(32 * S), dim3(ELP_MSM_TPB), 0, c->stream, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, S,
-                       (Jac<F>*)dpart.p);
-    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(32), dim3(ELP_MSM_TPB), 0, c->stream, (const Jac<F>*)dpart.p, S, (Jac<F>*)dwin.p);
+    msm_windows<F>(c->stream, 32, S, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, (Jac<F>*)dpart.p, (Jac<F>*)dwin.p);
   }
   hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, c->stream, (const void*)dwin.p, (u32*)dout.p);
   HIPCHK(c, hipGetLastError());
@@ -2552,15 +2591,15 @@ template <class C, int G>
 static size_t msm_ws_bytes(size_t n) {
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
-  const size_t S = (n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE;
+  const size_t S = (size_t)msm_slices(n, 16);      // the larger of the two launch shapes (16 windows for the pairs of aggregated verification, 32 otherwise)
   return ((n * AFF + 255) & ~(size_t)255) + ((32 * S * 256 * JAC + 255) & ~(size_t)255) + ((32 * JAC + 255) & ~(size_t)255) + 256;
 }
 template <class C, int G>
 static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs = false) {
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
-  const int S = (int)((n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE);
   const int NWL = glv_pairs ? 16 : 32;            // scalar bytes in use: the pairs (a, b) of aggregated verification fill 16
+  const int S = msm_slices(n, NWL);
   uint8_t* aff = ws;
   uint8_t* part = aff + ((n * AFF + 255) & ~(size_t)255);
   uint8_t* win = part + (((size_t)32 * S * 256 * JAC + 255) & ~(size_t)255);
@@ -2569,12 +2608,10 @@ static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, cons
   hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, (const u32*)d_pts_std, (void*)aff, bad, n);
   if (G == 1) {
     typedef F1<C> F;
-    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NWL * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
-    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(NWL), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+    msm_windows<F>(stream, NWL, S, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, (Jac<F>*)part, (Jac<F>*)win);
   } else {
     typedef F2<C> F;
-    hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NWL * S), dim3(ELP_MSM_TPB), 0, stream, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, S, (Jac<F>*)part);
-    hipLaunchKernelGGL((k_msm_reduce<F>), dim3(NWL), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S, (Jac<F>*)win);
+    msm_windows<F>(stream, NWL, S, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, (Jac<F>*)part, (Jac<F>*)win);
   }
   if constexpr (G == 1) {
     if (glv_pairs) {
@@ -2617,10 +2654,15 @@ struct Pair16Build<BLS12_381> {
 template <class B>
 void launch_pair16(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags,
                    void* d_accepted);
+// ... the product tree of aggregated verification (k_fp12_reduce16: every product one twelve-term step on a row; out[b] = the product of in[32 b .. 32 b + 32)) ...
+template <class B>
+void launch_fp12_reduce16(hipStream_t stream, const void* in, size_t n, void* out);
 // ... and the closing step of aggregated verification on one row (k_agg_final16): the fixed pair's Miller loop, the product with F, the final exponentiation
 template <class B>
 void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
 #ifndef ELP_PAIR16_TU
+extern template void launch_fp12_reduce16<BN254>(hipStream_t stream, const void* in, size_t n, void* out);
+extern template void launch_fp12_reduce16<BLS12_381>(hipStream_t stream, const void* in, size_t n, void* out);
 extern template void launch_agg_final16<BN254>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
 extern template void launch_agg_final16<BLS12_381>(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok);
 extern template void launch_pair16<BLS12_381>(hipStream_t stream, const void* gg_lines, size_t n, const void* d_records, int words, const uint8_t* todo, const u32* kws, size_t kstride, uint8_t* d_flags, void* d_accepted);
@@ -2661,7 +2703,7 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     two_per_lane = c->agg_two == 2 || (c->agg_two == 1 && 189 * r2 < 100 * r1);
   }
   const size_t nw = two_per_lane ? grid_for((n + 1) / 2) : grid_for(n);                       // waves = per-wave Miller products
-  const size_t nw2 = grid_for(nw);
+  const size_t nw2 = (nw + 31) / 32;                                                          // the larger of the two product trees' first level (rows: 32 values per workgroup)
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_flags = 0, o_delta = al(n), o_sig2 = o_delta + al(n * 32), o_f1 = o_sig2 + al(n * Sizes<C>::G1),
                o_f2 = o_f1 + al(nw * sizeof(Fp12<C>)), o_f3 = o_f2 + al(nw2 * sizeof(Fp12<C>)), o_s2 = o_f3 + al(sizeof(Fp12<C>)),
@@ -2723,19 +2765,22 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     HIPCHK(c, hipEventRecord(c->jev[0], stream));
     HIPCHK(c, hipStreamWaitEvent(c->jstream, c->jev[0], 0));
   }
-  hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nw2), dim3(ELP_BLOCK), 0, rstream, (const Fp12<C>*)(ws + o_f1), nw, (Fp12<C>*)(ws + o_f2));
-  const Fp12<C>* F = (const Fp12<C>*)(ws + o_f2);
-  size_t left = nw2;
-  uint8_t *cur = ws + o_f2, *nxt = ws + o_f1;   // ping-pong (o_f1 is free again after the first reduction)
-  while (left > 1) {
-    size_t nl = grid_for(left);
-    hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nl), dim3(ELP_BLOCK), 0, rstream, (const Fp12<C>*)cur, left, (Fp12<C>*)nxt);
+  bool tree16 = false;                                    // 32 values per wave, every product one step on a 16-lane row (round 6), or 64 per wave, one lane each
+  if constexpr (Pair16Build<C>::value) tree16 = c->pair16 != 0;
+  size_t left = nw;
+  uint8_t *cur = ws + o_f1, *nxt = ws + o_f2;             // ping-pong (o_f1 is free again after the first level)
+  do {
+    const size_t nl = tree16 ? (left + 31) / 32 : grid_for(left);
+    if constexpr (Pair16Build<C>::value) {
+      if (tree16) launch_fp12_reduce16<C>(rstream, cur, left, nxt);
+    }
+    if (!tree16) hipLaunchKernelGGL((k_fp12_reduce<C>), dim3(nl), dim3(ELP_BLOCK), 0, rstream, (const Fp12<C>*)cur, left, (Fp12<C>*)nxt);
     uint8_t* t = cur;
     cur = nxt;
     nxt = t;
     left = nl;
-  }
-  F = (const Fp12<C>*)cur;
+  } while (left > 1);
+  const Fp12<C>* F = (const Fp12<C>*)cur;
   if (c->overlap) HIPCHK(c, hipEventRecord(c->jev[1], c->jstream));
   // S2 = sum d_i sig2_i
   msm_launch<C, 1>(stream, n, ws + o_sig2, ws + o_delta, ws + o_s2, ws + o_msm, true);

@@ -353,8 +353,85 @@ __global__ void __launch_bounds__(64, 1) k_agg_final16(const LineMem<R16C>* gg_l
   if (threadIdx.x == 0) *agg_ok = (ok_in && verdict) ? 1 : 0;
 }
 
+// The product tree of aggregated verification on rows: out[b] = prod in[32 b .. min(n, 32 b + 32)).  One wave per 32 values: every row takes eight of them -- seven
+// times the step W0 <- W0 * W1 of the program (twelve terms per lane, one Montgomery reduction) -- and two more steps fold the four rows: nine products in sequence
+// where a lane of k_fp12_reduce walks 63 full Fp12 products (65 536 items: 1 024 values -> 32 -> 1 in two launches; timing in profiles/r06_aggregated.md).
+// Values are Fp12 in the plain layout (c0 <-> w^0, w^2, w^4; c1 <-> w^1, w^3, w^5), as k_verify_id_agg writes and k_agg_final16 reads them.
+ELP_INL int r16_plain_index(int q) { return ((q >> 1) & 1) * 6 + (q >> 2) * 2 + (q & 1); }
+ELP_INL void r16_mul_step(i32* L, const i32* K, const u32 (&tb)[12], int q, int c) {
+  const Fp<R16C> r = r16_dot<12>(L, K, tb);
+  const Fp<R16C> p = r16_pair_swap(r);
+  const Fp<R16C> xr = c == 0 ? fp_sub<R16C>(r, p) : fp_add<R16C>(p, r);      // xi * (W0 * W1) -> X0, xi = 1 + i
+  R16_SYNC();
+  if (q < 12) {
+    r16_st(L, r16t::SLOT_W0 + q, r);
+    r16_st(L, r16t::SLOT_X0 + q, xr);
+  }
+  R16_SYNC();
+}
+__global__ void __launch_bounds__(64, 1) k_fp12_reduce16(const Fp12<R16C>* in, size_t n, Fp12<R16C>* out) {
+  __shared__ __attribute__((aligned(16))) i32 lds[R16_LDS_WORDS];
+  const int row = (int)(threadIdx.x >> 4), q = (int)(threadIdx.x & 15), c = q & 1, ql = q < 12 ? q : 0;
+  i32* const L = lds + row * R16_ROW_SLOTS * R16_NLP;
+  i32* const K = lds + R16_ROWS * R16_ROW_SLOTS * R16_NLP;
+  for (int s = (int)threadIdx.x; s < r16t::NCONST; s += 64) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NL; w++) K[s * R16_NLP + w] = r16t::CONSTS[s][w];
+  }
+  for (int s = q; s < R16_ROW_SLOTS; s += 16) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NLP; w++) L[s * R16_NLP + w] = 0;
+  }
+  __syncthreads();
+  u32 tb[12];
+  ELP_UNROLL
+  for (int t = 0; t < 12; t++) tb[t] = r16t::STEP_TERMS[r16t::STEP_MUL_W0_W1][q][t];
+  Fp<R16C> one_q = r16_ld(L, K, r16t::SLOT_ONE);                       // the lane's coefficient of the value 1
+  if (q != 0) {
+    ELP_UNROLL
+    for (int w = 0; w < R16_NL; w++) one_q.v[w] = 0;
+  }
+  const size_t base = (size_t)blockIdx.x * 32 + (size_t)row * 8;
+  const int pi = r16_plain_index(ql);
+  {                                                                    // W0 <- the row's first value (1 beyond the end), X0 <- xi * W0
+    const Fp<R16C> v = base < n ? reinterpret_cast<const Fp<R16C>*>(in + base)[pi] : one_q;
+    const Fp<R16C> p = r16_pair_swap(v);
+    if (q < 12) {
+      r16_st(L, r16t::SLOT_W0 + q, v);
+      r16_st(L, r16t::SLOT_X0 + q, c == 0 ? fp_sub<R16C>(v, p) : fp_add<R16C>(p, v));
+    }
+  }
+  const size_t wg_left = n - (size_t)blockIdx.x * 32;
+  const int longest = wg_left < 8 ? (int)wg_left : 8;                  // values of row 0, the longest row (values fill the rows in order): uniform over the wave
+  Fp<R16C> nxt = base + 1 < n ? reinterpret_cast<const Fp<R16C>*>(in + base + 1)[pi] : one_q;
+  ELP_NOUNROLL
+  for (int j = 1; j < longest; j++) {
+    if (q < 12) r16_st(L, r16t::SLOT_W1 + q, nxt);
+    R16_SYNC();
+    nxt = (j + 1 < 8 && base + (size_t)j + 1 < n) ? reinterpret_cast<const Fp<R16C>*>(in + base + j + 1)[pi] : one_q;      // travels while the step computes
+    r16_mul_step(L, K, tb, q, c);
+  }
+  // rows 0, 2 <- * rows 1, 3; row 0 <- * row 2 (the rows that only lend their value multiply by 1: the wave stays in one instruction stream)
+  ELP_NOUNROLL
+  for (int lvl = 1; lvl <= 2; lvl++) {
+    const bool take = (row & (2 * lvl - 1)) == 0;
+    const i32* const Lo = lds + (row + lvl) * R16_ROW_SLOTS * R16_NLP;
+    const Fp<R16C> v = take ? r16_ld_row(Lo, r16t::SLOT_W0 + ql) : one_q;
+    if (q < 12) r16_st(L, r16t::SLOT_W1 + q, v);
+    R16_SYNC();
+    r16_mul_step(L, K, tb, q, c);
+  }
+  if (row == 0 && q < 12) reinterpret_cast<Fp<R16C>*>(out + blockIdx.x)[pi] = r16_ld(L, K, r16t::SLOT_W0 + q);
+}
+
 }  // namespace elp
 
+template <class B>
+void launch_fp12_reduce16(hipStream_t stream, const void* in, size_t n, void* out) {
+  static_assert(std::is_same<B, elp::R16C>::value, "this translation unit holds the other curve's tables");
+  if (n == 0) return;
+  hipLaunchKernelGGL(elp::k_fp12_reduce16, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, stream, (const elp::Fp12<elp::R16C>*)in, n, (elp::Fp12<elp::R16C>*)out);
+}
 template <class B>
 void launch_agg_final16(hipStream_t stream, const void* gg_lines, const void* F, const void* s2_std, int* agg_ok) {
   static_assert(std::is_same<B, elp::R16C>::value, "this translation unit holds the other curve's tables");

@@ -394,6 +394,23 @@ def test_pippenger_msm_vs_oracle(gpu_ctx):
     want = gpu_ctx.g1_mul(g1b(g), fb(total))
     assert gpu_ctx.g1_msm(pts, b"".join(fb(k) for k in ks)) == want
     assert gpu_ctx.g1_msm(b"", b"") == bytes(64)
+    # more than eight slices per window (k_msm_combine in front of the window reduction; 20 000 points above: 16 slices) in G2 (12 slices) and in G1 (300 000 points: 37 slices, more than the kernel's 32 lanes per bucket)
+    for grp, n in ((2, 12000), (1, 300000)):
+        kk = np.frombuffer(np.random.RandomState(5 + grp).bytes(n * 32), dtype=np.uint8).copy()
+        kk[8::32] &= 0x0f
+        for z in range(9, 32):
+            kk[z::32] = 0                                                         # a_i < 2^68: the expected total stays cheap to compute here
+        kk = kk.tobytes()
+        ks = [rnd.randrange(M.r) for _ in range(n)]
+        ks[7] = 0
+        total = sum(int.from_bytes(kk[32 * i:32 * i + 32], "little") * ks[i] for i in range(n)) % M.r
+        ksb = b"".join(fb(k) for k in ks)
+        if grp == 2:
+            assert gpu_ctx.g2_msm(gpu_ctx.g2_mul(g2b(gg) * n, kk), ksb) == gpu_ctx.g2_mul(g2b(gg), fb(total))
+            assert g2u(gpu_ctx.g2_mul(g2b(gg), fb(total))) == G.g2_mul(gg, total)
+        else:
+            assert gpu_ctx.g1_msm(gpu_ctx.g1_mul(g1b(g) * n, kk), ksb) == gpu_ctx.g1_mul(g1b(g), fb(total))
+            assert g1u(gpu_ctx.g1_mul(g1b(g), fb(total))) == G.g1_mul(g, total)
 
 
 def test_full_size_batches_properties(gpu_ctx):

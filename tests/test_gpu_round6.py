@@ -138,3 +138,49 @@ def test_records_staged_in_parts_equal_one_piece_submit(gpu_ctx):
     gpu_ctx._chk(lib.elp_verify_id_batch_wait(h, 0, ctypes.byref(acc)))
     assert (flags == expect).all()
     assert lib.elp_verify_id_batch_stage(h, 0, n, rsz, n - 1, 2, buf.ctypes.data) != 0              # a part beyond the batch
+
+
+def test_aggregated_product_tree_on_rows_vs_oracle(gpu_ctx, elp):
+    """The product of the per-wave Miller values of aggregated verification on 16-lane rows (k_fp12_reduce16, 32 values per wave; csrc/elpasso_pair16.h): batches whose
+    wave counts exercise a lone value (1 wave), one row (8), two rows (9), a full workgroup plus two values (34), plus a row and one (41), and a second level of five
+    values (129) -- (a) bad items fail the NIZK half only: the batch equation must HOLD, which it does only if the product is exact; (b) two swapped sig2: it must FAIL
+    and the per-item fallback decide.  Every verdict against the C oracle (elpo_verify_id_batch, src/ps-verifier.cc:37-138) and against the one-lane product tree
+    (ELP_OPT_PAIR16 = 0).  The BLS12-381 build of the same kernel at 34 and 41 waves."""
+    from elp_testlib import oracle_bls
+    seed = bytes(range(32, 64))
+    for curve in ("bn254", "bls12_381"):
+        L = oracle() if curve == "bn254" else oracle_bls()
+        ctx = gpu_ctx if curve == "bn254" else elp.Context(elp.CURVE_BLS12_381, 0)
+        G1B = 64 if curve == "bn254" else 96
+        A, H = 4, 2
+        wl = synth.Workload(ctx, A, seed=808, window_bits=8)
+        key = _oracle_key(L, wl, ctx, A)
+        try:
+            for n in ((1, 64 * 8, 64 * 8 + 1, 64 * 33 + 5, 64 * 41, 64 * 128 + 3) if curve == "bn254" else (64 * 33 + 5, 64 * 41)):
+                recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=True, corrupt_every=11, corrupt_at=min(3, n - 1))
+                rsz = len(recs) // n
+                ofl = np.zeros(n, dtype=np.uint8)
+                L.elpo_verify_id_batch(key, n, recs, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+                assert (ofl == expect).all(), (curve, n)
+                for rows in (1, 0):
+                    ctx.set_pair16(rows)
+                    fl, cnt, held = ctx.verify_id_batch_aggregated(recs, mask, True, wl.ad, seed)
+                    assert held and (fl == ofl).all() and cnt == int(ofl.sum()), (curve, n, rows)
+                if n >= 512:
+                    a, b = n - 2, n // 2                                 # two accepted items of different waves: swap their sig2
+                    while not (expect[a] and expect[b]):
+                        a, b = a - 1, b + 1
+                    r = bytearray(recs)
+                    r[a * rsz + G1B:a * rsz + 2 * G1B], r[b * rsz + G1B:b * rsz + 2 * G1B] = r[b * rsz + G1B:b * rsz + 2 * G1B], r[a * rsz + G1B:a * rsz + 2 * G1B]
+                    bad = bytes(r)
+                    L.elpo_verify_id_batch(key, n, bad, rsz, mask, 1, wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+                    assert ofl[a] == 0 and ofl[b] == 0 and int(ofl.sum()) == int(expect.sum()) - 2
+                    for rows in (1, 0):
+                        ctx.set_pair16(rows)
+                        fl, cnt, held = ctx.verify_id_batch_aggregated(bad, mask, True, wl.ad, seed)
+                        assert not held and (fl == ofl).all() and cnt == int(ofl.sum()), (curve, n, rows)
+        finally:
+            ctx.set_pair16(1)
+            L.elpo_key_free(key)
+            if curve != "bn254":
+                ctx.close()

@@ -858,6 +858,7 @@ def emit(path):
     A("constexpr int NSLOT = %d, NCONST = %d, CONST_BASE = %d, NSTEP = %d, NPROG = %d, NLINES = %d, NREG = %d;" % (NSLOT, len(CONSTS), CONST_BASE, len(STEPS), len(PROG), NLINES, NREG))
     A("constexpr int SLOT_T = %d, SLOT_Q = %d, SLOT_P1 = %d, SLOT_P2 = %d, SLOT_LF = %d, SLOT_W0 = %d, SLOT_X0 = %d, SLOT_W1 = %d, SLOT_ONE = %d, SLOT_E = %d;" % (T_, Q_, P1, P2, LF, W0, X0, W1, ONE, L1 + 4))
     A("constexpr int CONST_E_INIT = %d;      // four constants: E = 3 b' and E3 = 9 b' of a point with Z = 1" % E_INIT[0])
+    A("constexpr int STEP_MUL_W0_W1 = %d;    // the step W0 <- W0 * W1 (also used on its own by the product tree of aggregated verification)" % s_mul.id)
     A("// constants in Montgomery form, balanced %d-bit limbs" % LBITS)
     A("ROW16_DEV int32_t CONSTS[NCONST][%d] = {" % NLIMB)
     for name, (idx, val) in sorted(CONSTS.items(), key=lambda kv: kv[1][0]):
