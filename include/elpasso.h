@@ -95,8 +95,9 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_PAIR16 (default 1; round 6): PS verifications of at most 4 096 items (value > 1: that many) run the pairing check with ONE ITEM PER 16-LANE ROW of a wave --
  *   12 lanes hold one base-field coefficient each of the Fp12 value, every Fp12-level operation is one inner product per lane over operands published in LDS
  *   (csrc/elpasso_pair16.h; tables and program generated and simulated by tools/gen_row16.py for both curves) -- from the size at which that wins: 4 items on BN254,
- *   2 049 on BLS12-381 (below, the cooperative interpreter's 32 lane pairs per item are faster); on BN254 also the closing step of aggregated verification.
- *   0 = the interpreter keeps these sizes.  Measurements: profiles/r06_pair16.md.
+ *   2 049 on BLS12-381 (below, the cooperative interpreter's 32 lane pairs per item are faster); on BN254 also the closing step of aggregated verification, and on
+ *   both curves the product of its per-wave Miller values (k_fp12_reduce16: every product one step on a row).
+ *   0 = the interpreter and the one-lane product tree keep these jobs.  Measurements: profiles/r06_pair16.md.
  * ELP_OPT_FAULT_INJECT (default 0; test hook for callers' error paths): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  *   ELP_ERR_STATE before anything is queued.  No other entry point consumes or honours the counter.
  */

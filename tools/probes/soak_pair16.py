@@ -63,5 +63,17 @@ for it in range(max(20, calls // 10)):
         print("aggregated MISMATCH call %d n=%d" % (it, n), flush=True)
 print("aggregated (k_agg_final16): %d calls, %d mismatching" % (max(20, calls // 10), bad), flush=True)
 bad_total += bad
+# ... and through the host-buffer entry point, which also tells whether the batch equation HELD: a wrong product of the Miller values (k_fp12_reduce16) or a wrong
+# Pippenger sum (k_msm_combine) would send the batch to the per-item fallback with the verdicts still right
+rsz = len(recs) // B
+bad = 0
+for it in range(max(20, calls // 10)):
+    n = rnd.choice((1, 64, 513, 2117, 2624, 4097, 8192))
+    fl, cnt, held = ctx.verify_id_batch_aggregated(recs[:n * rsz], mask, True, wl.ad, None)
+    if not held or not (fl == expect[:n]).all() or cnt != int(expect[:n].sum()):
+        bad += 1
+        print("aggregated (host entry) MISMATCH call %d n=%d held=%s" % (it, n, held), flush=True)
+print("aggregated, batch equation held and verdicts equal: %d calls, %d failing" % (max(20, calls // 10), bad), flush=True)
+bad_total += bad
 ctx.close()
 sys.exit(1 if bad_total else 0)

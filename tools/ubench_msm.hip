@@ -1,0 +1,177 @@
+// Measurement tool (round 6): where the time of k_msm_buckets goes.  The library's kernel beside three cut-down copies of it on the same inputs:
+//   mode 0  the kernel as built into the library (histogram, scan, counting sort, bucket sums)
+//   mode 1  histogram + scan + counting sort only (every lane stores an empty sum)
+//   mode 2  bucket sums only: lane b adds M / 256 points at fixed positions (no histogram, no sort, uniform trip count)
+//   mode 3  as mode 0 with the two global passes over the scalars reading a byte array laid out per window (one byte per point)
+// Inputs are random field elements (not curve points: the formulas do not care), scalars random bytes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DELP_FP6_INLINE=1 -I ps-signature-and-el-passo_amd/csrc -I include tools/ubench_msm.hip -o build/ubench_msm
+#include "elpasso_impl.h"
+#include <stdio.h>
+#include <vector>
+using namespace elp;
+typedef F1<BN254> F;
+
+template <int MODE>
+__global__ void ELP_MSM_LAUNCH_BOUNDS k_variant(const Aff<F>* pts, const uint8_t* scalars, const uint8_t* digits, size_t n, int S, Jac<F>* partial) {
+  __shared__ unsigned cnt[256];
+  __shared__ unsigned start[256];
+  __shared__ unsigned wave_tot[4];
+  __shared__ unsigned short idx[ELP_MSM_SLICE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = blockIdx.x / S, s = blockIdx.x % S;
+  const size_t lo = n * (size_t)s / S, hi = n * (size_t)(s + 1) / S;
+  const int M = (int)(hi - lo);
+  Jac<F> acc;
+  jac_set_inf(acc);
+  if (MODE == 2) {
+    const int per = M / 256;
+    for (int t = 0; t < per; t++) jac_madd<F>(acc, acc, pts[lo + (size_t)tid * per + t]);
+    partial[(size_t)blockIdx.x * 256 + tid] = acc;
+    return;
+  }
+  cnt[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < M; j += ELP_MSM_TPB) {
+    unsigned d = MODE == 3 ? digits[(size_t)w * n + lo + j] : scalars[(lo + j) * 32 + w];
+    if (d != 0 && (MODE == 3 || !aff_is_inf(pts[lo + j]))) atomicAdd(&cnt[d], 1u);
+  }
+  __syncthreads();
+  unsigned c0 = cnt[tid], x = c0;
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wave_tot[wv] = x;
+  __syncthreads();
+  unsigned base = 0;
+  for (int k = 0; k < wv; k++) base += wave_tot[k];
+  const unsigned my_start = base + x - c0;
+  start[tid] = my_start;
+  __syncthreads();
+  cnt[tid] = my_start;
+  __syncthreads();
+  for (int j = tid; j < M; j += ELP_MSM_TPB) {
+    unsigned d = MODE == 3 ? digits[(size_t)w * n + lo + j] : scalars[(lo + j) * 32 + w];
+    if (d != 0 && (MODE == 3 || !aff_is_inf(pts[lo + j]))) idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)j;
+  }
+  __syncthreads();
+  if (MODE != 1) {
+    const unsigned t1 = start[tid] + c0;
+    for (unsigned t = start[tid]; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
+  } else if (c0 == 77777) {
+    acc.X.v[0] = (i32)idx[start[tid]];
+  }
+  partial[(size_t)blockIdx.x * 256 + tid] = acc;
+}
+
+
+// mode 4 / 5: LPB = 2 / 4 lanes per bucket (512 / 1 024 threads per workgroup): a bucket's run of the sorted list is split evenly over its lanes, their sums meet through shuffles
+template <int LPB>
+__global__ void __launch_bounds__(256 * LPB) k_split(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S, Jac<F>* partial) {
+  __shared__ unsigned cnt[256];
+  __shared__ unsigned start[256];
+  __shared__ unsigned cnt0[256];
+  __shared__ unsigned wave_tot[4];
+  __shared__ unsigned short idx[ELP_MSM_SLICE];
+  constexpr int TPB = 256 * LPB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = blockIdx.x / S, s = blockIdx.x % S;
+  const size_t lo = n * (size_t)s / S, hi = n * (size_t)(s + 1) / S;
+  const int M = (int)(hi - lo);
+  if (tid < 256) cnt[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < M; j += TPB) {
+    unsigned d = scalars[(lo + j) * 32 + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) atomicAdd(&cnt[d], 1u);
+  }
+  __syncthreads();
+  unsigned c0 = tid < 256 ? cnt[tid] : 0, x = c0;
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (tid < 256 && lane == 63) wave_tot[wv] = x;
+  __syncthreads();
+  if (tid < 256) {
+    unsigned base = 0;
+    for (int k = 0; k < wv; k++) base += wave_tot[k];
+    const unsigned my_start = base + x - c0;
+    start[tid] = my_start;
+    cnt0[tid] = c0;
+    cnt[tid] = my_start;
+  }
+  __syncthreads();
+  for (int j = tid; j < M; j += TPB) {
+    unsigned d = scalars[(lo + j) * 32 + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)j;
+  }
+  __syncthreads();
+  const int b = tid / LPB, part = tid % LPB;
+  const unsigned cb = cnt0[b], sb = start[b];
+  const unsigned t0 = sb + (cb * (unsigned)part) / LPB, t1 = sb + (cb * (unsigned)(part + 1)) / LPB;
+  Jac<F> acc;
+  jac_set_inf(acc);
+  for (unsigned t = t0; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
+  for (int d = 1; d < LPB; d <<= 1) {
+    Jac<F> o;
+    for (int i = 0; i < BN254::NL; i++) {
+      o.X.v[i] = __shfl_xor(acc.X.v[i], d);
+      o.Y.v[i] = __shfl_xor(acc.Y.v[i], d);
+      o.Z.v[i] = __shfl_xor(acc.Z.v[i], d);
+    }
+    jac_add<F>(acc, acc, o);
+  }
+  if (part == 0) partial[(size_t)blockIdx.x * 256 + b] = acc;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 65536;
+  const int NW = argc > 2 ? atoi(argv[2]) : 16;
+  std::vector<uint8_t> ks(n * 32), dg((size_t)32 * n);
+  std::vector<Aff<F>> pts(n);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  for (auto& b : ks) b = (uint8_t)rnd();
+  for (size_t i = 0; i < n; i++)
+    for (int w = 0; w < 32; w++) dg[(size_t)w * n + i] = ks[i * 32 + w];
+  for (auto& p : pts)
+    for (int i = 0; i < BN254::NL; i++) {
+      p.x.v[i] = (i32)(rnd() & 0x7FFFFFF);
+      p.y.v[i] = (i32)(rnd() & 0x7FFFFFF);
+    }
+  Aff<F>* dp; uint8_t *dk, *dd; Jac<F>* part;
+  CK(hipMalloc(&dp, n * sizeof(Aff<F>)));
+  CK(hipMalloc(&dk, n * 32));
+  CK(hipMalloc(&dd, n * 32));
+  CK(hipMalloc(&part, (size_t)32 * 256 * 256 * sizeof(Jac<F>)));
+  CK(hipMemcpy(dp, pts.data(), n * sizeof(Aff<F>), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dk, ks.data(), n * 32, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dd, dg.data(), n * 32, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int S : {8, 16, 32, 64, 128}) {
+    if ((size_t)S * 8192 < n || n / S < 256) continue;
+    for (int mode = 0; mode < 6; mode++) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 6; rep++) {
+        CK(hipEventRecord(e0, 0));
+        if (mode == 0) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, n, S, part);
+        if (mode == 1) hipLaunchKernelGGL((k_variant<1>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
+        if (mode == 2) hipLaunchKernelGGL((k_variant<2>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
+        if (mode == 3) hipLaunchKernelGGL((k_variant<3>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
+        if (mode == 4) hipLaunchKernelGGL((k_split<2>), dim3(NW * S), dim3(512), 0, 0, dp, dk, n, S, part);
+        if (mode == 5) hipLaunchKernelGGL((k_split<4>), dim3(NW * S), dim3(1024), 0, 0, dp, dk, n, S, part);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < best) best = ms;
+      }
+      printf("n=%zu windows=%d slices=%3d (%5zu points per workgroup, %5.1f per bucket)  mode %d: %8.1f us\n", n, NW, S, n / S, (double)n / S / 255.0, mode, best * 1e3);
+    }
+  }
+  return 0;
+}
