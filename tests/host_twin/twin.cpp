@@ -358,6 +358,15 @@ static void build_tables(std::vector<Aff<F>>& tbl, const std::vector<Aff<F>>& ba
     else                                                                                                               \
       touch_entries<F2<C>>((Aff<F2<C>>*)c->t2s + base * stride, c->b2[base], c->key.W, c->key.nwin, c->key.per, scalar_load_w(k)); \
   }                                                                                                                    \
+  /* replaces ONE G1 base (the relying party's H1(service_name) is base A + 1) and rebuilds its table only: what elp_set_rp does on the device */ \
+  int pfx##_ctx_set_g1_base(void* cv, int idx, const u32* pt) {                                                        \
+    TwinCtx<C>* c = (TwinCtx<C>*)cv;                                                                                   \
+    if (idx < 0 || idx >= (int)c->b1.size() || c->t1.empty() || !g1_load<C>(c->b1[idx], pt)) return 0;                 \
+    std::vector<Aff<F1<C>>> one(1, c->b1[idx]), tbl;                                                                   \
+    build_tables<F1<C>>(tbl, one, c->key.W, c->key.nwin, c->key.per);                                                  \
+    std::copy(tbl.begin(), tbl.end(), c->t1.begin() + (size_t)idx * c->key.nwin * c->key.per);                         \
+    return 1;                                                                                                          \
+  }                                                                                                                    \
   void pfx##_ctx_free(void* c) { delete (TwinCtx<C>*)c; }                                                              \
   void pfx##_ctx_set_flags(void* c, int flags) { ((TwinCtx<C>*)c)->key.flags = flags; } /* KEY_STRICT_SIG = 1, KEY_NO_SUBGROUP_CHECK = 2 */ \
   int pfx##_verify_id(void* c, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {             \
