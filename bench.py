@@ -401,7 +401,7 @@ def aggregated_section(ctx, wl, synth, dev, mask, H, B):
     sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)      # the second one from the other priority pool: surely another hardware queue
     nbat = NT // B
     # Exactly two side streams.  What overlaps is the TAIL of one batch with the tail of the other (a per-item kernel holds every SIMD's registers, so a tail cannot run
-    # beside it: profiles/r04_agg_two_stream_timeline.txt), and only if the two streams sit on two hardware queues.  More streams do not help and run into the runtime's
+    # beside it: profiles/r04_agg_two_stream_timeline.txt, r06_agg_two_stream_timeline.txt), and only if the two streams sit on two hardware queues.  More streams do not help and run into the runtime's
     # scratch reclaim between queues -- 80-295 ms per batch measured with three and four (profiles/r04_scratch_stall.md).
     for label, agg, streams in (("aggregated_two_streams", True, (sa, sb)), ("aggregated_one_stream", True, (sa,)), ("per_item_one_stream", False, (sa,))):
         for s_ in streams:
