@@ -573,6 +573,25 @@ def second_curve(pkg, synth, local_rank, dev, A, H, B, window):
         res["cpu_baseline"]["note"] = "the C oracle's BLS12-381 build (reference structure), pinned to the reference's wasm run on this curve by tests/test_oracle_bls_golden.py"
     except Exception as e:  # pragma: no cover
         res["cpu_baseline"] = {"error": str(e)}
+    try:     # aggregated verification of the same batch (round 6: main kernel on lane pairs, k_verify_id_agg_paired); the last of four calls timed with HIP events
+        d_afl = torch.zeros(B, dtype=torch.uint8, device=dev)
+        agg_ms = []
+        for _ in range(4):
+            d_cnt.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ctx._chk(ctx.lib.elp_verify_id_batch_aggregated_dev(ctx.h, stream, B, d_rec.data_ptr(), mask, 1, d_ad.data_ptr(), None, len(wl.ad), None, d_afl.data_ptr(),
+                                                                d_cnt.data_ptr()))
+            e1.record()
+            torch.cuda.synchronize()
+            agg_ms.append(e0.elapsed_time(e1))
+        am = min(agg_ms[1:])
+        res["aggregated_65536" if B == 65536 else "aggregated_%d" % B] = {
+            "value": B / (am * 1e-3), "unit": "verifications/s", "ms_per_batch": am, "per_item_ms_per_batch": float(ms.value),
+            "parity_ok": bool((d_afl.cpu().numpy() == expect).all()) and int(d_cnt.item()) == int(expect.sum()),
+            "kernels": "k_verify_id_agg_paired (two lanes per item) -> k_fp12_reduce16 -> Pippenger -> k_agg_final_coop; exact per-item fallback inside the call"}
+    except Exception as e:  # pragma: no cover
+        res["aggregated"] = {"error": str(e)}
     ctx.close()
     try:     # BASELINE config 2's shape on this curve: 4 096 PS verifications, A = 3 -- the row-of-16 pairing check (round 6) against the interpreter
         ctx = pkg.Context(pkg.CURVE_BLS12_381, local_rank)

@@ -27,6 +27,25 @@ ELP_INL Fp2<C> fp2_from_mem(const Fp2<typename PairInfo<C>::Base>& m) {
   return r;
 }
 
+// ... and back: this lane's component of every coefficient into a plain-layout value in memory (the two lanes of a pair write disjoint halves)
+template <class C>
+ELP_INL void fp2_to_mem(Fp2<typename PairInfo<C>::Base>& m, const Fp2<C>& r) {
+  if constexpr (is_paired<C>()) {
+    if (pair_odd()) m.c1 = fp_cast<typename PairInfo<C>::Base>(r.c);
+    else m.c0 = fp_cast<typename PairInfo<C>::Base>(r.c);
+  } else {
+    m = r;
+  }
+}
+template <class C>
+ELP_INL void fp12_to_mem(Fp12<typename PairInfo<C>::Base>& m, const Fp12<C>& r) {
+  fp2_to_mem<C>(m.c0.c0, r.c0.c0);
+  fp2_to_mem<C>(m.c0.c1, r.c0.c1);
+  fp2_to_mem<C>(m.c0.c2, r.c0.c2);
+  fp2_to_mem<C>(m.c1.c0, r.c1.c0);
+  fp2_to_mem<C>(m.c1.c1, r.c1.c1);
+  fp2_to_mem<C>(m.c1.c2, r.c1.c2);
+}
 template <class C>
 ELP_INL void fp12_from_mem(Fp12<C>& r, const Fp12<typename PairInfo<C>::Base>& m) {
   r.c0.c0 = fp2_from_mem<C>(m.c0.c0);

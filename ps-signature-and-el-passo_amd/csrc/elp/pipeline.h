@@ -1262,6 +1262,83 @@ ELP_HEAVY bool verify_id_item_paired(const KeyCtx<C>& key, const u32* rec, u64 h
   return ps_pairing_check<C>(key, sig1, sig2, aK);
 }
 
+// The item of AGGREGATED verification in the paired layout (round 6; kernel k_verify_id_agg_paired): what verify_id_agg_item does on one lane -- the NIZK half, the
+// multiplier d, [d]sig1 and ONE Miller loop f = f_K([d]sig1) -- on the lane pair of verify_id_item_paired.  The 14-limb field of BLS12-381 is what the two-lane
+// layout exists for: one lane per item runs this kernel at 35.7 ms per 32 768 items, slower than the per-item path it is meant to beat.
+// [d]sig1 is base-field work and does not split over the pair: both lanes compute it (both need the affine result for their halves of the line evaluations).
+// Same admission rules as the per-item paired path (its opening lines are repeated here rather than shared, so that the headline kernel's code is untouched).
+template <class C>
+ELP_HEAVY bool verify_id_agg_item_paired(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len, const uint8_t* seed,
+                                         u64 index, Fp12<C>& f, u32* delta_out, u32* sig2_out) {
+  static_assert(is_paired<C>(), "paired layout only");
+  const bool odd = pair_odd();
+  const int G1W = 2 * C::N;
+  Aff<F1<C>> sig1, sig2, P0, P1, aP;
+  Aff<F2<C>> kk, aK;
+  fp12_set_one(f);
+  if (!odd) {
+    for (int i = 0; i < 8; i++) delta_out[i] = 0;
+    for (int i = 0; i < 2 * C::N; i++) sig2_out[i] = 0;
+  }
+  bool ok = g1_load<C>(sig1, rec);
+  ok &= g1_load<C>(sig2, rec + G1W);
+  aff_set_inf(P0);
+  aff_set_inf(P1);
+  if (!odd || retr) ok &= g1_load<C>(P0, rec + (odd ? 4 : 2) * G1W);
+  if (!odd && retr) ok &= g1_load<C>(P1, rec + 3 * G1W);
+  if constexpr (!C::IS_BN) {
+    if (!(key.flags & KEY_NO_SUBGROUP_CHECK)) {
+      Aff<F1<C>> Q1;
+      Q1.x = fp_pair_swap(P1.x);
+      Q1.y = fp_pair_swap(P1.y);
+      if (!odd) {
+        if (key.flags & KEY_STRICT_SIG) Q1 = sig1; else aff_set_inf(Q1);
+      }
+      if (ok) ok = g1_in_subgroup<C>(P0) && g1_in_subgroup<C>(Q1);
+    }
+  }
+  ok = pair_and(ok);
+  const bool okk = g2_load<C>(kk, rec + (retr ? 5 : 3) * G1W);
+  if (!ok || !okk) return false;
+  if ((key.flags & KEY_STRICT_SIG) && aff_is_inf(sig1)) return false;
+  const Scalar c = scalar_load_w(rec + (retr ? 5 : 3) * G1W + 4 * C::N);
+  PairedRecordSrc<C> src;
+  src.init(rec, hidden_mask, key.A, retr);
+  if (!verify_id_paired_nizk<C, PairedRecordSrc<C>>(key, src, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
+  const Scalar d = agg_multiplier(seed, index);
+  Jac<F1<C>> P;
+  if (aff_is_inf(sig1)) {
+    jac_set_inf(P);
+  } else {
+    typedef F1<C> G1F;
+    Aff<G1F> tab[8];
+    {
+      Jac<G1F> jm[8];
+      jac_multiples8<G1F>(jm, sig1);
+      Fp<C> z[7], zi[7];
+      for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
+      batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);      // zero-guarded as in verify_id_agg_prepare (a small-order sig1 without the strict rule)
+      tab[0] = sig1;
+      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
+    }
+    u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;      // the lane's first G1 table: the NIZK half is done with it
+    if (ws1) {
+      for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1, i, tab[i]);
+      g1_mul_pair64_with<C, WsTab<G1F>>(P, WsTab<G1F>{ws1}, d);
+    } else {
+      g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
+    }
+  }
+  jac_to_aff<F1<C>>(aP, P);
+  if (!odd) {
+    for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
+    g1_store<C>(sig2_out, sig2);
+  }
+  const LineMem<C>* no_lines[1] = {key.gg_lines};
+  miller_loop<C, 1, 0>(f, &aP, &aK, &aP, no_lines);
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // G1 JOBS AS A KERNEL OF THEIR OWN (round 4; ELP_OPT_SPLIT_PHASES = 3, opt-in on both curves: measured no faster than the fused kernels).
 //

@@ -95,6 +95,7 @@ int elp_init(int curve, int device, elp_ctx** out) {
   if (const char* e = getenv("ELP_PHASE_MIX")) c->phase_mix = atoi(e);                                                      // A/B runs: KEY_PHASE_MIX
   if (const char* e = getenv("ELP_SMALL_DENSE_FROM")) c->small_dense_from = (size_t)atol(e);                               // A/B runs: k_vid_small2 above this many items
   if (const char* e = getenv("ELP_PAIR4_TWO_LAUNCHES")) c->mid_two_launches = atoi(e);                                      // A/B runs: the mid-size path as two launches
+  if (const char* e = getenv("ELP_AGG_PAIRED")) c->agg_paired = atoi(e) != 0;                                            // A/B runs: aggregated main kernel on lane pairs (BLS12-381)
   if (const char* e = getenv("ELP_AGG_TWO")) c->agg_two = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));      // A/B runs: ELP_OPT_AGG_TWO_PER_LANE from the environment
   if (const char* e = getenv("ELP_SMALL_ONE_MAX")) c->small_one_max = (size_t)atol(e);                                    // A/B runs: one launch (k_vid_small) up to this many items
   if (const char* e = getenv("ELP_OVERLAP")) c->overlap = atoi(e) != 0;                                                   // A/B runs: second-stream overlap inside a call

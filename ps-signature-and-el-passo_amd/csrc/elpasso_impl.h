@@ -1789,6 +1789,40 @@ __global__ void ELP_LAUNCH_BOUNDS k_verify_id_agg2(KeyCtx<C> key, const u32* rec
   if (threadIdx.x == 0) wave_prod[blockIdx.x] = f;
 }
 
+// The same on LANE PAIRS (round 6; BLS12-381, whose 14-limb field makes one lane per item the slowest layout): 32 items per wave, pipeline.h
+// verify_id_agg_item_paired; the wave's product is taken over the pairs (strides 32 ... 2 keep the halves of a value on their lanes) and written in the plain layout
+// the rest of the call works in.
+template <class C>
+__device__ __forceinline__ void wave_fp12_product_paired(Fp12<C>& f, Fp12<C>* sh) {   // sh: 64 entries in LDS; result valid in lanes 0 and 1
+  const int lane = threadIdx.x & 63;
+  for (int d = 32; d >= 2; d >>= 1) {
+    sh[lane] = f;
+    __syncthreads();
+    if (lane < d) fp12_mul<C>(f, f, sh[lane + d]);
+    __syncthreads();
+  }
+}
+template <class C>
+__global__ void ELP_PAIR_LAUNCH_BOUNDS k_verify_id_agg_paired(KeyCtx<C> key, const u32* recs, int rec_words, u64 mask, int retr, const uint8_t* ad, const u32* ad_off,
+                                                              u32 ad_len, AggSeed seed, uint8_t* nizk_flags, u32* deltas, u32* sig2s,
+                                                              Fp12<typename PairInfo<C>::Base>* wave_prod, size_t n) {
+  ELP_HOT_SETUP_PAIRED(key);
+  __shared__ __attribute__((aligned(16))) Fp12<C> sh[ELP_BLOCK];
+  if (key.vtab) key.vtab += ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)vtab_words<C>();
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  Fp12<C> f;
+  fp12_set_one(f);
+  if (i < n) {
+    const uint8_t* a = ad_off ? ad + ad_off[i] : ad;
+    size_t al = ad_off ? (size_t)(ad_off[i + 1] - ad_off[i]) : (size_t)ad_len;
+    const bool ok = verify_id_agg_item_paired<C>(key, recs + i * (size_t)rec_words, mask, retr != 0, a, al, seed.b, (u64)i, f, deltas + i * 8,
+                                                 sig2s + i * (size_t)(2 * C::N));
+    if ((threadIdx.x & 1) == 0) nizk_flags[i] = ok ? 1 : 0;
+  }
+  wave_fp12_product_paired<C>(f, sh);
+  if (threadIdx.x < 2) fp12_to_mem<C>(wave_prod[blockIdx.x], f);
+}
+
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_fp12_reduce(const Fp12<C>* in, size_t n, Fp12<C>* out) {
   __shared__ Fp12<C> sh[ELP_BLOCK];
@@ -2019,6 +2053,7 @@ struct elp_ctx {
   int mid_two_launches = 0;      // experiments (ELP_PAIR4_TWO_LAUNCHES=1): the mid-size path as k_vid_nizk4 then k_pair4 instead of the one launch k_vid_mid
   unsigned long long* wire_mask_host = nullptr;      // page-locked slot for the decoded wire path's 16-byte read-back
   int wire_decode = 1;           // ELP_OPT_WIRE_DECODE: wire batches of up to 16 384 messages are decoded into records and take the small / mid-size record paths
+  int agg_paired = 1;         // BLS12-381 with the two-lane layout allowed: the main kernel of aggregated verification on lane pairs (k_verify_id_agg_paired; ELP_AGG_PAIRED=0 for A/B runs)
   int agg_two = 0;            // ELP_OPT_AGG_TWO_PER_LANE: aggregated batches put two items on a lane (0 = never -- the default: 2 % at best, and the kernel's larger frame makes the runtime re-provision scratch --, 1 = where it saves rounds of lanes, 2 = always)
   int pair16 = 0;                // ELP_OPT_PAIR16 (set by elp_init): PS verifications of at most pair16_max items run the pairing check on one 16-lane row per item
   int pair16_tail = 1;           // the closing step of aggregated verification on one row (elp_init: BN254 yes; BLS12-381 no -- a lone item is faster on the interpreter there)
@@ -2683,6 +2718,9 @@ struct PairedBuild<BLS12_381> {
 };
 template <class B>
 void launch_agg_final_paired(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);   // defined with the other paired launchers below
+template <class B>
+void launch_verify_id_agg_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off,
+                                 size_t ad_len, const AggSeed& seed, uint8_t* nizk_flags, void* deltas, void* sig2s, void* wave_prod);
 
 template <class C>
 int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_records, uint64_t mask, int retr,
@@ -2702,7 +2740,9 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     const size_t round = (size_t)64 * c->simds, r1 = (n + round - 1) / round, r2 = (n + 2 * round - 1) / (2 * round);
     two_per_lane = c->agg_two == 2 || (c->agg_two == 1 && 189 * r2 < 100 * r1);
   }
-  const size_t nw = two_per_lane ? grid_for((n + 1) / 2) : grid_for(n);                       // waves = per-wave Miller products
+  bool paired_main = false;                                // BLS12-381: the main kernel on lane pairs (32 items per wave)
+  if constexpr (PairedBuild<C>::value && !C::IS_BN) paired_main = c->paired != 0 && c->agg_paired != 0;
+  const size_t nw = paired_main ? (size_t)((2 * n + ELP_BLOCK - 1) / ELP_BLOCK) : two_per_lane ? grid_for((n + 1) / 2) : grid_for(n);      // waves = per-wave Miller products
   const size_t nw2 = (nw + 31) / 32;                                                          // the larger of the two product trees' first level (rows: 32 values per workgroup)
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_flags = 0, o_delta = al(n), o_sig2 = o_delta + al(n * 32), o_f1 = o_sig2 + al(n * Sizes<C>::G1),
@@ -2743,7 +2783,10 @@ int elp_verify_id_batch_aggregated_dev_t(elp_ctx* c, void* stream_, size_t n, co
     return ELP_ERR_STATE;
   }
   KeyCtx<C> key = make_key_ws<C>(c, stream, (size_t)nw * ELP_BLOCK);
-  if (two_per_lane)
+  if (paired_main) {
+    if constexpr (PairedBuild<C>::value && !C::IS_BN)
+      launch_verify_id_agg_paired<C>(c, stream, n, d_records, words, mask, retr, d_ad, d_ad_off, ad_len, seed, ws + o_flags, ws + o_delta, ws + o_sig2, ws + o_f1);
+  } else if (two_per_lane)
     hipLaunchKernelGGL((k_verify_id_agg2<C>), dim3(nw), dim3(ELP_BLOCK), 0, stream, key, (const u32*)d_records, words, (u64)mask, retr,
                        (const uint8_t*)d_ad, (const u32*)d_ad_off, (u32)ad_len, seed, ws + o_flags, (u32*)(ws + o_delta), (u32*)(ws + o_sig2),
                        (Fp12<C>*)(ws + o_f1), n);
@@ -2865,6 +2908,13 @@ void launch_ps_verify_paired(elp_ctx* c, hipStream_t stream, size_t n, const voi
                      (const u32*)d_records, 4 * B::N + 8 * nattr, nattr, (uint8_t*)d_flags, (unsigned long long*)d_accepted, n);
 }
 template <class B>
+void launch_verify_id_agg_paired(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off,
+                                 size_t ad_len, const AggSeed& seed, uint8_t* nizk_flags, void* deltas, void* sig2s, void* wave_prod) {
+  hipLaunchKernelGGL((k_verify_id_agg_paired<Paired<B>>), dim3(grid_for_paired(n)), dim3(ELP_BLOCK), 0, stream,
+                     make_key_ws<Paired<B>>(c, stream, (size_t)grid_for_paired(n) * ELP_BLOCK), (const u32*)d_records, words, (u64)mask, retr, (const uint8_t*)d_ad,
+                     (const u32*)d_ad_off, (u32)ad_len, seed, nizk_flags, (u32*)deltas, (u32*)sig2s, (Fp12<B>*)wave_prod, n);
+}
+template <class B>
 void launch_agg_final_paired(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std) {
   hipLaunchKernelGGL((k_agg_final_paired<Paired<B>>), dim3(1), dim3(ELP_BLOCK), 0, stream, make_key<Paired<B>>(c), (const Fp12<B>*)F, (const u32*)s2_std,
                      c->agg_ok);
@@ -2935,6 +2985,9 @@ extern template void launch_verify_id_paired_g1<BN254>(elp_ctx* c, hipStream_t s
 extern template void launch_verify_id_paired_g1<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad, const void* d_ad_off, size_t ad_len, const u32* g1ws, size_t g1stride, void* d_flags, void* d_accepted, const KeyCtx<Paired<BLS12_381>>& key);
 extern template void launch_agg_final_paired<BN254>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
 extern template void launch_agg_final_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, const void* F, const void* s2_std);
+extern template void launch_verify_id_agg_paired<BLS12_381>(elp_ctx* c, hipStream_t stream, size_t n, const void* d_records, int words, uint64_t mask, int retr, const void* d_ad,
+                                                            const void* d_ad_off, size_t ad_len, const AggSeed& seed, uint8_t* nizk_flags, void* deltas, void* sig2s,
+                                                            void* wave_prod);
 #endif
 
 // the pairing check on FOUR lanes per item (elp/pair4.h, elpasso_pair4.h; translation units elpasso_<curve>_pair4.hip): reads K and `todo` like k_pair_rest

@@ -565,6 +565,33 @@ int twin_blsp_verify_id(void* cv, const u32* rec, uint64_t mask, int retr, const
     return verify_id_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen, (k.flags & KEY_PHASE_MIX) != 0) ? 1 : 0;      /* flags 4: the pairing check first */
   });
 }
+/* the item of aggregated verification: one lane (k_verify_id_agg) and the lane pair (k_verify_id_agg_paired); f_out = the twelve coefficients of the Miller value */
+int twin_bls_agg_item(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen, const uint8_t* seed, uint64_t index, u32* f_out, u32* delta,
+                      u32* sig2) {
+  TwinCtx<BLS12_381>* c = (TwinCtx<BLS12_381>*)cv;
+  Fp12<BLS12_381> f;
+  const bool ok = verify_id_agg_item<BLS12_381>(c->key, rec, mask, retr != 0, ad, adlen, seed, index, f, delta, sig2);
+  gt_store<BLS12_381>(f_out, f);
+  return ok ? 1 : 0;
+}
+int twin_blsp_agg_item(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen, const uint8_t* seed, uint64_t index, u32* f_out, u32* delta,
+                       u32* sig2) {
+  const TwinCtx<BLS12_381>* c = (const TwinCtx<BLS12_381>*)cv;
+  Fp12<BLS12_381> mem;
+  memset(&mem, 0x5a, sizeof mem);
+  const int r = run_pair([&](int) {
+    std::vector<u32> hot(ELP_HOT_WORDS_PAIRED, 0xdeadbeefu);
+    KeyCtx<BLSP> k = paired_key<BLS12_381>(c, hot.data());
+    std::vector<u32> vt(vtab_words<BLSP>(), 0xdeadbeefu);
+    k.vtab = getenv("ELP_TWIN_NO_VTAB") ? nullptr : vt.data();
+    Fp12<BLSP> f;
+    const bool ok = verify_id_agg_item_paired<BLSP>(k, rec, mask, retr != 0, ad, adlen, seed, index, f, delta, sig2);
+    fp12_to_mem<BLSP>(mem, f);
+    return ok ? 1 : 0;
+  });
+  gt_store<BLS12_381>(f_out, mem);
+  return r;
+}
 int twin_blsp_verify_id_g1split(void* cv, const u32* rec, uint64_t mask, int retr, const uint8_t* ad, size_t adlen) {
   return twin_verify_id_g1split<BLS12_381>((const TwinCtx<BLS12_381>*)cv, rec, mask, retr, ad, adlen);
 }

@@ -145,12 +145,19 @@ def test_aggregated_product_tree_on_rows_vs_oracle(gpu_ctx, elp):
     wave counts exercise a lone value (1 wave), one row (8), two rows (9), a full workgroup plus two values (34), plus a row and one (41), and a second level of five
     values (129) -- (a) bad items fail the NIZK half only: the batch equation must HOLD, which it does only if the product is exact; (b) two swapped sig2: it must FAIL
     and the per-item fallback decide.  Every verdict against the C oracle (elpo_verify_id_batch, src/ps-verifier.cc:37-138) and against the one-lane product tree
-    (ELP_OPT_PAIR16 = 0).  The BLS12-381 build of the same kernel at 34 and 41 waves."""
+    (ELP_OPT_PAIR16 = 0).  The BLS12-381 build of the same kernel at 34 and 41 waves, under both main kernels of that curve: on lane pairs (k_verify_id_agg_paired, the
+    default: 32 items per wave, so twice the waves) and on one lane per item (ELP_AGG_PAIRED=0)."""
+    import os
     from elp_testlib import oracle_bls
     seed = bytes(range(32, 64))
-    for curve in ("bn254", "bls12_381"):
+    for curve in ("bn254", "bls12_381", "bls12_381_one_lane"):
         L = oracle() if curve == "bn254" else oracle_bls()
-        ctx = gpu_ctx if curve == "bn254" else elp.Context(elp.CURVE_BLS12_381, 0)
+        if curve == "bls12_381_one_lane":
+            os.environ["ELP_AGG_PAIRED"] = "0"
+        try:
+            ctx = gpu_ctx if curve == "bn254" else elp.Context(elp.CURVE_BLS12_381, 0)
+        finally:
+            os.environ.pop("ELP_AGG_PAIRED", None)
         G1B = 64 if curve == "bn254" else 96
         A, H = 4, 2
         wl = synth.Workload(ctx, A, seed=808, window_bits=8)
@@ -184,3 +191,95 @@ def test_aggregated_product_tree_on_rows_vs_oracle(gpu_ctx, elp):
             L.elpo_key_free(key)
             if curve != "bn254":
                 ctx.close()
+
+
+def test_aggregated_verification_on_lane_pairs_bls12_381_vs_oracle(elp):
+    """k_verify_id_agg_paired (round 6): the main kernel of aggregated verification on BLS12-381 with two lanes per item.  Against the C oracle's BLS12-381 build
+    (elpo_verify_id / elpo_verify_id_batch, src/ps-verifier.cc:37-138) on every item: with and without id-retrieval, batches of 1 ... 1 061 items (one pair, a ragged
+    last wave, more than one level of the product tree), items failing the NIZK half (equation holds), a foreign sig1 and a swapped pair of sig2 (equation fails, the
+    per-item fallback decides), per-item associated data, sig1 = sig2 = infinity under the lenient and the strict rule, sig1 outside G1 (subgroup test on and off)."""
+    from elp_testlib import oracle_bls
+    L = oracle_bls()
+    ctx = elp.Context(elp.CURVE_BLS12_381, 0)
+    ctx.set_strict_signature(False)
+    seed = bytes(range(64, 96))
+    G1B = 96
+    try:
+        for A, H, retr in ((4, 2, True), (5, 3, False)):
+            wl = synth.Workload(ctx, A, seed=900 + A, window_bits=8)
+            key = _oracle_key(L, wl, ctx, A)
+            try:
+                for n in (1, 2, 31, 33, 64, 1061):
+                    recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=retr, corrupt_every=7, corrupt_at=min(2, n - 1))
+                    rsz = len(recs) // n
+                    ofl = np.zeros(n, dtype=np.uint8)
+                    L.elpo_verify_id_batch(key, n, recs, rsz, mask, int(retr), wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+                    assert (ofl == expect).all(), (A, n)
+                    fl, cnt, held = ctx.verify_id_batch_aggregated(recs, mask, retr, wl.ad, seed)
+                    assert held and (fl == ofl).all() and cnt == int(ofl.sum()), (A, n)
+                    if n >= 31:
+                        r = bytearray(recs)
+                        a, b = 5, n - 2
+                        while not expect[b]:
+                            b -= 1
+                        assert expect[a] and expect[b] and expect[10] and b > 12
+                        r[a * rsz + G1B:a * rsz + 2 * G1B], r[b * rsz + G1B:b * rsz + 2 * G1B] = r[b * rsz + G1B:b * rsz + 2 * G1B], r[a * rsz + G1B:a * rsz + 2 * G1B]
+                        r[10 * rsz:10 * rsz + G1B] = r[11 * rsz:11 * rsz + G1B]                  # a foreign sig1
+                        r[12 * rsz:12 * rsz + 2 * G1B] = bytes(2 * G1B)                        # (O, O): accepted by the reference's VerifyID
+                        bad = bytes(r)
+                        L.elpo_verify_id_batch(key, n, bad, rsz, mask, int(retr), wl.ad, len(wl.ad), ofl.ctypes.data, NT)
+                        assert ofl[a] == 0 and ofl[b] == 0 and ofl[10] == 0 and ofl[12] == 1
+                        fl, cnt, held = ctx.verify_id_batch_aggregated(bad, mask, retr, wl.ad, seed)
+                        assert not held and (fl == ofl).all() and cnt == int(ofl.sum()), (A, n)
+                        # only the (O, O) item: the equation still holds (its pair contributes 1) under the lenient rule; the strict rule rejects the item up front
+                        r = bytearray(recs)
+                        r[12 * rsz:12 * rsz + 2 * G1B] = bytes(2 * G1B)
+                        only = bytes(r)
+                        want = expect.copy()
+                        want[12] = 1
+                        fl, cnt, held = ctx.verify_id_batch_aggregated(only, mask, retr, wl.ad, seed)
+                        assert held and (fl == want).all()
+                        ctx.set_strict_signature(True)
+                        want[12] = 0
+                        fl, cnt, held = ctx.verify_id_batch_aggregated(only, mask, retr, wl.ad, seed)
+                        assert held and (fl == want).all()
+                        ctx.set_strict_signature(False)
+                # per-item associated data
+                n = 67
+                recs, mask, expect = wl.verify_id_batch(n, H, with_retrieval=retr, corrupt_every=9, corrupt_at=1)
+                rsz = len(recs) // n
+                ads = [wl.ad] * n
+                ads[6] = b"another session"
+                want = expect.copy()
+                want[6] = 0
+                fl, cnt, held = ctx.verify_id_batch_aggregated(recs, mask, retr, ads, seed)
+                assert held and (fl == want).all()
+                for i_ in (5, 6, 7):
+                    assert L.elpo_verify_id(key, recs[i_ * rsz:(i_ + 1) * rsz], mask, int(retr), ads[i_], len(ads[i_])) == want[i_]
+                # sig1 + T3 (T3 = (0, p - 2): order 3, outside G1): the pairing value is unchanged, so the reference accepts; the library's strict rule rejects
+                p381 = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+                s1 = recs[8 * rsz:8 * rsz + G1B]
+                t3 = bytes(48) + (p381 - 2).to_bytes(48, "little")
+                r = bytearray(recs)
+                r[8 * rsz:8 * rsz + G1B] = ctx.g1_add(s1, t3)
+                off = bytes(r)
+                assert expect[8]
+                ctx.set_subgroup_check(False)
+                L.elpo_set_subgroup_check(0)
+                try:
+                    assert L.elpo_verify_id(key, off[8 * rsz:9 * rsz], mask, int(retr), wl.ad, len(wl.ad)) == 1
+                    fl, cnt, held = ctx.verify_id_batch_aggregated(off, mask, retr, wl.ad, seed)
+                    assert held and (fl == expect).all()
+                finally:
+                    ctx.set_subgroup_check(True)
+                    L.elpo_set_subgroup_check(1)
+                ctx.set_strict_signature(True)
+                want = expect.copy()
+                want[8] = 0
+                fl, cnt, held = ctx.verify_id_batch_aggregated(off, mask, retr, wl.ad, seed)
+                assert held and (fl == want).all()
+                ctx.set_strict_signature(False)
+            finally:
+                L.elpo_key_free(key)
+    finally:
+        ctx.close()

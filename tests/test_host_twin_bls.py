@@ -120,6 +120,25 @@ def test_protocol_flows(L):
     P, Q = G.g1_mul(BLS_G1, 321), G.g2_mul(BLS_G2, 654)
     og, og2 = ctypes.create_string_buffer(12 * N), ctypes.create_string_buffer(12 * N)
     assert L.twin_blsp_pairing(g1b(P, N), g2b(Q, N), og) == 1 and L.twin_bls_pairing(g1b(P, N), g2b(Q, N), og2, 0) == 1 and og.raw == og2.raw
+    # the item of aggregated verification on the lane pair (k_verify_id_agg_paired, round 6) == on one lane (k_verify_id_agg): verdict of the NIZK half, the Miller
+    # value f_K([d]sig1) coefficient for coefficient, the multiplier and the copy of sig2 -- honest proof, wrong associated data (f stays 1), no retrieval, sig1 = infinity
+    # under the lenient rule
+    inf1 = copy.copy(pr2)
+    inf1.sig1, inf1.sig2 = None, None
+    seed32 = bytes(range(7, 39))
+    for rec, retr, adv, want_ok in ((pack_verify_id(M, pr), 1, b"sess", 1), (pack_verify_id(M, pr), 1, b"sesS", 0), (pack_verify_id(M, pr2), 0, b"sess", 1),
+                                    (pack_verify_id(M, inf1), 0, b"sess", 1)):
+        outs = []
+        for fn in (L.twin_bls_agg_item, L.twin_blsp_agg_item):
+            fo, de, s2 = ctypes.create_string_buffer(12 * N), ctypes.create_string_buffer(32), ctypes.create_string_buffer(2 * N)
+            L.twin_bls_ctx_set_flags(ctx, 0)                 # lenient signature rule: (O, O) reaches the Miller loop
+            r = fn(ctx, rec, mask, retr, adv, len(adv), seed32, ctypes.c_uint64(5), fo, de, s2)
+            outs.append((r, fo.raw, de.raw, s2.raw))
+        assert outs[0][0] == want_ok and outs[0] == outs[1], (retr, adv)
+        if not want_ok:
+            assert outs[0][1] == fb(1, N) + bytes(11 * N) and outs[0][2] == bytes(32)
+        else:
+            assert outs[0][2] != bytes(32)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------
