@@ -579,6 +579,39 @@ ELP_HD inline Scalar agg_multiplier(const uint8_t seed[32], u64 index) {
   k.v[3] |= 0x80000000u;   // exactly 128 bits, never zero
   return k;
 }
+// aP = [d]sig1 (affine) for the multiplier d = a + b lam of aggregated verification (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [a]sig1 + [b]phi(sig1)
+// over the affine multiples 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private
+// memory.  A function of its own: its 3 KB of tables then live in a frame that is not stacked on the NIZK half's (kernel frame 16 464 -> see profiles/r06_aggregated.md).
+template <class C>
+ELP_HEAVY void agg_scaled_sig1(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, const Scalar& d, Aff<F1<C>>& aP) {
+  typedef F1<C> G1F;
+  Jac<G1F> P;
+  if (aff_is_inf(sig1)) {
+    aff_set_inf(aP);
+    return;
+  }
+  Aff<G1F> tab[8];
+  {
+    Jac<G1F> jm[8];
+    jac_multiples8<G1F>(jm, sig1);
+    // Montgomery's trick over Z(2P) .. Z(8P) with batch_zinv's zero guard: without KEY_STRICT_SIG (or with ELP_OPT_SUBGROUP_CHECK = 0) sig1 may have a
+    // small order on a curve with a G1 cofactor and some multiple is the point at infinity (Z = 0); the guarded form keeps every other entry right and
+    // the batch equation / per-item fallback then decide such an item as the per-item path does
+    Fp<C> z[7], zi[7];
+    for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
+    batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
+    tab[0] = sig1;
+    for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
+  }
+  u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
+  if (ws1) {
+    for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1, i, tab[i]);
+    g1_mul_pair64_with<C, WsTab<G1F>>(P, WsTab<G1F>{ws1}, d);
+  } else {
+    g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
+  }
+  jac_to_aff<F1<C>>(aP, P);
+}
 // everything of an item up to its Miller loop: NIZK half, multiplier, [d]sig1 (affine) and K.  false = the item is rejected (aP, aK at infinity, multiplier 0)
 template <class C>
 ELP_HEAVY bool verify_id_agg_prepare(const KeyCtx<C>& key, const u32* rec, u64 hidden_mask, bool retr, const uint8_t* ad, size_t ad_len,
@@ -601,33 +634,7 @@ ELP_HEAVY bool verify_id_agg_prepare(const KeyCtx<C>& key, const u32* rec, u64 h
   // multiplier d = a + b lam (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [d]sig1 = [a]sig1 + [b]phi(sig1) over the affine multiples
   // 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private memory
   const Scalar d = agg_multiplier(seed, index);
-  Jac<F1<C>> P;
-  if (aff_is_inf(sig1)) {
-    jac_set_inf(P);
-  } else {
-    typedef F1<C> G1F;
-    Aff<G1F> tab[8];
-    {
-      Jac<G1F> jm[8];
-      jac_multiples8<G1F>(jm, sig1);
-      // Montgomery's trick over Z(2P) .. Z(8P) with batch_zinv's zero guard: without KEY_STRICT_SIG (or with ELP_OPT_SUBGROUP_CHECK = 0) sig1 may have a
-      // small order on a curve with a G1 cofactor and some multiple is the point at infinity (Z = 0); the guarded form keeps every other entry right and
-      // the batch equation / per-item fallback then decide such an item as the per-item path does
-      Fp<C> z[7], zi[7];
-      for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
-      batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
-      tab[0] = sig1;
-      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
-    }
-    u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
-    if (ws1) {
-      for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1, i, tab[i]);
-      g1_mul_pair64_with<C, WsTab<G1F>>(P, WsTab<G1F>{ws1}, d);
-    } else {
-      g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
-    }
-  }
-  jac_to_aff<F1<C>>(aP, P);
+  agg_scaled_sig1<C>(key, sig1, d, aP);
   for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
   g1_store<C>(sig2_out, sig2);
   return true;
@@ -1306,36 +1313,16 @@ ELP_HEAVY bool verify_id_agg_item_paired(const KeyCtx<C>& key, const u32* rec, u
   src.init(rec, hidden_mask, key.A, retr);
   if (!verify_id_paired_nizk<C, PairedRecordSrc<C>>(key, src, retr, P0, P1, kk, c, ad, ad_len, aK)) return false;
   const Scalar d = agg_multiplier(seed, index);
-  Jac<F1<C>> P;
-  if (aff_is_inf(sig1)) {
-    jac_set_inf(P);
-  } else {
-    typedef F1<C> G1F;
-    Aff<G1F> tab[8];
-    {
-      Jac<G1F> jm[8];
-      jac_multiples8<G1F>(jm, sig1);
-      Fp<C> z[7], zi[7];
-      for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
-      batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);      // zero-guarded as in verify_id_agg_prepare (a small-order sig1 without the strict rule)
-      tab[0] = sig1;
-      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
-    }
-    u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;      // the lane's first G1 table: the NIZK half is done with it
-    if (ws1) {
-      for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1, i, tab[i]);
-      g1_mul_pair64_with<C, WsTab<G1F>>(P, WsTab<G1F>{ws1}, d);
-    } else {
-      g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
-    }
-  }
-  jac_to_aff<F1<C>>(aP, P);
+  agg_scaled_sig1<C>(key, sig1, d, aP);
   if (!odd) {
     for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
     g1_store<C>(sig2_out, sig2);
   }
+  Fp12<C>* fh = hot_as<Fp12<C>, C>(key.hot);               // the accumulator of the loop in the lane's LDS slot, as in ps_pairing_check
+  Fp12<C>& fm = fh ? *fh : f;
   const LineMem<C>* no_lines[1] = {key.gg_lines};
-  miller_loop<C, 1, 0>(f, &aP, &aK, &aP, no_lines);
+  miller_loop<C, 1, 0>(fm, &aP, &aK, &aP, no_lines);
+  if (fh) f = fm;
   return true;
 }
 
