@@ -581,7 +581,8 @@ ELP_HD inline Scalar agg_multiplier(const uint8_t seed[32], u64 index) {
 }
 // aP = [d]sig1 (affine) for the multiplier d = a + b lam of aggregated verification (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [a]sig1 + [b]phi(sig1)
 // over the affine multiples 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private
-// memory.  A function of its own: its 3 KB of tables then live in a frame that is not stacked on the NIZK half's (kernel frame 16 464 -> see profiles/r06_aggregated.md).
+// memory.  A function of its own for the two-lane item (verify_id_agg_item_paired): its 3 KB of tables then live in a frame that is not stacked on the NIZK half's
+// (kernel frame 17 088 -> 14 064 B on BLS12-381, same time); the one-lane item keeps the same lines inline (see there).
 template <class C>
 ELP_HEAVY void agg_scaled_sig1(const KeyCtx<C>& key, const Aff<F1<C>>& sig1, const Scalar& d, Aff<F1<C>>& aP) {
   typedef F1<C> G1F;
@@ -633,8 +634,38 @@ ELP_HEAVY bool verify_id_agg_prepare(const KeyCtx<C>& key, const u32* rec, u64 h
   }
   // multiplier d = a + b lam (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [d]sig1 = [a]sig1 + [b]phi(sig1) over the affine multiples
   // 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private memory
+  // multiplier d = a + b lam (a = d.v[0..1], b = d.v[2..3], curve.h g1_mul_pair64_with): [d]sig1 = [a]sig1 + [b]phi(sig1) over the affine multiples
+  // 1 sig1 .. 8 sig1 (one inversion), kept in the lane's workspace slice (the NIZK half is done with it) rather than in lane-indexed private memory.
+  // Inline here on purpose: as a function of its own (agg_scaled_sig1 below, which the two-lane form uses) the kernel's frame shrinks by 2 KB but the
+  // BN254 kernel runs 0.2 ms slower (A/B in one lease, round 6)
   const Scalar d = agg_multiplier(seed, index);
-  agg_scaled_sig1<C>(key, sig1, d, aP);
+  Jac<F1<C>> P;
+  if (aff_is_inf(sig1)) {
+    jac_set_inf(P);
+  } else {
+    typedef F1<C> G1F;
+    Aff<G1F> tab[8];
+    {
+      Jac<G1F> jm[8];
+      jac_multiples8<G1F>(jm, sig1);
+      // Montgomery's trick over Z(2P) .. Z(8P) with batch_zinv's zero guard: without KEY_STRICT_SIG (or with ELP_OPT_SUBGROUP_CHECK = 0) sig1 may have a
+      // small order on a curve with a G1 cofactor and some multiple is the point at infinity (Z = 0); the guarded form keeps every other entry right and
+      // the batch equation / per-item fallback then decide such an item as the per-item path does
+      Fp<C> z[7], zi[7];
+      for (int i = 1; i < 8; i++) z[i - 1] = jm[i].Z;
+      batch_zinv<C, 7, 0>(zi, z, (Fp2<C>*)0, (const Fp2<C>*)0);
+      tab[0] = sig1;
+      for (int i = 1; i < 8; i++) jac_to_aff_with_zinv<G1F>(tab[i], jm[i], zi[i - 1]);
+    }
+    u32* const ws1 = key.vtab ? key.vtab + 8 * vtab_entry_words<F2<C>>() : nullptr;
+    if (ws1) {
+      for (int i = 0; i < 8; i++) vtab_store<G1F>(ws1, i, tab[i]);
+      g1_mul_pair64_with<C, WsTab<G1F>>(P, WsTab<G1F>{ws1}, d);
+    } else {
+      g1_mul_pair64_with<C, PrivTab<G1F>>(P, PrivTab<G1F>{tab}, d);
+    }
+  }
+  jac_to_aff<F1<C>>(aP, P);
   for (int i = 0; i < 8; i++) delta_out[i] = d.v[i];
   g1_store<C>(sig2_out, sig2);
   return true;
