@@ -102,11 +102,10 @@ int elp_init(int curve, int device, elp_ctx** out) {
   if (const char* e = getenv("ELP_STAGE")) c->stage_records = atoi(e) != 0;                                              // A/B runs: coalesced record loads
   if (const char* e = getenv("ELP_COOP")) c->coop = atoi(e) != 0;                                                      // A/B runs: cooperative pairing for small batches                                            // A/B runs: one fused kernel per verification
   c->pair16 = ELP_PAIR16_DEFAULT;
-  if (curve == ELP_CURVE_BLS12_381) {      // measured (profiles/r06_pair16.md): the interpreter serves up to 2 048 items in one round of 4.8 ms, the rows take 5.0-5.25 ms for any size up to 4 096
-    c->pair16_min = 2049;
-    c->pair16_tail = 0;
-  }
+  if (curve == ELP_CURVE_BLS12_381)        // measured (profiles/r06_pair16.md): the interpreter serves up to 2 048 items in one round of 4.8 ms, the rows take 5.0-5.25 ms for any size up to 4 096
+    c->pair16_min = 2049;                  // (the closing step of aggregated verification runs on a row on both curves: 2.21 against 2.63 ms on this one)
   if (const char* e = getenv("ELP_PAIR16_MIN")) c->pair16_min = (size_t)atol(e);                                       // A/B runs
+  if (const char* e = getenv("ELP_PAIR16_TAIL")) c->pair16_tail = atoi(e) != 0;                                        // A/B runs: the closing step of aggregated verification on one row
   if (const char* e = getenv("ELP_PAIR16")) c->pair16 = atoi(e) != 0;                                                  // A/B runs: the row-of-16 pairing check for small PS batches
   if (const char* e = getenv("ELP_VTAB")) c->use_vtab = strcmp(e, "0") != 0;                                         // A/B runs: tables of multiples in private memory
   hipDeviceProp_t prop;
