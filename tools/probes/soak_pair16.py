@@ -76,4 +76,20 @@ for it in range(max(20, calls // 10)):
 print("aggregated, batch equation held and verdicts equal: %d calls, %d failing" % (max(20, calls // 10), bad), flush=True)
 bad_total += bad
 ctx.close()
+# the same on BLS12-381: main kernel on lane pairs (k_verify_id_agg_paired), product tree and closing step on rows
+ctx = pkg.Context(pkg.CURVE_BLS12_381, 0)
+wl = synth.Workload(ctx, 6, seed=5151, window_bits=12)
+B = 4096
+recs, mask, expect = wl.verify_id_batch(B, 3, with_retrieval=True, corrupt_every=13, corrupt_at=5)
+rsz = len(recs) // B
+bad = 0
+for it in range(max(10, calls // 20)):
+    n = rnd.choice((1, 31, 64, 513, 2117, 4096))
+    fl, cnt, held = ctx.verify_id_batch_aggregated(recs[:n * rsz], mask, True, wl.ad, None)
+    if not held or not (fl == expect[:n]).all() or cnt != int(expect[:n].sum()):
+        bad += 1
+        print("BLS12-381 aggregated MISMATCH call %d n=%d held=%s" % (it, n, held), flush=True)
+print("BLS12-381 aggregated (lane pairs + rows), batch equation held and verdicts equal: %d calls, %d failing" % (max(10, calls // 20), bad), flush=True)
+bad_total += bad
+ctx.close()
 sys.exit(1 if bad_total else 0)
