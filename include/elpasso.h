@@ -68,7 +68,8 @@ int elp_field_bytes(int curve);               /* F */
  *
  * KERNEL SELECTION (verdicts identical):
  * ELP_OPT_PAIRED_LAYOUT: 0 = one lane per item; 1 = two lanes per item (the Fp2 tower split over a lane pair; BN254 builds); 2 (default) = by batch
- *   size: two lanes when the last round of 64 x SIMDs items would be at most half full and always on BLS12-381, one lane otherwise.
+ *   size: two lanes when the last round of 64 x SIMDs items would be at most half full and always on BLS12-381, one lane otherwise.  On BLS12-381 the
+ *   main kernel of elp_verify_id_batch_aggregated[_dev] follows the option too (two lanes unless the value is 0; on BN254 it is a one-lane kernel).
  * ELP_OPT_TABLE_WORKSPACE (default 1): the per-item tables of the variable-base multiplications live in a launch workspace in device memory (3 KB per
  *   item, see the *_dev entry points) instead of the lanes' private memory; 0 saves the memory at a few per cent of throughput.
  * ELP_OPT_SPLIT_PHASES (default 0): 1 = the one-lane el_passo_verify_id as two kernels (NIZK half as independent jobs, then the pairing check; BN254);
@@ -95,8 +96,8 @@ int elp_field_bytes(int curve);               /* F */
  * ELP_OPT_PAIR16 (default 1; round 6): PS verifications of at most 4 096 items (value > 1: that many) run the pairing check with ONE ITEM PER 16-LANE ROW of a wave --
  *   12 lanes hold one base-field coefficient each of the Fp12 value, every Fp12-level operation is one inner product per lane over operands published in LDS
  *   (csrc/elpasso_pair16.h; tables and program generated and simulated by tools/gen_row16.py for both curves) -- from the size at which that wins: 4 items on BN254,
- *   2 049 on BLS12-381 (below, the cooperative interpreter's 32 lane pairs per item are faster); on BN254 also the closing step of aggregated verification, and on
- *   both curves the product of its per-wave Miller values (k_fp12_reduce16: every product one step on a row).
+ *   2 049 on BLS12-381 (below, the cooperative interpreter's 32 lane pairs per item are faster); on both curves also the closing step of aggregated verification
+ *   (k_agg_final16) and the product of its per-wave Miller values (k_fp12_reduce16: every product one step on a row).
  *   0 = the interpreter and the one-lane product tree keep these jobs.  Measurements: profiles/r06_pair16.md.
  * ELP_OPT_FAULT_INJECT (default 0; test hook for callers' error paths): the next `value` calls of elp_verify_id_batch_submit on this context fail with
  *   ELP_ERR_STATE before anything is queued.  No other entry point consumes or honours the counter.
