@@ -1525,16 +1525,16 @@ __global__ void ELP_LAUNCH_BOUNDS k_pairing_check(const u32* g1, const u32* g2, 
 //   k_msm_reduce  : per window: slices combined, then sum_b b*B_b as a suffix scan + tree reduction through LDS
 //   k_msm_final   : Horner over the non-empty windows (of 32), normalisation, one std affine point out
 #define ELP_MSM_SLICE 8192
-// Slices per window: at least ceil(n / ELP_MSM_SLICE) (the LDS sort buffer), more -- down to 1 024 points per slice -- while the launch would otherwise leave compute
-// units idle: nwin x S workgroups should reach two per compute unit (65 536 points, 16 windows: 8 -> 32 slices, the bucket phase 0.62 -> see profiles/r06_aggregated.md)
+// Slices per window: at least ceil(n / ELP_MSM_SLICE) (the LDS sort buffer), more -- down to 512 points per slice -- while the launch would otherwise leave compute
+// units idle: nwin x S workgroups should reach four per compute unit (65 536 points, 16 windows: 8 -> 64 slices; profiles/r06_ubench_msm_buckets.log)
 static inline int msm_slices(size_t n, int nwin) {
   static const size_t target = [] {
     const char* e = getenv("ELP_MSM_WORKGROUPS");           // (measurements)
     const long v = e ? atol(e) : 0;
-    return (size_t)(v > 0 ? v : 512);
+    return (size_t)(v > 0 ? v : 1024);
   }();
   size_t s = (n + ELP_MSM_SLICE - 1) / ELP_MSM_SLICE;
-  const size_t want = (target + (size_t)nwin - 1) / (size_t)nwin, most = (n + 1023) / 1024;
+  const size_t want = (target + (size_t)nwin - 1) / (size_t)nwin, most = (n + 511) / 512;
   if (s < want) s = want < most ? want : most;
   return (int)(s ? s : 1);
 }
@@ -1566,6 +1566,8 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
                                                              Jac<F>* partial) {
   __shared__ unsigned cnt[256];
   __shared__ unsigned start[256];
+  __shared__ unsigned cnt0[256];
+  __shared__ unsigned char perm[256];
   __shared__ unsigned wave_tot[4];
   __shared__ unsigned short idx[ELP_MSM_SLICE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1586,11 +1588,23 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
     if (lane >= d) x += y;
   }
   if (lane == 63) wave_tot[wv] = x;
+  cnt0[tid] = c0;
   __syncthreads();
   unsigned base = 0;
   for (int k = 0; k < wv; k++) base += wave_tot[k];
   const unsigned my_start = base + x - c0;
   start[tid] = my_start;
+  // The buckets are dealt to the lanes IN THE ORDER OF THEIR SIZES (lane t takes the bucket of rank t, largest first): the 64 buckets of a wave are then of similar
+  // length -- a wave runs as long as its longest bucket, and with the buckets in digit order every wave waited for a Poisson tail (25 points where the mean is 8) --
+  // and the waves of the small buckets retire early.  tools/ubench_msm.hip: 2^20 points 4.16 -> 3.29 ms, 65 536 points x 16 windows 0.25 -> 0.17 ms.
+  {
+    unsigned rank = 0;
+    for (int k = 0; k < 256; k++) {
+      const unsigned ck = cnt0[k];
+      rank += (ck > c0 || (ck == c0 && k < tid)) ? 1u : 0u;
+    }
+    perm[rank] = (unsigned char)tid;
+  }
   __syncthreads();
   cnt[tid] = my_start;   // becomes the scatter cursor
   __syncthreads();
@@ -1599,11 +1613,12 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
     if (d != 0 && !aff_is_inf(pts[lo + j])) idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)j;
   }
   __syncthreads();
+  const int b = perm[tid];
   Jac<F> acc;
   jac_set_inf(acc);
-  const unsigned t1 = start[tid] + c0;
-  for (unsigned t = start[tid]; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
-  partial[(size_t)blockIdx.x * 256 + tid] = acc;
+  const unsigned t0 = start[b], t1 = t0 + cnt0[b];
+  for (unsigned t = t0; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
+  partial[(size_t)blockIdx.x * 256 + b] = acc;
 }
 
 // More than eight slices per window: their bucket sums are combined by 32 lanes per bucket (a tree of five additions through LDS) instead of one lane walking all of

@@ -2,6 +2,7 @@
 //   mode 0  the kernel as built into the library (histogram, scan, counting sort, bucket sums)
 //   mode 1  histogram + scan + counting sort only (every lane stores an empty sum)
 //   mode 2  bucket sums only: lane b adds M / 256 points at fixed positions (no histogram, no sort, uniform trip count)
+//   mode 6  buckets dealt to the lanes by size (see k_ranked)
 //   mode 3  as mode 0 with the two global passes over the scalars reading a byte array laid out per window (one byte per point)
 // Inputs are random field elements (not curve points: the formulas do not care), scalars random bytes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DELP_FP6_INLINE=1 -I ps-signature-and-el-passo_amd/csrc -I include tools/ubench_msm.hip -o build/ubench_msm
@@ -124,6 +125,62 @@ __global__ void __launch_bounds__(256 * LPB) k_split(const Aff<F>* pts, const ui
   if (part == 0) partial[(size_t)blockIdx.x * 256 + b] = acc;
 }
 
+// mode 6: as the library's kernel, with the buckets dealt to the lanes in the order of their sizes (lane t takes the bucket of rank t): a wave's 64 buckets are then
+// of similar length, so the waves of a workgroup finish at different times and release their SIMD slots -- for batches that are work, not latency
+__global__ void ELP_MSM_LAUNCH_BOUNDS k_ranked(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S, Jac<F>* partial) {
+  __shared__ unsigned cnt[256];
+  __shared__ unsigned start[256];
+  __shared__ unsigned cnt0[256];
+  __shared__ unsigned char perm[256];
+  __shared__ unsigned wave_tot[4];
+  __shared__ unsigned short idx[ELP_MSM_SLICE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = blockIdx.x / S, s = blockIdx.x % S;
+  const size_t lo = n * (size_t)s / S, hi = n * (size_t)(s + 1) / S;
+  const int M = (int)(hi - lo);
+  cnt[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < M; j += ELP_MSM_TPB) {
+    unsigned d = scalars[(lo + j) * 32 + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) atomicAdd(&cnt[d], 1u);
+  }
+  __syncthreads();
+  unsigned c0 = cnt[tid], x = c0;
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wave_tot[wv] = x;
+  cnt0[tid] = c0;
+  __syncthreads();
+  unsigned base = 0;
+  for (int k = 0; k < wv; k++) base += wave_tot[k];
+  const unsigned my_start = base + x - c0;
+  start[tid] = my_start;
+  {                                                          // rank of this bucket among the 256 by size, largest first (ties by index)
+    unsigned rank = 0;
+    for (int k = 0; k < 256; k++) {
+      const unsigned ck = cnt0[k];
+      rank += (ck > c0 || (ck == c0 && k < tid)) ? 1u : 0u;
+    }
+    perm[rank] = (unsigned char)tid;
+  }
+  __syncthreads();
+  cnt[tid] = my_start;
+  __syncthreads();
+  for (int j = tid; j < M; j += ELP_MSM_TPB) {
+    unsigned d = scalars[(lo + j) * 32 + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)j;
+  }
+  __syncthreads();
+  const int b = perm[tid];
+  Jac<F> acc;
+  jac_set_inf(acc);
+  const unsigned t0 = start[b], t1 = t0 + cnt0[b];
+  for (unsigned t = t0; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
+  partial[(size_t)blockIdx.x * 256 + b] = acc;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -154,7 +211,7 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   for (int S : {8, 16, 32, 64, 128}) {
     if ((size_t)S * 8192 < n || n / S < 256) continue;
-    for (int mode = 0; mode < 6; mode++) {
+    for (int mode = 0; mode < 7; mode++) {
       float best = 1e9f;
       for (int rep = 0; rep < 6; rep++) {
         CK(hipEventRecord(e0, 0));
@@ -164,6 +221,7 @@ int main(int argc, char** argv) {
         if (mode == 3) hipLaunchKernelGGL((k_variant<3>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
         if (mode == 4) hipLaunchKernelGGL((k_split<2>), dim3(NW * S), dim3(512), 0, 0, dp, dk, n, S, part);
         if (mode == 5) hipLaunchKernelGGL((k_split<4>), dim3(NW * S), dim3(1024), 0, 0, dp, dk, n, S, part);
+        if (mode == 6) hipLaunchKernelGGL(k_ranked, dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, n, S, part);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
