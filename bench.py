@@ -875,7 +875,7 @@ def msm_lines(ctx, wl, dev, stream, timed):
                                 "algorithmic_bytes_per_point": G1 + 32, "hbm_GBps": n * (G1 + 32) / (ms * 1e-3) / 1e9,
                                 "valu_bound": {"fp_mul_equivalents_per_point": per_point, "achieved": ach, "fp_mul_peak_per_s": peak, "frac": ach / peak, "unit": "modmul/s",
                                                "note": "bucket phase only (32 windows x one mixed addition of 11 field products per point); bucket reductions excluded"},
-                                "kernels": "k_msm_prepare -> k_msm_buckets (LDS histogram + counting sort, one workgroup per window and slice of at most 8 192 points) -> k_msm_combine (slices, above 8 per window) -> k_msm_reduce -> k_msm_final"}
+                                "kernels": "k_msm_prepare -> k_msm_buckets (LDS histogram + counting sort, one workgroup per window and slice of at most 8 192 points) -> k_msm_combine (slices, above 8 per window) -> k_msm_reduce -> k_msm_final_glv<17>; scalars split as +-k1 +- k2 lam first (k_msm_split_scalars), buckets dealt to the lanes by size"}
     # small case against the plain sum of scalar multiples
     n = 4096
     ref = ctx.g1_mul(bytes(pts[:n * G1]), k1[:n].tobytes())

@@ -1539,6 +1539,25 @@ static inline int msm_slices(size_t n, int nwin) {
   return (int)(s ? s : 1);
 }
 #define ELP_MSM_TPB 256
+// G1 sums over full-width scalars (round 6): every scalar is split as k = +-k1 +- k2 lam (mod r) with |k1|, |k2| < 2^136 (curve.h lattice_split, the split of g1_mul_glv),
+// the windows 0 .. 16 hold the bytes of |k1|, the windows 17 .. 33 those of |k2|, a sign byte tells the bucket kernel to add -P; the closing Horner chains then have 128
+// doublings each on two lanes instead of 248 on one (k_msm_final 1.30 -> k_msm_final_glv<17>; profiles/r06_aggregated.md).  Bytes per point of the split scalars:
+#define ELP_MSM_GLV_HW 17
+#define ELP_MSM_NWMAX 34           /* windows of the widest launch shape (2 x ELP_MSM_GLV_HW) */
+#define ELP_MSM_GLV_STRIDE 36      /* |k1| 0..16, |k2| 17..33, signs (bit 0: k1, bit 1: k2) 34, pad 35 */
+template <class C>
+__global__ void ELP_LAUNCH_BOUNDS k_msm_split_scalars(const u32* ks, uint8_t* out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 m[2][5];
+  bool neg[2];
+  lattice_split<2, 5, 5>(scalar_mod_r<C>(scalar_load_w(ks + i * 8)), m, neg, Glv1Lat<C>());
+  uint8_t* o = out + i * ELP_MSM_GLV_STRIDE;
+  for (int h = 0; h < 2; h++)
+    for (int b = 0; b < ELP_MSM_GLV_HW; b++) o[h * ELP_MSM_GLV_HW + b] = (uint8_t)(m[h][b >> 2] >> (8 * (b & 3)));
+  o[34] = (uint8_t)((neg[0] ? 1 : 0) | (neg[1] ? 2 : 0));
+  o[35] = 0;
+}
 
 template <class C, int G>
 __global__ void ELP_LAUNCH_BOUNDS k_msm_prepare(const u32* pts, void* out, int* bad, size_t n) {
@@ -1563,7 +1582,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_prepare(const u32* pts, void* out, int* 
 
 template <class F>
 __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
-                                                             Jac<F>* partial) {
+                                                             Jac<F>* partial, int kstride, int sign_off, int half_w) {      // plain scalars: 32, -1, 0; split ones: see k_msm_split_scalars
   __shared__ unsigned cnt[256];
   __shared__ unsigned start[256];
   __shared__ unsigned cnt0[256];
@@ -1577,7 +1596,7 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
   cnt[tid] = 0;
   __syncthreads();
   for (int j = tid; j < M; j += ELP_MSM_TPB) {
-    unsigned d = scalars[(lo + j) * 32 + w];
+    unsigned d = scalars[(lo + j) * (size_t)kstride + w];
     if (d != 0 && !aff_is_inf(pts[lo + j])) atomicAdd(&cnt[d], 1u);
   }
   __syncthreads();
@@ -1608,16 +1627,25 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
   __syncthreads();
   cnt[tid] = my_start;   // becomes the scatter cursor
   __syncthreads();
+  const int sign_shift = (sign_off >= 0 && w >= half_w) ? 1 : 0;
   for (int j = tid; j < M; j += ELP_MSM_TPB) {
-    unsigned d = scalars[(lo + j) * 32 + w];
-    if (d != 0 && !aff_is_inf(pts[lo + j])) idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)j;
+    unsigned d = scalars[(lo + j) * (size_t)kstride + w];
+    if (d != 0 && !aff_is_inf(pts[lo + j])) {
+      const unsigned sg = sign_off >= 0 ? (((unsigned)scalars[(lo + j) * (size_t)kstride + sign_off] >> sign_shift) & 1u) : 0u;
+      idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)((unsigned)j | (sg << 15));      // a slice has at most 8 192 points: bit 15 carries the sign of this half's sub-scalar
+    }
   }
   __syncthreads();
   const int b = perm[tid];
   Jac<F> acc;
   jac_set_inf(acc);
   const unsigned t0 = start[b], t1 = t0 + cnt0[b];
-  for (unsigned t = t0; t < t1; t++) jac_madd<F>(acc, acc, pts[lo + idx[t]]);
+  for (unsigned t = t0; t < t1; t++) {
+    const unsigned e = idx[t];
+    Aff<F> p = pts[lo + (e & 0x7FFFu)];
+    if (e & 0x8000u) aff_neg(p, p);
+    jac_madd<F>(acc, acc, p);
+  }
   partial[(size_t)blockIdx.x * 256 + b] = acc;
 }
 
@@ -1667,8 +1695,9 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S,
 
 // bucket sums per (window, slice) -> [slices combined] -> one sum per window
 template <class F>
-static void msm_windows(hipStream_t stream, int nwin, int S, const Aff<F>* aff, const uint8_t* ks, size_t n, Jac<F>* part, Jac<F>* win) {
-  hipLaunchKernelGGL((k_msm_buckets<F>), dim3(nwin * S), dim3(ELP_MSM_TPB), 0, stream, aff, ks, n, S, part);
+static void msm_windows(hipStream_t stream, int nwin, int S, const Aff<F>* aff, const uint8_t* ks, size_t n, Jac<F>* part, Jac<F>* win, bool split = false) {
+  hipLaunchKernelGGL((k_msm_buckets<F>), dim3(nwin * S), dim3(ELP_MSM_TPB), 0, stream, aff, ks, n, S, part, split ? ELP_MSM_GLV_STRIDE : 32, split ? 34 : -1,
+                     split ? ELP_MSM_GLV_HW : 0);
   if (S > 8) hipLaunchKernelGGL((k_msm_combine<F>), dim3(nwin * 32), dim3(ELP_MSM_TPB), 0, stream, part, S);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(nwin), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S > 8 ? 1 : S, S, win);
 }
@@ -1676,14 +1705,14 @@ static void msm_windows(hipStream_t stream, int nwin, int S, const Aff<F>* aff, 
 // Closing step for the multipliers of aggregated verification, d_i = a_i + b_i lam with a_i in scalar bytes 0-7 and b_i in bytes 8-15 (pipeline.h
 // verify_id_agg_item): windows 0-7 hold the bucket sums of sum a_i P_i =: A, windows 8-15 those of sum b_i P_i =: B; the result is A + phi(B).  The two Horner
 // chains (56 doublings each) run on two lanes.
-template <class C>
+template <class C, int HW = 8>      // HW windows per half: 8 for the 64-bit pairs of aggregated verification, ELP_MSM_GLV_HW for split full-width scalars
 __global__ void ELP_LAUNCH_BOUNDS k_msm_final_glv(const void* win_, u32* out) {
   typedef F1<C> F;
   __shared__ Jac<F> half[2];
   if (blockIdx.x != 0 || threadIdx.x >= 2) return;
-  const Jac<F>* win = (const Jac<F>*)win_ + 8 * threadIdx.x;
-  Jac<F> r = win[7];
-  for (int w = 6; w >= 0; w--) {
+  const Jac<F>* win = (const Jac<F>*)win_ + HW * threadIdx.x;
+  Jac<F> r = win[HW - 1];
+  for (int w = HW - 2; w >= 0; w--) {
     for (int k = 0; k < 8; k++) jac_dbl<F>(r, r);
     jac_add<F>(r, r, win[w]);
   }
@@ -2514,6 +2543,10 @@ static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, 
 }
 
 template <class C, int G>
+static size_t msm_ws_bytes(size_t n);
+template <class C, int G>
+static int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs = false);
+template <class C, int G>
 int msm_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
   if (!c || !out || (n && (!pts || !ks))) return ELP_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2524,30 +2557,17 @@ int msm_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint
     memset(out, 0, P);
     return ELP_OK;
   }
-  const int S = msm_slices(n, 32);
-  DevBuf dpts, dks, daff, dpart, dwin, dbad, dout;
+  DevBuf dpts, dks, dws, dout;
   HIPCHK(c, dpts.alloc(n * P));
   HIPCHK(c, dks.alloc(n * 32));
-  HIPCHK(c, daff.alloc(n * AFF));
-  HIPCHK(c, dpart.alloc((size_t)32 * S * 256 * JAC));
-  HIPCHK(c, dwin.alloc(32 * JAC));
-  HIPCHK(c, dbad.alloc(4));
+  HIPCHK(c, dws.alloc(msm_ws_bytes<C, G>(n)));
   HIPCHK(c, dout.alloc(P));
   HIPCHK(c, hipMemcpyAsync(dpts.p, pts, n * P, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dks.p, ks, n * 32, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(dbad.p, 0, 4, c->stream));
-  hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, c->stream, (const u32*)dpts.p, daff.p, (int*)dbad.p, n);
-  if (G == 1) {
-    typedef F1<C> F;
-    msm_windows<F>(c->stream, 32, S, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, (Jac<F>*)dpart.p, (Jac<F>*)dwin.p);
-  } else {
-    typedef F2<C> F;
-    msm_windows<F>(c->stream, 32, S, (const Aff<F>*)daff.p, (const uint8_t*)dks.p, n, (Jac<F>*)dpart.p, (Jac<F>*)dwin.p);
-  }
-  hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, c->stream, (const void*)dwin.p, (u32*)dout.p);
+  const int* d_bad = msm_launch<C, G>(c->stream, n, dpts.p, dks.p, dout.p, (uint8_t*)dws.p, false);
   HIPCHK(c, hipGetLastError());
   int hbad = 0;
-  HIPCHK(c, hipMemcpyAsync(&hbad, dbad.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&hbad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(out, dout.p, P, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (hbad) {
@@ -2641,23 +2661,33 @@ template <class C, int G>
 static size_t msm_ws_bytes(size_t n) {
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
-  const size_t S = (size_t)msm_slices(n, 16);      // the larger of the two launch shapes (16 windows for the pairs of aggregated verification, 32 otherwise)
-  return ((n * AFF + 255) & ~(size_t)255) + ((32 * S * 256 * JAC + 255) & ~(size_t)255) + ((32 * JAC + 255) & ~(size_t)255) + 256;
+  const size_t S = (size_t)msm_slices(n, 16);      // the largest of the launch shapes (16 windows for the pairs of aggregated verification, 32 / 34 otherwise)
+  return ((n * AFF + 255) & ~(size_t)255) + ((ELP_MSM_NWMAX * S * 256 * JAC + 255) & ~(size_t)255) + ((ELP_MSM_NWMAX * JAC + 255) & ~(size_t)255) + 256 +
+         (G == 1 ? ((n * ELP_MSM_GLV_STRIDE + 255) & ~(size_t)255) : 0);
 }
+// returns the device address of the count of invalid input points (an int, zero after a clean run)
 template <class C, int G>
-static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs = false) {
+static int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs) {
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
-  const int NWL = glv_pairs ? 16 : 32;            // scalar bytes in use: the pairs (a, b) of aggregated verification fill 16
+  const bool split = G == 1 && !glv_pairs;        // full-width scalars in G1: split in two halves of ELP_MSM_GLV_HW bytes each (k_msm_split_scalars)
+  const int NWL = glv_pairs ? 16 : split ? 2 * ELP_MSM_GLV_HW : 32;            // scalar bytes in use: the pairs (a, b) of aggregated verification fill 16
   const int S = msm_slices(n, NWL);
   uint8_t* aff = ws;
   uint8_t* part = aff + ((n * AFF + 255) & ~(size_t)255);
-  uint8_t* win = part + (((size_t)32 * S * 256 * JAC + 255) & ~(size_t)255);
-  int* bad = (int*)(win + ((32 * JAC + 255) & ~(size_t)255));
+  uint8_t* win = part + (((size_t)ELP_MSM_NWMAX * S * 256 * JAC + 255) & ~(size_t)255);
+  int* bad = (int*)(win + ((ELP_MSM_NWMAX * JAC + 255) & ~(size_t)255));
+  uint8_t* ks2 = (uint8_t*)bad + 256;
   (void)hipMemsetAsync(bad, 0, 4, stream);
   hipLaunchKernelGGL((k_msm_prepare<C, G>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, (const u32*)d_pts_std, (void*)aff, bad, n);
-  if (G == 1) {
+  if constexpr (G == 1) {
     typedef F1<C> F;
+    if (split) {
+      hipLaunchKernelGGL((k_msm_split_scalars<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, (const u32*)d_ks, ks2, n);
+      msm_windows<F>(stream, NWL, S, (const Aff<F>*)aff, ks2, n, (Jac<F>*)part, (Jac<F>*)win, true);
+      hipLaunchKernelGGL((k_msm_final_glv<C, ELP_MSM_GLV_HW>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
+      return bad;
+    }
     msm_windows<F>(stream, NWL, S, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, (Jac<F>*)part, (Jac<F>*)win);
   } else {
     typedef F2<C> F;
@@ -2666,10 +2696,11 @@ static void msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, cons
   if constexpr (G == 1) {
     if (glv_pairs) {
       hipLaunchKernelGGL((k_msm_final_glv<C>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
-      return;
+      return bad;
     }
   }
   hipLaunchKernelGGL((k_msm_final<C, G>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
+  return bad;
 }
 
 // elp_g1_msm_dev / elp_g2_msm_dev: the same launch sequence over the caller's device buffers and workspace, asynchronous on the caller's stream
