@@ -283,3 +283,37 @@ def test_aggregated_verification_on_lane_pairs_bls12_381_vs_oracle(elp):
                 L.elpo_key_free(key)
     finally:
         ctx.close()
+
+
+def test_g1_msm_with_split_scalars_on_exceptional_values(gpu_ctx, elp):
+    """elp_g1_msm after round 6 splits every scalar with the GLV lattice (k_msm_split_scalars) and carries the signs of the halves into the bucket kernel.  Scalars that
+    stress the split -- 0, 1, r - 1, r, r + 1, 2^256 - 1 (reduced modulo r first), lam and -lam (one half is 0 or +-1), 2^127, 2^128, values just around the lattice's
+    rounding points -- on distinct points, a repeated point and the point at infinity, both curves: the sum must be the big-int model's (oracle/pymodel.py Groups.g1_mul / g1_add)."""
+    import random
+    from elp_testlib import BLS12_381, BLS_G1, BN254, Mcl, fb, g1b, g1u
+    for curve, ctx, close in (("bn254", gpu_ctx, False), ("bls12_381", elp.Context(elp.CURVE_BLS12_381, 0), True)):
+        try:
+            M_ = Mcl(BN254 if curve == "bn254" else BLS12_381)
+            G_ = M_.G
+            N_ = 32 if curve == "bn254" else 48
+            base = M_.hash_to_g1("msm-edge") if curve == "bn254" else BLS_G1
+            lam = next(v for v in (pow(x, (M_.r - 1) // 3, M_.r) for x in range(2, 50)) if v != 1)      # a primitive cube root of unity modulo r: lam or lam^2 of the lattice
+            rnd = random.Random(606)
+            ks = [0, 1, M_.r - 1, M_.r, M_.r + 1, (1 << 256) - 1, 1 << 127, 1 << 128, (1 << 128) - 1, (M_.r + 1) // 2, M_.r // 3, 2 * M_.r // 3]
+            if lam:
+                ks += [lam, M_.r - lam, lam + 1, lam - 1, (lam * lam) % M_.r, (1 << 64) * lam % M_.r]
+            ks += [rnd.randrange(1 << 256) for _ in range(14)]
+            pts = [G_.g1_mul(base, rnd.randrange(1, M_.r)) for _ in ks]
+            pts[3] = pts[2]                                            # a repeated point with r - 1 and r
+            pts[7] = None                                              # the point at infinity with a full-size scalar
+            want = None
+            for P, k in zip(pts, ks):
+                want = G_.g1_add(want, G_.g1_mul(P, k % M_.r))
+            got = ctx.g1_msm(b"".join(g1b(P, N_) for P in pts), b"".join((k % (1 << 256)).to_bytes(32, "little") for k in ks))
+            assert g1u(got, N_) == want, curve
+            # the same scalars over one point: (sum k_i) P
+            got1 = ctx.g1_msm(g1b(base, N_) * len(ks), b"".join((k % (1 << 256)).to_bytes(32, "little") for k in ks))
+            assert g1u(got1, N_) == G_.g1_mul(base, sum(ks) % M_.r), curve
+        finally:
+            if close:
+                ctx.close()
