@@ -869,12 +869,12 @@ def msm_lines(ctx, wl, dev, stream, timed):
         o = d_out.cpu().numpy().tobytes()
         lin = ctx.g1_add(o[:G1], o[G1:2 * G1]) == o[2 * G1:] and o[:G1] != bytes(G1)
         # 32 windows of 8 bits: one mixed addition (11 field products: 7 M + 4 S) per point and window is the bucket phase; the reductions are O(windows x buckets)
-        per_point = 32 * 11
+        per_point = 34 * 11      # 2 x 17 byte-windows of the split scalars
         ach = per_point * n / (ms * 1e-3)
         out["msm_g1_%d" % n] = {"value": n / (ms * 1e-3), "unit": "points/s", "ms": ms, "linearity_ok": bool(lin),
                                 "algorithmic_bytes_per_point": G1 + 32, "hbm_GBps": n * (G1 + 32) / (ms * 1e-3) / 1e9,
                                 "valu_bound": {"fp_mul_equivalents_per_point": per_point, "achieved": ach, "fp_mul_peak_per_s": peak, "frac": ach / peak, "unit": "modmul/s",
-                                               "note": "bucket phase only (32 windows x one mixed addition of 11 field products per point); bucket reductions excluded"},
+                                               "note": "bucket phase only (2 x 17 windows of the GLV-split scalars x one mixed addition of 11 field products per point); bucket reductions excluded"},
                                 "kernels": "k_msm_prepare -> k_msm_buckets (LDS histogram + counting sort, one workgroup per window and slice of at most 8 192 points) -> k_msm_combine (slices, above 8 per window) -> k_msm_reduce -> k_msm_final_glv<17>; scalars split as +-k1 +- k2 lam first (k_msm_split_scalars), buckets dealt to the lanes by size"}
     # small case against the plain sum of scalar multiples
     n = 4096
