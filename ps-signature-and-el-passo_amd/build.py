@@ -69,7 +69,7 @@ HIP_UNITS = [("elpasso_capi.hip", []), ("elpasso_bn254.hip", ["-DELP_FP6_INLINE=
              ("elpasso_bls12_381.hip", []), ("elpasso_bls12_381_pair.hip", ["-DELP_FP6_INLINE=1", "-DELP_NONLEAF_GUARD=1", "-DELP_PAIR_WAVES=1"]), ("elpasso_bls12_381_g1jobs.hip", []), ("elpasso_bn254_g1jobs.hip", []),
              ("elpasso_bls12_381_coop.hip", []), ("elpasso_bls12_381_nizk.hip", []), ("elpasso_bn254_small2.hip", ["-DELP_WAVES_PER_EU=2"]),
              ("elpasso_bn254_pair4.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bls12_381_pair4.hip", ["-DELP_FP6_INLINE=1", "-DELP_NONLEAF_GUARD=1"]),
-             ("elpasso_bn254_pair16.hip", []), ("elpasso_bls12_381_pair16.hip", [])]
+             ("elpasso_bn254_pair16.hip", []), ("elpasso_bls12_381_pair16.hip", []), ("elpasso_bn254_msm.hip", ["-DELP_FP6_INLINE=1"]), ("elpasso_bls12_381_msm.hip", [])]
 
 
 def build_hip(force=False, verbose=False):

@@ -234,8 +234,14 @@ ELP_HEAVY void jac_dbl(Jac<F>& r, const Jac<F>& p) {
 // this representation: H^2 is needed anyway, and a Montgomery product of two multiples of p is LITERALLY zero
 // ((kp * lp + m p)/R with m = -kl p exactly), while H != 0 (mod p) gives H^2 != 0.  So no modular reduction or
 // comparison is needed on the hot path.
+template <class F, bool DBL_INLINE>
+ELP_INL void jac_madd_inl_t(Jac<F>& r, const Jac<F>& p, const Aff<F>& q);
 template <class F>
 ELP_INL void jac_madd_inl(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
+  jac_madd_inl_t<F, false>(r, p, q);
+}
+template <class F, bool DBL_INLINE>      // DBL_INLINE: the exceptional doubling inlined too (kernels with a register bound of their own: a call brings the callee's allocation)
+ELP_INL void jac_madd_inl_t(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   typedef typename F::T T;
   if (aff_is_inf(q)) {
     r = p;
@@ -255,7 +261,8 @@ ELP_INL void jac_madd_inl(Jac<F>& r, const Jac<F>& p, const Aff<F>& q) {
   T HH = F::sqr(H);
   if (F::is_zero_exact(HH)) {            // H == 0 (mod p): same x-coordinate
     if (F::is_zero_exact(F::sqr(F::carry(rr)))) {  // and same y: doubling
-      jac_dbl<F>(r, p);
+      if constexpr (DBL_INLINE) jac_dbl_inl<F>(r, p);
+      else jac_dbl<F>(r, p);
     } else {
       jac_set_inf(r);
     }

@@ -1580,8 +1580,11 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_prepare(const u32* pts, void* out, int* 
   }
 }
 
+// G1: four waves per SIMD (at most 128 registers, the mixed addition inlined): a launch of 1 024 workgroups is then resident at once.  Left to itself the
+// compiler took 164 registers -- three waves per SIMD, a quarter of the workgroups in a second round -- and the phase ran 2.5 x longer (0.68 against 0.27 ms for
+// 65 536 points x 32 windows; tools/ubench_msm.hip had the tighter allocation by accident of its other kernels).
 template <class F>
-__global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
+__global__ void __launch_bounds__(ELP_MSM_TPB, (F::IS_EXT ? 1 : 4)) k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
                                                              Jac<F>* partial, int kstride, int sign_off, int half_w) {      // plain scalars: 32, -1, 0; split ones: see k_msm_split_scalars
   __shared__ unsigned cnt[256];
   __shared__ unsigned start[256];
@@ -1644,7 +1647,8 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_buckets(const Aff<F>* pts, const uin
     const unsigned e = idx[t];
     Aff<F> p = pts[lo + (e & 0x7FFFu)];
     if (e & 0x8000u) aff_neg(p, p);
-    jac_madd<F>(acc, acc, p);
+    if constexpr (F::IS_EXT) jac_madd<F>(acc, acc, p);
+    else jac_madd_inl_t<F, true>(acc, acc, p);      // inlined with its exceptional doubling: a call would bring the callee's own register allocation (134) with it
   }
   partial[(size_t)blockIdx.x * 256 + b] = acc;
 }
@@ -2544,8 +2548,11 @@ static int msm_fixed_impl(elp_ctx* c, size_t n, int nterms, const int32_t* ids, 
 
 template <class C, int G>
 static size_t msm_ws_bytes(size_t n);
+// The Pippenger launch sequence lives in a translation unit of its own (elpasso_<curve>_msm.hip, round 6): compiled beside the verification kernels, the group law it
+// shares with them (jac_madd, jac_add: real functions) took their register budget -- 164 registers for k_msm_buckets instead of 120, three waves per SIMD instead of
+// four -- and the bucket phase ran 2.7 x slower than the same source in tools/ubench_msm.hip.
 template <class C, int G>
-static int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs = false);
+int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs = false);
 template <class C, int G>
 int msm_impl_t(elp_ctx* c, size_t n, const uint8_t* pts, const uint8_t* ks, uint8_t* out) {
   if (!c || !out || (n && (!pts || !ks))) return ELP_ERR_ARG;
@@ -2667,7 +2674,7 @@ static size_t msm_ws_bytes(size_t n) {
 }
 // returns the device address of the count of invalid input points (an int, zero after a clean run)
 template <class C, int G>
-static int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs) {
+int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs) {
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
   const bool split = G == 1 && !glv_pairs;        // full-width scalars in G1: split in two halves of ELP_MSM_GLV_HW bytes each (k_msm_split_scalars)
@@ -2703,6 +2710,12 @@ static int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, cons
   return bad;
 }
 
+#ifndef ELP_MSM_TU
+extern template int* msm_launch<BN254, 1>(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs);
+extern template int* msm_launch<BN254, 2>(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs);
+extern template int* msm_launch<BLS12_381, 1>(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs);
+extern template int* msm_launch<BLS12_381, 2>(hipStream_t stream, size_t n, const void* d_pts_std, const void* d_ks, void* d_out_std, uint8_t* ws, bool glv_pairs);
+#endif
 // elp_g1_msm_dev / elp_g2_msm_dev: the same launch sequence over the caller's device buffers and workspace, asynchronous on the caller's stream
 template <class C, int G>
 int msm_dev_t(elp_ctx* c, void* stream_, size_t n, const void* d_points, const void* d_scalars, void* d_workspace, void* d_out) {

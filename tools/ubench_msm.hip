@@ -1,7 +1,8 @@
 // Measurement tool (round 6): where the time of k_msm_buckets goes.  The library's kernel beside three cut-down copies of it on the same inputs:
-//   mode 0  the kernel as built into the library (histogram, scan, counting sort, bucket sums)
+//   mode 0  the kernel as built into the library (histogram, scan, counting sort, size-ranked bucket sums since the last build of round 6)
 //   mode 1  histogram + scan + counting sort only (every lane stores an empty sum)
 //   mode 2  bucket sums only: lane b adds M / 256 points at fixed positions (no histogram, no sort, uniform trip count)
+//   mode 7  the library's kernel on the layout of split scalars (36-byte stride, sign byte, negated points)
 //   mode 6  buckets dealt to the lanes by size (see k_ranked)
 //   mode 3  as mode 0 with the two global passes over the scalars reading a byte array laid out per window (one byte per point)
 // Inputs are random field elements (not curve points: the formulas do not care), scalars random bytes.
@@ -202,8 +203,31 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dp, n * sizeof(Aff<F>)));
   CK(hipMalloc(&dk, n * 32));
   CK(hipMalloc(&dd, n * 32));
+  uint8_t* dk36;
+  CK(hipMalloc(&dk36, n * 36));
+  {
+    std::vector<uint8_t> k36(n * 36);
+    for (auto& b : k36) b = (uint8_t)rnd();
+    CK(hipMemcpy(dk36, k36.data(), n * 36, hipMemcpyHostToDevice));
+  }
+  if (NW > 32) { printf("at most 32 windows (the plain scalars have 32 bytes)\n"); return 1; }
   CK(hipMalloc(&part, (size_t)32 * 256 * 256 * sizeof(Jac<F>)));
   CK(hipMemcpy(dp, pts.data(), n * sizeof(Aff<F>), hipMemcpyHostToDevice));
+  if (argc > 3) {      // real curve points (std affine, 64 bytes each, e.g. written by tools/probes/msm_points.py) instead of random field elements
+    FILE* fh = fopen(argv[3], "rb");
+    std::vector<uint8_t> raw(n * 64);
+    if (!fh || fread(raw.data(), 64, n, fh) != n) { printf("cannot read %zu points from %s\n", n, argv[3]); return 1; }
+    fclose(fh);
+    u32* draw; int* dbad;
+    CK(hipMalloc(&draw, n * 64));
+    CK(hipMalloc(&dbad, 4));
+    CK(hipMemset(dbad, 0, 4));
+    CK(hipMemcpy(draw, raw.data(), n * 64, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_msm_prepare<BN254, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, draw, (void*)dp, dbad, n);
+    int hb = 0;
+    CK(hipMemcpy(&hb, dbad, 4, hipMemcpyDeviceToHost));
+    printf("real points: %zu loaded, %d invalid\n", n, hb);
+  }
   CK(hipMemcpy(dk, ks.data(), n * 32, hipMemcpyHostToDevice));
   CK(hipMemcpy(dd, dg.data(), n * 32, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
@@ -211,11 +235,12 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   for (int S : {8, 16, 32, 64, 128}) {
     if ((size_t)S * 8192 < n || n / S < 256) continue;
-    for (int mode = 0; mode < 7; mode++) {
+    for (int mode = 0; mode < 8; mode++) {
       float best = 1e9f;
       for (int rep = 0; rep < 6; rep++) {
         CK(hipEventRecord(e0, 0));
-        if (mode == 0) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, n, S, part);
+        if (mode == 0) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, n, S, part, 32, -1, 0);
+        if (mode == 7) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk36, n, S, part, ELP_MSM_GLV_STRIDE, 34, ELP_MSM_GLV_HW);
         if (mode == 1) hipLaunchKernelGGL((k_variant<1>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
         if (mode == 2) hipLaunchKernelGGL((k_variant<2>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
         if (mode == 3) hipLaunchKernelGGL((k_variant<3>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
