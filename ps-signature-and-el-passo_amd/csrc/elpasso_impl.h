@@ -1544,7 +1544,8 @@ static inline int msm_slices(size_t n, int nwin) {
 // doublings each on two lanes instead of 248 on one (k_msm_final 1.30 -> k_msm_final_glv<17>; profiles/r06_aggregated.md).  Bytes per point of the split scalars:
 #define ELP_MSM_GLV_HW 17
 #define ELP_MSM_NWMAX 34           /* windows of the widest launch shape (2 x ELP_MSM_GLV_HW) */
-#define ELP_MSM_GLV_STRIDE 36      /* |k1| 0..16, |k2| 17..33, signs (bit 0: k1, bit 1: k2) 34, pad 35 */
+#define ELP_MSM_GLV_STRIDE 36      /* bytes per point in the workspace: 34 digit bytes -- stored WINDOW-MAJOR, digit w of point i at [w * n + i], so that a workgroup's pass over its slice
+                                      reads consecutive bytes (point-major, every digit byte cost a cache line: 0.53 -> see profiles/r06_aggregated.md) --, one sign byte at [34 * n + i], pad */
 template <class C>
 __global__ void ELP_LAUNCH_BOUNDS k_msm_split_scalars(const u32* ks, uint8_t* out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1552,11 +1553,9 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_split_scalars(const u32* ks, uint8_t* ou
   u32 m[2][5];
   bool neg[2];
   lattice_split<2, 5, 5>(scalar_mod_r<C>(scalar_load_w(ks + i * 8)), m, neg, Glv1Lat<C>());
-  uint8_t* o = out + i * ELP_MSM_GLV_STRIDE;
   for (int h = 0; h < 2; h++)
-    for (int b = 0; b < ELP_MSM_GLV_HW; b++) o[h * ELP_MSM_GLV_HW + b] = (uint8_t)(m[h][b >> 2] >> (8 * (b & 3)));
-  o[34] = (uint8_t)((neg[0] ? 1 : 0) | (neg[1] ? 2 : 0));
-  o[35] = 0;
+    for (int b = 0; b < ELP_MSM_GLV_HW; b++) out[(size_t)(h * ELP_MSM_GLV_HW + b) * n + i] = (uint8_t)(m[h][b >> 2] >> (8 * (b & 3)));
+  out[(size_t)(2 * ELP_MSM_GLV_HW) * n + i] = (uint8_t)((neg[0] ? 1 : 0) | (neg[1] ? 2 : 0));
 }
 
 template <class C, int G>
@@ -1585,7 +1584,7 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_prepare(const u32* pts, void* out, int* 
 // 65 536 points x 32 windows; tools/ubench_msm.hip had the tighter allocation by accident of its other kernels).
 template <class F>
 __global__ void __launch_bounds__(ELP_MSM_TPB, (F::IS_EXT ? 1 : 4)) k_msm_buckets(const Aff<F>* pts, const uint8_t* scalars, size_t n, int S,
-                                                             Jac<F>* partial, int kstride, int sign_off, int half_w) {      // plain scalars: 32, -1, 0; split ones: see k_msm_split_scalars
+                                                             Jac<F>* partial, int kstride, int sign_off, int half_w) {      // plain scalars: 32, -1, 0; split ones (window-major): 0, 34, 17 -- see k_msm_split_scalars
   __shared__ unsigned cnt[256];
   __shared__ unsigned start[256];
   __shared__ unsigned cnt0[256];
@@ -1596,10 +1595,13 @@ __global__ void __launch_bounds__(ELP_MSM_TPB, (F::IS_EXT ? 1 : 4)) k_msm_bucket
   const int w = blockIdx.x / S, s = blockIdx.x % S;
   const size_t lo = n * (size_t)s / S, hi = n * (size_t)(s + 1) / S;
   const int M = (int)(hi - lo);
+  // digit w of point i: point-major scalars (kstride bytes per point) or window-major digits (kstride == 0: digit w of all points, then digit w + 1 ...)
+  const uint8_t* const digits = kstride ? scalars + w : scalars + (size_t)w * n;
+  const size_t dstep = kstride ? (size_t)kstride : 1;
   cnt[tid] = 0;
   __syncthreads();
   for (int j = tid; j < M; j += ELP_MSM_TPB) {
-    unsigned d = scalars[(lo + j) * (size_t)kstride + w];
+    unsigned d = digits[(size_t)(lo + j) * dstep];
     if (d != 0 && !aff_is_inf(pts[lo + j])) atomicAdd(&cnt[d], 1u);
   }
   __syncthreads();
@@ -1632,9 +1634,9 @@ __global__ void __launch_bounds__(ELP_MSM_TPB, (F::IS_EXT ? 1 : 4)) k_msm_bucket
   __syncthreads();
   const int sign_shift = (sign_off >= 0 && w >= half_w) ? 1 : 0;
   for (int j = tid; j < M; j += ELP_MSM_TPB) {
-    unsigned d = scalars[(lo + j) * (size_t)kstride + w];
+    unsigned d = digits[(size_t)(lo + j) * dstep];
     if (d != 0 && !aff_is_inf(pts[lo + j])) {
-      const unsigned sg = sign_off >= 0 ? (((unsigned)scalars[(lo + j) * (size_t)kstride + sign_off] >> sign_shift) & 1u) : 0u;
+      const unsigned sg = sign_off >= 0 ? (((unsigned)scalars[(size_t)sign_off * n + lo + j] >> sign_shift) & 1u) : 0u;
       idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)((unsigned)j | (sg << 15));      // a slice has at most 8 192 points: bit 15 carries the sign of this half's sub-scalar
     }
   }
@@ -1700,7 +1702,7 @@ __global__ void ELP_MSM_LAUNCH_BOUNDS k_msm_reduce(const Jac<F>* partial, int S,
 // bucket sums per (window, slice) -> [slices combined] -> one sum per window
 template <class F>
 static void msm_windows(hipStream_t stream, int nwin, int S, const Aff<F>* aff, const uint8_t* ks, size_t n, Jac<F>* part, Jac<F>* win, bool split = false) {
-  hipLaunchKernelGGL((k_msm_buckets<F>), dim3(nwin * S), dim3(ELP_MSM_TPB), 0, stream, aff, ks, n, S, part, split ? ELP_MSM_GLV_STRIDE : 32, split ? 34 : -1,
+  hipLaunchKernelGGL((k_msm_buckets<F>), dim3(nwin * S), dim3(ELP_MSM_TPB), 0, stream, aff, ks, n, S, part, split ? 0 : 32, split ? 2 * ELP_MSM_GLV_HW : -1,
                      split ? ELP_MSM_GLV_HW : 0);
   if (S > 8) hipLaunchKernelGGL((k_msm_combine<F>), dim3(nwin * 32), dim3(ELP_MSM_TPB), 0, stream, part, S);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(nwin), dim3(ELP_MSM_TPB), 0, stream, (const Jac<F>*)part, S > 8 ? 1 : S, S, win);

@@ -2,7 +2,7 @@
 //   mode 0  the kernel as built into the library (histogram, scan, counting sort, size-ranked bucket sums since the last build of round 6)
 //   mode 1  histogram + scan + counting sort only (every lane stores an empty sum)
 //   mode 2  bucket sums only: lane b adds M / 256 points at fixed positions (no histogram, no sort, uniform trip count)
-//   mode 7  the library's kernel on the layout of split scalars (36-byte stride, sign byte, negated points)
+//   mode 7  the library's kernel on the layout of split scalars (window-major digits, sign bytes, negated points)
 //   mode 6  buckets dealt to the lanes by size (see k_ranked)
 //   mode 3  as mode 0 with the two global passes over the scalars reading a byte array laid out per window (one byte per point)
 // Inputs are random field elements (not curve points: the formulas do not care), scalars random bytes.
@@ -213,6 +213,8 @@ int main(int argc, char** argv) {
   if (NW > 32) { printf("at most 32 windows (the plain scalars have 32 bytes)\n"); return 1; }
   CK(hipMalloc(&part, (size_t)32 * 256 * 256 * sizeof(Jac<F>)));
   CK(hipMemcpy(dp, pts.data(), n * sizeof(Aff<F>), hipMemcpyHostToDevice));
+  u32* draw_pts = nullptr;
+  int* dbad_pts = nullptr;
   if (argc > 3) {      // real curve points (std affine, 64 bytes each, e.g. written by tools/probes/msm_points.py) instead of random field elements
     FILE* fh = fopen(argv[3], "rb");
     std::vector<uint8_t> raw(n * 64);
@@ -227,6 +229,8 @@ int main(int argc, char** argv) {
     int hb = 0;
     CK(hipMemcpy(&hb, dbad, 4, hipMemcpyDeviceToHost));
     printf("real points: %zu loaded, %d invalid\n", n, hb);
+    draw_pts = draw;
+    dbad_pts = dbad;
   }
   CK(hipMemcpy(dk, ks.data(), n * 32, hipMemcpyHostToDevice));
   CK(hipMemcpy(dd, dg.data(), n * 32, hipMemcpyHostToDevice));
@@ -238,9 +242,10 @@ int main(int argc, char** argv) {
     for (int mode = 0; mode < 8; mode++) {
       float best = 1e9f;
       for (int rep = 0; rep < 6; rep++) {
+        if (draw_pts && getenv("UB_REPREPARE")) hipLaunchKernelGGL((k_msm_prepare<BN254, 1>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, draw_pts, (void*)dp, dbad_pts, n);      // as in the library: the points are rewritten before every sum
         CK(hipEventRecord(e0, 0));
         if (mode == 0) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, n, S, part, 32, -1, 0);
-        if (mode == 7) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk36, n, S, part, ELP_MSM_GLV_STRIDE, 34, ELP_MSM_GLV_HW);
+        if (mode == 7) hipLaunchKernelGGL((k_msm_buckets<F>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk36, n, S, part, 0, 2 * ELP_MSM_GLV_HW, ELP_MSM_GLV_HW);
         if (mode == 1) hipLaunchKernelGGL((k_variant<1>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
         if (mode == 2) hipLaunchKernelGGL((k_variant<2>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
         if (mode == 3) hipLaunchKernelGGL((k_variant<3>), dim3(NW * S), dim3(ELP_MSM_TPB), 0, 0, dp, dk, dd, n, S, part);
