@@ -1543,7 +1543,12 @@ static inline int msm_slices(size_t n, int nwin) {
 // the windows 0 .. 16 hold the bytes of |k1|, the windows 17 .. 33 those of |k2|, a sign byte tells the bucket kernel to add -P; the closing Horner chains then have 128
 // doublings each on two lanes instead of 248 on one (k_msm_final 1.30 -> k_msm_final_glv<17>; profiles/r06_aggregated.md).  Bytes per point of the split scalars:
 #define ELP_MSM_GLV_HW 17
-#define ELP_MSM_NWMAX 34           /* windows of the widest launch shape (2 x ELP_MSM_GLV_HW) */
+#define ELP_MSM_VPARTS 4           /* the window of a half's top byte is worked on in this many parts (a power of two) */
+#define ELP_MSM_NWMAX (2 * ELP_MSM_GLV_HW + 2 * (ELP_MSM_VPARTS - 1))      /* windows of the widest launch shape: 2 x ELP_MSM_GLV_HW and the virtual windows below */
+// The halves have 126 - 128 bits, so the digits of their top byte (windows HW - 2 and 2 HW - 2) take few of the 256 values -- 49 on BN254 --: those buckets are five times
+// as long as the others' and their workgroups finished last (0.53 ms for 65 536 points where uniformly distributed digits take 0.27).  Each of the two windows is therefore
+// worked on in ELP_MSM_VPARTS parts: the real window takes the points whose index is 0 modulo VPARTS, VPARTS - 1 virtual windows behind the real ones (2 HW ...) the other
+// residues; k_msm_final_glv adds the parts.
 #define ELP_MSM_GLV_STRIDE 36      /* bytes per point in the workspace: 34 digit bytes -- stored WINDOW-MAJOR, digit w of point i at [w * n + i], so that a workgroup's pass over its slice
                                       reads consecutive bytes (point-major, every digit byte cost a cache line: 0.53 -> see profiles/r06_aggregated.md) --, one sign byte at [34 * n + i], pad */
 template <class C>
@@ -1595,13 +1600,25 @@ __global__ void __launch_bounds__(ELP_MSM_TPB, (F::IS_EXT ? 1 : 4)) k_msm_bucket
   const int w = blockIdx.x / S, s = blockIdx.x % S;
   const size_t lo = n * (size_t)s / S, hi = n * (size_t)(s + 1) / S;
   const int M = (int)(hi - lo);
+  // split scalars (sign_off >= 0): the windows of the halves' top bytes take the even points only, the virtual windows behind the real ones their odd points
+  int wr = w, par = -1;                                     // the real window whose digits this workgroup reads; the parity of the points it takes (-1: all)
+  if (sign_off >= 0) {
+    if (w >= 2 * half_w) {
+      const int v = w - 2 * half_w;                         // half v / (VPARTS - 1), part 1 + v % (VPARTS - 1)
+      wr = (v / (ELP_MSM_VPARTS - 1) + 1) * half_w - 2;
+      par = 1 + v % (ELP_MSM_VPARTS - 1);
+    } else if (w == half_w - 2 || w == 2 * half_w - 2) {
+      par = 0;
+    }
+  }
   // digit w of point i: point-major scalars (kstride bytes per point) or window-major digits (kstride == 0: digit w of all points, then digit w + 1 ...)
-  const uint8_t* const digits = kstride ? scalars + w : scalars + (size_t)w * n;
+  const uint8_t* const digits = kstride ? scalars + wr : scalars + (size_t)wr * n;
   const size_t dstep = kstride ? (size_t)kstride : 1;
   cnt[tid] = 0;
   __syncthreads();
   for (int j = tid; j < M; j += ELP_MSM_TPB) {
     unsigned d = digits[(size_t)(lo + j) * dstep];
+    if (par >= 0 && (int)((lo + j) & (ELP_MSM_VPARTS - 1)) != par) d = 0;
     if (d != 0 && !aff_is_inf(pts[lo + j])) atomicAdd(&cnt[d], 1u);
   }
   __syncthreads();
@@ -1632,9 +1649,10 @@ __global__ void __launch_bounds__(ELP_MSM_TPB, (F::IS_EXT ? 1 : 4)) k_msm_bucket
   __syncthreads();
   cnt[tid] = my_start;   // becomes the scatter cursor
   __syncthreads();
-  const int sign_shift = (sign_off >= 0 && w >= half_w) ? 1 : 0;
+  const int sign_shift = (sign_off >= 0 && wr >= half_w) ? 1 : 0;
   for (int j = tid; j < M; j += ELP_MSM_TPB) {
     unsigned d = digits[(size_t)(lo + j) * dstep];
+    if (par >= 0 && (int)((lo + j) & (ELP_MSM_VPARTS - 1)) != par) d = 0;
     if (d != 0 && !aff_is_inf(pts[lo + j])) {
       const unsigned sg = sign_off >= 0 ? (((unsigned)scalars[(size_t)sign_off * n + lo + j] >> sign_shift) & 1u) : 0u;
       idx[atomicAdd(&cnt[d], 1u)] = (unsigned short)((unsigned)j | (sg << 15));      // a slice has at most 8 192 points: bit 15 carries the sign of this half's sub-scalar
@@ -1711,7 +1729,7 @@ static void msm_windows(hipStream_t stream, int nwin, int S, const Aff<F>* aff, 
 // Closing step for the multipliers of aggregated verification, d_i = a_i + b_i lam with a_i in scalar bytes 0-7 and b_i in bytes 8-15 (pipeline.h
 // verify_id_agg_item): windows 0-7 hold the bucket sums of sum a_i P_i =: A, windows 8-15 those of sum b_i P_i =: B; the result is A + phi(B).  The two Horner
 // chains (56 doublings each) run on two lanes.
-template <class C, int HW = 8>      // HW windows per half: 8 for the 64-bit pairs of aggregated verification, ELP_MSM_GLV_HW for split full-width scalars
+template <class C, int HW = 8, bool VIRT = false>      // HW windows per half: 8 for the 64-bit pairs of aggregated verification, ELP_MSM_GLV_HW for split full-width scalars (VIRT: with the virtual windows)
 __global__ void ELP_LAUNCH_BOUNDS k_msm_final_glv(const void* win_, u32* out) {
   typedef F1<C> F;
   __shared__ Jac<F> half[2];
@@ -1721,6 +1739,9 @@ __global__ void ELP_LAUNCH_BOUNDS k_msm_final_glv(const void* win_, u32* out) {
   for (int w = HW - 2; w >= 0; w--) {
     for (int k = 0; k < 8; k++) jac_dbl<F>(r, r);
     jac_add<F>(r, r, win[w]);
+    if (VIRT && w == HW - 2) {                                // the other parts of the top byte's window
+      for (int v = 0; v < ELP_MSM_VPARTS - 1; v++) jac_add<F>(r, r, ((const Jac<F>*)win_)[2 * HW + (ELP_MSM_VPARTS - 1) * threadIdx.x + v]);
+    }
   }
   if (threadIdx.x == 1) {
     Fp<C> beta;
@@ -2680,7 +2701,7 @@ int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void*
   const size_t AFF = G == 1 ? sizeof(Aff<F1<C>>) : sizeof(Aff<F2<C>>);
   const size_t JAC = G == 1 ? sizeof(Jac<F1<C>>) : sizeof(Jac<F2<C>>);
   const bool split = G == 1 && !glv_pairs;        // full-width scalars in G1: split in two halves of ELP_MSM_GLV_HW bytes each (k_msm_split_scalars)
-  const int NWL = glv_pairs ? 16 : split ? 2 * ELP_MSM_GLV_HW : 32;            // scalar bytes in use: the pairs (a, b) of aggregated verification fill 16
+  const int NWL = glv_pairs ? 16 : split ? ELP_MSM_NWMAX : 32;                 // windows: the pairs (a, b) of aggregated verification fill 16 bytes; split scalars 2 x 17 + the virtual windows
   const int S = msm_slices(n, NWL);
   uint8_t* aff = ws;
   uint8_t* part = aff + ((n * AFF + 255) & ~(size_t)255);
@@ -2694,7 +2715,7 @@ int* msm_launch(hipStream_t stream, size_t n, const void* d_pts_std, const void*
     if (split) {
       hipLaunchKernelGGL((k_msm_split_scalars<C>), dim3(grid_for(n)), dim3(ELP_BLOCK), 0, stream, (const u32*)d_ks, ks2, n);
       msm_windows<F>(stream, NWL, S, (const Aff<F>*)aff, ks2, n, (Jac<F>*)part, (Jac<F>*)win, true);
-      hipLaunchKernelGGL((k_msm_final_glv<C, ELP_MSM_GLV_HW>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
+      hipLaunchKernelGGL((k_msm_final_glv<C, ELP_MSM_GLV_HW, true>), dim3(1), dim3(ELP_BLOCK), 0, stream, (const void*)win, (u32*)d_out_std);
       return bad;
     }
     msm_windows<F>(stream, NWL, S, (const Aff<F>*)aff, (const uint8_t*)d_ks, n, (Jac<F>*)part, (Jac<F>*)win);
